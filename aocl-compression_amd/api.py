@@ -1,0 +1,231 @@
+"""ctypes binding of libaocl_compression_gpu.so (include/aocl_gpu_codec.h, include/aocl_compression.h).
+
+Host-side mirror of the reference's interfaces for the hot path:
+  * Engine.compress_chunks / decompress_chunks  <->  the per-codec native one-shot calls applied to every
+    chunk of a batch (LZ4_compress_default / snappy::RawCompress / ZSTD_compress and their inverses);
+  * Engine.llc_compress / llc_decompress        <->  aocl_llc_compress / aocl_llc_decompress
+    (api/aocl_compression.h:170-207) on host buffers.
+PyTorch is used only as the owner of device memory and streams; every compute call goes through the
+C-ABI.  There is no CPU fallback: if the shared library is missing, or no gfx950 device is visible,
+construction raises EngineError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LZ4, SNAPPY, ZSTD = 0, 1, 2
+_NAMES = {LZ4: "lz4", SNAPPY: "snappy", ZSTD: "zstd"}
+# aocl_compression_type values (api/aocl_compression.h:109-119)
+_LLC_ENUM = {LZ4: 0, SNAPPY: 4, ZSTD: 6}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libaocl_compression_gpu.so")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Batch(C.Structure):
+    """aoclgpu_batch (include/aocl_gpu_codec.h)."""
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("src_off", C.c_void_p), ("src_len", C.c_void_p), ("dst_off", C.c_void_p), ("dst_cap", C.c_void_p),
+        ("out_len", C.c_void_p),
+        ("nchunks", C.c_uint32), ("reserved", C.c_uint32),
+        ("total_bytes", C.c_uint64), ("chunk_bytes", C.c_uint64), ("slot_bytes", C.c_uint64),
+    ]
+
+
+class LlcDesc(C.Structure):
+    """aocl_compression_desc (api/aocl_compression.h:125-152)."""
+    _fields_ = [
+        ("inBuf", C.c_void_p), ("outBuf", C.c_void_p), ("workBuf", C.c_void_p),
+        ("inSize", C.c_size_t), ("outSize", C.c_size_t), ("level", C.c_size_t), ("optVar", C.c_size_t),
+        ("numThreads", C.c_int), ("numMPIranks", C.c_int), ("memLimit", C.c_size_t), ("measureStats", C.c_int),
+        ("cSize", C.c_uint64), ("dSize", C.c_uint64), ("cTime", C.c_uint64), ("dTime", C.c_uint64),
+        ("cSpeed", C.c_float), ("dSpeed", C.c_float), ("optOff", C.c_int), ("optLevel", C.c_int),
+    ]
+
+
+EXPORTS = [
+    "aoclgpu_device_count", "aoclgpu_init", "aoclgpu_last_error", "aoclgpu_version", "aoclgpu_compress_bound",
+    "aoclgpu_lz4_compress_chunks", "aoclgpu_lz4_decompress_chunks",
+    "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
+    "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks",
+    "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_decompress_host",
+    "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
+]
+
+
+def load_library() -> C.CDLL:
+    p = lib_path()
+    if not os.path.exists(p):
+        raise EngineError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback)")
+    lib = C.CDLL(p)
+    lib.aoclgpu_last_error.restype = C.c_char_p
+    lib.aoclgpu_version.restype = C.c_char_p
+    lib.aocl_llc_version.restype = C.c_char_p
+    lib.aoclgpu_compress_bound.restype = C.c_size_t
+    lib.aoclgpu_compress_bound.argtypes = [C.c_int, C.c_size_t]
+    for n in EXPORTS:
+        if n.endswith("_chunks"):
+            f = getattr(lib, n)
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(Batch), C.c_void_p]
+    lib.aoclgpu_compact_slots.restype = C.c_int
+    lib.aoclgpu_compact_slots.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.aoclgpu_time_batch.restype = C.c_double
+    lib.aoclgpu_time_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Batch), C.c_int, C.c_void_p]
+    for n in ("aoclgpu_compress_host", "aoclgpu_decompress_host"):
+        f = getattr(lib, n)
+        f.restype = C.c_int64
+        f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    for n in ("aocl_llc_compress", "aocl_llc_decompress"):
+        f = getattr(lib, n)
+        f.restype = C.c_int64
+        f.argtypes = [C.POINTER(LlcDesc), C.c_int]
+    lib.aocl_llc_setup.restype = C.c_int32
+    lib.aocl_llc_setup.argtypes = [C.POINTER(LlcDesc), C.c_int]
+    lib.aocl_llc_destroy.restype = None
+    lib.aocl_llc_destroy.argtypes = [C.POINTER(LlcDesc), C.c_int]
+    return lib
+
+
+def compress_bound(codec: int, n: int) -> int:
+    """LZ4_COMPRESSBOUND / snappy MaxCompressedLength / ZSTD_COMPRESSBOUND (pure arithmetic, no GPU)."""
+    if codec == LZ4:
+        return 0 if n > 0x7E000000 else n + n // 255 + 16
+    if codec == SNAPPY:
+        return 32 + n + n // 6
+    return n + (n >> 8) + (((128 << 10) - n) >> 11 if n < (128 << 10) else 0)
+
+
+class Engine:
+    """One process / one GPU.  All tensors are torch uint8 / int32 tensors on that GPU."""
+
+    def __init__(self, device: int = 0):
+        import torch  # device memory + streams only
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the engine has no CPU fallback")
+        rc = self.lib.aoclgpu_init(device)
+        if rc != 0:
+            raise EngineError(f"aoclgpu_init({device}) failed: {self.lib.aoclgpu_last_error().decode()}")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+
+    # ---- helpers ----
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _fn(self, codec: int, op: str):
+        return getattr(self.lib, f"aoclgpu_{_NAMES[codec]}_{op}_chunks")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.aoclgpu_last_error().decode()}")
+
+    def uniform_compress_batch(self, src, chunk_bytes: int, slots, out_len, slot_bytes: int) -> Batch:
+        n = int(src.numel())
+        nchunks = max(1, -(-n // chunk_bytes))
+        assert slots.numel() >= nchunks * slot_bytes and out_len.numel() >= nchunks
+        return Batch(src=src.data_ptr(), dst=slots.data_ptr(), out_len=out_len.data_ptr(), nchunks=nchunks,
+                     total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes)
+
+    def uniform_decompress_batch(self, slots, comp_len, slot_bytes: int, dst, chunk_bytes: int, out_len) -> Batch:
+        n = int(dst.numel())
+        nchunks = max(1, -(-n // chunk_bytes))
+        assert comp_len.numel() >= nchunks and out_len.numel() >= nchunks
+        return Batch(src=slots.data_ptr(), dst=dst.data_ptr(), src_len=comp_len.data_ptr(), out_len=out_len.data_ptr(),
+                     nchunks=nchunks, total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes)
+
+    # ---- batch API on device tensors ----
+    def compress_chunks(self, codec: int, src, chunk_bytes: int, slot_bytes: int | None = None):
+        """Compress every chunk_bytes-sized chunk of `src` independently.
+        Returns (slots uint8[nchunks*slot_bytes], out_len int32[nchunks], slot_bytes)."""
+        t = self.torch
+        if slot_bytes is None:
+            slot_bytes = (compress_bound(codec, chunk_bytes) + 15) & ~15
+        nchunks = max(1, -(-int(src.numel()) // chunk_bytes))
+        slots = t.empty(nchunks * slot_bytes, dtype=t.uint8, device=self.device)
+        out_len = t.zeros(nchunks, dtype=t.int32, device=self.device)
+        b = self.uniform_compress_batch(src, chunk_bytes, slots, out_len, slot_bytes)
+        self._check(self._fn(codec, "compress")(C.byref(b), self._stream()), f"{_NAMES[codec]} compress")
+        return slots, out_len, slot_bytes
+
+    def decompress_chunks(self, codec: int, slots, comp_len, slot_bytes: int, total_bytes: int, chunk_bytes: int):
+        """Inverse of compress_chunks.  Returns (dst uint8[total_bytes], out_len int32[nchunks])."""
+        t = self.torch
+        nchunks = max(1, -(-total_bytes // chunk_bytes))
+        dst = t.empty(total_bytes, dtype=t.uint8, device=self.device)
+        out_len = t.zeros(nchunks, dtype=t.int32, device=self.device)
+        comp_u32 = comp_len.to(t.int32).contiguous()
+        b = self.uniform_decompress_batch(slots, comp_u32, slot_bytes, dst, chunk_bytes, out_len)
+        self._check(self._fn(codec, "decompress")(C.byref(b), self._stream()), f"{_NAMES[codec]} decompress")
+        return dst, out_len
+
+    def compact(self, slots, slot_bytes: int, out_len):
+        """Gather the used prefix of each slot into one stream; returns (packed, offsets uint64-as-int64[n+1])."""
+        t = self.torch
+        n = int(out_len.numel())
+        total = int(out_len.clamp(min=0).sum().item())
+        packed = t.empty(max(total, 1), dtype=t.uint8, device=self.device)
+        off = t.zeros(n + 1, dtype=t.int64, device=self.device)
+        self._check(self.lib.aoclgpu_compact_slots(slots.data_ptr(), slot_bytes, out_len.data_ptr(), n, packed.data_ptr(),
+                                                   off.data_ptr(), self._stream()), "compact")
+        return packed[:total], off
+
+    def time_batch(self, codec: int, op: int, batch: Batch, iters: int) -> float:
+        ms = self.lib.aoclgpu_time_batch(codec, op, C.byref(batch), iters, self._stream())
+        if ms < 0:
+            raise EngineError(f"time_batch failed: {self.lib.aoclgpu_last_error().decode()}")
+        return ms
+
+    # ---- host one-shot (native-API contract) ----
+    def compress_host(self, codec: int, data: bytes, cap: int | None = None) -> bytes | None:
+        cap = compress_bound(codec, len(data)) if cap is None else cap
+        out = C.create_string_buffer(max(cap, 1))
+        r = self.lib.aoclgpu_compress_host(codec, data, len(data), out, cap)
+        if r < 0:
+            raise EngineError(f"compress_host failed ({r}): {self.lib.aoclgpu_last_error().decode()}")
+        return out.raw[:r] if r > 0 else None
+
+    def decompress_host(self, codec: int, data: bytes, cap: int) -> bytes | None:
+        out = C.create_string_buffer(max(cap, 1))
+        r = self.lib.aoclgpu_decompress_host(codec, data, len(data), out, cap)
+        if r <= -(1 << 39):
+            raise EngineError(f"decompress_host failed ({r}): {self.lib.aoclgpu_last_error().decode()}")
+        return out.raw[:r] if r >= 0 else None
+
+    # ---- unified API (aocl_llc_*) on host buffers ----
+    def llc_compress(self, codec: int, data: bytes, cap: int, level: int = 1, stats: bool = False):
+        out = C.create_string_buffer(max(cap, 1))
+        inb = C.create_string_buffer(data, len(data)) if data else None
+        d = LlcDesc(inBuf=C.cast(inb, C.c_void_p) if inb else None, outBuf=C.cast(out, C.c_void_p), inSize=len(data),
+                    outSize=cap, level=level, measureStats=1 if stats else 0)
+        r = self.lib.aocl_llc_compress(C.byref(d), _LLC_ENUM[codec])
+        return r, (out.raw[:r] if r > 0 else b""), d
+
+    def llc_decompress(self, codec: int, data: bytes, cap: int, stats: bool = False):
+        out = C.create_string_buffer(max(cap, 1))
+        inb = C.create_string_buffer(data, len(data)) if data else None
+        d = LlcDesc(inBuf=C.cast(inb, C.c_void_p) if inb else None, outBuf=C.cast(out, C.c_void_p), inSize=len(data),
+                    outSize=cap, measureStats=1 if stats else 0)
+        r = self.lib.aocl_llc_decompress(C.byref(d), _LLC_ENUM[codec])
+        return r, (out.raw[:r] if r > 0 else b""), d
+
+
+_ENGINE = None
+
+
+def engine(device: int = 0) -> Engine:
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = Engine(device)
+    return _ENGINE

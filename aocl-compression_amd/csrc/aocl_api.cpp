@@ -1,0 +1,122 @@
+// csrc/aocl_api.cpp -- the reference's unified API (api/aocl_compression.h:170-231) on top of the GPU engine.
+//
+// Mirrors api/api.cpp:45-189 + the LZ4 / SNAPPY / ZSTD wrappers of api/codec.cpp:115-157,262-308,352-436:
+// same return codes (wrapper result < 0 -> ERR_COMPRESSION_FAILED), same measureStats fields (ns,
+// bytes*1000/ns), same argument checks.  Buffers are HOST buffers as in the reference; one call moves the
+// input to HBM, runs ONE chunk (= exactly the bytes the reference's one-shot native call emits) and moves
+// the result back.  Bulk work should use the device-resident batch entry points of aocl_gpu_codec.h instead.
+// There is no CPU fallback: without a gfx950 device every call fails with ERR_COMPRESSION_FAILED.
+#include "../../include/aocl_compression.h"
+#include "../../include/aocl_gpu_codec.h"
+#include <time.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+const int64_t kCodecError = -1;   // api/codec.h CODEC_ERROR
+
+uint64_t now_ns()
+{   // utils/utils.h:244-247: clock_gettime(CLOCK_REALTIME), nanoseconds
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+bool gpu_codec(aocl_compression_type t, aoclgpu_codec* out)
+{
+    switch (t) {
+    case LZ4: *out = AOCLGPU_LZ4; return true;
+    case SNAPPY: *out = AOCLGPU_SNAPPY; return true;
+    case ZSTD: *out = AOCLGPU_ZSTD; return true;
+    default: return false;
+    }
+}
+
+int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
+{
+    aoclgpu_codec c;
+    if (!gpu_codec(t, &c)) return kCodecError;
+    if (!h->outBuf || (!h->inBuf && h->inSize != 0)) return kCodecError;
+    if (t == LZ4) {                                   // api/codec.cpp:126-134: LZ4_compress_default takes int sizes
+        if (h->inSize > 0x7E000000u) return kCodecError;
+        size_t cap = h->outSize > 0x7FFFFFFFu ? 0x7FFFFFFFu : h->outSize;
+        int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, cap);
+        return r > 0 ? r : kCodecError;
+    }
+    if (t == SNAPPY) {                                // api/codec.cpp:268-290
+        if (h->outSize < aoclgpu_compress_bound(c, h->inSize)) return kCodecError;
+        int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+        return r > 0 ? r : kCodecError;
+    }
+    // ZSTD (api/codec.cpp:396-422): only the level-1 "fast" strategy has a GPU backend
+    if (h->level != 1 && h->level != 0) return kCodecError;
+    int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+    return r > 0 ? r : kCodecError;
+}
+
+int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
+{
+    aoclgpu_codec c;
+    if (!gpu_codec(t, &c)) return kCodecError;
+    if (!h->inBuf || !h->outBuf) return kCodecError;
+    int64_t r = aoclgpu_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+    return r >= 0 ? r : kCodecError;                  // api/codec.cpp:143-151
+}
+
+}  // namespace
+
+extern "C" int64_t aocl_llc_compress(aocl_compression_desc* handle, aocl_compression_type codec_type)
+{
+    if (!handle) return ERR_COMPRESSION_FAILED;
+    const uint64_t t0 = now_ns();
+    const int64_t ret = wrap_compress(codec_type, handle);
+    const uint64_t t1 = now_ns();
+    if (handle->measureStats == 1) {                  // api/api.cpp:70-75
+        handle->cSize = (uint64_t)ret;
+        handle->cTime = t1 - t0;
+        handle->cSpeed = (float)((handle->inSize * 1000.0) / (double)handle->cTime);
+    }
+    return ret < 0 ? ERR_COMPRESSION_FAILED : ret;
+}
+
+extern "C" int64_t aocl_llc_decompress(aocl_compression_desc* handle, aocl_compression_type codec_type)
+{
+    if (!handle) return ERR_COMPRESSION_FAILED;
+    const uint64_t t0 = now_ns();
+    const int64_t ret = wrap_decompress(codec_type, handle);
+    const uint64_t t1 = now_ns();
+    if (handle->measureStats == 1) {                  // api/api.cpp:111-116
+        handle->dSize = (uint64_t)ret;
+        handle->dTime = t1 - t0;
+        handle->dSpeed = (float)((handle->dSize * 1000.0) / (double)handle->dTime);
+    }
+    return ret < 0 ? ERR_COMPRESSION_FAILED : ret;
+}
+
+extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compression_type codec_type)
+{
+    if ((int)codec_type < (int)LZ4 || (int)codec_type >= (int)AOCL_COMPRESSOR_ALGOS_NUM)
+        return ERR_UNSUPPORTED_METHOD;                // api/api.cpp:133-138
+    aoclgpu_codec c;
+    if (!gpu_codec(codec_type, &c)) return ERR_EXCLUDED_METHOD;   // api/api.cpp:155-161 (no backend in this build)
+    if (handle) {
+        // utils/utils.cpp:148-175 derives optLevel from CPUID; host ISA levels are meaningless for the GPU
+        // backend, so it reports 0 ("no host SIMD path selected").  workBuf: LZ4/Snappy keep no context
+        // (api/codec.cpp:118-122,262-266); the Zstd tables live on the device per launch.
+        handle->optLevel = 0;
+        handle->workBuf = NULL;
+    }
+    if (aoclgpu_init(0) != AOCLGPU_OK) return ERR_EXCLUDED_METHOD;
+    return 0;
+}
+
+extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression_type)
+{
+    if (handle) handle->workBuf = NULL;
+}
+
+extern "C" const char* aocl_llc_version(void)
+{
+    return AOCL_COMPRESSION_LIBRARY_VERSION " Build gfx950";   // api/api.cpp:186-189
+}

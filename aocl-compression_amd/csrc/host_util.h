@@ -1,0 +1,11 @@
+// csrc/host_util.h -- host-side helpers shared by the C-ABI launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/aocl_gpu_codec.h"
+
+namespace aoclgpu {
+void set_error(const char* what, hipError_t e);
+void set_error_msg(const char* msg);
+int check_batch(const aoclgpu_batch* b, bool decompress);
+int check_launch(const char* kernel);
+}  // namespace aoclgpu

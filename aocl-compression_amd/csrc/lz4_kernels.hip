@@ -1,0 +1,321 @@
+// csrc/lz4_kernels.hip -- LZ4 block format, level 1, for gfx950 (MI355X).
+//
+// Bit-exact wave-parallel restatement of the reference's greedy parser and a safe decoder:
+//   compress   : AOCL_LZ4_compress_generic_validated   /root/reference algos/lz4/lz4.c:1371-1845
+//                (entry LZ4_compress_default :2967-2975; table-type / limitedOutput selection :2513-2541)
+//   decompress : AOCL_LZ4_decompress_generic (safe)    algos/lz4/lz4.c:3367-3803, entry :4898-4923
+//
+// How a sequential greedy parse runs on a 64-lane wavefront without changing one output byte
+// ------------------------------------------------------------------------------------------
+// Between two matches the reference visits a data-INDEPENDENT schedule of probe positions
+// (step = searchMatchNb++ >> 6, lz4.c:1490-1510).  Lane k of the wave therefore evaluates probe k of
+// the schedule speculatively: hash, LDS table lookup, 4-byte compare.  The only data dependence
+// inside a batch is through the hash table (probe k must see the table writes of probes < k), so
+//   1. the first lane f whose hash slot was already written by an earlier lane of the same batch is
+//      found exactly (per-slot minimum via LDS write/read-back rounds);
+//   2. lanes < f have exactly the candidates the sequential code would see; the first of them with a
+//      valid 4-byte match (ballot + ctz) is the reference's match;
+//   3. only the table writes of probes the reference would have executed are committed
+//      (lanes <= match lane, or lanes < f when the batch is cut), then the next batch starts at f.
+// The "test next position" probe after a match (lz4.c:1763-1800) is probe -1 of the next batch, and
+// the ip-2 back-fill (:1750) is applied before that batch reads the table.  Backward catch-up and
+// forward match extension compare 64 / 256 bytes per step with ballot; token, length bytes and
+// literals are written cooperatively.
+#include "common.hip.h"
+
+namespace aoclgpu {
+namespace {
+
+constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMfLimit = 12, kMinLength = 13;
+constexpr uint32_t kDistMax = 65535, k64KLimit = 65536 + 11, kMaxInput = 0x7E000000u;
+constexpr uint32_t kTableBytes = 16384;   // LZ4_MEMORY_USAGE 14 (lz4.h:163)
+
+__device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }   // lz4.h:261
+
+// Sum of the first i steps of the search schedule (lz4.c:1486-1510): step_0 = 1, step_j = (63+j)>>6.
+__device__ __forceinline__ uint32_t sched(uint32_t i)
+{
+    if (i == 0) return 0;
+    const uint32_t n = 62 + i, q = n >> 6, r = n & 63;
+    return 1 + 32 * q * (q - 1) + q * (r + 1);
+}
+
+template <bool U16>
+__device__ __forceinline__ uint32_t lz4_hash(uint64_t seq)
+{   // lz4.c:759-823: byU16 -> 13-bit hash of 4 bytes; byU32 -> 12-bit hash of the low 5 bytes
+    if (U16) return ((uint32_t)seq * 2654435761u) >> (32 - 13);
+    return (uint32_t)(((seq << 24) * 889523592379ull) >> (64 - 12));
+}
+
+// write the LZ4 "length - 15" continuation bytes (255,255,...,rem); returns bytes written
+__device__ __forceinline__ uint32_t put_len_bytes(uint8_t* d, uint32_t rem, int lane)
+{
+    const uint32_t nff = rem / 255;
+    for (uint32_t i = (uint32_t)lane; i < nff; i += kWave) d[i] = 255;
+    if (lane == 0) d[nff] = (uint8_t)(rem - nff * 255);
+    return nff + 1;
+}
+
+template <bool U16>
+__device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t n,
+                                 uint8_t* __restrict__ dst, const uint32_t cap, void* lds)
+{
+    using T = typename std::conditional<U16, uint16_t, uint32_t>::type;
+    T* table = reinterpret_cast<T*>(lds);
+    const int lane = lane_id();
+
+    // LZ4_initStream: zero-filled table (lz4.c:2519).  The "first byte" insert (:1443) stores 0 -> no-op.
+    for (uint32_t i = (uint32_t)lane; i < kTableBytes / 16; i += kWave)
+        reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    wave_fence();
+
+    const bool limited = cap < lz4_bound(n);              // lz4.c:2522
+    const uint32_t mfl1 = n - kMfLimit + 1;               // mflimitPlusOne
+    const uint32_t matchlimit = n - kLastLiterals;
+    uint32_t ip = 1, anchor = 0, op = 0;
+    bool extra = false;                                   // next batch starts with the post-match probe
+
+    if (n >= kMinLength) {
+        for (;;) {
+            // ---------------- search (lz4.c:1483-1608, 1746-1804) ----------------
+            const uint32_t base = extra ? ip + 1 : ip;
+            if (extra) {                                  // back-fill ip-2 (lz4.c:1750)
+                const uint32_t h2 = lz4_hash<U16>(ld64(src + ip - 2));
+                if (lane == 0) table[h2] = (T)(ip - 2);
+                wave_fence();
+            }
+            uint32_t i0 = 0, m_pos = 0, m_cand = 0;
+            bool found = false;
+            for (;;) {
+                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
+                const uint32_t pos = (j < 0) ? ip : base + sched((uint32_t)j);
+                const bool valid = base + sched((uint32_t)(j + 1)) <= mfl1;     // lz4.c:1513
+                uint64_t seq = 0;
+                if (valid) seq = ld64(src + pos);
+                const uint32_t h = lz4_hash<U16>(seq);
+                uint32_t cand = 0;
+                if (valid) cand = table[h];
+                uint32_t m4 = ~(uint32_t)seq;
+                if (valid) m4 = ld32(src + cand);
+                // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
+                wave_fence();
+                bool pending = valid;
+                uint32_t w = (uint32_t)lane;
+                do {
+                    if (pending) table[h] = (T)lane;
+                    wave_fence();
+                    if (valid) w = table[h];
+                    wave_fence();
+                    pending = valid && (uint32_t)lane < w;
+                } while (ballot(pending) != 0);
+                const int f = first_lane(ballot(valid && w != (uint32_t)lane));
+                const int e = first_lane(ballot(!valid));
+                const int lim = f < e ? f : e;
+                const bool ok = lane < lim && m4 == (uint32_t)seq && (U16 || cand + kDistMax >= pos);
+                const int m = first_lane(ballot(ok));
+                // restore every touched slot, then commit the probes the reference really executed
+                if (valid) table[h] = (T)cand;
+                wave_fence();
+                const int ncommit = (m < 64) ? m + 1 : lim;
+                if (lane < ncommit) table[h] = (T)pos;
+                wave_fence();
+                if (m < 64) {
+                    m_pos = lane_get(pos, m); m_cand = lane_get(cand, m);
+                    found = true;
+                    break;
+                }
+                if (e <= f) break;                        // ran past mflimitPlusOne: last literals
+                i0 += (uint32_t)lim;
+            }
+            if (!found) break;
+
+            // ---------------- catch up (lz4.c:1611-1623) ----------------
+            uint32_t back = 0;
+            {
+                const uint32_t a = m_pos - anchor;
+                const uint32_t maxback = a < m_cand ? a : m_cand;
+                while (back < maxback) {
+                    const uint32_t k = back + (uint32_t)lane;
+                    bool eq = false;
+                    if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
+                    const int c = first_lane(ballot(!eq));
+                    back += (uint32_t)c;
+                    if (c < 64) break;
+                }
+            }
+            // ---------------- forward extension: LZ4_count (lz4.c:656-679) ----------------
+            uint32_t fwd = 0;
+            {
+                const uint32_t a = m_pos + kMinMatch, b = m_cand + kMinMatch;
+                for (;;) {
+                    const uint32_t o = fwd + 4u * (uint32_t)lane;
+                    const uint32_t pa = a + o;
+                    uint32_t x = 0xFFFFFFFFu;
+                    if (pa < matchlimit) {
+                        x = ld32(src + pa) ^ ld32(src + b + o);
+                        const uint32_t avail = matchlimit - pa;
+                        if (avail < 4) x |= 0xFFFFFFFFu << (8 * avail);
+                    }
+                    const int l = first_lane(ballot(x != 0));
+                    if (l == 64) { fwd += 256; continue; }
+                    fwd += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+                    break;
+                }
+            }
+            // ---------------- emit sequence (lz4.c:1626-1740) ----------------
+            const uint32_t mstart = m_pos - back;
+            const uint32_t lit = mstart - anchor;
+            const uint32_t mcode = back + fwd;
+            const uint32_t token_pos = op++;
+            if (limited && (uint64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
+            if (lit >= 15) op += put_len_bytes(dst + op, lit - 15, lane);
+            wave_copy(dst + op, src + anchor, lit, lane);
+            op += lit;
+            if (lane == 0) st16(dst + op, m_pos - m_cand);
+            op += 2;
+            if (limited && (uint64_t)op + (1 + kLastLiterals) + (mcode + 240) / 255 > cap) return 0;
+            if (mcode >= 15) op += put_len_bytes(dst + op, mcode - 15, lane);
+            if (lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
+            ip = mstart + kMinMatch + mcode;
+            anchor = ip;
+            if (ip >= mfl1) break;                        // lz4.c:1747
+            extra = true;
+        }
+    }
+    // ---------------- last literals (lz4.c:1808-1834) ----------------
+    {
+        const uint32_t lastRun = n - anchor;
+        if (limited && (uint64_t)op + lastRun + 1 + (lastRun + 255 - 15) / 255 > cap) return 0;
+        if (lane == 0) dst[op] = (uint8_t)((lastRun < 15 ? lastRun : 15) << 4);
+        op++;
+        if (lastRun >= 15) op += put_len_bytes(dst + op, lastRun - 15, lane);
+        wave_copy(dst + op, src + anchor, lastRun, lane);
+        op += lastRun;
+    }
+    return (int)op;
+}
+
+// Safe decoder: accepts exactly the streams the reference's safe loop accepts (lz4.c:3563-3790).
+__device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_t n, uint8_t* dst, const int32_t cap)
+{
+    const int lane = lane_id();
+    if (cap == 0) return (n == 1 && src[0] == 0) ? 0 : -1;   // lz4.c:3412-3416
+    if (n <= 0) return -1;                                    // lz4.c:3418
+    const int32_t iend = n, oend = cap;
+    int32_t ip = 0, op = 0;
+    for (;;) {
+        const uint32_t token = uni(src[ip]);
+        ip++;
+        int64_t len = token >> 4;
+        if (len == 15) {                                      // read_variable_length (lz4.c:3331-3352)
+            if (ip >= iend - 15) return -ip - 1;
+            uint32_t s;
+            do {
+                s = uni(src[ip]); ip++; len += s;
+                if (ip >= iend - 15) break;
+            } while (s == 255);
+        }
+        if (op + len > (int64_t)oend - (int64_t)kMfLimit || ip + len > (int64_t)iend - (2 + 1 + (int64_t)kLastLiterals)) {
+            if (ip + len != iend || op + len > oend) return -ip - 1;        // lz4.c:3654-3664
+            wave_copy(dst + op, src + ip, (uint32_t)len, lane);
+            op += (int32_t)len;
+            break;
+        }
+        wave_copy(dst + op, src + ip, (uint32_t)len, lane);
+        ip += (int32_t)len; op += (int32_t)len;
+        const uint32_t offset = uni(ld16(src + ip));
+        ip += 2;
+        int64_t ml = token & 15;
+        if (ml == 15) {
+            uint32_t s;
+            do {
+                s = uni(src[ip]); ip++; ml += s;
+                if (ip >= iend - (int32_t)kLastLiterals + 1) return -ip - 1;
+            } while (s == 255);
+        }
+        ml += kMinMatch;
+        if ((int64_t)offset > op) return -ip - 1;                               // offset outside the block
+        if (op + ml > (int64_t)oend - (int64_t)kLastLiterals) return -ip - 1;   // last 5 bytes are literals
+        // match copy; every source byte lies before `op`, so (i mod offset) never reads a byte this
+        // sequence has not produced yet within one 64-lane round
+        wave_fence();
+        uint8_t* d = dst + op;
+        const uint32_t mlen = (uint32_t)ml;
+        if (offset == 0) {                                    // lz4.c:3745-3753: run of zeros
+            for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) d[i] = 0;
+        } else if (offset >= kWave) {
+            const uint8_t* s = d - offset;
+            for (uint32_t r = 0; r < mlen; r += kWave) {
+                const uint32_t i = r + (uint32_t)lane;
+                uint8_t v = 0;
+                if (i < mlen) v = s[i];
+                if (i < mlen) d[i] = v;
+                wave_fence();
+            }
+        } else {
+            const uint8_t* s = d - offset;
+            uint32_t k = (uint32_t)lane % offset;
+            const uint32_t adv = kWave % offset;
+            for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) {
+                d[i] = s[k];
+                k += adv; if (k >= offset) k -= offset;
+            }
+        }
+        wave_fence();
+        op += (int32_t)mlen;
+    }
+    return op;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kTableBytes];
+    const uint32_t c = blockIdx.x;
+    if (c >= b.nchunks) return;
+    const ChunkView v = compress_view(b, c);
+    int r;
+    if (v.src_len > kMaxInput) r = 0;                                       // lz4.c:2417
+    else if (v.src_len == 0) {                                              // lz4.c:2418-2429
+        r = 0;
+        if (v.dst_cap >= 1) { if (threadIdx.x == 0) v.dst[0] = 0; r = 1; }
+    }
+    else if (v.src_len < k64KLimit) r = lz4_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, lds);
+    else r = lz4_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, lds);
+    if (threadIdx.x == 0) b.out_len[c] = r;
+}
+
+__global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= b.nchunks) return;
+    const ChunkView v = decompress_view(b, c);
+    int r;
+    if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
+    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap);
+    if (threadIdx.x == 0) b.out_len[c] = r;
+}
+
+}  // namespace aoclgpu
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI launchers (include/aocl_gpu_codec.h)
+// ------------------------------------------------------------------------------------------------
+#include "host_util.h"
+
+extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
+{
+    if (int rc = aoclgpu::check_batch(b, /*decompress=*/false)) return rc;
+    if (b->nchunks == 0) return AOCLGPU_OK;
+    hipLaunchKernelGGL(aoclgpu::lz4_compress_kernel, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
+    return aoclgpu::check_launch("lz4_compress_kernel");
+}
+
+extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream)
+{
+    if (int rc = aoclgpu::check_batch(b, /*decompress=*/true)) return rc;
+    if (b->nchunks == 0) return AOCLGPU_OK;
+    hipLaunchKernelGGL(aoclgpu::lz4_decompress_kernel, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
+    return aoclgpu::check_launch("lz4_decompress_kernel");
+}

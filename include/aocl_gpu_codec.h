@@ -1,0 +1,104 @@
+/* include/aocl_gpu_codec.h -- C-ABI of the MI355X block-codec engine (libaocl_compression_gpu.so).
+ *
+ * Device-side batch entry points: every pointer below is a DEVICE pointer (HBM) unless the name
+ * says `host`; sizes are plain integers; `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  No torch / C++ types cross this boundary.
+ *
+ * One CHUNK is one independent block in the reference's sense: it is compressed exactly as the
+ * reference compresses one buffer with the codec's one-shot native API, and chunk i of a batch is
+ * handled by one 64-lane wavefront with its hash table in LDS.  This is the GPU counterpart of one
+ * RAP partition of the reference's OpenMP path (threads/threads.c:121-153, lz4.c:2684-2731,
+ * snappy.cc:2533-2562, zstd_compress.c:5443-5489).
+ *
+ * What each entry point replaces in the reference:
+ *   aoclgpu_lz4_compress_chunks      LZ4_compress_default            algos/lz4/lz4.c:2967-2975
+ *                                    (-> AOCL_LZ4_compress_generic_validated :1371-1845)
+ *   aoclgpu_lz4_decompress_chunks    LZ4_decompress_safe             algos/lz4/lz4.c:4898-4923
+ *                                    (-> AOCL_LZ4_decompress_generic :3367-3803)
+ *   aoclgpu_snappy_compress_chunks   snappy::RawCompress             algos/snappy/snappy.cc:2494-2666
+ *                                    (-> AOCL_CompressFragment :846-1046)
+ *   aoclgpu_snappy_decompress_chunks snappy::RawUncompress           algos/snappy/snappy.cc:2271-2390
+ *   aoclgpu_zstd_compress_chunks     ZSTD_compress(level 1)          algos/zstd/lib/compress/zstd_compress.c:5388
+ *                                    (-> zstd_fast.c:427-706 + entropy stage zstd_compress.c:2910-3064)
+ *   aoclgpu_zstd_decompress_chunks   ZSTD_decompress                 algos/zstd/lib/decompress/zstd_decompress.c:1252
+ * Output bytes are identical to those functions' output on the same chunk.
+ */
+#ifndef AOCL_GPU_CODEC_H
+#define AOCL_GPU_CODEC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Return codes of the batch launchers (per-chunk results are reported in out_len[]). */
+#define AOCLGPU_OK            0
+#define AOCLGPU_ERR_ARG      -1   /* NULL / inconsistent arguments */
+#define AOCLGPU_ERR_HIP      -2   /* a HIP runtime call failed (see aoclgpu_last_error) */
+#define AOCLGPU_ERR_NO_DEVICE -3  /* no gfx950 device visible */
+
+typedef enum { AOCLGPU_LZ4 = 0, AOCLGPU_SNAPPY = 1, AOCLGPU_ZSTD = 2 } aoclgpu_codec;
+
+/* A batch of chunks.  Two addressing modes:
+ *  - explicit : src_off/src_len/dst_off/dst_cap are device arrays of nchunks entries;
+ *  - uniform  : src_off == NULL; chunk i covers src[i*chunk_bytes, min(total_bytes,(i+1)*chunk_bytes))
+ *               and owns the output slot dst[i*slot_bytes, (i+1)*slot_bytes).
+ * out_len[i] (device, int32): compress  -> compressed size, 0 if the chunk does not fit dst_cap
+ *                                          (same contract as LZ4_compress_default / api/codec.cpp:126-134);
+ *                             decompress-> decoded size, or a negative value for a malformed chunk. */
+typedef struct {
+    const uint8_t*  src;
+    uint8_t*        dst;
+    const uint64_t* src_off;   /* NULL => uniform mode */
+    const uint32_t* src_len;
+    const uint64_t* dst_off;
+    const uint32_t* dst_cap;
+    int32_t*        out_len;
+    uint32_t        nchunks;
+    uint32_t        reserved;
+    uint64_t        total_bytes;  /* uniform mode */
+    uint64_t        chunk_bytes;  /* uniform mode */
+    uint64_t        slot_bytes;   /* uniform mode */
+} aoclgpu_batch;
+
+/* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
+ * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at
+ * i*chunk_bytes and may hold up to min(chunk_bytes, total_bytes - i*chunk_bytes) bytes. */
+
+int aoclgpu_device_count(void);
+int aoclgpu_init(int device);                 /* selects the device, checks it is gfx950 */
+const char* aoclgpu_last_error(void);
+const char* aoclgpu_version(void);
+
+/* worst-case compressed size of an n-byte chunk (lz4.h:261, snappy.cc:160-182, zstd.h:473) */
+size_t aoclgpu_compress_bound(aoclgpu_codec codec, size_t n);
+
+int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream);
+int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream);
+int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stream);
+int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
+int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
+int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
+
+/* Compaction: gather the used prefix of every slot into one contiguous stream (the serial memcpy join
+ * of the reference's MT path, lz4.c:2736-2906 / snappy.cc:2567-2654 / zstd_compress.c:5499-5517).
+ * out_off[i] (device, uint64, nchunks+1 entries) receives the exclusive prefix sum of out_len. */
+int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, const int32_t* out_len, uint32_t nchunks,
+                          uint8_t* packed, uint64_t* out_off, void* stream);
+
+/* Timing helper used by bench.py: runs `iters` back-to-back launches of one batch op on `stream`
+ * bracketed by HIP events recorded on that same stream; returns the average milliseconds per launch
+ * (negative on error).  op: 0 = compress, 1 = decompress. */
+double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, int iters, void* stream);
+
+/* Host-buffer convenience (H2D, one launch of ONE chunk, D2H).  Return value = the per-chunk result of the
+ * native one-shot API (compress: size, 0 = does not fit; decompress: size, small negative = malformed),
+ * or a value <= AOCLGPU_HOST_FAIL/2 when the GPU path itself failed (AOCLGPU_HOST_FAIL + AOCLGPU_ERR_*). */
+#define AOCLGPU_HOST_FAIL (-(1LL << 40))
+int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
+int64_t aoclgpu_decompress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

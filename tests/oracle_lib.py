@@ -1,0 +1,132 @@
+"""ctypes access to the CPU checkers: oracle/liboracle.so (this repo's C restatement) and, when present,
+oracle/_ref/libaocl_ref.so (the real reference compiled in place).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libaocl_ref.so")
+
+LZ4, SNAPPY, ZSTD = 0, 1, 2
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    return ORACLE_SO
+
+
+def bound(codec, n):
+    if codec == LZ4:
+        return n + n // 255 + 16
+    if codec == SNAPPY:
+        return 32 + n + n // 6
+    return n + (n >> 8) + (((128 << 10) - n) >> 11 if n < (128 << 10) else 0)
+
+
+class Oracle:
+    def __init__(self):
+        build_oracle()
+        L = self.L = C.CDLL(ORACLE_SO)
+        def sig(name, restype, argtypes=None):
+            f = getattr(L, name, None)
+            if f is None:       # codec restatement not built yet
+                return
+            f.restype = restype
+            if argtypes is not None:
+                f.argtypes = argtypes
+        sig("orc_lz4_compress", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int])
+        sig("orc_lz4_decompress", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int])
+        sig("orc_snappy_compress", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p])
+        sig("orc_snappy_max_compressed_length", C.c_size_t, [C.c_size_t])
+        sig("orc_snappy_uncompress", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
+        sig("orc_snappy_uncompressed_length", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)])
+        sig("orc_zstd_compress_bound", C.c_size_t, [C.c_size_t])
+        sig("orc_zstd_compress", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
+        sig("orc_zstd_decompress", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
+        sig("orc_compress_chunks", C.c_int,
+            [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int])
+        sig("orc_decompress_chunks", C.c_int,
+            [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int])
+
+    def compress(self, codec, data: bytes, cap=None):
+        """bytes or None (failure)"""
+        n = len(data)
+        cap = bound(codec, n) if cap is None else cap
+        out = C.create_string_buffer(max(cap, 1))
+        if codec == LZ4:
+            r = self.L.orc_lz4_compress(data, n, out, cap)
+        elif codec == SNAPPY:
+            assert cap >= bound(SNAPPY, n)
+            r = self.L.orc_snappy_compress(data, n, out)
+        else:
+            r = self.L.orc_zstd_compress(data, n, out, cap)
+        return out.raw[:r] if r > 0 else None
+
+    def decompress(self, codec, data: bytes, cap: int):
+        out = C.create_string_buffer(max(cap, 1))
+        if codec == LZ4:
+            r = self.L.orc_lz4_decompress(data, len(data), out, cap)
+            return out.raw[:r] if r >= 0 else None
+        if codec == SNAPPY:
+            ok = self.L.orc_snappy_uncompress(data, len(data), out, cap)
+            if not ok:
+                return None
+            ln = C.c_size_t(0)
+            self.L.orc_snappy_uncompressed_length(data, len(data), C.byref(ln))
+            return out.raw[:ln.value]
+        r = self.L.orc_zstd_decompress(data, len(data), out, cap)
+        return None if r == C.c_size_t(-1).value else out.raw[:r]
+
+
+class Ref:
+    """The real reference (native one-shot APIs + aocl_llc_*)."""
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            if os.path.exists("/root/reference/api/api.cpp"):
+                subprocess.run(["bash", os.path.join(ORACLE_DIR, "build_ref.sh")], check=True)
+            else:
+                raise FileNotFoundError(REF_SO)
+        L = self.L = C.CDLL(REF_SO)
+        L.ZSTD_compress.restype = C.c_size_t
+        L.ZSTD_decompress.restype = C.c_size_t
+        L.ZSTD_isError.restype = C.c_uint
+        L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ZSTD_isError.argtypes = [C.c_size_t]
+        L.snappy_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.snappy_uncompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+
+    def compress(self, codec, data: bytes, cap=None):
+        n = len(data)
+        cap = bound(codec, n) if cap is None else cap
+        out = C.create_string_buffer(max(cap, 1))
+        if codec == LZ4:
+            r = self.L.LZ4_compress_default(data, out, n, cap)
+            return out.raw[:r] if r > 0 else None
+        if codec == SNAPPY:
+            ln = C.c_size_t(cap)
+            st = self.L.snappy_compress(data, n, out, C.byref(ln))
+            return out.raw[:ln.value] if st == 0 else None
+        r = self.L.ZSTD_compress(out, cap, data, n, 1)
+        return None if self.L.ZSTD_isError(r) else out.raw[:r]
+
+    def decompress(self, codec, data: bytes, cap: int):
+        out = C.create_string_buffer(max(cap, 1))
+        if codec == LZ4:
+            r = self.L.LZ4_decompress_safe(data, out, len(data), cap)
+            return out.raw[:r] if r >= 0 else None
+        if codec == SNAPPY:
+            ln = C.c_size_t(cap)
+            st = self.L.snappy_uncompress(data, len(data), out, C.byref(ln))
+            return out.raw[:ln.value] if st == 0 else None
+        r = self.L.ZSTD_decompress(out, cap, data, len(data))
+        return None if self.L.ZSTD_isError(r) else out.raw[:r]
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO) or os.path.exists("/root/reference/api/api.cpp")

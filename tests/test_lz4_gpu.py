@@ -1,0 +1,177 @@
+"""GPU parity: HIP LZ4 kernels (through the C-ABI) vs the CPU oracle -- bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import aocl_compression_amd as a
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+KNOWN = [  # (input, reference output) -- from the compiled reference
+    (b"", "00"), (b"a" * 13, "13610100506161616161"), (b"a" * 100, "1f6101004b506161616161"),
+    (b"abcd" * 8, "4f61626364040004506461626364"), (b"hello world!", "c068656c6c6f20776f726c6421"),
+]
+
+
+def _chunks(raw, chunk):
+    return [raw[i:i + chunk] for i in range(0, max(len(raw), 1), chunk)]
+
+
+def _compress_and_check(eng, oracle, data: np.ndarray, chunk: int):
+    src = torch.from_numpy(data).to(eng.device)
+    slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
+    lens = out_len.cpu().tolist()
+    host = slots.cpu().numpy()
+    raw = data.tobytes()
+    parts = _chunks(raw, chunk)
+    assert len(lens) == len(parts)
+    for i, part in enumerate(parts):
+        want = oracle.compress(ol.LZ4, part)
+        got = host[i * slot:i * slot + lens[i]].tobytes()
+        assert lens[i] == len(want), (i, lens[i], len(want))
+        assert got == want, f"chunk {i} differs"
+    return src, slots, out_len, slot
+
+
+def test_known_answers(eng):
+    for inp, hexout in KNOWN:
+        assert eng.compress_host(a.LZ4, inp).hex() == hexout
+        assert eng.decompress_host(a.LZ4, bytes.fromhex(hexout), len(inp)) == inp
+
+
+@pytest.mark.parametrize("kind", list(a.corpus.KINDS))
+@pytest.mark.parametrize("chunk", [65536, 262144])
+def test_compress_bit_exact(eng, oracle, kind, chunk):
+    data = a.corpus.make(kind, (2 << 20) + 777, seed=11)
+    src, slots, out_len, slot = _compress_and_check(eng, oracle, data, chunk)
+    dst, dl = eng.decompress_chunks(a.LZ4, slots, out_len, slot, len(data), chunk)
+    assert torch.equal(dst, src)
+    exp = [len(c) for c in _chunks(data.tobytes(), chunk)]
+    assert dl.cpu().tolist() == exp
+
+
+@pytest.mark.parametrize("size", [1, 5, 12, 13, 14, 63, 64, 65, 4096, 65535, 65546, 65547, 65548, 100001, 1 << 20])
+def test_ragged_sizes(eng, oracle, size):
+    data = a.corpus.make("text", size, seed=size)
+    raw = data.tobytes()
+    got = eng.compress_host(a.LZ4, raw)
+    assert got == oracle.compress(ol.LZ4, raw)
+    assert eng.decompress_host(a.LZ4, got, size) == raw
+
+
+def test_special_inputs(eng, oracle):
+    rng = np.random.default_rng(5)
+    cases = [
+        bytes(300000), b"\xff" * 70000, bytes(range(256)) * 1200, b"ab" * 50000, b"abc" * 40000,
+        rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(),
+        rng.integers(0, 2, 300000, dtype=np.uint8).tobytes(),
+        (b"x" * 100 + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()) * 40,
+    ]
+    for raw in cases:
+        got = eng.compress_host(a.LZ4, raw)
+        assert got == oracle.compress(ol.LZ4, raw)
+        assert eng.decompress_host(a.LZ4, got, len(raw)) == raw
+
+
+def test_limited_output(eng, oracle):
+    raw = a.corpus.make("jsonlog", 65536, seed=3).tobytes()
+    full = oracle.compress(ol.LZ4, raw)
+    for cap in [len(full) + 20, len(full) + 1, len(full), len(full) - 1, len(full) // 2, 16, 1, 0]:
+        want = oracle.compress(ol.LZ4, raw, cap)
+        got = eng.compress_host(a.LZ4, raw, cap)
+        assert got == want, cap
+
+
+def test_decode_foreign_and_malformed(eng, oracle):
+    rng = np.random.default_rng(9)
+    raw = a.corpus.make("binary", 200000, seed=4).tobytes()
+    comp = oracle.compress(ol.LZ4, raw)
+    assert eng.decompress_host(a.LZ4, comp, len(raw)) == raw
+    assert eng.decompress_host(a.LZ4, comp, len(raw) - 1) is None      # output too small
+    assert eng.decompress_host(a.LZ4, comp[:-3], len(raw)) is None     # truncated
+    assert eng.decompress_host(a.LZ4, b"\x10\x61\x05\x00", 64) is None  # offset before start of block
+    n_checked = 0
+    for it in range(200):
+        c = bytearray(comp[:4000] if it % 2 else comp)
+        for _ in range(1 + it % 3):
+            c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
+        want = oracle.decompress(ol.LZ4, bytes(c), len(raw))
+        got = eng.decompress_host(a.LZ4, bytes(c), len(raw))
+        assert got == want
+        n_checked += 1
+    assert n_checked == 200
+
+
+def test_explicit_batch_ragged(eng, oracle):
+    """Explicit (offset/length array) addressing with empty and ragged chunks."""
+    import ctypes as C
+    data = a.corpus.make("text", 500000, seed=21)
+    raw = data.tobytes()
+    lens = [0, 1, 13, 70000, 0, 262144, 65547, 12, 100000]
+    offs = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    caps = [a.compress_bound(a.LZ4, n) for n in lens]
+    doffs = np.cumsum([0] + caps[:-1]).astype(np.uint64)
+    t = torch
+    dev = eng.device
+    src = t.from_numpy(data).to(dev)
+    dst = t.zeros(int(sum(caps)), dtype=t.uint8, device=dev)
+    out_len = t.zeros(len(lens), dtype=t.int32, device=dev)
+    d_so = t.from_numpy(offs.view(np.int64)).to(dev)
+    d_sl = t.tensor(lens, dtype=t.int32, device=dev)
+    d_do = t.from_numpy(doffs.view(np.int64)).to(dev)
+    d_dc = t.tensor(caps, dtype=t.int32, device=dev)
+    b = a.Batch(src=src.data_ptr(), dst=dst.data_ptr(), src_off=d_so.data_ptr(), src_len=d_sl.data_ptr(),
+                dst_off=d_do.data_ptr(), dst_cap=d_dc.data_ptr(), out_len=out_len.data_ptr(), nchunks=len(lens))
+    rc = eng.lib.aoclgpu_lz4_compress_chunks(C.byref(b), None)
+    assert rc == 0
+    t.cuda.synchronize()
+    got_len = out_len.cpu().tolist()
+    host = dst.cpu().numpy()
+    for i, n in enumerate(lens):
+        want = oracle.compress(ol.LZ4, raw[int(offs[i]):int(offs[i]) + n])
+        assert host[int(doffs[i]):int(doffs[i]) + got_len[i]].tobytes() == want, i
+
+
+def test_compaction(eng):
+    data = a.corpus.make("jsonlog", 3 << 20, seed=2)
+    src = torch.from_numpy(data).to(eng.device)
+    slots, out_len, slot = eng.compress_chunks(a.LZ4, src, 262144)
+    packed, off = eng.compact(slots, slot, out_len)
+    lens = out_len.cpu().tolist()
+    offs = off.cpu().tolist()
+    assert offs[0] == 0 and offs[-1] == sum(lens) == packed.numel()
+    hs, hp = slots.cpu().numpy(), packed.cpu().numpy()
+    for i, ln in enumerate(lens):
+        assert offs[i + 1] - offs[i] == ln
+        assert np.array_equal(hp[offs[i]:offs[i] + ln], hs[i * slot:i * slot + ln])
+
+
+def test_llc_api(eng, oracle):
+    """aocl_llc_compress/decompress on host buffers keep the reference's contract (api/api.cpp:45-124)."""
+    raw = a.corpus.make("text", 65536, seed=1).tobytes()      # BASELINE config 1
+    r, out, d = eng.llc_compress(a.LZ4, raw, a.compress_bound(a.LZ4, len(raw)), stats=True)
+    assert r == len(out) and out == oracle.compress(ol.LZ4, raw)
+    assert d.cSize == r and d.cTime > 0 and d.cSpeed > 0
+    r2, back, d2 = eng.llc_decompress(a.LZ4, out, len(raw), stats=True)
+    assert r2 == len(raw) and back == raw and d2.dSize == len(raw)
+    assert eng.llc_compress(a.LZ4, raw, 100)[0] == -2          # ERR_COMPRESSION_FAILED
+    assert eng.llc_decompress(a.LZ4, out[:100], len(raw))[0] == -2
+    assert eng.llc_compress(a.LZ4, b"", 16)[0] == 1            # api_gtest.cpp:638-673: inSize 0 -> 1
+
+
+def test_full_size_round_trip(eng):
+    """BASELINE config 2 size: 8 GiB of 256 KiB chunks -- round trip + per-chunk size sanity on device."""
+    base = torch.from_numpy(a.corpus.silesia_mix(48 << 20, seed=0xA0C1)).to(eng.device)
+    total = 8 << 30
+    reps = -(-total // base.numel())
+    src = base.repeat(reps)[:total].contiguous()
+    chunk = 262144
+    slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
+    assert int((out_len <= 0).sum().item()) == 0
+    dst, dl = eng.decompress_chunks(a.LZ4, slots, out_len, slot, total, chunk)
+    assert int((dl != chunk).sum().item()) == 0
+    assert torch.equal(dst, src)
+    # identical chunks (the base repeats every 48 MiB = 192 chunks) must compress identically
+    per = (48 << 20) // chunk
+    assert torch.equal(out_len[:per], out_len[per:2 * per])
