@@ -124,7 +124,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
                     found = true;
                     break;
                 }
-                if (e <= f) break;                        // ran past mflimitPlusOne: last literals
+                if (e < 64 && e <= f) break;              // ran past mflimitPlusOne: last literals
                 i0 += (uint32_t)lim;
             }
             if (!found) break;

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X block-codec engine.
+
+Metric (BASELINE.json): GiB/s compress + decompress on a Silesia-shaped mix, 1/2/4/8 GPUs.
+Workload at N=1 = BASELINE config[1]: LZ4 level 1, 256 KiB independent chunks, the (synthetic) Silesia
+corpus concatenated to 8 GiB, inputs resident in HBM before the timed region starts.
+
+One STEP = one pass of the hot path over the rank's shard:
+    compress every chunk -> [N>1: compact + RCCL all-gather of the compressed segments] -> decompress.
+`value` = uncompressed GiB that went through that compress+decompress round trip per second, summed
+over ranks (weak scaling: every rank owns `--gib` GiB), using the max-over-ranks time of K steps.
+The per-direction rates are reported next to it (compress_GiBps / decompress_GiBps).
+
+Extra objects on the JSON line: `roofline` (dominant kernel vs the 8 TB/s HBM peak; live HIP-event
+timing of that kernel on its own stream) and `cpu_baseline` (the real reference's LZ4_compress_default /
+LZ4_decompress_safe -- oracle/_ref -- or, if that prebuilt library is absent, this repo's C port, timed
+on the host cores over a bounded sample of the same chunks; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GIB = float(1 << 30)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SILESIA_BYTES = 211_938_580     # size of the real Silesia corpus; the synthetic base matches it
+CODECS = {"lz4": (0, 262144), "snappy": (1, 65536), "zstd": (2, 131072)}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--codec", default="lz4", choices=list(CODECS))
+    p.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
+    p.add_argument("--chunk", type=int, default=0, help="chunk bytes (default: the codec's BASELINE chunk)")
+    p.add_argument("--base-mib", type=float, default=SILESIA_BYTES / (1 << 20), help="size of the synthetic base corpus")
+    p.add_argument("--cpu-sample-gib", type=float, default=2.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib):
+    """Time the reference CPU path over the first `sample_gib` GiB of the same chunk stream."""
+    import numpy as np
+    import oracle_lib as ol
+    if codec_name != "lz4":
+        return None
+    orc = ol.Oracle()
+    kind, fc, fd = "port", None, None
+    if os.path.exists(ol.REF_SO):
+        ref = C.CDLL(ol.REF_SO)
+        fc = C.cast(ref.LZ4_compress_default, C.c_void_p)
+        fd = C.cast(ref.LZ4_decompress_safe, C.c_void_p)
+        kind = "reference"
+    n = int(min(total, sample_gib * GIB)) // chunk * chunk
+    reps = -(-n // len(base_np))
+    sample = np.ascontiguousarray(np.tile(base_np, reps)[:n])
+    nchunks = n // chunk
+    dst = np.empty(nchunks * slot, np.uint8)
+    out_len = np.zeros(nchunks, np.int32)
+    back = np.empty(n, np.uint8)
+    cores = os.cpu_count() or 1
+    L = orc.L
+    L.orc_lz4_compress_chunks_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_int]
+    L.orc_lz4_decompress_chunks_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                               C.c_size_t, C.c_size_t, C.c_int]
+    t0 = time.perf_counter()
+    fails = L.orc_lz4_compress_chunks_fn(fc, sample.ctypes.data, n, chunk, dst.ctypes.data, slot, out_len.ctypes.data, cores)
+    t1 = time.perf_counter()
+    fails += L.orc_lz4_decompress_chunks_fn(fd, dst.ctypes.data, slot, out_len.ctypes.data, nchunks, back.ctypes.data,
+                                            chunk, n, cores)
+    t2 = time.perf_counter()
+    assert fails == 0 and np.array_equal(back, sample)
+    tc, td = t1 - t0, t2 - t1
+    return {
+        "value": round(n / GIB / (tc + td), 3), "unit": "GiB/s", "cores": cores, "kind": kind,
+        "compress_GiBps": round(n / GIB / tc, 3), "decompress_GiBps": round(n / GIB / td, 3),
+        "sample": f"first {n / GIB:.2f} GiB of the same {chunk // 1024} KiB chunk stream, "
+                  f"LZ4_compress_default + LZ4_decompress_safe, OpenMP over chunks on {cores} host threads",
+    }, out_len
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import aocl_compression_amd as a
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    eng = a.Engine(local)
+    dev = eng.device
+    codec, def_chunk = CODECS[args.codec]
+    chunk = args.chunk or def_chunk
+    total = int(args.gib * GIB) // chunk * chunk
+    nchunks = total // chunk
+    slot = (a.compress_bound(codec, chunk) + 15) & ~15
+
+    # ---- synthetic "Silesia concatenated to N GiB", resident in HBM; every rank gets a different rotation ----
+    base_np = a.corpus.silesia_mix(int(args.base_mib * (1 << 20)), seed=0xA0C1)
+    base = torch.from_numpy(base_np).to(dev)
+    shift = (rank * 7919 * 4096) % base.numel()
+    if shift:
+        base = torch.roll(base, -shift)
+    reps = -(-total // base.numel())
+    src = base.repeat(reps)[:total].contiguous()
+    del base
+    slots = torch.empty(nchunks * slot, dtype=torch.uint8, device=dev)
+    clen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+    dst = torch.empty(total, dtype=torch.uint8, device=dev)
+    dlen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+    cb = eng.uniform_compress_batch(src, chunk, slots, clen, slot)
+    db = eng.uniform_decompress_batch(slots, clen, slot, dst, chunk, dlen)
+
+    gather_buf = None
+    if world > 1:
+        # compressed segment per rank, padded to a common size for ncclAllGather (RCCL has no allgatherv).
+        # Sizes are deterministic, so one untimed compress pass fixes the padded segment size.
+        eng.time_batch(codec, 0, cb, 1)
+        mx = clen.sum().to(torch.int64).reshape(1)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        seg_cap = (int(mx.item()) + (1 << 20)) & ~0xFFFFF
+        packed = torch.empty(seg_cap, dtype=torch.uint8, device=dev)
+        off = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
+        gather_buf = torch.empty(world * seg_cap, dtype=torch.uint8, device=dev)
+        len_all = torch.zeros(world * nchunks, dtype=torch.int32, device=dev)
+
+    kt = {"c": [], "d": []}
+
+    def step(record):
+        tc = eng.time_batch(codec, 0, cb, 1)          # HIP events around the compress kernel, same stream
+        if world > 1:
+            rc = eng.lib.aoclgpu_compact_slots(slots.data_ptr(), slot, clen.data_ptr(), nchunks, packed.data_ptr(),
+                                               off.data_ptr(), eng._stream())
+            assert rc == 0
+            dist.all_gather_into_tensor(len_all, clen)
+            dist.all_gather_into_tensor(gather_buf, packed)
+        td = eng.time_batch(codec, 1, db, 1)
+        if record:
+            kt["c"].append(tc)
+            kt["d"].append(td)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- checks outside the timed region ----
+    comp_bytes = int(clen.sum().item())
+    if not args.no_verify:
+        assert int((clen <= 0).sum().item()) == 0, "a chunk failed to compress"
+        assert int((dlen != chunk).sum().item()) == 0, "a chunk failed to decompress"
+        assert torch.equal(dst, src), "round trip mismatch"
+
+    ms_c = sum(kt["c"]) / len(kt["c"])
+    ms_d = sum(kt["d"]) / len(kt["d"])
+    if world > 1:
+        agg = torch.tensor([ms_c, ms_d, float(comp_bytes)], dtype=torch.float64, device=dev)
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        ms_c, ms_d = float(mx[0]), float(mx[1])
+        comp_total = float(agg[2])
+    else:
+        comp_total = float(comp_bytes)
+
+    if rank == 0:
+        unc_total = float(total) * world
+        ms_step = elapsed / args.steps * 1e3
+        value = unc_total / GIB / (elapsed / args.steps)
+        # dominant kernel = the slower of the two launches; algorithmic bytes per launch = N + C
+        dom = "compress" if ms_c >= ms_d else "decompress"
+        alg_bytes = float(total) + float(comp_bytes)
+        ach = alg_bytes / ((ms_c if dom == "compress" else ms_d) * 1e-3) / 1e9
+        out = {
+            "metric": "GiB/s compress + decompress (Silesia mix), ratio parity",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": f"{args.codec} level-1, {chunk // 1024} KiB independent chunks, synthetic Silesia-shaped "
+                            f"corpus ({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
+                "codec": args.codec, "chunk_bytes": chunk, "chunks_per_gpu": nchunks, "gib_per_gpu": args.gib,
+                "step": "compress" + (" -> compact -> RCCL all-gather of compressed segments" if world > 1 else "")
+                        + " -> decompress",
+                "parallelism": f"chunks sharded over {world} GPU(s), one wavefront per chunk",
+            },
+            "compress_GiBps": round(unc_total / GIB / (ms_c * 1e-3), 3),
+            "decompress_GiBps": round(unc_total / GIB / (ms_d * 1e-3), 3),
+            "ratio": round(unc_total / comp_total, 4),
+            "roofline": {
+                "bound": "hbm", "kernel": f"{args.codec}_{dom}_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_c if dom == "compress" else ms_d, 4),
+                "other_kernel_ms": round(ms_d if dom == "compress" else ms_c, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res = cpu_baseline(args.codec, base_np, total, chunk, slot, args.cpu_sample_gib)
+                if res:
+                    cpu, cpu_len = res
+                    # ratio parity on the sample: GPU sizes == reference sizes, chunk by chunk
+                    import numpy as np
+                    gl = clen[:len(cpu_len)].cpu().numpy()
+                    cpu["sizes_identical_to_gpu"] = bool(np.array_equal(gl, cpu_len))
+                    out["cpu_baseline"] = cpu
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
