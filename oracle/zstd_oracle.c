@@ -1,1 +1,802 @@
+/* oracle/zstd_oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * CPU restatement of the reference's Zstandard level-1 one-shot path for inputs of at most 128 KiB
+ * (= one block per frame, the GPU engine's chunk contract):
+ *
+ *   ZSTD_compress(dst,cap,src,n,1) (algos/zstd/lib/compress/zstd_compress.c:5534-5560)
+ *     parameters   ZSTD_getCParams_internal :7295-7331 + clevels.h:76-108 + ZSTD_adjustCParams_internal :1539-1633
+ *     frame        ZSTD_writeFrameHeader :4586-4632, ZSTD_compress_frameChunk :4504-4583, ZSTD_writeEpilogue
+ *     block        ZSTD_compressBlock_internal :4333-4395, ZSTD_buildSeqStore :3259-3418
+ *     match finder AOCL_ZSTD_compressBlock_fast_noDict_generic  zstd_fast.c:427-706  (mls 5 or 6, step 2)
+ *     entropy      ZSTD_entropyCompressSeqStore(_internal) zstd_compress.c:2910-3064
+ *                  literals  zstd_compress_literals.c:39-235, huf_compress.c (sort :624, tree :685,
+ *                            setMaxHeight :378, CTable :735, writeCTable :256-295, weights :173-213,
+ *                            1X/4X streams :1051-1211, HUF_compress_internal :1326-1434), hist.c
+ *                  sequences zstd_compress.c:2715-2902, zstd_compress_sequences.c:156-382,
+ *                            fse_compress.c (optimalTableLog :370, normalizeCount :464, writeNCount :236-329,
+ *                            buildCTable :68-214, compress_usingCTable :558-615), fse.h:451-480, bitstream.h
+ *   ZSTD_decompress (algos/zstd/lib/decompress/zstd_decompress.c:1252, zstd_decompress_block.c) -- restated from
+ *     the frame format (blocks raw/RLE/compressed, Huffman literals, FSE sequences, repeat offsets).
+ *
+ * The output of orc_zstd_compress is byte-identical to the reference's ZSTD_compress(level 1) for every
+ * n <= 128 KiB (pinned by tests/test_oracle_vs_ref.py).  Destination capacity must be >= ZSTD_compressBound(n).
+ */
 #include "oracle.h"
+#include <string.h>
+#include <stdlib.h>
+
+typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
+typedef int16_t s16;
+
+static u32 z_rd32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
+static u64 z_rd64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+static int z_hb(u32 v) { int r = 0; while (v >>= 1) r++; return r; }   /* ZSTD_highbit32 (v != 0) */
+
+size_t orc_zstd_compress_bound(size_t n)
+{   /* zstd.h:473 ZSTD_COMPRESSBOUND */
+    return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bit writer: LSB-first, forward growing (bitstream.h:153-240); close adds the 1-bit end mark
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { u8* p; u64 acc; int nb; size_t pos; } bw_t;
+static void bw_init(bw_t* b, u8* dst) { b->p = dst; b->acc = 0; b->nb = 0; b->pos = 0; }
+static void bw_add(bw_t* b, u64 v, int n)
+{
+    if (n == 0) return;
+    v &= (n >= 64) ? ~0ull : ((1ull << n) - 1);
+    b->acc |= v << b->nb; b->nb += n;
+    while (b->nb >= 8) { b->p[b->pos++] = (u8)b->acc; b->acc >>= 8; b->nb -= 8; }
+}
+static size_t bw_close(bw_t* b)
+{
+    bw_add(b, 1, 1);
+    if (b->nb > 0) { b->p[b->pos++] = (u8)b->acc; b->acc = 0; b->nb = 0; }
+    return b->pos;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FSE compression tables (fse_compress.c)
+ * ------------------------------------------------------------------------------------------ */
+enum { FSE_MINLOG = 5, FSE_MAXLOG = 12, FSE_MAXSYM = 255 };
+typedef struct {
+    int tableLog;
+    u16 stateTable[1 << 9];           /* big enough for every table this path builds (log <= 9) */
+    int deltaNbBits[64]; int deltaFindState[64];
+} fse_ct;
+
+static u32 fse_min_log(size_t srcSize, u32 maxSym)
+{   /* fse_compress.c:346-354 */
+    u32 a = (u32)z_hb((u32)srcSize) + 1, b = (u32)z_hb(maxSym) + 2;
+    return a < b ? a : b;
+}
+static u32 fse_optimal_log(u32 maxLog, size_t srcSize, u32 maxSym, u32 minus)
+{   /* fse_compress.c:356-373 */
+    u32 maxBitsSrc = (u32)z_hb((u32)(srcSize - 1)) - minus;
+    u32 t = maxLog, minBits = fse_min_log(srcSize, maxSym);
+    if (t == 0) t = 11;
+    if (maxBitsSrc < t) t = maxBitsSrc;
+    if (minBits > t) t = minBits;
+    if (t < FSE_MINLOG) t = FSE_MINLOG;
+    if (t > FSE_MAXLOG) t = FSE_MAXLOG;
+    return t;
+}
+
+/* returns 0 on success, -1 on failure (fse_compress.c:376-461) */
+static int fse_normalize_m2(s16* norm, u32 tableLog, const u32* count, size_t total, u32 maxSym, s16 lowProb)
+{
+    const s16 NYA = -2;
+    u32 s, distributed = 0, toDist;
+    const u32 lowThreshold = (u32)(total >> tableLog);
+    u32 lowOne = (u32)((total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProb; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NYA;
+    }
+    toDist = (1u << tableLog) - distributed;
+    if (toDist == 0) return 0;
+    if ((total / toDist) > lowOne) {
+        lowOne = (u32)((total * 3) / (toDist * 2));
+        for (s = 0; s <= maxSym; s++)
+            if (norm[s] == NYA && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        toDist = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSym + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (s16)toDist;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; toDist > 0; s = (s + 1) % (maxSym + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+        return 0;
+    }
+    {   const u64 vStepLog = 62 - tableLog, mid = (1ull << (vStepLog - 1)) - 1;
+        const u64 rStep = ((((u64)1 << vStepLog) * toDist) + mid) / (u32)total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSym; s++) if (norm[s] == NYA) {
+            const u64 end = tmpTotal + (count[s] * rStep);
+            const u32 w = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
+            if (w < 1) return -1;
+            norm[s] = (s16)w; tmpTotal = end;
+        }
+    }
+    return 0;
+}
+
+/* fse_compress.c:464-526.  returns tableLog, 0 for the rle special case, -1 on error */
+static int fse_normalize(s16* norm, u32 tableLog, const u32* count, size_t total, u32 maxSym, int useLowProb)
+{
+    static const u32 rtb[] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    if (tableLog == 0) tableLog = 11;
+    if (tableLog < FSE_MINLOG || tableLog > FSE_MAXLOG) return -1;
+    if (tableLog < fse_min_log(total, maxSym)) return -1;
+    {   const s16 lowProb = useLowProb ? -1 : 1;
+        const u64 scale = 62 - tableLog, step = ((u64)1 << 62) / (u32)total, vStep = 1ull << (scale - 20);
+        int still = 1 << tableLog;
+        u32 s, largest = 0; s16 largestP = 0;
+        const u32 lowThreshold = (u32)(total >> tableLog);
+        for (s = 0; s <= maxSym; s++) {
+            if (count[s] == total) return 0;
+            if (count[s] == 0) { norm[s] = 0; continue; }
+            if (count[s] <= lowThreshold) { norm[s] = lowProb; still--; }
+            else {
+                s16 proba = (s16)((count[s] * step) >> scale);
+                if (proba < 8) {
+                    const u64 rest = vStep * rtb[proba];
+                    proba += (count[s] * step) - ((u64)proba << scale) > rest;
+                }
+                if (proba > largestP) { largestP = proba; largest = s; }
+                norm[s] = proba; still -= proba;
+            }
+        }
+        if (-still >= (norm[largest] >> 1)) {
+            if (fse_normalize_m2(norm, tableLog, count, total, maxSym, lowProb)) return -1;
+        } else norm[largest] += (s16)still;
+    }
+    return (int)tableLog;
+}
+
+/* fse_compress.c:236-329; returns bytes written (the reference also stores one spill byte past it) */
+static size_t fse_write_ncount(u8* out, const s16* norm, u32 maxSym, u32 tableLog)
+{
+    u8* const ostart = out;
+    const int tableSize = 1 << tableLog;
+    int nbBits = (int)tableLog + 1, remaining = tableSize + 1, threshold = tableSize, bitCount = 0, previousIs0 = 0;
+    u32 bitStream = 0, symbol = 0;
+    const u32 alphabetSize = maxSym + 1;
+    bitStream += (tableLog - FSE_MINLOG) << bitCount; bitCount += 4;
+    while (symbol < alphabetSize && remaining > 1) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while (symbol < alphabetSize && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24; bitStream += 0xFFFFu << bitCount;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {   int count = norm[symbol++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount;
+            bitCount += nbBits; bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return 0;
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (size_t)(out - ostart);
+}
+
+/* fse_compress.c:68-214 */
+static void fse_build_ctable(fse_ct* ct, const s16* norm, u32 maxSym, u32 tableLog)
+{
+    const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    u16 cumul[FSE_MAXSYM + 2];
+    u8 tableSymbol[1 << 9];
+    u32 high = tableSize - 1, u, s, pos = 0;
+    ct->tableLog = (int)tableLog;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSym + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[high--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSym + 1] = (u16)(tableSize + 1);
+    /* spread: both reference code paths (with / without low-probability symbols) visit the cells in this order */
+    for (s = 0; s <= maxSym; s++) {
+        int i;
+        for (i = 0; i < norm[s]; i++) {
+            tableSymbol[pos] = (u8)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (u = 0; u < tableSize; u++) { const u8 sym = tableSymbol[u]; ct->stateTable[cumul[sym]++] = (u16)(tableSize + u); }
+    {   u32 total = 0;
+        for (s = 0; s <= maxSym; s++) {
+            if (norm[s] == 0) { ct->deltaNbBits[s] = (int)(((tableLog + 1) << 16) - (1u << tableLog)); ct->deltaFindState[s] = 0; }
+            else if (norm[s] == -1 || norm[s] == 1) {
+                ct->deltaNbBits[s] = (int)((tableLog << 16) - (1u << tableLog));
+                ct->deltaFindState[s] = (int)(total - 1); total++;
+            } else {
+                const u32 maxBitsOut = tableLog - (u32)z_hb((u32)norm[s] - 1), minStatePlus = (u32)norm[s] << maxBitsOut;
+                ct->deltaNbBits[s] = (int)((maxBitsOut << 16) - minStatePlus);
+                ct->deltaFindState[s] = (int)(total - (u32)norm[s]); total += (u32)norm[s];
+            }
+        }
+    }
+}
+static void fse_build_rle(fse_ct* ct, u32 sym)
+{   /* fse_compress.c:530-548 */
+    ct->tableLog = 0; ct->stateTable[0] = 0; ct->stateTable[1] = 0;
+    ct->deltaNbBits[sym] = 0; ct->deltaFindState[sym] = 0;
+}
+static u32 fse_init_state(const fse_ct* ct, u32 sym)
+{   /* fse.h:451-463 FSE_initCState2 */
+    const u32 nb = (u32)(ct->deltaNbBits[sym] + (1 << 15)) >> 16;
+    const u32 v = (nb << 16) - (u32)ct->deltaNbBits[sym];
+    return ct->stateTable[(int)(v >> nb) + ct->deltaFindState[sym]];
+}
+static u32 fse_encode(bw_t* b, const fse_ct* ct, u32 state, u32 sym)
+{   /* fse.h:465-472 */
+    const u32 nb = (state + (u32)ct->deltaNbBits[sym]) >> 16;
+    bw_add(b, state, (int)nb);
+    return ct->stateTable[(int)(state >> nb) + ct->deltaFindState[sym]];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Huffman (huf_compress.c)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { u32 count; u16 parent; u8 byte; u8 nbBits; } hnode;
+typedef struct { u8 nbBits[256]; u16 val[256]; u32 tableLog; } huf_ct;
+
+/* huf_compress.c:552-563.  RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) = 165 (the reference's
+ * own comment says 166): counts < 165 get one bucket each, larger counts share log2 buckets. */
+enum { HUF_CUTOFF = 165 };
+static u32 huf_rank_index(u32 c) { return c < HUF_CUTOFF ? c : (u32)z_hb(c) + 158; }
+
+static void huf_insertion_sort(hnode* a, int low, int high)
+{
+    int i; const int size = high - low + 1; a += low;
+    for (i = 1; i < size; i++) {
+        const hnode key = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+static int huf_partition(hnode* a, int low, int high)
+{
+    const u32 pivot = a[high].count; int i = low - 1, j;
+    for (j = low; j < high; j++) if (a[j].count > pivot) { hnode t; i++; t = a[i]; a[i] = a[j]; a[j] = t; }
+    { hnode t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
+    return i + 1;
+}
+static void huf_quicksort(hnode* a, int low, int high)
+{   /* huf_compress.c:603-622 */
+    if (high - low < 8) { huf_insertion_sort(a, low, high); return; }
+    while (low < high) {
+        const int idx = huf_partition(a, low, high);
+        if (idx - low < high - idx) { huf_quicksort(a, low, idx - 1); low = idx + 1; }
+        else { huf_quicksort(a, idx + 1, high); high = idx - 1; }
+    }
+}
+static void huf_sort(hnode* node, const u32* count, u32 maxSym)
+{   /* huf_compress.c:624-668 */
+    struct { u16 base, curr; } rp[192];
+    u32 n; const u32 n1 = maxSym + 1;
+    memset(rp, 0, sizeof(rp));
+    for (n = 0; n < n1; n++) rp[huf_rank_index(count[n])].base++;
+    for (n = 191; n > 0; n--) { rp[n - 1].base += rp[n].base; rp[n - 1].curr = rp[n - 1].base; }
+    for (n = 0; n < n1; n++) {
+        const u32 c = count[n], r = huf_rank_index(c) + 1, pos = rp[r].curr++;
+        node[pos].count = c; node[pos].byte = (u8)n;
+    }
+    for (n = HUF_CUTOFF; n < 191; n++) {
+        const int size = rp[n].curr - rp[n].base;
+        if (size > 1) huf_quicksort(node + rp[n].base, 0, size - 1);
+    }
+}
+static int huf_build_tree(hnode* node /* node[-1] valid */, u32 maxSym)
+{   /* huf_compress.c:685-725 */
+    enum { START = 256 };
+    int nonNull = (int)maxSym, lowS, lowN, nodeNb = START, n, root;
+    while (node[nonNull].count == 0) nonNull--;
+    lowS = nonNull; root = nodeNb + lowS - 1; lowN = nodeNb;
+    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (n = nodeNb; n <= root; n++) node[n].count = 1u << 30;
+    node[-1].count = 1u << 31;
+    while (nodeNb <= root) {
+        const int n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        const int n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        node[nodeNb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    node[root].nbBits = 0;
+    for (n = root - 1; n >= START; n--) node[n].nbBits = (u8)(node[node[n].parent].nbBits + 1);
+    for (n = 0; n <= nonNull; n++) node[n].nbBits = (u8)(node[node[n].parent].nbBits + 1);
+    return nonNull;
+}
+static u32 huf_set_max_height(hnode* node, u32 lastNonNull, u32 target)
+{   /* huf_compress.c:378-495 */
+    const u32 largest = node[lastNonNull].nbBits;
+    if (largest <= target) return largest;
+    {   int totalCost = 0, n = (int)lastNonNull;
+        const u32 baseCost = 1u << (largest - target);
+        while (node[n].nbBits > target) {
+            totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits)));
+            node[n].nbBits = (u8)target; n--;
+        }
+        while (node[n].nbBits == target) --n;
+        totalCost >>= (largest - target);
+        {   const u32 noSym = 0xF0F0F0F0u;
+            u32 rankLast[14]; int pos; u32 cur = target;
+            for (pos = 0; pos < 14; pos++) rankLast[pos] = noSym;
+            for (pos = n; pos >= 0; pos--) {
+                if (node[pos].nbBits >= cur) continue;
+                cur = node[pos].nbBits; rankLast[target - cur] = (u32)pos;
+            }
+            while (totalCost > 0) {
+                u32 dec = (u32)z_hb((u32)totalCost) + 1;
+                for (; dec > 1; dec--) {
+                    const u32 highPos = rankLast[dec], lowPos = rankLast[dec - 1];
+                    if (highPos == noSym) continue;
+                    if (lowPos == noSym) break;
+                    if (node[highPos].count <= 2 * node[lowPos].count) break;
+                }
+                while (dec <= 12 && rankLast[dec] == noSym) dec++;
+                totalCost -= 1 << (dec - 1);
+                node[rankLast[dec]].nbBits++;
+                if (rankLast[dec - 1] == noSym) rankLast[dec - 1] = rankLast[dec];
+                if (rankLast[dec] == 0) rankLast[dec] = noSym;
+                else { rankLast[dec]--; if (node[rankLast[dec]].nbBits != target - dec) rankLast[dec] = noSym; }
+            }
+            while (totalCost < 0) {
+                if (rankLast[1] == noSym) {
+                    while (node[n].nbBits == target) n--;
+                    node[n + 1].nbBits--; rankLast[1] = (u32)(n + 1); totalCost++;
+                    continue;
+                }
+                node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+            }
+        }
+    }
+    return target;
+}
+/* HUF_buildCTable_wksp (huf_compress.c:758-794); returns maxNbBits */
+static u32 huf_build(huf_ct* ct, const u32* count, u32 maxSym, u32 maxNbBits)
+{
+    hnode tbl[513]; hnode* const node = tbl + 1;
+    int nonNull, n; u32 bits;
+    u16 nbPerRank[13] = {0}, valPerRank[13] = {0};
+    memset(tbl, 0, sizeof(tbl));
+    huf_sort(node, count, maxSym);
+    nonNull = huf_build_tree(node, maxSym);
+    bits = huf_set_max_height(node, (u32)nonNull, maxNbBits);
+    for (n = 0; n <= nonNull; n++) nbPerRank[node[n].nbBits]++;
+    {   u16 min = 0;
+        for (n = (int)bits; n > 0; n--) { valPerRank[n] = min; min = (u16)(min + nbPerRank[n]); min >>= 1; }
+    }
+    memset(ct->nbBits, 0, sizeof(ct->nbBits)); memset(ct->val, 0, sizeof(ct->val));
+    for (n = 0; n <= (int)maxSym; n++) ct->nbBits[node[n].byte] = node[n].nbBits;
+    for (n = 0; n <= (int)maxSym; n++) ct->val[n] = ct->nbBits[n] ? valPerRank[ct->nbBits[n]]++ : 0;
+    ct->tableLog = bits;
+    return bits;
+}
+
+/* FSE_compress_usingCTable for the Huffman weights (fse_compress.c:558-615): two interleaved states,
+ * symbol i handled by state (i even ? 1 : 2), processed from the last symbol to the first */
+static size_t fse_compress_weights(u8* dst, const u8* w, size_t n, const fse_ct* ct)
+{
+    bw_t b; u32 st[2]; int init[2] = {0, 0}; size_t i;
+    if (n <= 2) return 0;
+    bw_init(&b, dst);
+    for (i = n; i-- > 0;) {
+        const int k = (int)(i & 1);      /* 0 -> CState1, 1 -> CState2 */
+        if (!init[k]) { st[k] = fse_init_state(ct, w[i]); init[k] = 1; }
+        else st[k] = fse_encode(&b, ct, st[k], w[i]);
+    }
+    bw_add(&b, st[1], ct->tableLog);     /* FSE_flushCState(CState2) then (CState1) */
+    bw_add(&b, st[0], ct->tableLog);
+    return bw_close(&b);
+}
+/* HUF_compressWeights (huf_compress.c:173-213): 0 = not compressible, 1 = rle */
+static size_t huf_compress_weights(u8* dst, const u8* w, size_t n)
+{
+    u32 count[13] = {0}, maxSym = 0, maxCount = 0, i, tableLog; s16 norm[13]; fse_ct ct; size_t h, c;
+    if (n <= 1) return 0;
+    for (i = 0; i < n; i++) count[w[i]]++;
+    for (i = 0; i <= 12; i++) { if (count[i]) maxSym = i; if (count[i] > maxCount) maxCount = count[i]; }
+    if (maxCount == n) return 1;
+    if (maxCount == 1) return 0;
+    tableLog = fse_optimal_log(6, n, maxSym, 2);
+    if (fse_normalize(norm, tableLog, count, n, maxSym, 0) < 0) return 0;
+    h = fse_write_ncount(dst, norm, maxSym, tableLog);
+    if (!h) return 0;
+    fse_build_ctable(&ct, norm, maxSym, tableLog);
+    c = fse_compress_weights(dst + h, w, n, &ct);
+    if (!c) return 0;
+    return h + c;
+}
+/* HUF_writeCTable_wksp (huf_compress.c:256-295); returns 0 on failure */
+static size_t huf_write_ctable(u8* op, const huf_ct* ct, u32 maxSym, u32 huffLog)
+{
+    u8 weight[256]; u32 n;
+    for (n = 0; n < maxSym; n++) weight[n] = ct->nbBits[n] ? (u8)(huffLog + 1 - ct->nbBits[n]) : 0;
+    {   const size_t h = huf_compress_weights(op + 1, weight, maxSym);
+        if (h > 1 && h < maxSym / 2) { op[0] = (u8)h; return h + 1; }
+    }
+    if (maxSym > 128) return 0;
+    op[0] = (u8)(128 + (maxSym - 1));
+    weight[maxSym] = 0;
+    for (n = 0; n < maxSym; n += 2) op[(n / 2) + 1] = (u8)((weight[n] << 4) + weight[n + 1]);
+    return ((maxSym + 1) / 2) + 1;
+}
+/* HUF_compress1X_usingCTable (huf_compress.c:1051-1116): symbols last -> first, then the end mark */
+static size_t huf_encode_1x(u8* dst, const u8* src, size_t n, const huf_ct* ct)
+{
+    bw_t b; size_t i;
+    bw_init(&b, dst);
+    for (i = n; i-- > 0;) bw_add(&b, ct->val[src[i]], ct->nbBits[src[i]]);
+    return bw_close(&b);
+}
+static size_t huf_encode_4x(u8* dst, const u8* src, size_t n, const huf_ct* ct)
+{   /* huf_compress.c:1163-1211 */
+    const size_t seg = (n + 3) / 4; u8* op = dst + 6; size_t c; int i;
+    if (n < 12) return 0;
+    for (i = 0; i < 3; i++) {
+        c = huf_encode_1x(op, src + (size_t)i * seg, seg, ct);
+        if (c == 0 || c > 65535) return 0;
+        dst[2 * i] = (u8)c; dst[2 * i + 1] = (u8)(c >> 8); op += c;
+    }
+    c = huf_encode_1x(op, src + 3 * seg, n - 3 * seg, ct);
+    if (c == 0 || c > 65535) return 0;
+    op += c;
+    return (size_t)(op - dst);
+}
+
+/* HUF_compress_internal without table reuse (huf_compress.c:1326-1434): 0 = not compressible, 1 = rle */
+static size_t huf_compress(u8* dst, const u8* src, size_t n, int single, int suspect)
+{
+    u32 count[256], maxSym = 255, largest = 0, i, huffLog; huf_ct ct; size_t h, c;
+    if (!n) return 0;
+    if (suspect && n >= 4096 * 10) {                                  /* :1361-1375 */
+        u32 cnt[256], lb = 0, le = 0;
+        memset(cnt, 0, sizeof(cnt)); for (i = 0; i < 4096; i++) cnt[src[i]]++;
+        for (i = 0; i < 256; i++) if (cnt[i] > lb) lb = cnt[i];
+        memset(cnt, 0, sizeof(cnt)); for (i = 0; i < 4096; i++) cnt[src[n - 4096 + i]]++;
+        for (i = 0; i < 256; i++) if (cnt[i] > le) le = cnt[i];
+        if (lb + le <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    memset(count, 0, sizeof(count));
+    for (i = 0; i < n; i++) count[src[i]]++;
+    maxSym = 0;
+    for (i = 0; i < 256; i++) { if (count[i]) maxSym = i; if (count[i] > largest) largest = count[i]; }
+    if (largest == n) { dst[0] = src[0]; return 1; }
+    if (largest <= (n >> 7) + 4) return 0;
+    huffLog = fse_optimal_log(11, n, maxSym, 1);                      /* HUF_optimalTableLog :1268-1283 */
+    huffLog = huf_build(&ct, count, maxSym, huffLog);
+    h = huf_write_ctable(dst, &ct, maxSym, huffLog);
+    if (!h) return 0;                                                 /* error -> raw literals */
+    if (h + 12 >= n) return 0;
+    c = single ? huf_encode_1x(dst + h, src, n, &ct) : huf_encode_4x(dst + h, src, n, &ct);
+    if (!c) return 0;
+    if (h + c >= n - 1) return 0;                                     /* HUF_compressCTable_internal :1232-1236 */
+    return h + c;
+}
+
+/* ZSTD_compressLiterals for a first block (zstd_compress_literals.c:129-235) */
+static size_t lit_raw(u8* dst, const u8* src, size_t n, u32 type)
+{
+    const u32 fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) dst[0] = (u8)(type + (n << 3));
+    else if (fl == 2) { const u32 v = type + (1 << 2) + ((u32)n << 4); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); }
+    else { const u32 v = type + (3 << 2) + ((u32)n << 4); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
+    if (type == 0) { memcpy(dst + fl, src, n); return fl + n; }
+    dst[fl] = src[0]; return fl + 1;
+}
+static size_t compress_literals(u8* dst, const u8* src, size_t n, int suspect)
+{
+    const size_t lh = 3 + (n >= 1024) + (n >= 16384);
+    const int single = n < 256;
+    size_t c;
+    if (n < 64) return lit_raw(dst, src, n, 0);                       /* ZSTD_minLiteralsToCompress: 8 << 3 */
+    c = huf_compress(dst + lh, src, n, single, suspect);
+    if (c == 0 || c >= n - ((n >> 6) + 2)) return lit_raw(dst, src, n, 0);   /* ZSTD_minGain */
+    if (c == 1) return lit_raw(dst, src, n, 1);                       /* n >= 64 >= 8: rle */
+    if (lh == 3) { const u32 v = 2 + ((u32)(!single) << 2) + ((u32)n << 4) + ((u32)c << 14); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
+    else if (lh == 4) { const u32 v = 2 + (2 << 2) + ((u32)n << 4) + ((u32)c << 18); memcpy(dst, &v, 4); }
+    else { const u32 v = 2 + (3 << 2) + ((u32)n << 4) + ((u32)c << 22); memcpy(dst, &v, 4); dst[4] = (u8)(c >> 10); }
+    return lh + c;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sequences
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { u32 offBase; u32 litLength; u32 matchLength; } zseq;   /* full-width values */
+
+static const u8 kLLbits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+static const u8 kMLbits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+static const s16 kLLnorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+static const s16 kMLnorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                 1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+static const s16 kOFnorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+static u32 ll_code(u32 v)
+{   /* zstd_compress_internal.h:527-540 */
+    if (v > 63) return (u32)z_hb(v) + 19;
+    if (v < 16) return v;
+    if (v < 24) return 16 + ((v - 16) >> 1);
+    if (v < 32) return 20 + ((v - 24) >> 2);
+    if (v < 48) return 22 + ((v - 32) >> 3);
+    return 24;
+}
+static u32 ml_code(u32 v)
+{   /* zstd_compress_internal.h:545-556 (v = matchLength - 3) */
+    if (v > 127) return (u32)z_hb(v) + 36;
+    if (v < 32) return v;
+    if (v < 40) return 32 + ((v - 32) >> 1);
+    if (v < 48) return 36 + ((v - 40) >> 2);
+    if (v < 64) return 38 + ((v - 48) >> 3);
+    if (v < 96) return 39 + ((v - 48) >> 4);    /* 64..79 -> 40, 80..95 -> 41 */
+    return 42;
+}
+
+/* ZSTD_selectEncodingType for strategy ZSTD_fast, first block (zstd_compress_sequences.c:156-204): 0 basic,1 rle,2 compressed */
+static int select_type(u32 mostFrequent, size_t nbSeq, u32 defaultNormLog, int defaultAllowed)
+{
+    if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+    if (defaultAllowed) {
+        const size_t dynMin = (((size_t)1 << defaultNormLog) * 9) >> 3;
+        if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defaultNormLog - 1))) return 0;
+    }
+    return 2;
+}
+
+/* one of the three symbol streams: histogram -> mode -> table description -> CTable (ZSTD_buildCTable :242-288) */
+static int build_stream(u8** op, fse_ct* ct, const u8* codes, size_t nbSeq, u32 maxCode, u32 fseLog,
+                        const s16* defNorm, u32 defLog, u32 defMax, int* lastCountSize)
+{
+    u32 count[64], max = 0, most = 0, i; int type, defaultAllowed;
+    memset(count, 0, sizeof(count));
+    for (i = 0; i < nbSeq; i++) count[codes[i]]++;
+    for (i = 0; i <= maxCode; i++) { if (count[i]) max = i; if (count[i] > most) most = count[i]; }
+    defaultAllowed = (defMax == 28) ? (max <= 28) : 1;                /* zstd_compress.c:2847-2848 */
+    type = select_type(most, nbSeq, defLog, defaultAllowed);
+    if (type == 1) { fse_build_rle(ct, max); *(*op)++ = codes[0]; }
+    else if (type == 0) fse_build_ctable(ct, defNorm, defMax, defLog);
+    else {
+        s16 norm[64]; size_t nbSeq1 = nbSeq, h;
+        const u32 tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
+        if (count[codes[nbSeq - 1]] > 1) { count[codes[nbSeq - 1]]--; nbSeq1--; }
+        if (fse_normalize(norm, tableLog, count, nbSeq1, max, nbSeq1 >= 2048) < 0) return -1;
+        h = fse_write_ncount(*op, norm, max, tableLog);
+        if (!h) return -1;
+        fse_build_ctable(ct, norm, max, tableLog);
+        *op += h; *lastCountSize = (int)h;
+    }
+    return type;
+}
+
+/* ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027); returns block content size, 0 = emit raw */
+static size_t entropy_compress(u8* dst, const u8* lits, size_t litSize, const zseq* seqs, size_t nbSeq)
+{
+    u8* op = dst;
+    const int suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
+    op += compress_literals(op, lits, litSize, suspect);
+    if (nbSeq < 128) *op++ = (u8)nbSeq;
+    else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
+    else { op[0] = 0xFF; op[1] = (u8)(nbSeq - 0x7F00); op[2] = (u8)((nbSeq - 0x7F00) >> 8); op += 3; }
+    if (nbSeq == 0) return (size_t)(op - dst);
+    {   u8* llc = (u8*)malloc(nbSeq * 3); u8* ofc = llc + nbSeq; u8* mlc = ofc + nbSeq;
+        fse_ct ctLL, ctOF, ctML; int tLL, tOF, tML, lastCount = 0; size_t i, bs; u8* seqHead; bw_t b;
+        u32 sLL, sOF, sML;
+        for (i = 0; i < nbSeq; i++) {                                 /* ZSTD_seqToCodes :2715-2741 */
+            llc[i] = (u8)(seqs[i].litLength > 0xFFFF ? 35 : ll_code(seqs[i].litLength));
+            ofc[i] = (u8)z_hb(seqs[i].offBase);
+            mlc[i] = (u8)(seqs[i].matchLength - 3 > 0xFFFF ? 52 : ml_code(seqs[i].matchLength - 3));
+        }
+        seqHead = op++;
+        tLL = build_stream(&op, &ctLL, llc, nbSeq, 35, 9, kLLnorm, 6, 35, &lastCount);
+        tOF = tLL < 0 ? -1 : build_stream(&op, &ctOF, ofc, nbSeq, 31, 8, kOFnorm, 5, 28, &lastCount);
+        tML = tOF < 0 ? -1 : build_stream(&op, &ctML, mlc, nbSeq, 52, 9, kMLnorm, 6, 52, &lastCount);
+        if (tML < 0) { free(llc); return 0; }
+        /* lastCount = size of the LAST table description written in compressed mode (zstd_compress.c:2836,2866,2894) */
+        *seqHead = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
+        /* ZSTD_encodeSequences_body (zstd_compress_sequences.c:290-382), 64-bit, no long offsets */
+        bw_init(&b, op);
+        sML = fse_init_state(&ctML, mlc[nbSeq - 1]); sOF = fse_init_state(&ctOF, ofc[nbSeq - 1]); sLL = fse_init_state(&ctLL, llc[nbSeq - 1]);
+        bw_add(&b, seqs[nbSeq - 1].litLength, kLLbits[llc[nbSeq - 1]]);
+        bw_add(&b, seqs[nbSeq - 1].matchLength - 3, kMLbits[mlc[nbSeq - 1]]);
+        bw_add(&b, seqs[nbSeq - 1].offBase, ofc[nbSeq - 1]);
+        for (i = nbSeq - 1; i-- > 0;) {
+            sOF = fse_encode(&b, &ctOF, sOF, ofc[i]);
+            sML = fse_encode(&b, &ctML, sML, mlc[i]);
+            sLL = fse_encode(&b, &ctLL, sLL, llc[i]);
+            bw_add(&b, seqs[i].litLength, kLLbits[llc[i]]);
+            bw_add(&b, seqs[i].matchLength - 3, kMLbits[mlc[i]]);
+            bw_add(&b, seqs[i].offBase, ofc[i]);
+        }
+        bw_add(&b, sML, ctML.tableLog); bw_add(&b, sOF, ctOF.tableLog); bw_add(&b, sLL, ctLL.tableLog);
+        bs = bw_close(&b);
+        free(llc);
+        op += bs;
+        if (lastCount && (size_t)lastCount + bs < 4) return 0;        /* zstd_compress.c:3017-3023 */
+    }
+    return (size_t)(op - dst);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * match finder: AOCL_ZSTD_compressBlock_fast_noDict_generic (zstd_fast.c:427-706), fresh context:
+ * table indices are position + 2 (ZSTD_WINDOW_START_INDEX), so 0 means "empty" (< prefixStartIndex)
+ * ------------------------------------------------------------------------------------------ */
+static u32 z_hash(const u8* p, u32 hlog, u32 mls)
+{
+    const u64 v = z_rd64(p);
+    if (mls == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
+    return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+}
+static u32 z_count(const u8* s, u32 a, u32 b, u32 end)
+{   /* ZSTD_count: common prefix of s[a..end) and s[b..] */
+    u32 n = 0; while (a + n < end && s[a + n] == s[b + n]) n++; return n;
+}
+#define PUT(pos) table[z_hash(src + (pos), hlog, mls)] = (pos) + 2
+
+static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+{
+    u32* table = (u32*)calloc((size_t)1 << hlog, sizeof(u32));
+    size_t nbSeq = 0, litSize = 0;
+    u32 anchor = 0, ip0 = 1, rep1 = 1, rep2 = 0;                      /* rep {1,4,8}: 4 > maxRep=1 is parked (:484-489) */
+    if (n < 16 + 4) goto cleanup;                                     /* ilimit = n - 16 must leave room for ip3 */
+    {   const u32 ilimit = n - 16;
+        for (;;) {                                                    /* _start */
+            u32 step = 2, nextStep = ip0 + 128, ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
+            u32 hash0, hash1, idx, current0 = 0, match0 = 0, offcode = 0, mLength = 0;
+            int found = 0;
+            if (ip3 >= ilimit) goto cleanup;
+            hash0 = z_hash(src + ip0, hlog, mls); hash1 = z_hash(src + ip1, hlog, mls);
+            idx = table[hash0];
+            do {
+                const u32 rval = (ip2 >= rep1) ? z_rd32(src + ip2 - rep1) : 0;
+                current0 = ip0; table[hash0] = ip0 + 2;
+                if (rep1 > 0 && z_rd32(src + ip2) == rval) {          /* repcode at ip2 (:529-542) */
+                    u32 back;
+                    ip0 = ip2; match0 = ip0 - rep1;
+                    back = (src[ip0 - 1] == src[match0 - 1]);
+                    ip0 -= back; match0 -= back; offcode = 1; mLength = back + 4;
+                    table[hash1] = ip1 + 2;
+                    found = 2; break;
+                }
+                if (idx >= 2 && z_rd32(src + idx - 2) == z_rd32(src + ip0)) { table[hash1] = ip1 + 2; found = 1; break; }
+                idx = table[hash1];
+                hash0 = hash1; hash1 = z_hash(src + ip2, hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip3;
+                current0 = ip0; table[hash0] = ip0 + 2;
+                if (idx >= 2 && z_rd32(src + idx - 2) == z_rd32(src + ip0)) {
+                    if (step <= 4) table[hash1] = ip1 + 2;
+                    found = 1; break;
+                }
+                idx = table[hash1];
+                hash0 = hash1; hash1 = z_hash(src + ip2, hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+                if (ip2 >= nextStep) { step++; nextStep += 128; }
+            } while (ip3 < ilimit);
+            if (!found) goto cleanup;
+            if (found == 1) {                                         /* _offset (:651-665) */
+                match0 = idx - 2;
+                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3; mLength = 4;
+                while (ip0 > anchor && match0 > 0 && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+            }
+            mLength += z_count(src, ip0 + mLength, match0 + mLength, n);      /* _match */
+            seqs[nbSeq].litLength = ip0 - anchor; seqs[nbSeq].offBase = offcode; seqs[nbSeq].matchLength = mLength; nbSeq++;
+            memcpy(lits + litSize, src + anchor, ip0 - anchor); litSize += ip0 - anchor;
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {
+                PUT(current0 + 2);
+                PUT(ip0 - 2);
+                if (rep2 > 0) {
+                    while (ip0 <= ilimit && z_rd32(src + ip0) == z_rd32(src + ip0 - rep2)) {
+                        const u32 rLength = z_count(src, ip0 + 4, ip0 + 4 - rep2, n) + 4;
+                        const u32 t = rep2; rep2 = rep1; rep1 = t;
+                        PUT(ip0);
+                        ip0 += rLength;
+                        seqs[nbSeq].litLength = 0; seqs[nbSeq].offBase = 1; seqs[nbSeq].matchLength = rLength; nbSeq++;
+                        anchor = ip0;
+                    }
+                }
+            }
+        }
+    }
+cleanup:
+    memcpy(lits + litSize, src + anchor, n - anchor); litSize += n - anchor;     /* ZSTD_storeLastLiterals */
+    *litSizeOut = litSize;
+    free(table);
+    return nbSeq;
+}
+
+/* cParams for level 1 and a known source size (clevels.h:80,107 + zstd_compress.c:1575-1595) */
+static void level1_params(size_t n, u32* hlog, u32* mls)
+{
+    const u32 srcLog = (n < 64) ? 6 : (u32)z_hb((u32)n - 1) + 1;
+    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = 5; }
+    else { const u32 w = srcLog < 17 ? srcLog : 17; *hlog = (13 < w + 1) ? 13 : w + 1; *mls = 6; }
+}
+
+size_t orc_zstd_compress(const u8* src, size_t n, u8* dst, size_t dstCap)
+{
+    u8* op = dst;
+    if (n > (128u << 10) || dstCap < orc_zstd_compress_bound(n) || dstCap < 9) return 0;
+    /* frame header: magic, FHD (single segment, FCS size code), FCS (zstd_compress.c:4586-4632) */
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
+    {   const u32 fcs = (n >= 256) + (n >= 65536 + 256);
+        *op++ = (u8)((1 << 5) | (fcs << 6));
+        if (fcs == 0) *op++ = (u8)n;
+        else if (fcs == 1) { const u32 v = (u32)n - 256; *op++ = (u8)v; *op++ = (u8)(v >> 8); }
+        else { const u32 v = (u32)n; memcpy(op, &v, 4); op += 4; }
+    }
+    if (n == 0) { op[0] = 1; op[1] = 0; op[2] = 0; return (size_t)(op + 3 - dst); }   /* ZSTD_writeEpilogue */
+    {   size_t cSize = 0;
+        if (n >= 7) {                                                 /* ZSTD_buildSeqStore :3268 (MIN_CBLOCK_SIZE+3+1+1) */
+            u32 hlog, mls; size_t litSize, nbSeq;
+            zseq* seqs = (zseq*)malloc(sizeof(zseq) * (n / 3 + 8));
+            u8* lits = (u8*)malloc(n + 8);
+            u8* tmp = (u8*)malloc(2 * n + 1024);
+            level1_params(n, &hlog, &mls);
+            nbSeq = fast_block(src, (u32)n, hlog, mls, seqs, lits, &litSize);
+            cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq);
+            if (cSize >= n - ((n >> 6) + 2)) cSize = 0;               /* ZSTD_minGain, zstd_compress.c:3055-3057 */
+            if (cSize) memcpy(op + 3, tmp, cSize);
+            free(seqs); free(lits); free(tmp);
+        }
+        if (cSize == 0) {                                             /* ZSTD_noCompressBlock */
+            const u32 h = 1 + (0 << 1) + ((u32)n << 3);
+            op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16);
+            memcpy(op + 3, src, n); op += 3 + n;
+        } else {
+            const u32 h = 1 + (2 << 1) + ((u32)cSize << 3);
+            op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16); op += 3 + cSize;
+        }
+    }
+    return (size_t)(op - dst);
+}
+
+size_t orc_zstd_decompress(const u8* src, size_t n, u8* dst, size_t dstCap)
+{
+    (void)src; (void)n; (void)dst; (void)dstCap;
+    return (size_t)-1;
+}
+
+/* ---- debug hooks: let tests fuzz the building blocks against the reference's exported functions ---- */
+int orc_dbg_fse_normalize(int16_t* norm, unsigned tableLog, const unsigned* count, size_t total, unsigned maxSym, int useLowProb)
+{ return fse_normalize(norm, tableLog, count, total, maxSym, useLowProb); }
+unsigned orc_dbg_huf_build(uint8_t* nbBitsOut, const unsigned* count, unsigned maxSym, unsigned maxNbBits)
+{ huf_ct ct; unsigned r = huf_build(&ct, count, maxSym, maxNbBits); memcpy(nbBitsOut, ct.nbBits, 256); return r; }
+size_t orc_dbg_write_ncount(uint8_t* out, const int16_t* norm, unsigned maxSym, unsigned tableLog)
+{ return fse_write_ncount(out, norm, maxSym, tableLog); }
+size_t orc_dbg_huf_write(uint8_t* out, const unsigned* count, unsigned maxSym, unsigned maxNbBits)
+{ huf_ct ct; unsigned r = huf_build(&ct, count, maxSym, maxNbBits); return huf_write_ctable(out, &ct, maxSym, r); }
+/* sequences of the match finder: out[4*i] = {litLength, offBase, matchLength, 0}; returns nbSeq */
+size_t orc_dbg_zstd_sequences(const uint8_t* src, size_t n, uint32_t* out, size_t* litSize)
+{
+    u32 hlog, mls; zseq* seqs = (zseq*)malloc(sizeof(zseq) * (n / 3 + 8)); u8* lits = (u8*)malloc(n + 8); size_t i, nb;
+    level1_params(n, &hlog, &mls);
+    nb = fast_block(src, (u32)n, hlog, mls, seqs, lits, litSize);
+    for (i = 0; i < nb; i++) { out[4*i] = seqs[i].litLength; out[4*i+1] = seqs[i].offBase; out[4*i+2] = seqs[i].matchLength; out[4*i+3] = 0; }
+    free(seqs); free(lits); return nb;
+}
