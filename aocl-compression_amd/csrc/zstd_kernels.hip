@@ -548,6 +548,460 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     return (int)(op + 3 + cSize);
 }
 
+
+// ================================================================================================
+// Decoder: ZSTD_decompress (algos/zstd/lib/decompress/zstd_decompress.c:1252-1389, :1005-1111;
+// zstd_decompress_block.c:162-364, :497-707, :1339-1460, :1007-1210, :2444-2552; huf_decompress.c;
+// fse_decompress.c; entropy_common.c:40-200, 234-310).  Any malformed input yields -1.
+// ================================================================================================
+struct BitR {                       // backward bit reader (bitstream.h:262-420); never loads outside [p, p+n)
+    const u8* p; int pos; u64 win; int wbase;
+    __device__ bool init(const u8* s, u32 len)
+    {
+        if (!len) return false;
+        const u32 last = s[len - 1];
+        if (!last) return false;
+        p = s; pos = (int)(len - 1) * 8 + hb(last); wbase = 0x7FFFFFFF; win = 0;
+        return true;
+    }
+    __device__ void refill()
+    {
+        const int q = ((pos + 7) >> 3) - 8;
+        if (q >= 0) { win = ld64(p + q); wbase = q * 8; }
+        else {
+            const int cnt = (pos + 7) >> 3;
+            win = 0;
+            for (int i = 0; i < cnt; ++i) win |= (u64)p[i] << (8 * i);
+            wbase = 0;
+        }
+    }
+    __device__ u32 peek(int nb)     // bits [pos-nb, pos), zero-padded below bit 0; nb <= 32
+    {
+        if (nb == 0 || pos <= 0) return 0;
+        if (pos - nb < wbase || pos > wbase + 64) refill();
+        const u64 mask = (1ull << nb) - 1;
+        if (pos - nb >= wbase) return (u32)((win >> (pos - nb - wbase)) & mask);
+        return (u32)((win << (nb - pos)) & mask);               // wbase == 0 and pos < nb
+    }
+    __device__ u32 read(int nb) { const u32 v = peek(nb); pos -= nb; return v; }
+};
+
+struct FseD { u16 newState; u8 symbol; u8 nbBits; };
+
+struct DecLds {
+    u16 huf[4096];                  // symbol | nbBits << 8
+    FseD ll[512], of[256], ml[512];
+    u32 llLog, ofLog, mlLog, hufLog;
+    u32 haveLL, haveOF, haveML, haveHuf;
+    u32 rep[3];
+    s16 norm[256];
+    u16 next[256];
+    u8 weights[256];
+    FseD wdt[64];
+    u32 seqLL[64], seqML[64], seqOff[64];
+    u32 streamOk[4];
+};
+
+// FSE_readNCount (entropy_common.c:40-186), lane-serial; bytes consumed or 0xFFFFFFFF
+__device__ u32 fse_read_ncount(s16* norm, u32* maxSym, u32* tableLog, const u8* src, u32 n, u32 maxLog)
+{
+    u32 bp = 0, charnum = 0, nbBits; int previous0 = 0, remaining, threshold;
+    const u32 maxSV1 = *maxSym + 1;
+    auto peek32 = [&](u32 bitpos) -> u32 {
+        u32 v = 0; const u32 by = bitpos >> 3;
+        for (u32 i = 0; i < 5; ++i) if (by + i < n) v |= 0;   // placeholder to keep structure simple
+        u64 w = 0;
+        for (u32 i = 0; i < 5; ++i) if (by + i < n) w |= (u64)src[by + i] << (8 * i);
+        return (u32)(w >> (bitpos & 7)) | v;
+    };
+    for (u32 i = 0; i < maxSV1; ++i) norm[i] = 0;
+    if (n < 1) return 0xFFFFFFFFu;
+    nbBits = (peek32(0) & 0xF) + 5; bp = 4;
+    if (nbBits > 15 || nbBits > maxLog) return 0xFFFFFFFFu;
+    *tableLog = nbBits;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    for (;;) {
+        if (previous0) {
+            for (;;) {
+                const u32 c = peek32(bp) & 3; bp += 2;
+                if (c == 3) { charnum += 3; if (bp > 8 * n + 64) return 0xFFFFFFFFu; continue; }
+                charnum += c; break;
+            }
+            if (charnum >= maxSV1) break;
+        }
+        {   const u32 bits = peek32(bp);
+            const int max = (2 * threshold - 1) - remaining; int count;
+            if ((bits & (u32)(threshold - 1)) < (u32)max) { count = (int)(bits & (u32)(threshold - 1)); bp += nbBits - 1; }
+            else { count = (int)(bits & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bp += nbBits; }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            norm[charnum++] = (s16)count;
+            previous0 = !count;
+            if (remaining < threshold) {
+                if (remaining <= 1) break;
+                nbBits = (u32)hb((u32)remaining) + 1; threshold = 1 << (nbBits - 1);
+            }
+            if (charnum >= maxSV1) break;
+        }
+    }
+    if (remaining != 1 || charnum > maxSV1) return 0xFFFFFFFFu;
+    *maxSym = charnum - 1;
+    const u32 used = (bp + 7) >> 3;
+    if (used > n) return 0xFFFFFFFFu;
+    return used;
+}
+// FSE decoding table (zstd_decompress_block.c:497-615); lane-serial
+__device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tableLog, u16* next)
+{
+    const u32 size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    u32 high = size - 1, pos = 0;
+    for (u32 s = 0; s <= maxSym; ++s) {
+        if (norm[s] == -1) { dt[high--].symbol = (u8)s; next[s] = 1; }
+        else next[s] = (u16)norm[s];
+    }
+    for (u32 s = 0; s <= maxSym; ++s)
+        for (int i = 0; i < norm[s]; ++i) {
+            dt[pos].symbol = (u8)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    if (pos != 0) return false;
+    for (u32 u = 0; u < size; ++u) {
+        const u8 sym = dt[u].symbol; const u32 ns = next[sym]++;
+        dt[u].nbBits = (u8)(tableLog - (u32)hb(ns));
+        dt[u].newState = (u16)((ns << dt[u].nbBits) - size);
+    }
+    return true;
+}
+
+// HUF_readStats + X1 table (entropy_common.c:234-310, huf_decompress.c:380-470); lane-serial; bytes used or 0xFFFFFFFF
+__device__ u32 huf_read_table(DecLds* L, const u8* src, u32 n)
+{
+    u8* w = L->weights; u32 nsym, total = 0, used, rank[14];
+    for (int i = 0; i < 14; ++i) rank[i] = 0;
+    if (!n) return 0xFFFFFFFFu;
+    if (src[0] >= 128) {
+        nsym = src[0] - 127; used = 1 + (nsym + 1) / 2;
+        if (used > n) return 0xFFFFFFFFu;
+        for (u32 i = 0; i < nsym; i += 2) { w[i] = src[1 + i / 2] >> 4; w[i + 1] = src[1 + i / 2] & 15; }
+    } else {
+        u32 maxSym = 255, tl; BitR b;
+        const u32 isz = src[0];
+        used = 1 + isz;
+        if (used > n || isz < 2) return 0xFFFFFFFFu;
+        const u32 h = fse_read_ncount(L->norm, &maxSym, &tl, src + 1, isz, 6);
+        if (h == 0xFFFFFFFFu || h >= isz) return 0xFFFFFFFFu;
+        if (!fse_build_dtable(L->wdt, L->norm, maxSym, tl, L->next)) return 0xFFFFFFFFu;
+        if (!b.init(src + 1 + h, isz - h)) return 0xFFFFFFFFu;
+        u32 s1 = b.read((int)tl), s2 = b.read((int)tl);
+        nsym = 0;
+        for (;;) {                                                       // FSE_decompress_usingDTable tail (fse_decompress.c:220-245)
+            if (nsym > 253) return 0xFFFFFFFFu;
+            w[nsym++] = L->wdt[s1].symbol; s1 = L->wdt[s1].newState + b.read(L->wdt[s1].nbBits);
+            if (b.pos < 0) { w[nsym++] = L->wdt[s2].symbol; break; }
+            if (nsym > 253) return 0xFFFFFFFFu;
+            w[nsym++] = L->wdt[s2].symbol; s2 = L->wdt[s2].newState + b.read(L->wdt[s2].nbBits);
+            if (b.pos < 0) { w[nsym++] = L->wdt[s1].symbol; break; }
+        }
+    }
+    for (u32 i = 0; i < nsym; ++i) { if (w[i] > 12) return 0xFFFFFFFFu; rank[w[i]]++; total += (1u << w[i]) >> 1; }
+    if (total == 0) return 0xFFFFFFFFu;
+    const u32 tableLog = (u32)hb(total) + 1;
+    if (tableLog > 12) return 0xFFFFFFFFu;
+    {   const u32 rest = (1u << tableLog) - total;
+        if ((1u << hb(rest)) != rest) return 0xFFFFFFFFu;
+        w[nsym] = (u8)(hb(rest) + 1); rank[w[nsym]]++; nsym++;
+    }
+    if (rank[1] < 2 || (rank[1] & 1)) return 0xFFFFFFFFu;
+    u32 start[14], cur = 0;
+    for (u32 wg = 1; wg <= tableLog; ++wg) { start[wg] = cur; cur += rank[wg] << (wg - 1); }
+    for (u32 i = 0; i < nsym; ++i) if (w[i]) {
+        const u32 len = 1u << (w[i] - 1), nb = tableLog + 1 - w[i];
+        const u16 cell = (u16)(i | (nb << 8));
+        for (u32 k = 0; k < len; ++k) L->huf[start[w[i]] + k] = cell;
+        start[w[i]] += len;
+    }
+    L->hufLog = tableLog;
+    return used;
+}
+// one Huffman stream, executed by ONE lane
+__device__ bool huf_decode_stream(u8* out, u32 nout, const u8* src, u32 n, const DecLds* L)
+{
+    BitR b; const int tl = (int)L->hufLog;
+    if (!b.init(src, n)) return false;
+    for (u32 i = 0; i < nout; ++i) {
+        const u32 cell = L->huf[b.peek(tl)];
+        out[i] = (u8)cell; b.pos -= (int)(cell >> 8);
+    }
+    return b.pos == 0;
+}
+
+// ZSTD_buildSeqTable (zstd_decompress_block.c:659-705); lane-serial
+__device__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
+                          const s16* defNorm, u32 defMax, u32 defLog, DecLds* L)
+{
+    if (mode == 0) {
+        for (u32 i = 0; i <= defMax; ++i) L->norm[i] = defNorm[i];
+        fse_build_dtable(dt, L->norm, defMax, defLog, L->next); *log = defLog; *have = 1; return true;
+    }
+    if (mode == 1) {
+        if (*ip >= iend || src[*ip] > maxSym) return false;
+        dt[0].symbol = src[*ip]; dt[0].nbBits = 0; dt[0].newState = 0; *log = 0; *have = 1; (*ip)++; return true;
+    }
+    if (mode == 2) {
+        u32 ms = maxSym, tl;
+        const u32 h = fse_read_ncount(L->norm, &ms, &tl, src + *ip, iend - *ip, maxLog);
+        if (h == 0xFFFFFFFFu) return false;
+        if (!fse_build_dtable(dt, L->norm, ms, tl, L->next)) return false;
+        *log = tl; *have = 1; *ip += h; return true;
+    }
+    return *have != 0;
+}
+
+// copy of `len` bytes inside dst from distance `offset` back (overlap allowed), whole wave
+__device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int lane)
+{
+    const u8* s = d - offset;
+    if (offset >= kWave) {
+        for (u32 r = 0; r < len; r += kWave) {
+            const u32 i = r + (u32)lane;
+            u8 v = 0;
+            if (i < len) v = s[i];
+            if (i < len) d[i] = v;
+            wave_fence();
+        }
+    } else {
+        u32 k = (u32)lane % offset; const u32 adv = kWave % offset;
+        for (u32 i = (u32)lane; i < len; i += kWave) { d[i] = s[k]; k += adv; if (k >= offset) k -= offset; }
+    }
+    wave_fence();
+}
+
+// one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
+__device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
+                            u8* litBuf, int lane)
+{
+    if (n < 1) return 0xFFFFFFFFu;
+    u32 ip = 0, litSize = 0; const u8* litPtr = nullptr;
+    {   // ---- literals (ZSTD_decodeLiteralsBlock :162-364) ----
+        const u32 b0 = src[0], type = b0 & 3, fmt = (b0 >> 2) & 3;
+        if (type < 2) {
+            u32 lh;
+            if (fmt == 0 || fmt == 2) { lh = 1; litSize = b0 >> 3; }
+            else if (fmt == 1) { if (n < 2) return 0xFFFFFFFFu; lh = 2; litSize = (b0 | ((u32)src[1] << 8)) >> 4; }
+            else { if (n < 3) return 0xFFFFFFFFu; lh = 3; litSize = (b0 | ((u32)src[1] << 8) | ((u32)src[2] << 16)) >> 4; }
+            if (litSize > blockMax) return 0xFFFFFFFFu;
+            if (type == 0) { if (lh + litSize > n) return 0xFFFFFFFFu; litPtr = src + lh; ip = lh + litSize; }
+            else {
+                if (lh + 1 > n) return 0xFFFFFFFFu;
+                const u8 v = src[lh];
+                for (u32 i = (u32)lane; i < litSize; i += kWave) litBuf[i] = v;
+                wave_fence();
+                litPtr = litBuf; ip = lh + 1;
+            }
+        } else {
+            u32 lh, csize; bool streams4 = true;
+            if (fmt < 2) { if (n < 3) return 0xFFFFFFFFu; const u32 v = b0 | ((u32)src[1] << 8) | ((u32)src[2] << 16); lh = 3; streams4 = (fmt == 1); litSize = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+            else if (fmt == 2) { if (n < 4) return 0xFFFFFFFFu; const u32 v = ld32(src); lh = 4; litSize = (v >> 4) & 0x3FFF; csize = v >> 18; }
+            else { if (n < 5) return 0xFFFFFFFFu; const u32 v = ld32(src); lh = 5; litSize = (v >> 4) & 0x3FFFF; csize = (v >> 22) + ((u32)src[4] << 10); }
+            if (litSize > blockMax || litSize == 0 || lh + csize > n) return 0xFFFFFFFFu;
+            u32 hoff = lh, hsz = csize;
+            if (type == 2) {
+                u32 used = 0;
+                if (lane == 0) used = huf_read_table(L, src + hoff, hsz);
+                wave_fence();
+                used = uni(used);
+                if (used == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+                if (lane == 0) L->haveHuf = 1;
+                hoff += used; hsz -= used;
+            } else if (!uni(L->haveHuf)) return 0xFFFFFFFFu;
+            wave_fence();
+            bool ok = true;
+            if (!streams4) { if (lane == 0) ok = huf_decode_stream(litBuf, litSize, src + hoff, hsz, L); }
+            else {
+                if (litSize < 6 || hsz < 10) return 0xFFFFFFFFu;
+                const u32 s1 = ld16(src + hoff), s2 = ld16(src + hoff + 2), s3 = ld16(src + hoff + 4), seg = (litSize + 3) / 4;
+                if (6 + s1 + s2 + s3 > hsz || 3 * seg > litSize) return 0xFFFFFFFFu;
+                const u32 s4 = hsz - 6 - s1 - s2 - s3;
+                if (lane < 4) {
+                    const u32 so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
+                    const u32 sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
+                    const u32 no = lane < 3 ? seg : litSize - 3 * seg;
+                    ok = huf_decode_stream(litBuf + (u32)lane * seg, no, src + hoff + 6 + so, sl, L);
+                }
+            }
+            if (ballot(!ok) != 0) return 0xFFFFFFFFu;
+            wave_fence();
+            litPtr = litBuf; ip = lh + csize;
+        }
+    }
+    // ---- sequences header (ZSTD_decodeSeqHeaders :707-790) ----
+    if (ip >= n) return 0xFFFFFFFFu;
+    u32 nbSeq = src[ip++];
+    if (nbSeq > 0x7F) {
+        if (nbSeq == 0xFF) { if (ip + 2 > n) return 0xFFFFFFFFu; nbSeq = ld16(src + ip) + 0x7F00; ip += 2; }
+        else { if (ip >= n) return 0xFFFFFFFFu; nbSeq = ((nbSeq - 0x80) << 8) + src[ip++]; }
+    }
+    u32 out = opos, litPos = 0;
+    if (nbSeq == 0) { if (ip != n) return 0xFFFFFFFFu; }
+    else {
+        if (ip >= n) return 0xFFFFFFFFu;
+        const u32 modes = src[ip++];
+        if (modes & 3) return 0xFFFFFFFFu;
+        u32 okT = 1, ipT = ip;
+        if (lane == 0) {
+            okT = seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ipT, n, 35, 9, kLLnorm, 35, 6, L)
+               && seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ipT, n, 31, 8, kOFnorm, 28, 5, L)
+               && seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ipT, n, 52, 9, kMLnorm, 52, 6, L);
+        }
+        wave_fence();
+        okT = uni(okT); ip = uni(ipT);
+        if (!okT) return 0xFFFFFFFFu;
+        // lane 0 decodes 64 sequences (ZSTD_decodeSequence :1339-1460), the wave executes them (:1007-1108)
+        BitR b; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
+        if (lane == 0) {
+            okB = b.init(src + ip, n - ip) ? 1u : 0u;
+            if (okB) { sLL = b.read((int)L->llLog); sOF = b.read((int)L->ofLog); sML = b.read((int)L->mlLog); if (b.pos < 0) okB = 0; }
+        }
+        if (!uni(okB)) return 0xFFFFFFFFu;
+        for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
+            const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
+            u32 okS = 1;
+            if (lane == 0) {
+                for (u32 k = 0; k < cnt; ++k) {
+                    const FseD dl = L->ll[sLL], dof = L->of[sOF], dm = L->ml[sML];
+                    const u32 llc = dl.symbol, ofc = dof.symbol, mlc = dm.symbol;
+                    if (ofc > 31) { okS = 0; break; }
+                    const u32 ofv = (1u << ofc) + b.read((int)ofc);
+                    const u32 ml = kMLbase[mlc] + b.read(kMLbits[mlc]);
+                    const u32 ll = kLLbase[llc] + b.read(kLLbits[llc]);
+                    u32 offset;
+                    if (ofv > 3) { offset = ofv - 3; L->rep[2] = L->rep[1]; L->rep[1] = L->rep[0]; L->rep[0] = offset; }
+                    else {
+                        const u32 idx = ofv - 1 + (ll == 0);
+                        if (idx == 0) offset = L->rep[0];
+                        else {
+                            u32 t = (idx == 3) ? L->rep[0] - 1 : L->rep[idx];
+                            t += !t;
+                            if (idx != 1) L->rep[2] = L->rep[1];
+                            L->rep[1] = L->rep[0]; L->rep[0] = t; offset = t;
+                        }
+                    }
+                    if (q0 + k + 1 < nbSeq) {
+                        sLL = dl.newState + b.read(dl.nbBits);
+                        sML = dm.newState + b.read(dm.nbBits);
+                        sOF = dof.newState + b.read(dof.nbBits);
+                    }
+                    L->seqLL[k] = ll; L->seqML[k] = ml; L->seqOff[k] = offset;
+                }
+            }
+            wave_fence();
+            if (!uni(okS)) return 0xFFFFFFFFu;
+            // execute: prefix sums give every sequence its literal source and its output position
+            u32 ll = 0, ml = 0, off = 0;
+            if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
+            u32 incL = ll, incO = ll + ml;
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 tl = __shfl_up(incL, d), to = __shfl_up(incO, d);
+                if (lane >= d) { incL += tl; incO += to; }
+            }
+            const u32 totL = lane_get(incL, 63), totO = lane_get(incO, 63);
+            if (totL > litSize - litPos) return 0xFFFFFFFFu;
+            if ((u64)out + totO > cap || (u64)(out - opos) + totO > blockMax) return 0xFFFFFFFFu;
+            const u32 myLit = litPos + incL - ll, myOut = out + incO - (ll + ml);
+            // offsets must point inside what is already produced
+            if (ballot((u32)lane < cnt && off > myOut + ll) != 0) return 0xFFFFFFFFu;
+            for (u32 i = 0; i < ll; ++i) dst[myOut + i] = litPtr[myLit + i];     // literals: one sequence per lane
+            wave_fence();
+            for (u32 k = 0; k < cnt; ++k) {                                      // matches: in order, 64 lanes each
+                const u32 mo = lane_get(myOut, (int)k) + lane_get(ll, (int)k);
+                wave_match_copy(dst + mo, lane_get(off, (int)k), lane_get(ml, (int)k), lane);
+            }
+            litPos += totL; out += totO;
+        }
+        u32 endOk = 1;
+        if (lane == 0) endOk = b.pos <= 0 ? 1u : 0u;                             // bitstream fully consumed
+        if (!uni(endOk)) return 0xFFFFFFFFu;
+    }
+    const u32 rest = litSize - litPos;
+    if ((u64)out + rest > cap || (u64)(out - opos) + rest > blockMax) return 0xFFFFFFFFu;
+    wave_copy(dst + out, litPtr + litPos, rest, lane);
+    wave_fence();
+    out += rest;
+    return out - opos;
+}
+
+__device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8* dst, const u32 cap, DecLds* L,
+                                    u8* litBuf, int lane)
+{
+    u32 ip = 0, op = 0;
+    if (n == 0) return cap == 0 ? 0 : -1;
+    while (ip < n) {
+        if (n - ip < 4) return -1;
+        const u32 magic = ld32(src + ip);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                              // skippable frame
+            if (n - ip < 8) return -1;
+            const u32 sz = ld32(src + ip + 4);
+            if ((u64)sz + 8 > n - ip) return -1;
+            ip += 8 + sz; continue;
+        }
+        if (magic != 0xFD2FB528u) return -1;
+        if (n - ip < 5) return -1;
+        const u32 fhd = src[ip + 4]; ip += 5;                                    // ZSTD_getFrameHeader_advanced :438-560
+        const u32 fcsId = fhd >> 6, single = (fhd >> 5) & 1, hasCk = (fhd >> 2) & 1, dictIdSz = fhd & 3;
+        if (fhd & 0x08) return -1;
+        u64 windowSize = 0, fcs = 0; bool haveFcs = false;
+        if (!single) {
+            if (ip >= n) return -1;
+            const u32 wb = src[ip++], wl = (wb >> 3) + 10;
+            if (wl > 31) return -1;
+            windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wb & 7);
+        }
+        {   const u32 dsz = dictIdSz == 3 ? 4 : dictIdSz; u32 id = 0;
+            if (n - ip < dsz) return -1;
+            for (u32 k = 0; k < dsz; ++k) id |= (u32)src[ip + k] << (8 * k);
+            ip += dsz;
+            if (id != 0) return -1;                                              // no dictionary support
+        }
+        if (fcsId == 0) { if (single) { if (ip >= n) return -1; fcs = src[ip++]; haveFcs = true; } }
+        else if (fcsId == 1) { if (n - ip < 2) return -1; fcs = (u64)ld16(src + ip) + 256; ip += 2; haveFcs = true; }
+        else if (fcsId == 2) { if (n - ip < 4) return -1; fcs = ld32(src + ip); ip += 4; haveFcs = true; }
+        else { if (n - ip < 8) return -1; fcs = ld64(src + ip); ip += 8; haveFcs = true; }
+        if (single) windowSize = fcs;
+        const u32 frameStart = op;
+        if (lane == 0) { L->rep[0] = 1; L->rep[1] = 4; L->rep[2] = 8; L->haveLL = L->haveOF = L->haveML = L->haveHuf = 0; }
+        wave_fence();
+        const u32 blockMax = windowSize < kBlockMax ? (u32)windowSize : kBlockMax;
+        for (;;) {                                                               // ZSTD_decompressFrame :1005-1111
+            if (n - ip < 3) return -1;
+            const u32 bh = src[ip] | ((u32)src[ip + 1] << 8) | ((u32)src[ip + 2] << 16); ip += 3;
+            const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+            if (type == 3) return -1;
+            if (type == 1) {
+                if (ip >= n || bsz > cap - op || bsz > blockMax) return -1;
+                const u8 v = src[ip];
+                for (u32 i = (u32)lane; i < bsz; i += kWave) dst[op + i] = v;
+                wave_fence();
+                ip += 1; op += bsz;
+            } else if (type == 0) {
+                if (bsz > n - ip || bsz > cap - op || bsz > blockMax) return -1;
+                wave_copy(dst + op, src + ip, bsz, lane);
+                wave_fence();
+                ip += bsz; op += bsz;
+            } else {
+                if (bsz > n - ip || bsz > kBlockMax) return -1;
+                const u32 r = decode_block(L, src + ip, bsz, dst + frameStart, op - frameStart, cap - frameStart, blockMax, litBuf, lane);
+                if (r == 0xFFFFFFFFu) return -1;
+                ip += bsz; op += r;
+            }
+            if (last) break;
+        }
+        if (haveFcs && (u64)(op - frameStart) != fcs) return -1;
+        if (hasCk) { if (n - ip < 4) return -1; ip += 4; }                       // content checksum present: skipped, not verified
+    }
+    return (int)op;
+}
+
 }  // namespace
 
 __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
@@ -559,6 +1013,19 @@ __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint
     for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
         const int r = zstd_compress_wave(v.src, v.src_len, v.dst, v.dst_cap, lds, ldsBytes, ws, lane);
+        if (lane == 0) b.out_len[c] = r;
+        wave_fence();
+    }
+}
+
+__global__ void __launch_bounds__(64) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase)
+{
+    __shared__ DecLds L;
+    uint8_t* litBuf = litBase + (size_t)blockIdx.x * (kBlockMax + 64);
+    const int lane = lane_id();
+    for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
+        const ChunkView v = decompress_view(b, c);
+        const int r = zstd_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, &L, litBuf, lane);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -632,8 +1099,15 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
     return AOCLGPU_OK;
 }
 
-extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch*, void*)
+extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream)
 {
-    aoclgpu::set_error_msg("zstd decompress: not implemented");
-    return AOCLGPU_ERR_ARG;
+    if (int rc = aoclgpu::check_batch(b, true)) return rc;
+    if (b->nchunks == 0) return AOCLGPU_OK;
+    uint32_t grid = 256u * 8u;
+    if (grid > b->nchunks) grid = b->nchunks;
+    // the decoder's literal buffers share the workspace pool with the compressor's (same stream order)
+    void* ws = get_workspace((size_t)grid * ((128u << 10) + 64));
+    if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+    hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws);
+    return aoclgpu::check_launch("zstd_decompress_kernel");
 }

@@ -65,3 +65,73 @@ def test_special_inputs(eng, oracle):
 def test_small_output_buffer_fails(eng):
     raw = a.corpus.make("text", 5000, seed=3).tobytes()
     assert eng.compress_host(a.ZSTD, raw, a.compress_bound(a.ZSTD, len(raw)) - 1) is None
+
+
+@pytest.mark.parametrize("kind", list(a.corpus.KINDS))
+@pytest.mark.parametrize("chunk", [131072, 16384])
+def test_round_trip(eng, kind, chunk):
+    data = a.corpus.make(kind, (1 << 20) + 555, seed=14)
+    src = torch.from_numpy(data).to(eng.device)
+    slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk)
+    dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, len(data), chunk)
+    assert torch.equal(dst, src)
+    assert dl.cpu().tolist() == [len(p) for p in _chunks(data.tobytes(), chunk)]
+
+
+def test_decode_reference_frames(eng, ref):
+    """Frames produced by the real reference at several levels (multi-block, other strategies) decode on the GPU."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    pools = {k: a.corpus.make(k, 1 << 20, seed=6).tobytes() for k in ("text", "jsonlog", "binary", "database", "image16")}
+    ref.L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    for it in range(60):
+        k = list(pools)[it % len(pools)]
+        size = int(rng.choice([0, 1, 100, 5000, 70000, 131072, 300000, 600000]))
+        off = int(rng.integers(0, len(pools[k]) - size))
+        raw = pools[k][off:off + size]
+        level = int(rng.choice([1, 1, 3, 5, 9, 19, -3]))
+        out = C.create_string_buffer(len(raw) + len(raw) // 200 + 1024)
+        r = ref.L.ZSTD_compress(out, len(out), raw, len(raw), level)
+        assert eng.decompress_host(a.ZSTD, out.raw[:r], max(len(raw), 1)) == raw, (k, size, level)
+
+
+def test_decode_malformed(eng, oracle):
+    rng = np.random.default_rng(9)
+    raw = a.corpus.make("text", 90000, seed=4).tobytes()
+    comp = oracle.compress(ol.ZSTD, raw)
+    assert eng.decompress_host(a.ZSTD, comp, len(raw)) == raw
+    assert eng.decompress_host(a.ZSTD, comp, len(raw) - 1) is None
+    assert eng.decompress_host(a.ZSTD, comp[:-3], len(raw)) is None
+    assert eng.decompress_host(a.ZSTD, b"\x00\x01\x02\x03\x04", 64) is None
+    for it in range(150):
+        c = bytearray(comp)
+        for _ in range(1 + it % 3):
+            c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
+        want = oracle.decompress(ol.ZSTD, bytes(c), len(raw))
+        got = eng.decompress_host(a.ZSTD, bytes(c), len(raw))
+        assert got == want, it
+
+
+def test_llc_api(eng, oracle):
+    raw = a.corpus.make("text", 131072, seed=1).tobytes()      # BASELINE config 4 block
+    cap = a.compress_bound(a.ZSTD, len(raw))
+    r, out, d = eng.llc_compress(a.ZSTD, raw, cap, level=1, stats=True)
+    assert r == len(out) and out == oracle.compress(ol.ZSTD, raw) and d.cSize == r
+    r2, back, _ = eng.llc_decompress(a.ZSTD, out, len(raw))
+    assert r2 == len(raw) and back == raw
+    assert eng.llc_decompress(a.ZSTD, out[:50], len(raw))[0] == -2
+    assert eng.llc_compress(a.ZSTD, b"", 64)[0] == 9           # api_gtest.cpp:638-673: inSize 0 -> > 0
+
+
+def test_full_size_round_trip(eng):
+    """BASELINE config 4 size: 8 GiB of 128 KiB blocks -- round trip on device."""
+    base = torch.from_numpy(a.corpus.silesia_mix(48 << 20, seed=0xA0C4)).to(eng.device)
+    total = 8 << 30
+    reps = -(-total // base.numel())
+    src = base.repeat(reps)[:total].contiguous()
+    chunk = 131072
+    slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk)
+    assert int((out_len <= 0).sum().item()) == 0
+    dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, total, chunk)
+    assert int((dl != chunk).sum().item()) == 0
+    assert torch.equal(dst, src)
