@@ -12,9 +12,9 @@ over ranks (weak scaling: every rank owns `--gib` GiB), using the max-over-ranks
 The per-direction rates are reported next to it (compress_GiBps / decompress_GiBps).
 
 Extra objects on the JSON line: `roofline` (dominant kernel vs the 8 TB/s HBM peak; live HIP-event
-timing of that kernel on its own stream) and `cpu_baseline` (the real reference's LZ4_compress_default /
-LZ4_decompress_safe -- oracle/_ref -- or, if that prebuilt library is absent, this repo's C port, timed
-on the host cores over a bounded sample of the same chunks; rank 0, N=1 only).
+timing of that kernel on its own stream) and `cpu_baseline` (the real reference's one-shot functions --
+oracle/_ref -- or, if that prebuilt library is absent, this repo's C port, timed on the host cores over a
+bounded sample of the same chunks; rank 0, N=1 only).  `--codec snappy|zstd` runs BASELINE configs 3 / 4.
 """
 from __future__ import annotations
 
@@ -50,18 +50,22 @@ def parse():
     return p.parse_args()
 
 
+REF_FUNCS = {"lz4": ("LZ4_compress_default", "LZ4_decompress_safe"), "snappy": ("snappy_compress", "snappy_uncompress"),
+             "zstd": ("ZSTD_compress", "ZSTD_decompress")}
+
+
 def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib):
     """Time the reference CPU path over the first `sample_gib` GiB of the same chunk stream."""
     import numpy as np
     import oracle_lib as ol
-    if codec_name != "lz4":
-        return None
+    codec = CODECS[codec_name][0]
     orc = ol.Oracle()
     kind, fc, fd = "port", None, None
+    cname, dname = REF_FUNCS[codec_name]
     if os.path.exists(ol.REF_SO):
         ref = C.CDLL(ol.REF_SO)
-        fc = C.cast(ref.LZ4_compress_default, C.c_void_p)
-        fd = C.cast(ref.LZ4_decompress_safe, C.c_void_p)
+        fc = C.cast(getattr(ref, cname), C.c_void_p)
+        fd = C.cast(getattr(ref, dname), C.c_void_p)
         kind = "reference"
     n = int(min(total, sample_gib * GIB)) // chunk * chunk
     reps = -(-n // len(base_np))
@@ -72,15 +76,15 @@ def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib):
     back = np.empty(n, np.uint8)
     cores = os.cpu_count() or 1
     L = orc.L
-    L.orc_lz4_compress_chunks_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
-                                             C.c_void_p, C.c_int]
-    L.orc_lz4_decompress_chunks_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
-                                               C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_compress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_int]
+    L.orc_decompress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_size_t, C.c_size_t, C.c_int]
     t0 = time.perf_counter()
-    fails = L.orc_lz4_compress_chunks_fn(fc, sample.ctypes.data, n, chunk, dst.ctypes.data, slot, out_len.ctypes.data, cores)
+    fails = L.orc_compress_chunks_fn(codec, fc, sample.ctypes.data, n, chunk, dst.ctypes.data, slot, out_len.ctypes.data, cores)
     t1 = time.perf_counter()
-    fails += L.orc_lz4_decompress_chunks_fn(fd, dst.ctypes.data, slot, out_len.ctypes.data, nchunks, back.ctypes.data,
-                                            chunk, n, cores)
+    fails += L.orc_decompress_chunks_fn(codec, fd, dst.ctypes.data, slot, out_len.ctypes.data, nchunks, back.ctypes.data,
+                                        chunk, n, cores)
     t2 = time.perf_counter()
     assert fails == 0 and np.array_equal(back, sample)
     tc, td = t1 - t0, t2 - t1
@@ -88,7 +92,7 @@ def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib):
         "value": round(n / GIB / (tc + td), 3), "unit": "GiB/s", "cores": cores, "kind": kind,
         "compress_GiBps": round(n / GIB / tc, 3), "decompress_GiBps": round(n / GIB / td, 3),
         "sample": f"first {n / GIB:.2f} GiB of the same {chunk // 1024} KiB chunk stream, "
-                  f"LZ4_compress_default + LZ4_decompress_safe, OpenMP over chunks on {cores} host threads",
+                  f"{cname} + {dname}, OpenMP over chunks on {cores} host threads",
     }, out_len
 
 
@@ -119,7 +123,12 @@ def main():
     slot = (a.compress_bound(codec, chunk) + 15) & ~15
 
     # ---- synthetic "Silesia concatenated to N GiB", resident in HBM; every rank gets a different rotation ----
-    base_np = a.corpus.silesia_mix(int(args.base_mib * (1 << 20)), seed=0xA0C1)
+    if args.codec == "snappy":     # BASELINE config 3: JSON/log-style data
+        base_np = a.corpus.make("jsonlog", int(args.base_mib * (1 << 20)), seed=0xA0C3)
+        corpus_name = "synthetic JSON/log records"
+    else:                           # configs 2 / 4: Silesia-shaped mix
+        base_np = a.corpus.silesia_mix(int(args.base_mib * (1 << 20)), seed=0xA0C1)
+        corpus_name = "synthetic Silesia-shaped corpus"
     base = torch.from_numpy(base_np).to(dev)
     shift = (rank * 7919 * 4096) % base.numel()
     if shift:
@@ -213,8 +222,8 @@ def main():
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": f"{args.codec} level-1, {chunk // 1024} KiB independent chunks, synthetic Silesia-shaped "
-                            f"corpus ({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
+                "workload": f"{args.codec} level-1, {chunk // 1024} KiB independent chunks, {corpus_name} "
+                            f"({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
                 "codec": args.codec, "chunk_bytes": chunk, "chunks_per_gpu": nchunks, "gib_per_gpu": args.gib,
                 "step": "compress" + (" -> compact -> RCCL all-gather of compressed segments" if world > 1 else "")
                         + " -> decompress",

@@ -217,46 +217,3 @@ int orc_lz4_decompress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap
     return (int)op;
 }
 
-/* ---- chunked drivers (OpenMP over independent chunks; the decomposition of the reference's RAP loop,
- *      lz4.c:2684-2731).  `fn` lets bench.py time the REAL reference's one-shot function (passed in as a
- *      function pointer taken from oracle/_ref/libaocl_ref.so) under the same driver as the port. ---- */
-#include <omp.h>
-typedef int (*lz4_comp_fn)(const char*, char*, int, int);
-typedef int (*lz4_decomp_fn)(const char*, char*, int, int);
-
-static int lz4_comp_port(const char* s, char* d, int n, int cap) { return orc_lz4_compress((const uint8_t*)s, n, (uint8_t*)d, cap); }
-static int lz4_decomp_port(const char* s, char* d, int n, int cap) { return orc_lz4_decompress((const uint8_t*)s, n, (uint8_t*)d, cap); }
-
-int orc_lz4_compress_chunks_fn(void* fn, const uint8_t* src, size_t n, size_t chunk,
-                               uint8_t* dst, size_t slot, int32_t* out_len, int threads)
-{
-    lz4_comp_fn f = fn ? (lz4_comp_fn)fn : lz4_comp_port;
-    const long nchunks = n ? (long)((n + chunk - 1) / chunk) : 1;
-    int fails = 0;
-    if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+:fails)
-    for (long i = 0; i < nchunks; i++) {
-        const size_t o = (size_t)i * chunk;
-        const size_t len = (n - o < chunk) ? n - o : chunk;
-        const int r = f((const char*)src + o, (char*)dst + (size_t)i * slot, (int)len, (int)slot);
-        out_len[i] = r;
-        if (r <= 0) fails++;
-    }
-    return fails;
-}
-
-int orc_lz4_decompress_chunks_fn(void* fn, const uint8_t* src, size_t slot, const int32_t* in_len, size_t nchunks,
-                                 uint8_t* dst, size_t chunk, size_t n, int threads)
-{
-    lz4_decomp_fn f = fn ? (lz4_decomp_fn)fn : lz4_decomp_port;
-    int fails = 0;
-    if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+:fails)
-    for (long i = 0; i < (long)nchunks; i++) {
-        const size_t o = (size_t)i * chunk;
-        const size_t len = (n - o < chunk) ? n - o : chunk;
-        const int r = f((const char*)src + (size_t)i * slot, (char*)dst + o, in_len[i], (int)len);
-        if (r != (int)len) fails++;
-    }
-    return fails;
-}
