@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every symbol the headers in include/ declare; host-side
+argument checks and pure arithmetic work on CPU; compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import aocl_compression_amd as a
+from aocl_compression_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = set()
+    for h in ("aocl_gpu_codec.h", "aocl_compression.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(aoclgpu_[a-z0-9_]+|aocl_llc_[a-z_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = api.load_library()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert set(api.EXPORTS) <= declared | {"aoclgpu_time_batch"}
+
+
+def test_versions_and_bounds():
+    lib = api.load_library()
+    assert lib.aocl_llc_version().startswith(b"AOCL-Compression 4.2.0")
+    for n in (0, 1, 1000, 65536, 131072, 262144, 1 << 20):
+        for codec in (a.LZ4, a.SNAPPY, a.ZSTD):
+            assert lib.aoclgpu_compress_bound(codec, n) == a.compress_bound(codec, n)
+    assert a.compress_bound(a.LZ4, 262144) == 263188 and a.compress_bound(a.SNAPPY, 65536) == 76490
+
+
+def test_struct_layouts_match_the_reference_abi():
+    # aocl_compression_desc on LP64 (api/aocl_compression.h:125-152): 3 pointers, 4 size_t, 2 int, size_t, int, 4 u64, 2 float, 2 int
+    assert C.sizeof(api.LlcDesc) == 128
+    assert api.LlcDesc.inSize.offset == 24 and api.LlcDesc.measureStats.offset == 72 and api.LlcDesc.cSize.offset == 80
+    assert api.LlcDesc.optOff.offset == 120
+    assert C.sizeof(api.Batch) == 88
+
+
+def test_argument_checks_without_gpu():
+    lib = api.load_library()
+    assert lib.aoclgpu_lz4_compress_chunks(None, None) == -1            # AOCLGPU_ERR_ARG
+    b = api.Batch(nchunks=3, total_bytes=10, chunk_bytes=4)            # NULL buffers
+    assert lib.aoclgpu_snappy_compress_chunks(C.byref(b), None) == -1
+    assert b"NULL" in lib.aoclgpu_last_error()
+    d = api.LlcDesc()
+    assert lib.aocl_llc_setup(C.byref(d), 99) == -4                    # ERR_UNSUPPORTED_METHOD (api/api.cpp:133-138)
+    assert lib.aocl_llc_setup(C.byref(d), 1) == -3                     # LZ4HC: ERR_EXCLUDED_METHOD (no backend)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    with pytest.raises(api.EngineError):
+        api.Engine(0)
+    lib = api.load_library()
+    d = api.LlcDesc()
+    buf = C.create_string_buffer(b"hello", 5)
+    out = C.create_string_buffer(64)
+    d.inBuf = C.cast(buf, C.c_void_p); d.inSize = 5; d.outBuf = C.cast(out, C.c_void_p); d.outSize = 64
+    assert lib.aocl_llc_compress(C.byref(d), 0) == -2                  # ERR_COMPRESSION_FAILED, never a silent CPU path

@@ -1,0 +1,94 @@
+"""Pins the C oracle against the REAL reference compiled in place (oracle/_ref).  Skipped where neither the
+prebuilt library nor /root/reference exists."""
+import random
+
+import numpy as np
+import pytest
+
+import aocl_compression_amd as a
+import oracle_lib as ol
+
+CODECS = [ol.LZ4, ol.SNAPPY, ol.ZSTD]
+SIZES = [0, 1, 6, 7, 12, 13, 14, 15, 16, 19, 20, 21, 63, 64, 65, 255, 256, 257, 1000, 1024, 4096, 16383, 16384, 16385, 40000,
+         65535, 65536, 65546, 65547, 65548, 100000, 131071, 131072]
+
+
+@pytest.mark.parametrize("kind", list(a.corpus.KINDS))
+def test_compress_bit_exact(oracle, ref, kind):
+    d = a.corpus.make(kind, 1 << 20, seed=31).tobytes()
+    for codec in CODECS:
+        for size in SIZES + ([262144, 1 << 20] if codec != ol.ZSTD else []):
+            for off in (0, 4321):
+                raw = d[off:off + size]
+                got, want = oracle.compress(codec, raw), ref.compress(codec, raw)
+                assert got == want, (codec, size, off)
+                assert oracle.decompress(codec, got, max(len(raw), 1)) == raw
+
+
+def test_special_inputs(oracle, ref):
+    rng = np.random.default_rng(5)
+    cases = [bytes(131072), b"\xff" * 70000, bytes(range(256)) * 512, b"ab" * 50000, b"abc" * 40000,
+             rng.integers(0, 256, 131072, dtype=np.uint8).tobytes(), rng.integers(0, 2, 131072, dtype=np.uint8).tobytes(),
+             rng.integers(0, 16, 131072, dtype=np.uint8).tobytes(),
+             rng.integers(0, 256, 40942, dtype=np.uint8).tobytes() + a.corpus.make("text", 40942, seed=8).tobytes()]
+    for raw in cases:
+        for codec in CODECS:
+            assert oracle.compress(codec, raw) == ref.compress(codec, raw)
+
+
+def test_lz4_limited_output(oracle, ref):
+    raw = a.corpus.make("jsonlog", 65536, seed=3).tobytes()
+    full = ref.compress(ol.LZ4, raw)
+    for cap in [len(full) + 20, len(full) + 1, len(full), len(full) - 1, len(full) // 2, 16, 1, 0]:
+        assert oracle.compress(ol.LZ4, raw, cap) == ref.compress(ol.LZ4, raw, cap), cap
+
+
+def test_random_slices_zstd(oracle, ref):
+    rng = random.Random(7)
+    pools = {k: a.corpus.make(k, 2 << 20, seed=99).tobytes() for k in a.corpus.KINDS}
+    for it in range(300):
+        k = rng.choice(list(pools))
+        size = rng.choice([rng.randrange(1, 300), rng.randrange(300, 20000), rng.randrange(20000, 131073)])
+        off = rng.randrange(0, len(pools[k]) - size)
+        raw = pools[k][off:off + size]
+        if rng.random() < 0.2:
+            k2 = rng.choice(list(pools))
+            raw = raw[:size // 2] + pools[k2][off:off + size - size // 2]
+        assert oracle.compress(ol.ZSTD, raw) == ref.compress(ol.ZSTD, raw), (k, size, off)
+
+
+@pytest.mark.parametrize("codec", CODECS)
+def test_decoder_on_mutated_streams(oracle, ref, codec):
+    """Whatever the oracle accepts, the reference accepts with identical bytes (the oracle is at least as strict)."""
+    rng = random.Random(codec)
+    stricter = 0
+    for it in range(400):
+        n = rng.choice([50, 300, 5000, 70000])
+        base = a.corpus.make(rng.choice(["text", "jsonlog", "binary"]), n, seed=it).tobytes()
+        c = bytearray(ref.compress(codec, base))
+        for _ in range(rng.randint(1, 3)):
+            c[rng.randrange(len(c))] = rng.randrange(256)
+        if rng.random() < 0.2:
+            c = c[:rng.randrange(1, len(c) + 1)]
+        cap = n + 64
+        x, y = oracle.decompress(codec, bytes(c), cap), ref.decompress(codec, bytes(c), cap)
+        if x is not None:
+            assert y == x, it
+        elif y is not None:
+            stricter += 1
+    if codec != ol.ZSTD:
+        assert stricter == 0     # LZ4 / Snappy: identical accept set on this fuzz corpus
+
+
+def test_decode_foreign_zstd_frames(oracle, ref):
+    import ctypes as C
+    rng = random.Random(3)
+    pool = a.corpus.make("text", 1 << 20, seed=6).tobytes()
+    ref.L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    for it in range(40):
+        size = rng.choice([0, 1, 100, 5000, 70000, 131072, 300000, 600000])
+        off = rng.randrange(0, len(pool) - size)
+        raw = pool[off:off + size]
+        out = C.create_string_buffer(len(raw) + len(raw) // 200 + 1024)
+        r = ref.L.ZSTD_compress(out, len(out), raw, len(raw), rng.choice([1, 3, 5, 9, 19, -3]))
+        assert oracle.decompress(ol.ZSTD, out.raw[:r], max(len(raw), 1)) == raw
