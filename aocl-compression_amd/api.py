@@ -136,7 +136,8 @@ class Engine:
         nchunks = max(1, -(-n // chunk_bytes))
         assert slots.numel() >= nchunks * slot_bytes and out_len.numel() >= nchunks
         return Batch(src=src.data_ptr(), dst=slots.data_ptr(), out_len=out_len.data_ptr(), nchunks=nchunks,
-                     total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes)
+                     total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes,
+                     reserved=int(os.environ.get("AOCLGPU_EXPERIMENT", "0")))
 
     def uniform_decompress_batch(self, slots, comp_len, slot_bytes: int, dst, chunk_bytes: int, out_len) -> Batch:
         n = int(dst.numel())

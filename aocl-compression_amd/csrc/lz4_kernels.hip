@@ -56,130 +56,222 @@ __device__ __forceinline__ uint32_t put_len_bytes(uint8_t* d, uint32_t rem, int 
     return nff + 1;
 }
 
-template <bool U16>
+__device__ unsigned long long g_lz4_prof[8];
+
+// 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
+struct Win { uint64_t lo, hi; };
+__device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_t p)
+{
+    Win w;
+    w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
+    w.hi = ld64(src + p + 4);
+    return w;
+}
+
+template <bool U16, bool PROF>
 __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t n,
-                                 uint8_t* __restrict__ dst, const uint32_t cap, void* lds)
+                                 uint8_t* __restrict__ dst, const uint32_t cap, void* lds, const uint32_t expf)
 {
     using T = typename std::conditional<U16, uint16_t, uint32_t>::type;
     T* table = reinterpret_cast<T*>(lds);
     const int lane = lane_id();
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (PROF) tprev = __builtin_amdgcn_s_memtime();
+#define STAGE(k) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[k] += t_ - tprev; tprev = t_; } } while (0)
 
-    // LZ4_initStream: zero-filled table (lz4.c:2519).  The "first byte" insert (:1443) stores 0 -> no-op.
-    for (uint32_t i = (uint32_t)lane; i < kTableBytes / 16; i += kWave)
-        reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+    // Table entries of the u32 table carry, above the position, a few "check" bits derived from the 4 bytes at
+    // that position.  They never change a decision (a probe whose check bits differ cannot pass the 4-byte test);
+    // they only spare the 64 speculative lanes a cache-line fetch each for candidates that cannot match.
+    // posBits = bits needed for a position of this chunk; an empty slot aliases position 0 exactly as in the
+    // reference's zero-filled table (lz4.c:2519), so the table is filled with entry(0).
+    const uint32_t posBits = U16 ? 16u : (32u - (uint32_t)__builtin_clz(n - 1));
+    const uint32_t posMask = U16 ? 0xFFFFu : ((posBits >= 32) ? 0xFFFFFFFFu : ((1u << posBits) - 1));
+    auto chk = [&](uint32_t v4) -> uint32_t { return U16 ? 0u : (((v4 * 2654435761u) >> posBits) << posBits); };
+    {
+        const uint32_t e0 = (n >= 4) ? chk(ld32(src)) : 0u;
+        const uint32_t fill = U16 ? 0u : e0;
+        for (uint32_t i = (uint32_t)lane; i < kTableBytes / 16; i += kWave)
+            reinterpret_cast<uint4*>(lds)[i] = make_uint4(fill, fill, fill, fill);
+    }
     wave_fence();
 
     const bool limited = cap < lz4_bound(n);              // lz4.c:2522
+    const bool do_st = !(expf & 1);                       // experiment: suppress per-sequence stores (timing only)
     const uint32_t mfl1 = n - kMfLimit + 1;               // mflimitPlusOne
     const uint32_t matchlimit = n - kLastLiterals;
     uint32_t ip = 1, anchor = 0, op = 0;
     bool extra = false;                                   // next batch starts with the post-match probe
+    // software pipeline: the probe windows of the NEXT search's first batch (and the ip-2 back-fill bytes) are
+    // requested as soon as the current match length is known, ahead of the table commit and the emission
+    bool have_pre = false; Win pre = {0, 0}; uint64_t pre_fill = 0;
 
     if (n >= kMinLength) {
+        uint32_t i0 = 0;                                  // probes of the current search already examined
         for (;;) {
-            // ---------------- search (lz4.c:1483-1608, 1746-1804) ----------------
+            // ---------------- one batch of 64 speculative probes (lz4.c:1483-1608, 1746-1804) ----------------
             const uint32_t base = extra ? ip + 1 : ip;
-            if (extra) {                                  // back-fill ip-2 (lz4.c:1750)
-                const uint32_t h2 = lz4_hash<U16>(ld64(src + ip - 2));
-                if (lane == 0) table[h2] = (T)(ip - 2);
+            const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
+            const uint32_t pos = (j < 0) ? ip : base + sched((uint32_t)j);
+            const bool valid = base + sched((uint32_t)(j + 1)) <= mfl1;         // lz4.c:1513
+            // 16-byte windows [p-4, p+12) around the probe and around its candidate: the 4 bytes of the match
+            // test, 4 bytes of catch-up and 8 bytes of forward extension arrive in one round trip
+            Win pw = {0, 0};
+            if (i0 == 0 && have_pre) pw = pre;
+            else if (valid) pw = load_win(src, pos);
+            if (extra && i0 == 0) {                       // back-fill ip-2 (lz4.c:1750) before the batch reads the table
+                const uint64_t fb = have_pre ? pre_fill : ld64(src + ip - 2);
+                const uint32_t h2 = lz4_hash<U16>(fb);
+                if (lane == 0) table[h2] = (T)((ip - 2) | chk((uint32_t)fb));
                 wave_fence();
             }
-            uint32_t i0 = 0, m_pos = 0, m_cand = 0;
-            bool found = false;
-            for (;;) {
-                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-                const uint32_t pos = (j < 0) ? ip : base + sched((uint32_t)j);
-                const bool valid = base + sched((uint32_t)(j + 1)) <= mfl1;     // lz4.c:1513
-                uint64_t seq = 0;
-                if (valid) seq = ld64(src + pos);
-                const uint32_t h = lz4_hash<U16>(seq);
-                uint32_t cand = 0;
-                if (valid) cand = table[h];
-                uint32_t m4 = ~(uint32_t)seq;
-                if (valid) m4 = ld32(src + cand);
-                // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
+            have_pre = false;
+            STAGE(0);
+            const uint64_t seq = (pw.lo >> 32) | (pw.hi << 32);
+            const uint32_t h = lz4_hash<U16>(seq);
+            uint32_t ent = 0;
+            if (valid) ent = table[h];
+            const uint32_t cand = ent & posMask;
+            const uint32_t mychk = chk((uint32_t)(pw.lo >> 32));
+            // only lanes that can still pass the test fetch their candidate window
+            const bool plausible = valid && (U16 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
+            STAGE(1);
+            Win cw = {~pw.lo, 0};
+            if (plausible) cw = load_win(src, cand);
+            // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
+            wave_fence();
+            bool pending = valid;
+            uint32_t w = (uint32_t)lane;
+            do {
+                if (pending) table[h] = (T)lane;
                 wave_fence();
-                bool pending = valid;
-                uint32_t w = (uint32_t)lane;
-                do {
-                    if (pending) table[h] = (T)lane;
-                    wave_fence();
-                    if (valid) w = table[h];
-                    wave_fence();
-                    pending = valid && (uint32_t)lane < w;
-                } while (ballot(pending) != 0);
-                const int f = first_lane(ballot(valid && w != (uint32_t)lane));
-                const int e = first_lane(ballot(!valid));
-                const int lim = f < e ? f : e;
-                const bool ok = lane < lim && m4 == (uint32_t)seq && (U16 || cand + kDistMax >= pos);
-                const int m = first_lane(ballot(ok));
-                // restore every touched slot, then commit the probes the reference really executed
-                if (valid) table[h] = (T)cand;
+                if (valid) w = table[h];
                 wave_fence();
-                const int ncommit = (m < 64) ? m + 1 : lim;
-                if (lane < ncommit) table[h] = (T)pos;
-                wave_fence();
-                if (m < 64) {
-                    m_pos = lane_get(pos, m); m_cand = lane_get(cand, m);
-                    found = true;
-                    break;
-                }
-                if (e < 64 && e <= f) break;              // ran past mflimitPlusOne: last literals
-                i0 += (uint32_t)lim;
-            }
-            if (!found) break;
+                pending = valid && (uint32_t)lane < w;
+            } while (ballot(pending) != 0);
+            if (valid) table[h] = (T)ent;                 // undo the lane ids
+            wave_fence();
+            STAGE(2);
+            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
+            const int e = first_lane(ballot(!valid));
+            const int lim = f < e ? f : e;                // lanes < lim saw exactly the sequential candidates
+            const uint64_t okmask = ballot(lane < lim && plausible && (uint32_t)(cw.lo >> 32) == (uint32_t)(pw.lo >> 32));
+            const uint32_t pos0 = lane_get(pos, 0);
+            const bool linear = (i0 == 0);                // lane L probes pos0 + L (sched is the identity below 66)
+            // in-lane forward extension (<= 8 bytes), LZ4_count lz4.c:656-679
+            const uint64_t xf = pw.hi ^ cw.hi;
+            uint32_t fw = xf ? ((uint32_t)__builtin_ctzll(xf) >> 3) : 8;
+            const uint32_t maxfwd = matchlimit - (pos + kMinMatch);
+            const bool mf = fw == 8 && maxfwd > 8;
+            fw = fw < maxfwd ? fw : maxfwd;
+            const uint32_t yb = (uint32_t)pw.lo ^ (uint32_t)cw.lo;
+            const uint32_t bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
+            const uint32_t litbyte = (uint32_t)(pw.lo >> 32) & 0xFF;
 
-            // ---------------- catch up (lz4.c:1611-1623) ----------------
-            uint32_t back = 0;
-            {
-                const uint32_t a = m_pos - anchor;
-                const uint32_t maxback = a < m_cand ? a : m_cand;
-                while (back < maxback) {
-                    const uint32_t k = back + (uint32_t)lane;
-                    bool eq = false;
-                    if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
-                    const int c = first_lane(ballot(!eq));
-                    back += (uint32_t)c;
-                    if (c < 64) break;
-                }
-            }
-            // ---------------- forward extension: LZ4_count (lz4.c:656-679) ----------------
-            uint32_t fwd = 0;
-            {
-                const uint32_t a = m_pos + kMinMatch, b = m_cand + kMinMatch;
-                for (;;) {
-                    const uint32_t o = fwd + 4u * (uint32_t)lane;
-                    const uint32_t pa = a + o;
-                    uint32_t x = 0xFFFFFFFFu;
-                    if (pa < matchlimit) {
-                        x = ld32(src + pa) ^ ld32(src + b + o);
-                        const uint32_t avail = matchlimit - pa;
-                        if (avail < 4) x |= 0xFFFFFFFFu << (8 * avail);
-                    }
-                    const int l = first_lane(ballot(x != 0));
-                    if (l == 64) { fwd += 256; continue; }
-                    fwd += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+            // ---------------- resolve as many sequences as this batch holds ----------------
+            int start = 0;                                // first lane of the search being resolved
+            bool done = false, next_batch = false;
+            for (;;) {
+                const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull);
+                const int m = first_lane(rem);
+                if (m >= 64) {                            // no match among lanes [start, lim): they were all probed
+                    if (lane >= start && lane < lim) table[h] = (T)(pos | mychk);
+                    wave_fence();
+                    if (e < 64 && e <= f) { done = true; break; }          // next probe would pass mflimitPlusOne
+                    if (start == 0) i0 += (uint32_t)lim;
+                    else { i0 = (uint32_t)(lim - start); }                 // ip/extra already describe the chained search
+                    next_batch = true;
                     break;
                 }
+                if (lane >= start && lane <= m) table[h] = (T)(pos | mychk);   // probes the reference executed
+                wave_fence();
+                const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
+                // catch-up (lz4.c:1611-1623): <= 4 bytes from the window, longer ones by the loop below
+                uint32_t back, fwd = lane_get(fw, m);
+                bool more_back, more_fwd = lane_get((uint32_t)mf, m) != 0;
+                {
+                    const uint32_t a = m_pos - anchor, maxback = a < m_cand ? a : m_cand;
+                    const uint32_t b4 = lane_get(bk4, m);
+                    more_back = b4 == 4 && maxback > 4;
+                    back = b4 < maxback ? b4 : maxback;
+                }
+                STAGE(3);
+                if (more_back) {
+                    const uint32_t a = m_pos - anchor;
+                    const uint32_t maxback = a < m_cand ? a : m_cand;
+                    while (back < maxback) {
+                        const uint32_t k = back + (uint32_t)lane;
+                        bool eq = false;
+                        if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
+                        const int c = first_lane(ballot(!eq));
+                        back += (uint32_t)c;
+                        if (c < 64) break;
+                    }
+                }
+                if (more_fwd) {
+                    const uint32_t a = m_pos + kMinMatch, b = m_cand + kMinMatch;
+                    for (;;) {
+                        const uint32_t o = fwd + 4u * (uint32_t)lane;
+                        const uint32_t pa = a + o;
+                        uint32_t x = 0xFFFFFFFFu;
+                        if (pa < matchlimit) {
+                            x = ld32(src + pa) ^ ld32(src + b + o);
+                            const uint32_t avail = matchlimit - pa;
+                            if (avail < 4) x |= 0xFFFFFFFFu << (8 * avail);
+                        }
+                        const int l = first_lane(ballot(x != 0));
+                        if (l == 64) { fwd += 256; continue; }
+                        fwd += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+                        break;
+                    }
+                }
+                // ---------------- emit sequence (lz4.c:1626-1740) ----------------
+                const uint32_t mstart = m_pos - back;
+                const uint32_t lit = mstart - anchor;
+                const uint32_t mcode = back + fwd;
+                const uint32_t token_pos = op++;
+                if (limited && (uint64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
+                if (lit >= 15) { if (do_st) put_len_bytes(dst + op, lit - 15, lane); op += (lit - 15) / 255 + 1; }
+                if (do_st) {
+                    if (linear && anchor >= pos0) {       // the literals are this batch's own bytes: lane L holds src[pos0+L]
+                        const uint32_t aL = anchor - pos0;
+                        if ((uint32_t)lane >= aL && (uint32_t)lane < aL + lit) dst[op + lane - aL] = (uint8_t)litbyte;
+                    } else wave_copy(dst + op, src + anchor, lit, lane);
+                }
+                op += lit;
+                if (do_st && lane == 0) st16(dst + op, m_pos - m_cand);
+                op += 2;
+                if (limited && (uint64_t)op + (1 + kLastLiterals) + (mcode + 240) / 255 > cap) return 0;
+                if (mcode >= 15) { if (do_st) put_len_bytes(dst + op, mcode - 15, lane); op += (mcode - 15) / 255 + 1; }
+                if (do_st && lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
+                STAGE(4);
+                ip = mstart + kMinMatch + mcode;
+                anchor = ip;
+                if (ip >= mfl1) { done = true; break; }   // lz4.c:1747
+                extra = true; i0 = 0;
+                // The next search (back-fill ip-2, probe ip, ip+1, ...) can be resolved from THIS batch when its
+                // probes are lanes of the batch whose table slots nobody before them touched (lanes < lim).
+                const uint32_t Ln = ip - pos0;
+                if (linear && !more_fwd && Ln < (uint32_t)lim) {
+                    if ((uint32_t)lane == Ln - 2) table[h] = (T)(pos | mychk);        // back-fill ip-2 (lz4.c:1750)
+                    wave_fence();
+                    start = (int)Ln;
+                    continue;
+                }
+                // otherwise request the windows of the next batch now, ahead of everything else
+                {
+                    const uint32_t npos = ip + (uint32_t)lane;                         // probe -1 at ip, then ip+1+j
+                    const bool nvalid = lane == 0 || (ip + 1) + sched((uint32_t)lane) <= mfl1;
+                    pre.lo = 0; pre.hi = 0;
+                    if (nvalid) pre = load_win(src, npos);
+                    pre_fill = ld64(src + ip - 2);
+                    have_pre = true;
+                }
+                next_batch = true;
+                break;
             }
-            // ---------------- emit sequence (lz4.c:1626-1740) ----------------
-            const uint32_t mstart = m_pos - back;
-            const uint32_t lit = mstart - anchor;
-            const uint32_t mcode = back + fwd;
-            const uint32_t token_pos = op++;
-            if (limited && (uint64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
-            if (lit >= 15) op += put_len_bytes(dst + op, lit - 15, lane);
-            wave_copy(dst + op, src + anchor, lit, lane);
-            op += lit;
-            if (lane == 0) st16(dst + op, m_pos - m_cand);
-            op += 2;
-            if (limited && (uint64_t)op + (1 + kLastLiterals) + (mcode + 240) / 255 > cap) return 0;
-            if (mcode >= 15) op += put_len_bytes(dst + op, mcode - 15, lane);
-            if (lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
-            ip = mstart + kMinMatch + mcode;
-            anchor = ip;
-            if (ip >= mfl1) break;                        // lz4.c:1747
-            extra = true;
+            if (done) break;
+            (void)next_batch;
         }
     }
     // ---------------- last literals (lz4.c:1808-1834) ----------------
@@ -192,6 +284,8 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
         wave_copy(dst + op, src + anchor, lastRun, lane);
         op += lastRun;
     }
+    if (PROF && lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]);
+#undef STAGE
     return (int)op;
 }
 
@@ -281,8 +375,9 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b)
         r = 0;
         if (v.dst_cap >= 1) { if (threadIdx.x == 0) v.dst[0] = 0; r = 1; }
     }
-    else if (v.src_len < k64KLimit) r = lz4_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, lds);
-    else r = lz4_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, lds);
+    else if (v.src_len < k64KLimit) r = lz4_compress_wave<true, false>(v.src, v.src_len, v.dst, v.dst_cap, lds, b.reserved);
+    else if (b.reserved & 8) r = lz4_compress_wave<false, true>(v.src, v.src_len, v.dst, v.dst_cap, lds, b.reserved);
+    else r = lz4_compress_wave<false, false>(v.src, v.src_len, v.dst, v.dst_cap, lds, b.reserved);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 
@@ -303,6 +398,14 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 // C-ABI launchers (include/aocl_gpu_codec.h)
 // ------------------------------------------------------------------------------------------------
 #include "host_util.h"
+
+extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host8)
+{   /* experiment support: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::g_lz4_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_prof), z, sizeof(z));
+    return 0;
+}
 
 extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
 {

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Experiment: per-stage cycle breakdown of lz4_compress_kernel (batch.reserved & 8 build path)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import aocl_compression_amd as a
+eng = a.engine(0)
+data = a.corpus.silesia_mix(64 << 20)
+src = torch.from_numpy(data).to(eng.device).repeat(16)
+chunk = 262144
+os.environ["AOCLGPU_EXPERIMENT"] = "8"
+slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 8)()
+eng.lib.aoclgpu_debug_lz4_prof(buf)
+names = ["emit-tail+probe loads+backfill", "hash+table lookup", "cand loads+slot-reuse", "decision+prefetch+commit", "extension+emit", "-"]
+tot = sum(buf[:6]); nseq = src.numel() / 17.97
+for n, v in zip(names, buf[:6]):
+    print(f"{n:20s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
+print("total cyc/seq", tot / nseq)
