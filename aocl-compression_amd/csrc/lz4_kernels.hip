@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t put_len_bytes(uint8_t* d, uint32_t rem, int 
     return nff + 1;
 }
 
-__device__ unsigned long long g_lz4_prof[8];
+__device__ unsigned long long g_lz4_prof[16];
 
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
 struct Win { uint64_t lo, hi; };
@@ -76,6 +76,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
     T* table = reinterpret_cast<T*>(lds);
     const int lane = lane_id();
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PROF: batches, sequences, stop: beyond-batch, lim, more_fwd, nomatch, sum(lim), -
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #define STAGE(k) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[k] += t_ - tprev; tprev = t_; } } while (0)
@@ -158,16 +159,31 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
             const uint64_t okmask = ballot(lane < lim && plausible && (uint32_t)(cw.lo >> 32) == (uint32_t)(pw.lo >> 32));
             const uint32_t pos0 = lane_get(pos, 0);
             const bool linear = (i0 == 0);                // lane L probes pos0 + L (sched is the identity below 66)
-            // in-lane forward extension (<= 8 bytes), LZ4_count lz4.c:656-679
-            const uint64_t xf = pw.hi ^ cw.hi;
-            uint32_t fw = xf ? ((uint32_t)__builtin_ctzll(xf) >> 3) : 8;
-            const uint32_t maxfwd = matchlimit - (pos + kMinMatch);
-            const bool mf = fw == 8 && maxfwd > 8;
-            fw = fw < maxfwd ? fw : maxfwd;
+            // in-lane forward extension (<= 24 bytes), LZ4_count lz4.c:656-679: the probe-side bytes beyond +12 sit in
+            // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
+            uint32_t fw; bool mf;
+            {
+                const uint64_t p2 = __shfl_down(pw.hi, 8), p3 = __shfl_down(pw.hi, 16);
+                uint64_t c2 = 0, c3 = 0;
+                const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // those lanes hold real bytes
+                const bool have2 = plausible && linear && lane + 8 < 64 && v2 && cand + 20 <= n;
+                const bool have3 = have2 && lane + 16 < 64 && v3 && cand + 28 <= n;
+                if (have2) c2 = ld64(src + cand + 12);
+                if (have3) c3 = ld64(src + cand + 20);
+                const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
+                uint32_t avail = 8;                       // bytes of forward data compared in registers
+                fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                if (fw == 8 && have2) { avail = 16; fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8; }
+                if (fw == 16 && have3) { avail = 24; fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8; }
+                const uint32_t maxfwd = matchlimit - (pos + kMinMatch);
+                mf = fw == avail && maxfwd > avail;
+                fw = fw < maxfwd ? fw : maxfwd;
+            }
             const uint32_t yb = (uint32_t)pw.lo ^ (uint32_t)cw.lo;
             const uint32_t bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
             const uint32_t litbyte = (uint32_t)(pw.lo >> 32) & 0xFF;
 
+            if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
             // ---------------- resolve as many sequences as this batch holds ----------------
             int start = 0;                                // first lane of the search being resolved
             bool done = false, next_batch = false;
@@ -178,6 +194,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
                     if (lane >= start && lane < lim) table[h] = (T)(pos | mychk);
                     wave_fence();
                     if (e < 64 && e <= f) { done = true; break; }          // next probe would pass mflimitPlusOne
+                    if (PROF) cnt[5]++;
                     if (start == 0) i0 += (uint32_t)lim;
                     else { i0 = (uint32_t)(lim - start); }                 // ip/extra already describe the chained search
                     next_batch = true;
@@ -245,6 +262,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
                 if (mcode >= 15) { if (do_st) put_len_bytes(dst + op, mcode - 15, lane); op += (mcode - 15) / 255 + 1; }
                 if (do_st && lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
                 STAGE(4);
+                if (PROF) cnt[1]++;
                 ip = mstart + kMinMatch + mcode;
                 anchor = ip;
                 if (ip >= mfl1) { done = true; break; }   // lz4.c:1747
@@ -258,6 +276,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
                     start = (int)Ln;
                     continue;
                 }
+                if (PROF) { if (more_fwd) cnt[4]++; else if (Ln >= 64) cnt[2]++; else cnt[3]++; }
                 // otherwise request the windows of the next batch now, ahead of everything else
                 {
                     const uint32_t npos = ip + (uint32_t)lane;                         // probe -1 at ip, then ip+1+j
@@ -284,7 +303,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
         wave_copy(dst + op, src + anchor, lastRun, lane);
         op += lastRun;
     }
-    if (PROF && lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]);
+    if (PROF && lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
 #undef STAGE
     return (int)op;
 }
@@ -399,10 +418,10 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 // ------------------------------------------------------------------------------------------------
 #include "host_util.h"
 
-extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host8)
+extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host16)
 {   /* experiment support: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */
-    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::g_lz4_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_lz4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_prof), z, sizeof(z));
     return 0;
 }

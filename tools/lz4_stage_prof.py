@@ -11,10 +11,14 @@ chunk = 262144
 os.environ["AOCLGPU_EXPERIMENT"] = "8"
 slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_lz4_prof(buf)
 names = ["emit-tail+probe loads+backfill", "hash+table lookup", "cand loads+slot-reuse", "decision+prefetch+commit", "extension+emit", "-"]
 tot = sum(buf[:6]); nseq = src.numel() / 17.97
 for n, v in zip(names, buf[:6]):
     print(f"{n:20s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
 print("total cyc/seq", tot / nseq)
+
+c = list(buf[8:16])
+print("batches", c[0], "sequences", c[1], "seq/batch", c[1] / c[0], "avg lim", c[6] / c[0])
+print("chain stops: next search beyond batch", c[2], " cut by lim", c[3], " long match", c[4], " no-match remainder", c[5])
