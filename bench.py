@@ -110,8 +110,15 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # AOCLGPU_BENCH_BACKEND=gloo + AOCLGPU_BENCH_ONE_GPU=1 exercise the N>1 code path on a 1-GPU box (validation only)
+        backend = os.environ.get("AOCLGPU_BENCH_BACKEND", "nccl")
+        if os.environ.get("AOCLGPU_BENCH_ONE_GPU") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     eng = a.Engine(local)
