@@ -308,74 +308,210 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
     return (int)op;
 }
 
+// ------------------------------------------------------------------------------------------------
 // Safe decoder: accepts exactly the streams the reference's safe loop accepts (lz4.c:3563-3790).
-__device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_t n, uint8_t* dst, const int32_t cap)
+//
+// Two paths over the same state (ip, op):
+//  * window path: the compressed bytes are staged through a 2 KB LDS ring; lane k parses "a token at ip+k"
+//    (token, literal length, offset), a scalar walk over the lanes picks the real token starts, prefix sums give
+//    every sequence its output position, then all literals and all matches whose source lies before the window
+//    are copied at once (one global round trip for the whole window); matches that read this window's own
+//    output follow in order.  Only sequences without length-extension bytes and far from both buffer ends take
+//    this path, so every bound the reference checks is implied;
+//  * sequential path (one sequence per call): everything else, including every error and the last sequence.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kRing = 2048, kRingMask = kRing - 1;
+
+// one sequence, all rules of lz4.c:3563-3790.  returns 0 = continue, 1 = block finished, <0 = malformed
+__device__ int lz4_decode_one(const uint8_t* __restrict__ src, const int32_t iend, uint8_t* dst, const int32_t oend,
+                              int32_t& ip, int32_t& op, int lane)
+{
+    const uint32_t token = uni(src[ip]);
+    ip++;
+    int64_t len = token >> 4;
+    if (len == 15) {                                      // read_variable_length (lz4.c:3331-3352)
+        if (ip >= iend - 15) return -ip - 1;
+        uint32_t s;
+        do {
+            s = uni(src[ip]); ip++; len += s;
+            if (ip >= iend - 15) break;
+        } while (s == 255);
+    }
+    if (op + len > (int64_t)oend - (int64_t)kMfLimit || ip + len > (int64_t)iend - (2 + 1 + (int64_t)kLastLiterals)) {
+        if (ip + len != iend || op + len > oend) return -ip - 1;        // lz4.c:3654-3664
+        wave_copy(dst + op, src + ip, (uint32_t)len, lane);
+        op += (int32_t)len;
+        return 1;
+    }
+    wave_copy(dst + op, src + ip, (uint32_t)len, lane);
+    ip += (int32_t)len; op += (int32_t)len;
+    const uint32_t offset = uni(ld16(src + ip));
+    ip += 2;
+    int64_t ml = token & 15;
+    if (ml == 15) {
+        uint32_t s;
+        do {
+            s = uni(src[ip]); ip++; ml += s;
+            if (ip >= iend - (int32_t)kLastLiterals + 1) return -ip - 1;
+        } while (s == 255);
+    }
+    ml += kMinMatch;
+    if ((int64_t)offset > op) return -ip - 1;                               // offset outside the block
+    if (op + ml > (int64_t)oend - (int64_t)kLastLiterals) return -ip - 1;   // last 5 bytes are literals
+    // match copy; every source byte lies before `op`, so (i mod offset) never reads a byte this
+    // sequence has not produced yet within one 64-lane round
+    wave_fence();
+    uint8_t* d = dst + op;
+    const uint32_t mlen = (uint32_t)ml;
+    if (offset == 0) {                                    // lz4.c:3745-3753: run of zeros
+        for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) d[i] = 0;
+    } else if (offset >= kWave) {
+        const uint8_t* s = d - offset;
+        for (uint32_t r = 0; r < mlen; r += kWave) {
+            const uint32_t i = r + (uint32_t)lane;
+            uint8_t v = 0;
+            if (i < mlen) v = s[i];
+            if (i < mlen) d[i] = v;
+            wave_fence();
+        }
+    } else {
+        const uint8_t* s = d - offset;
+        uint32_t k = (uint32_t)lane % offset;
+        const uint32_t adv = kWave % offset;
+        for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) {
+            d[i] = s[k];
+            k += adv; if (k >= offset) k -= offset;
+        }
+    }
+    wave_fence();
+    op += (int32_t)mlen;
+    return 0;
+}
+
+// bytes [o, o+8) of the 24-byte little-endian string v0|v1|v2 (o <= 16)
+__device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2, uint32_t o)
+{
+    const uint64_t a = o < 8 ? v0 : v1, b = o < 8 ? v1 : v2;
+    const uint32_t sh = (o & 7) * 8;
+    return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+
+__device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_t n, uint8_t* dst, const int32_t cap,
+                                   uint8_t* ring)
 {
     const int lane = lane_id();
     if (cap == 0) return (n == 1 && src[0] == 0) ? 0 : -1;   // lz4.c:3412-3416
     if (n <= 0) return -1;                                    // lz4.c:3418
     const int32_t iend = n, oend = cap;
-    int32_t ip = 0, op = 0;
+    int32_t ip = 0, op = 0, rend = 0;                         // ring holds compressed bytes [.., rend)
+    uint4 pend = make_uint4(0, 0, 0, 0); bool have_pend = false;
     for (;;) {
-        const uint32_t token = uni(src[ip]);
-        ip++;
-        int64_t len = token >> 4;
-        if (len == 15) {                                      // read_variable_length (lz4.c:3331-3352)
-            if (ip >= iend - 15) return -ip - 1;
-            uint32_t s;
-            do {
-                s = uni(src[ip]); ip++; len += s;
-                if (ip >= iend - 15) break;
-            } while (s == 255);
+        // ---- keep >= 160 staged bytes ahead of ip (requested one iteration early) ----
+        if (ip > rend) { rend = ip & ~15; have_pend = false; }
+        if (have_pend) {
+            *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
+            wave_fence();
+            rend += 1024; have_pend = false;
         }
-        if (op + len > (int64_t)oend - (int64_t)kMfLimit || ip + len > (int64_t)iend - (2 + 1 + (int64_t)kLastLiterals)) {
-            if (ip + len != iend || op + len > oend) return -ip - 1;        // lz4.c:3654-3664
-            wave_copy(dst + op, src + ip, (uint32_t)len, lane);
-            op += (int32_t)len;
-            break;
-        }
-        wave_copy(dst + op, src + ip, (uint32_t)len, lane);
-        ip += (int32_t)len; op += (int32_t)len;
-        const uint32_t offset = uni(ld16(src + ip));
-        ip += 2;
-        int64_t ml = token & 15;
-        if (ml == 15) {
-            uint32_t s;
-            do {
-                s = uni(src[ip]); ip++; ml += s;
-                if (ip >= iend - (int32_t)kLastLiterals + 1) return -ip - 1;
-            } while (s == 255);
-        }
-        ml += kMinMatch;
-        if ((int64_t)offset > op) return -ip - 1;                               // offset outside the block
-        if (op + ml > (int64_t)oend - (int64_t)kLastLiterals) return -ip - 1;   // last 5 bytes are literals
-        // match copy; every source byte lies before `op`, so (i mod offset) never reads a byte this
-        // sequence has not produced yet within one 64-lane round
-        wave_fence();
-        uint8_t* d = dst + op;
-        const uint32_t mlen = (uint32_t)ml;
-        if (offset == 0) {                                    // lz4.c:3745-3753: run of zeros
-            for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) d[i] = 0;
-        } else if (offset >= kWave) {
-            const uint8_t* s = d - offset;
-            for (uint32_t r = 0; r < mlen; r += kWave) {
-                const uint32_t i = r + (uint32_t)lane;
-                uint8_t v = 0;
-                if (i < mlen) v = s[i];
-                if (i < mlen) d[i] = v;
+        if (rend - ip < 640 && rend + 1024 <= iend) {
+            __builtin_memcpy(&pend, src + rend + 16 * lane, 16);
+            have_pend = true;
+            if (rend - ip < 160) {
+                *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
                 wave_fence();
-            }
-        } else {
-            const uint8_t* s = d - offset;
-            uint32_t k = (uint32_t)lane % offset;
-            const uint32_t adv = kWave % offset;
-            for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) {
-                d[i] = s[k];
-                k += adv; if (k >= offset) k -= offset;
+                rend += 1024; have_pend = false;
             }
         }
-        wave_fence();
-        op += (int32_t)mlen;
+        bool window = rend - ip >= 352;
+        uint64_t mask = 0; int cur = 0;
+        uint32_t lit = 0, mlen = 0, off = 0, litsrc = 0;
+        const uint32_t p = (uint32_t)ip + (uint32_t)lane;
+        if (window) {
+            // lane k parses "a sequence starts at ip+k"; at most one length-extension byte (< 255) per field
+            const uint32_t t = ring[p & kRingMask];
+            uint32_t q = p + 1;
+            bool simple = true;
+            lit = t >> 4;
+            if (lit == 15) { const uint32_t e1 = ring[q & kRingMask]; q++; lit += e1; simple = e1 != 255; }
+            litsrc = q; q += lit;
+            off = (uint32_t)ring[q & kRingMask] | ((uint32_t)ring[(q + 1) & kRingMask] << 8);
+            q += 2;
+            mlen = (t & 15) + kMinMatch;
+            if ((t & 15) == 15) { const uint32_t e2 = ring[q & kRingMask]; q++; mlen += e2; simple = simple && e2 != 255; }
+            const uint32_t nx = simple ? q - (uint32_t)ip : 0xFFFFu;     // lane index of the next token
+            while (cur < 64) {                                // walk the real token starts
+                const uint32_t v = lane_get(nx, cur);
+                if (v == 0xFFFFu) break;
+                mask |= 1ull << cur; cur = (int)v;
+            }
+            if (mask == 0) window = false;
+        }
+        if (window) {
+            const bool marked = (mask >> lane) & 1;
+            const uint32_t olen = marked ? lit + mlen : 0;
+            uint32_t inc = olen;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
+            const uint32_t opos = (uint32_t)op + inc - olen;  // output position of this sequence's literals
+            const uint32_t mstart = opos + lit;
+            // stop in front of the first sequence the window path must not handle
+            const bool bad = marked && (off == 0 || off > mstart);
+            const int fb = first_lane(ballot(bad));
+            uint32_t total = lane_get(inc, 63);
+            if (fb < 64) { mask &= (1ull << fb) - 1; cur = fb; total = lane_get(inc - olen, fb); }
+            if (mask == 0 || (int64_t)op + total + 32 > oend) window = false;
+            else {
+                const bool act = (mask >> lane) & 1;
+                // short literal runs: straight from the ring, one sequence per lane
+                if (act && lit < 15) for (uint32_t i = 0; i < lit; ++i) dst[opos + i] = ring[(litsrc + i) & kRingMask];
+                // long literal runs: whole wave, from the compressed stream
+                for (uint64_t lm = ballot(act && lit >= 15); lm; lm &= lm - 1) {
+                    const int k = (int)__builtin_ctzll(lm);
+                    wave_copy(dst + lane_get(opos, k), src + lane_get(litsrc, k), lane_get(lit, k), lane);
+                }
+                // short matches whose source was produced before this window: one round of loads for all of them
+                const uint32_t spos = mstart - off;
+                const bool indep = act && mlen <= 18 && spos + mlen <= (uint32_t)op;
+                if (indep) {
+                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
+                    uint8_t* d = dst + mstart;
+                    if (mlen >= 8) {
+                        __builtin_memcpy(d, &v0, 8);
+                        if (mlen > 8) { const uint64_t x = ext64(v0, v1, v2, mlen > 16 ? 8 : mlen - 8); __builtin_memcpy(d + (mlen > 16 ? 8 : mlen - 8), &x, 8); }
+                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); __builtin_memcpy(d + mlen - 8, &x, 8); }
+                    } else {
+                        const uint32_t lo = (uint32_t)v0; __builtin_memcpy(d, &lo, 4);
+                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); __builtin_memcpy(d + mlen - 4, &hi, 4);
+                    }
+                }
+                wave_fence();
+                // the other matches (long, or reading this window's own output, or overlapping themselves):
+                // in order, whole wave, 64 bytes per round
+                for (uint64_t dm = ballot(act && !indep); dm; dm &= dm - 1) {
+                    const int k = (int)__builtin_ctzll(dm);
+                    const uint32_t ms = lane_get(mstart, k), ml = lane_get(mlen, k), of = lane_get(off, k);
+                    uint8_t* d = dst + ms; const uint8_t* sp = d - of;
+                    if (of >= kWave) {
+                        for (uint32_t r = 0; r < ml; r += kWave) {
+                            const uint32_t i = r + (uint32_t)lane;
+                            uint8_t v = 0;
+                            if (i < ml) v = sp[i];
+                            if (i < ml) d[i] = v;
+                            wave_fence();
+                        }
+                    } else {
+                        uint32_t kk = (uint32_t)lane % of; const uint32_t adv = kWave % of;
+                        for (uint32_t i = (uint32_t)lane; i < ml; i += kWave) { d[i] = sp[kk]; kk += adv; if (kk >= of) kk -= of; }
+                        wave_fence();
+                    }
+                }
+                ip += cur; op += (int32_t)total;
+            }
+        }
+        if (!window) {
+            const int r = lz4_decode_one(src, iend, dst, oend, ip, op, lane);
+            if (r < 0) return r;
+            if (r == 1) break;
+        }
     }
     return op;
 }
@@ -402,12 +538,13 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b)
 
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = decompress_view(b, c);
     int r;
     if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
-    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap);
+    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 
