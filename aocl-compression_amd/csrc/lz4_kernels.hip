@@ -110,6 +110,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
     if (n >= kMinLength) {
         uint32_t i0 = 0;                                  // probes of the current search already examined
         for (;;) {
+            asm volatile("; MARK_BATCH_BEGIN" ::: "memory");
             // ---------------- one batch of 64 speculative probes (lz4.c:1483-1608, 1746-1804) ----------------
             const uint32_t base = extra ? ip + 1 : ip;
             const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
@@ -184,6 +185,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
             const uint32_t litbyte = (uint32_t)(pw.lo >> 32) & 0xFF;
 
             if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
+            asm volatile("; MARK_CHAIN_BEGIN" ::: "memory");
             // ---------------- resolve as many sequences as this batch holds ----------------
             int start = 0;                                // first lane of the search being resolved
             bool done = false, next_batch = false;
@@ -289,6 +291,7 @@ __device__ int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t
                 next_batch = true;
                 break;
             }
+            asm volatile("; MARK_CHAIN_END" ::: "memory");
             if (done) break;
             (void)next_batch;
         }

@@ -55,6 +55,7 @@ struct Workspace {
     u32 seqOff[kMaxSeq];     // offBase
     u32 seqLL[kMaxSeq];      // literal length
     u32 seqML[kMaxSeq];      // match length
+    u32 seqSrc[kMaxSeq];     // position of the sequence's literals in the chunk
     u8  llc[kMaxSeq], ofc[kMaxSeq], mlc[kMaxSeq];
     u8  pad[8];
     u8  tmp[2 * kBlockMax + 1024];
@@ -114,6 +115,17 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
     const u32 tsize = 1u << hlog;
     for (u32 i = (u32)lane; i < tsize; i += kWave) table[i] = 0;
     wave_fence();
+    // u32 entries: index (position + 2, 18 bits) plus 14 check bits of the 4 bytes at that position.  The check
+    // bits never change a decision; they spare the speculative lanes a cache-line fetch for hopeless candidates.
+    constexpr bool kChk = sizeof(T) == 4;
+    constexpr u32 kPosMask = kChk ? 0x3FFFFu : 0xFFFFu;
+    auto chk = [&](u32 v4) -> u32 { return kChk ? ((v4 * 2654435761u) & ~kPosMask) : 0u; };
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {       // one 4-lane store per sequence
+        if (lane < 4) {
+            u32* arr = lane == 0 ? ws->seqLL : (lane == 1 ? ws->seqOff : (lane == 2 ? ws->seqML : ws->seqSrc));
+            arr[idx] = lane == 0 ? ll : (lane == 1 ? off : (lane == 2 ? ml : srcpos));
+        }
+    };
     u32 nbSeq = 0, litSize = 0, anchor = 0, s = 1, rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
@@ -131,15 +143,17 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                 u64 seq = 0;
                 if (valid) seq = ld64(src + pos);
                 const u32 h = z_hash<MLS>(seq, hlog);
-                u32 cand = 0;
-                if (valid) cand = table[h];
+                u32 ent = 0;
+                if (valid) ent = table[h];
+                const u32 cand = ent & kPosMask;
+                const u32 mychk = chk((u32)seq);
                 bool rep_hit = false;
                 if (valid && half == 0) {                               // repcode at ip2 (:519-542)
                     const u32 r = pos + sg;
                     rep_hit = ld32(src + r) == ld32(src + r - rep1);
                 }
                 u32 m4 = ~(u32)seq;
-                if (valid && cand >= 2) m4 = ld32(src + cand - 2);
+                if (valid && cand >= 2 && ((ent ^ mychk) & ~kPosMask) == 0) m4 = ld32(src + cand - 2);
                 wave_fence();
                 bool pending = valid; u32 w = (u32)lane;
                 do {
@@ -154,10 +168,10 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                 const int lim = f < e ? f : e;
                 const bool mat_hit = m4 == (u32)seq;
                 const int el = first_lane(ballot(lane < lim && (rep_hit || mat_hit)));
-                if (valid) table[h] = (T)cand;
+                if (valid) table[h] = (T)ent;
                 wave_fence();
                 const int ncommit = (el < 64) ? el + 1 : lim;
-                if (lane < ncommit) table[h] = (T)(pos + 2);
+                if (lane < ncommit) table[h] = (T)((pos + 2) | mychk);
                 wave_fence();
                 if (el < 64) {
                     ev = lane_get((u32)rep_hit, el) ? 2 : 1;
@@ -173,8 +187,9 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
             {
                 const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
                 if (e_half == 0 || e_st <= 4) {
-                    const u32 h1 = z_hash<MLS>(ld64(src + ip1), hlog);
-                    if (lane == 0) table[h1] = (T)(ip1 + 2);
+                    const u64 v1 = ld64(src + ip1);
+                    const u32 h1 = z_hash<MLS>(v1, hlog);
+                    if (lane == 0) table[h1] = (T)((ip1 + 2) | chk((u32)v1));
                     wave_fence();
                 }
             }
@@ -202,25 +217,23 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
             mLength += wave_count(src, ip0 + mLength, match0 + mLength, n, lane);       // _match (:669)
             {
                 const u32 ll = ip0 - anchor;
-                if (lane == 0) { ws->seqLL[nbSeq] = ll; ws->seqOff[nbSeq] = offcode; ws->seqML[nbSeq] = mLength; }
-                wave_copy(ws->lits + litSize, src + anchor, ll, lane);
+                put_seq(nbSeq, ll, offcode, mLength, anchor);
                 litSize += ll; nbSeq++;
             }
             ip0 += mLength; anchor = ip0;
             if (ip0 <= ilimit) {                                        // :678-702
-                const u32 ha = z_hash<MLS>(ld64(src + current0 + 2), hlog);
-                const u32 hb2 = z_hash<MLS>(ld64(src + ip0 - 2), hlog);
-                if (lane == 0) { table[ha] = (T)(current0 + 2 + 2); table[hb2] = (T)(ip0 - 2 + 2); }
+                const u64 va = ld64(src + current0 + 2), vb = ld64(src + ip0 - 2);
+                const u32 ha = z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
+                if (lane == 0) { table[ha] = (T)((current0 + 2 + 2) | chk((u32)va)); table[hb2] = (T)((ip0 - 2 + 2) | chk((u32)vb)); }
                 wave_fence();
                 if (rep2 > 0) {
                     while (ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u)) {
                         const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
                         const u32 t = rep2; rep2 = rep1; rep1 = t;
-                        const u32 hc = z_hash<MLS>(ld64(src + ip0), hlog);
-                        if (lane == 0) {
-                            table[hc] = (T)(ip0 + 2);
-                            ws->seqLL[nbSeq] = 0; ws->seqOff[nbSeq] = 1; ws->seqML[nbSeq] = rLength;
-                        }
+                        const u64 vc = ld64(src + ip0);
+                        const u32 hc = z_hash<MLS>(vc, hlog);
+                        if (lane == 0) table[hc] = (T)((ip0 + 2) | chk((u32)vc));
+                        put_seq(nbSeq, 0, 1, rLength, ip0);
                         wave_fence();
                         nbSeq++;
                         ip0 += rLength; anchor = ip0;
@@ -230,8 +243,28 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
             s = ip0;
         }
     }
-    wave_copy(ws->lits + litSize, src + anchor, n - anchor, lane);       // ZSTD_storeLastLiterals
+    // ---- literal buffer: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the
+    //      search loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal
+    //      lengths, short runs one per lane, long runs by the whole wave.
+    wave_fence();
+    u32 lpos = 0;
+    for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
+        const u32 q = q0 + (u32)lane;
+        u32 ll = 0, sp = 0;
+        if (q < nbSeq) { ll = ws->seqLL[q]; sp = ws->seqSrc[q]; }
+        u32 inc = ll;
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        const u32 dp = lpos + inc - ll;
+        if (ll <= 24) for (u32 i = 0; i < ll; ++i) ws->lits[dp + i] = src[sp + i];
+        for (u64 lm = ballot(ll > 24); lm; lm &= lm - 1) {
+            const int k = (int)__builtin_ctzll(lm);
+            wave_copy(ws->lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
+        }
+        lpos += lane_get(inc, 63);
+    }
+    wave_copy(ws->lits + lpos, src + anchor, n - anchor, lane);
     litSize += n - anchor;
+    wave_fence();
     *litSizeOut = litSize;
     return nbSeq;
 }
@@ -508,7 +541,7 @@ __device__ __forceinline__ void level1_params(u32 n, u32* hlog, u32* mls)
 }
 
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
-                                  void* lds, u32 ldsBytes, Workspace* ws, int lane)
+                                  void* lds, u32 ldsBytes, Workspace* ws, int lane, u32 expf)
 {
     const u32 bound = n + (n >> 8) + (n < kBlockMax ? ((kBlockMax - n) >> 11) : 0);
     if (n > kBlockMax || cap < bound || cap < 9) return 0;
@@ -532,7 +565,8 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         if (mls == 5) nbSeq = fast_block<5, u16>(src, n, hlog, reinterpret_cast<u16*>(lds), ws, &litSize, lane);
         else nbSeq = fast_block<6, u32>(src, n, hlog, reinterpret_cast<u32*>(lds), ws, &litSize, lane);
         wave_fence();
-        cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
+        if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
+        else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
         if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                      // ZSTD_minGain, zstd_compress.c:3055-3057
     }
     if (cSize == 0) {                                                    // ZSTD_noCompressBlock
@@ -1012,7 +1046,7 @@ __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint
     const int lane = lane_id();
     for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = zstd_compress_wave(v.src, v.src_len, v.dst, v.dst_cap, lds, ldsBytes, ws, lane);
+        const int r = zstd_compress_wave(v.src, v.src_len, v.dst, v.dst_cap, lds, ldsBytes, ws, lane, b.reserved);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
