@@ -108,17 +108,33 @@ __device__ u32 wave_count(const u8* __restrict__ src, u32 a, u32 b, u32 end, int
 // ------------------------------------------------------------------------------------------------
 // match finder: fills ws->seq*, ws->lits; returns nbSeq, *litSizeOut
 // ------------------------------------------------------------------------------------------------
+// Table layout: u16 per slot (low 16 bits of index = position + 2) and, for chunks above 16 KiB, one extra bit per
+// slot in a packed word array (indices stay below 2^17 because nothing within 14 bytes of the chunk end is ever
+// inserted).  17 KB of LDS per chunk instead of 32 KB lets 9 instead of 5 chunks be resident per CU.
 template <int MLS, typename T>
 __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlog, T* table, Workspace* ws,
                           u32* litSizeOut, int lane)
 {
+    static_assert(sizeof(T) == 2, "u16 slots");
+    constexpr bool kHi = (MLS == 6);
     const u32 tsize = 1u << hlog;
-    for (u32 i = (u32)lane; i < tsize; i += kWave) table[i] = 0;
+    u32* hib = reinterpret_cast<u32*>(table + tsize);                   // kHi: tsize/32 words
+    for (u32 i = (u32)lane; i < tsize / 2; i += kWave) reinterpret_cast<u32*>(table)[i] = 0;
+    if (kHi) for (u32 i = (u32)lane; i < tsize / 32; i += kWave) hib[i] = 0;
     wave_fence();
+    auto tget = [&](u32 h) -> u32 {
+        u32 v = table[h];
+        if (kHi) v |= ((hib[h >> 5] >> (h & 31)) & 1u) << 16;
+        return v;
+    };
+    auto tput = [&](u32 h, u32 v) {
+        table[h] = (T)v;
+        if (kHi) { if (v >> 16) atomicOr(&hib[h >> 5], 1u << (h & 31)); else atomicAnd(&hib[h >> 5], ~(1u << (h & 31))); }
+    };
     // u32 entries: index (position + 2, 18 bits) plus 14 check bits of the 4 bytes at that position.  The check
     // bits never change a decision; they spare the speculative lanes a cache-line fetch for hopeless candidates.
-    constexpr bool kChk = sizeof(T) == 4;
-    constexpr u32 kPosMask = kChk ? 0x3FFFFu : 0xFFFFu;
+    constexpr bool kChk = false;
+    constexpr u32 kPosMask = 0x3FFFFu;
     auto chk = [&](u32 v4) -> u32 { return kChk ? ((v4 * 2654435761u) & ~kPosMask) : 0u; };
     auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {       // one 4-lane store per sequence
         if (lane < 4) {
@@ -144,7 +160,7 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                 if (valid) seq = ld64(src + pos);
                 const u32 h = z_hash<MLS>(seq, hlog);
                 u32 ent = 0;
-                if (valid) ent = table[h];
+                if (valid) ent = tget(h);
                 const u32 cand = ent & kPosMask;
                 const u32 mychk = chk((u32)seq);
                 bool rep_hit = false;
@@ -168,10 +184,10 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                 const int lim = f < e ? f : e;
                 const bool mat_hit = m4 == (u32)seq;
                 const int el = first_lane(ballot(lane < lim && (rep_hit || mat_hit)));
-                if (valid) table[h] = (T)ent;
+                if (valid) table[h] = (T)ent;                           // low halves only: the extra bits were not touched
                 wave_fence();
                 const int ncommit = (el < 64) ? el + 1 : lim;
-                if (lane < ncommit) table[h] = (T)((pos + 2) | mychk);
+                if (lane < ncommit) tput(h, pos + 2);
                 wave_fence();
                 if (el < 64) {
                     ev = lane_get((u32)rep_hit, el) ? 2 : 1;
@@ -189,7 +205,7 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                 if (e_half == 0 || e_st <= 4) {
                     const u64 v1 = ld64(src + ip1);
                     const u32 h1 = z_hash<MLS>(v1, hlog);
-                    if (lane == 0) table[h1] = (T)((ip1 + 2) | chk((u32)v1));
+                    if (lane == 0) tput(h1, ip1 + 2);
                     wave_fence();
                 }
             }
@@ -224,7 +240,7 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
             if (ip0 <= ilimit) {                                        // :678-702
                 const u64 va = ld64(src + current0 + 2), vb = ld64(src + ip0 - 2);
                 const u32 ha = z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
-                if (lane == 0) { table[ha] = (T)((current0 + 2 + 2) | chk((u32)va)); table[hb2] = (T)((ip0 - 2 + 2) | chk((u32)vb)); }
+                if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
                 wave_fence();
                 if (rep2 > 0) {
                     while (ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u)) {
@@ -232,7 +248,7 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
                         const u32 t = rep2; rep2 = rep1; rep1 = t;
                         const u64 vc = ld64(src + ip0);
                         const u32 hc = z_hash<MLS>(vc, hlog);
-                        if (lane == 0) table[hc] = (T)((ip0 + 2) | chk((u32)vc));
+                        if (lane == 0) tput(hc, ip0 + 2);
                         put_seq(nbSeq, 0, 1, rLength, ip0);
                         wave_fence();
                         nbSeq++;
@@ -560,10 +576,10 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 hlog, mls, litSize = 0, nbSeq;
         level1_params(n, &hlog, &mls);
-        const u32 need = (mls == 5 ? 2u : 4u) << hlog;
+        const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8);
         if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
         if (mls == 5) nbSeq = fast_block<5, u16>(src, n, hlog, reinterpret_cast<u16*>(lds), ws, &litSize, lane);
-        else nbSeq = fast_block<6, u32>(src, n, hlog, reinterpret_cast<u32*>(lds), ws, &litSize, lane);
+        else nbSeq = fast_block<6, u16>(src, n, hlog, reinterpret_cast<u16*>(lds), ws, &litSize, lane);
         wave_fence();
         if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
         else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
@@ -1094,7 +1110,7 @@ uint32_t lds_for_chunk(uint64_t n)
         uint32_t srcLog = 6; if (n >= 64) { srcLog = 0; uint64_t t = n - 1; while (t) { srcLog++; t >>= 1; } }
         const uint32_t w = srcLog < 14 ? srcLog : 14, hl = (15 < w + 1) ? 15 : w + 1;
         need = 2u << hl;
-    } else need = 4u << 13;
+    } else need = (2u << 13) + (1u << 13) / 8;
     const uint32_t ent = (uint32_t)aoclgpu::zstd_entropy_lds_bytes();
     need = need > ent ? need : ent;
     return (need + 255u) & ~255u;
@@ -1120,7 +1136,7 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         const uint32_t perCU = 160u * 1024u / L[i].lds;
         uint32_t grid = 256u * (perCU ? perCU : 1u);
         if (grid > L[i].count) grid = L[i].count;
-        if (grid > 2048) grid = 2048;
+        if (grid > 2304) grid = 2304;
         void* ws = get_workspace((size_t)grid * aoclgpu::zstd_workspace_bytes());
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         if (L[i].lds > 65536u) {
