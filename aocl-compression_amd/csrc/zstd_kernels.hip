@@ -1129,8 +1129,11 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
     else {
         const uint64_t tail = b->total_bytes - (uint64_t)(b->nchunks - 1) * b->chunk_bytes;
         if (b->chunk_bytes > (128u << 10) && b->nchunks > 1) { aoclgpu::set_error_msg("zstd: chunk_bytes > 128 KiB"); return AOCLGPU_ERR_ARG; }
-        if (b->nchunks > 1) L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes) };
-        L[nl++] = { b->nchunks - 1, 1, lds_for_chunk(tail) };
+        // a separate launch for the ragged tail chunk only when it needs more LDS than the body (a lone chunk is slow)
+        if (b->nchunks > 1 && lds_for_chunk(tail) > lds_for_chunk(b->chunk_bytes)) {
+            L[nl++] = { b->nchunks - 1, 1, lds_for_chunk(tail) };
+            L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes) };
+        } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail) };
     }
     for (int i = 0; i < nl; ++i) {
         const uint32_t perCU = 160u * 1024u / L[i].lds;
