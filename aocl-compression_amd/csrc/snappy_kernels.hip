@@ -82,8 +82,21 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t* op, uint32_t offset, uint
 }
 
 // One <=64 KiB fragment (AOCL_CompressFragment).  Returns bytes written.
-__device__ uint32_t sn_compress_fragment(const uint8_t* __restrict__ in, const uint32_t n, uint8_t* __restrict__ out,
-                                         uint16_t* table, int lane)
+// 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the fragment start read as 0)
+struct Win { uint64_t lo, hi; };
+__device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_t p)
+{
+    Win w;
+    w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
+    w.hi = ld64(src + p + 4);
+    return w;
+}
+
+// Same batch machinery as lz4_kernels.hip (windowed loads, in-register extension up to 28 bytes, several copies
+// resolved per batch, next windows requested early); Snappy specifics: the schedule is consecutive only for its
+// first 33 probes, the table has no spare bits for check bits, no catch-up, matches may run to the fragment end.
+__device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const uint8_t* __restrict__ in, const uint32_t n,
+                                                                   uint8_t* __restrict__ out, uint16_t* table, int lane)
 {
     uint32_t tsize = n > kMaxTable ? kMaxTable : (n < kMinTable ? kMinTable : (2u << log2floor(n - 1)));   // :619-632
     const int shift = 32 - log2floor(tsize);
@@ -91,81 +104,154 @@ __device__ uint32_t sn_compress_fragment(const uint8_t* __restrict__ in, const u
         reinterpret_cast<uint4*>(table)[i] = make_uint4(0, 0, 0, 0);
     wave_fence();
 
-    uint32_t ip = 0, op = 0;
+    uint32_t ip = 0, op = 0, anchor = 0;                                  // anchor = next_emit
     if (n >= kMargin) {
         const uint32_t ip_limit = n - kMargin;
-        bool extra = false;
+        bool extra = false, have_pre = false; Win pre = {0, 0}; uint32_t pre_fill = 0;
+        uint32_t i0 = 0;
         for (;;) {
-            // -------- search (snappy.cc:903-974 and 1016-1032) --------
-            const uint32_t next_emit = ip, base = ip + 1;
-            if (extra) {                                                  // back-fill ip-1 (:1016-1017)
-                const uint32_t h1 = sn_hash(ld32(in + ip - 1), shift);
+            asm volatile("; batch begin" ::: "memory");
+            // -------- one batch of 64 speculative probes (snappy.cc:903-974, 1016-1032) --------
+            const uint32_t base = ip + 1;
+            const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
+            const uint32_t pos = (j < 0) ? ip : base + sn_off((uint32_t)j);
+            const bool valid = (j < 0) || (uint64_t)base + sn_off((uint32_t)(j + 1)) <= ip_limit;       // :946-950
+            Win pw = {0, 0};
+            if (i0 == 0 && have_pre) pw = pre;
+            else if (valid) pw = load_win(in, pos);
+            if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
+                const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
+                const uint32_t h1 = sn_hash(fb, shift);
                 if (lane == 0) table[h1] = (uint16_t)(ip - 1);
                 wave_fence();
             }
-            uint32_t i0 = 0, m_pos = 0, m_cand = 0;
-            bool found = false;
-            for (;;) {
-                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-                const uint32_t pos = (j < 0) ? ip : base + sn_off((uint32_t)j);
-                const bool valid = (j < 0) || (uint64_t)base + sn_off((uint32_t)(j + 1)) <= ip_limit;   // :946-950
-                uint32_t seq = 0;
-                if (valid) seq = ld32(in + pos);
-                const uint32_t h = sn_hash(seq, shift);
-                uint32_t cand = 0;
-                if (valid) cand = table[h];
-                uint32_t m4 = ~seq;
-                if (valid) m4 = ld32(in + cand);
+            have_pre = false;
+            const uint32_t seq = (uint32_t)(pw.lo >> 32);
+            const uint32_t h = sn_hash(seq, shift);
+            uint32_t cand = 0;
+            if (valid) cand = table[h];
+            Win cw = {~pw.lo, 0};
+            if (valid) cw = load_win(in, cand);
+            wave_fence();
+            bool pending = valid;
+            uint32_t w = (uint32_t)lane;
+            do {                                                          // exact per-slot minimum lane
+                if (pending) table[h] = (uint16_t)lane;
                 wave_fence();
-                bool pending = valid;
-                uint32_t w = (uint32_t)lane;
-                do {                                                      // exact per-slot minimum lane
-                    if (pending) table[h] = (uint16_t)lane;
-                    wave_fence();
-                    if (valid) w = table[h];
-                    wave_fence();
-                    pending = valid && (uint32_t)lane < w;
-                } while (ballot(pending) != 0);
-                const int f = first_lane(ballot(valid && w != (uint32_t)lane));
-                const int e = first_lane(ballot(!valid));
-                const int lim = f < e ? f : e;
-                const int m = first_lane(ballot(lane < lim && m4 == seq));
-                if (valid) table[h] = (uint16_t)cand;
+                if (valid) w = table[h];
                 wave_fence();
-                const int ncommit = (m < 64) ? m + 1 : lim;
-                if (lane < ncommit) table[h] = (uint16_t)pos;
-                wave_fence();
-                if (m < 64) { m_pos = lane_get(pos, m); m_cand = lane_get(cand, m); found = true; break; }
-                if (e < 64 && e <= f) break;                              // next_ip > ip_limit: emit_remainder
-                i0 += (uint32_t)lim;
+                pending = valid && (uint32_t)lane < w;
+            } while (ballot(pending) != 0);
+            if (valid) table[h] = (uint16_t)cand;                         // undo the lane ids
+            wave_fence();
+            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
+            const int e = first_lane(ballot(!valid));
+            const int lim = f < e ? f : e;
+            const uint64_t okmask = ballot(lane < lim && (uint32_t)(cw.lo >> 32) == seq);
+            const uint32_t pos0 = lane_get(pos, 0);
+            // lanes [0, linlim) probe consecutive positions pos0 + lane (the schedule's first 33 steps are 1 byte)
+            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;
+            // in-lane forward extension (<= 24 bytes beyond the 4 tested), FindMatchLength snappy-internal.h:228-352
+            uint32_t fw; bool mf;
+            {
+                const uint64_t p2 = __shfl_down(pw.hi, 8), p3 = __shfl_down(pw.hi, 16);
+                uint64_t c2 = 0, c3 = 0;
+                const bool cm = valid && (uint32_t)(cw.lo >> 32) == seq;
+                const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
+                const bool have2 = cm && lane + 8 < linlim && v2 && cand + 20 <= n;
+                const bool have3 = have2 && lane + 16 < linlim && v3 && cand + 28 <= n;
+                if (have2) c2 = ld64(in + cand + 12);
+                if (have3) c3 = ld64(in + cand + 20);
+                const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
+                uint32_t avail = 8;
+                fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                if (fw == 8 && have2) { avail = 16; fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8; }
+                if (fw == 16 && have3) { avail = 24; fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8; }
+                const uint32_t maxfwd = n - (pos + 4);
+                mf = fw == avail && maxfwd > avail;
+                fw = fw < maxfwd ? fw : maxfwd;
             }
-            if (!found) { ip = next_emit; break; }
-            // -------- literal [next_emit, m_pos) (:979); none after an immediate re-probe hit --------
-            if (m_pos > next_emit) op += emit_literal(out + op, in + next_emit, m_pos - next_emit, lane);
-            // -------- FindMatchLength(cand+4, ip+4, ip_end) (snappy-internal.h:228-352) --------
-            uint32_t matched = 4;
+            const uint32_t litbyte = seq & 0xFF;
+
+            asm volatile("; chain begin" ::: "memory");
+            // -------- resolve as many copies as this batch holds --------
+            int start = 0;
+            bool done = false;
             for (;;) {
-                const uint32_t o = matched + 4u * (uint32_t)lane;
-                const uint32_t pa = m_pos + o;
-                uint32_t x = 0xFFFFFFFFu;
-                if (pa + 4 <= n) x = ld32(in + pa) ^ ld32(in + m_cand + o);
-                else if (pa < n) {
-                    x = 0;
-                    for (uint32_t t = 0; t < n - pa; ++t) x |= (uint32_t)(in[pa + t] ^ in[m_cand + o + t]) << (8 * t);
-                    x |= 0xFFFFFFFFu << (8 * (n - pa));
+                const int hi = start == 0 ? lim : (lim < linlim ? lim : linlim);     // lanes usable by the search being resolved
+                const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
+                const int m = first_lane(rem);
+                if (m >= 64) {                                            // lanes [start, hi) were probed without a match
+                    if (lane >= start && lane < hi) table[h] = (uint16_t)pos;
+                    wave_fence();
+                    if (hi == lim && e < 64 && e <= f) { done = true; break; }       // next_ip > ip_limit: emit_remainder
+                    if (start == 0) i0 += (uint32_t)hi;
+                    else i0 = (uint32_t)(hi - start);
+                    break;
                 }
-                const int l = first_lane(ballot(x != 0));
-                if (l == 64) { matched += 256; continue; }
-                matched += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+                if (lane >= start && lane <= m) table[h] = (uint16_t)pos;            // probes the reference executed
+                wave_fence();
+                const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
+                uint32_t matched = 4 + lane_get(fw, m);
+                const bool more_fwd = lane_get((uint32_t)mf, m) != 0;
+                if (more_fwd) {
+                    for (;;) {
+                        const uint32_t o = matched + 4u * (uint32_t)lane;
+                        const uint32_t pa = m_pos + o;
+                        uint32_t x = 0xFFFFFFFFu;
+                        if (pa + 4 <= n) x = ld32(in + pa) ^ ld32(in + m_cand + o);
+                        else if (pa < n) {
+                            x = 0;
+                            for (uint32_t t = 0; t < n - pa; ++t) x |= (uint32_t)(in[pa + t] ^ in[m_cand + o + t]) << (8 * t);
+                            x |= 0xFFFFFFFFu << (8 * (n - pa));
+                        }
+                        const int l = first_lane(ballot(x != 0));
+                        if (l == 64) { matched += 256; continue; }
+                        matched += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+                        break;
+                    }
+                }
+                // -------- literal [anchor, m_pos) (:979); none after an immediate re-probe hit --------
+                const uint32_t lit = m_pos - anchor;
+                if (lit) {
+                    if (linlim && anchor >= pos0 && m < linlim) {         // the literal is this batch's own bytes
+                        const uint32_t nl = lit - 1, hdr = nl < 60 ? 1u : 2u, aL = anchor - pos0;
+                        if (lane == 0) { out[op] = (uint8_t)(nl < 60 ? (nl << 2) : (60u << 2)); if (nl >= 60) out[op + 1] = (uint8_t)nl; }
+                        if ((uint32_t)lane >= aL && (uint32_t)lane < aL + lit) out[op + hdr + lane - aL] = (uint8_t)litbyte;
+                        op += hdr + lit;
+                    } else op += emit_literal(out + op, in + anchor, lit, lane);
+                }
+                op += emit_copy(out + op, m_pos - m_cand, matched, lane);
+                ip = m_pos + matched;
+                anchor = ip;
+                if (ip >= ip_limit) { done = true; break; }               // :1006-1008
+                extra = true; i0 = 0;
+                // the next search (back-fill ip-1, probe ip, ip+1, ...) can be resolved from this batch when its probes
+                // are consecutive lanes of the batch whose slots nobody before them touched
+                const uint32_t Ln = ip - pos0;
+                const int hi2 = lim < linlim ? lim : linlim;
+                if (!more_fwd && (int)Ln < hi2) {
+                    if ((uint32_t)lane == Ln - 1) table[h] = (uint16_t)pos;           // back-fill ip-1 (:1016-1017)
+                    wave_fence();
+                    start = (int)Ln;
+                    continue;
+                }
+                {   // otherwise request the windows of the next batch now
+                    const int32_t nj = (int32_t)lane - 1;
+                    const uint32_t npos = nj < 0 ? ip : ip + 1 + sn_off((uint32_t)nj);
+                    const bool nvalid = nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit;
+                    pre.lo = 0; pre.hi = 0;
+                    if (nvalid) pre = load_win(in, npos);
+                    pre_fill = ld32(in + ip - 1);
+                    have_pre = true;
+                }
                 break;
             }
-            op += emit_copy(out + op, m_pos - m_cand, matched, lane);
-            ip = m_pos + matched;
-            if (ip >= ip_limit) break;                                    // :1006-1008
-            extra = true;
+            asm volatile("; chain end" ::: "memory");
+            if (done) break;
         }
     }
-    if (ip < n) op += emit_literal(out + op, in + ip, n - ip, lane);     // emit_remainder (:1039-1043)
+    if (anchor < n) op += emit_literal(out + op, in + anchor, n - anchor, lane);     // emit_remainder (:1039-1043)
     return op;
 }
 
