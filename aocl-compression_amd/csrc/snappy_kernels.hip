@@ -184,7 +184,11 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const uint8_t
                 if (m >= 64) {                                            // lanes [start, hi) were probed without a match
                     if (lane >= start && lane < hi) table[h] = (uint16_t)pos;
                     wave_fence();
-                    if (hi == lim && e < 64 && e <= f) { done = true; break; }       // next_ip > ip_limit: emit_remainder
+                    // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
+                    // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
+                    const bool at_end = start == 0 ? (hi == lim && e < 64 && e <= f)
+                                                   : ((uint64_t)pos0 + (uint32_t)hi + 1 > ip_limit);
+                    if (at_end) { done = true; break; }
                     if (start == 0) i0 += (uint32_t)hi;
                     else i0 = (uint32_t)(hi - start);
                     break;
@@ -273,7 +277,61 @@ __device__ int sn_compress_wave(const uint8_t* __restrict__ src, const uint32_t 
 }
 
 // RawUncompress: returns the decoded length, or -1 for any malformed stream (the reference returns false).
-__device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* dst, const uint32_t cap)
+constexpr uint32_t kRing = 2048, kRingMask = kRing - 1;
+
+// one element (literal or copy), all rules of DecompressAllTags / SnappyArrayWriter (:1466-1570, :2131-2209).
+// returns 0 = continue, <0 = malformed
+__device__ int sn_decode_one(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* dst, const uint32_t ulen,
+                             uint32_t& ip, uint32_t& op, int lane)
+{
+    const uint32_t c = uni(src[ip]);
+    const uint32_t type = c & 3;
+    const uint32_t taglen = type == 0 ? ((c >> 2) < 60 ? 1 : (c >> 2) - 58) : (type == 1 ? 2 : (type == 2 ? 3 : 5));
+    if (ip + taglen > n) return -1;                                       // RefillTag :1598-1653
+    if (type == 0) {
+        uint32_t len = (c >> 2) + 1;
+        if (len > 60) {
+            const uint32_t nb = len - 60;
+            uint32_t v = 0;
+            for (uint32_t i = 0; i < nb; ++i) v |= uni(src[ip + 1 + i]) << (8 * i);
+            if (v == 0xFFFFFFFFu) return -1;
+            len = v + 1;
+        }
+        ip += taglen;
+        if (len > n - ip || len > ulen - op) return -1;                   // :2149-2158
+        wave_copy(dst + op, src + ip, len, lane);
+        ip += len; op += len;
+    } else {
+        uint32_t len, offset;
+        if (type == 1) { len = 4 + ((c >> 2) & 7); offset = ((c >> 5) << 8) | uni(src[ip + 1]); }
+        else if (type == 2) { len = (c >> 2) + 1; offset = uni(ld16(src + ip + 1)); }
+        else { len = (c >> 2) + 1; offset = uni(ld32(src + ip + 1)); }
+        ip += taglen;
+        if (offset == 0 || offset > op || len > ulen - op) return -1;     // AppendFromSelf :2189-2207
+        wave_fence();
+        uint8_t* d = dst + op;
+        const uint8_t* s = d - offset;
+        if ((uint32_t)lane < len) d[lane] = s[offset >= kWave ? (uint32_t)lane : (uint32_t)lane % offset];
+        wave_fence();
+        op += len;                                                         // copy elements are <= 64 bytes
+    }
+    return 0;
+}
+
+// bytes [o, o+8) of the 24-byte little-endian string v0|v1|v2 (o <= 16)
+__device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2, uint32_t o)
+{
+    const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : v2), b = o < 8 ? v1 : v2;
+    const uint32_t sh = (o & 7) * 8;
+    return sh ? (a >> sh) | (b << (64 - sh)) : a;
+}
+
+// RawUncompress: decoded length, or -1 for any malformed stream (the reference returns false).  Same two-path
+// structure as the LZ4 decoder: elements far from the end of the input are parsed 64 byte positions at a time from an
+// LDS ring (lane k = "an element starts at ip+k", scalar walk over the real starts, prefix sum for the output
+// positions, all short literals and all short copies of earlier output at once); everything else one at a time.
+__device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* dst, const uint32_t cap,
+                                  uint8_t* ring)
 {
     const int lane = lane_id();
     uint32_t ulen = 0, shift = 0, ip = 0;
@@ -287,38 +345,100 @@ __device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_
         shift += 7;
     }
     if (ulen > cap) return -1;                                            // api/codec.cpp:296-303
-    uint32_t op = 0;
+    uint32_t op = 0, rend = 0;
+    uint4 pend = make_uint4(0, 0, 0, 0); bool have_pend = false;
     while (ip < n) {                                                      // DecompressAllTags :1466-1570
-        const uint32_t c = uni(src[ip]);
-        const uint32_t type = c & 3;
-        const uint32_t taglen = type == 0 ? ((c >> 2) < 60 ? 1 : (c >> 2) - 58) : (type == 1 ? 2 : (type == 2 ? 3 : 5));
-        if (ip + taglen > n) return -1;                                   // RefillTag :1598-1653
-        if (type == 0) {
-            uint32_t len = (c >> 2) + 1;
-            if (len > 60) {
-                const uint32_t nb = len - 60;
-                uint32_t v = 0;
-                for (uint32_t i = 0; i < nb; ++i) v |= uni(src[ip + 1 + i]) << (8 * i);
-                if (v == 0xFFFFFFFFu) return -1;
-                len = v + 1;
+        if (ip > rend) { rend = ip & ~15u; have_pend = false; }
+        if (have_pend) {
+            *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
+            wave_fence();
+            rend += 1024; have_pend = false;
+        }
+        if ((int32_t)(rend - ip) < 640 && (uint64_t)rend + 1024 <= n) {
+            __builtin_memcpy(&pend, src + rend + 16 * lane, 16);
+            have_pend = true;
+            if ((int32_t)(rend - ip) < 352) {
+                *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
+                wave_fence();
+                rend += 1024; have_pend = false;
             }
-            ip += taglen;
-            if (len > n - ip || len > ulen - op) return -1;               // :2149-2158
-            wave_copy(dst + op, src + ip, len, lane);
-            ip += len; op += len;
-        } else {
-            uint32_t len, offset;
-            if (type == 1) { len = 4 + ((c >> 2) & 7); offset = ((c >> 5) << 8) | uni(src[ip + 1]); }
-            else if (type == 2) { len = (c >> 2) + 1; offset = uni(ld16(src + ip + 1)); }
-            else { len = (c >> 2) + 1; offset = uni(ld32(src + ip + 1)); }
-            ip += taglen;
-            if (offset == 0 || offset > op || len > ulen - op) return -1; // AppendFromSelf :2189-2207
-            wave_fence();
-            uint8_t* d = dst + op;
-            const uint8_t* s = d - offset;
-            if ((uint32_t)lane < len) d[lane] = s[offset >= kWave ? (uint32_t)lane : (uint32_t)lane % offset];
-            wave_fence();
-            op += len;                                                     // copy elements are <= 64 bytes
+        }
+        bool window = (int32_t)(rend - ip) >= 352;
+        uint64_t mask = 0; uint32_t cur = 0;
+        uint32_t lit = 0, mlen = 0, off = 0, litsrc = 0;
+        const uint32_t p = ip + (uint32_t)lane;
+        if (window) {
+            const uint32_t t = ring[p & kRingMask], type = t & 3, b1 = ring[(p + 1) & kRingMask], b2 = ring[(p + 2) & kRingMask];
+            uint32_t nx = 0xFFFFu;
+            if (type == 0) {
+                const uint32_t l6 = t >> 2;
+                if (l6 < 60) { lit = l6 + 1; litsrc = p + 1; nx = (uint32_t)lane + 1 + lit; }
+                else if (l6 == 60) { lit = b1 + 1; litsrc = p + 2; nx = (uint32_t)lane + 2 + lit; }
+                // longer literals: sequential path
+            } else if (type == 1) { mlen = 4 + ((t >> 2) & 7); off = ((t >> 5) << 8) | b1; nx = (uint32_t)lane + 2; }
+            else if (type == 2) { mlen = (t >> 2) + 1; off = b1 | (b2 << 8); nx = (uint32_t)lane + 3; }
+            else {
+                mlen = (t >> 2) + 1;
+                off = b1 | (b2 << 8) | ((uint32_t)ring[(p + 3) & kRingMask] << 16) | ((uint32_t)ring[(p + 4) & kRingMask] << 24);
+                nx = (uint32_t)lane + 5;
+            }
+            while (cur < 64) {                                            // walk the real element starts
+                const uint32_t v = lane_get(nx, (int)cur);
+                if (v == 0xFFFFu) break;
+                mask |= 1ull << cur; cur = v;
+            }
+            if (mask == 0) window = false;
+        }
+        if (window) {
+            const bool marked = (mask >> lane) & 1;
+            const uint32_t olen = marked ? lit + mlen : 0;
+            uint32_t inc = olen;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
+            const uint32_t opos = op + inc - olen;
+            // stop in front of the first element that breaks a rule (the sequential path reports it)
+            const bool bad = marked && ((mlen && (off == 0 || off > opos)) || (uint64_t)opos + olen > ulen);
+            const int fb = first_lane(ballot(bad));
+            uint32_t total = lane_get(inc, 63);
+            if (fb < 64) { mask &= (1ull << fb) - 1; cur = (uint32_t)fb; total = lane_get(inc - olen, fb); }
+            if (mask == 0) window = false;
+            else {
+                const bool act = (mask >> lane) & 1;
+                // short literals from the ring, long ones by the whole wave from the compressed stream
+                if (act && lit && lit <= 32) for (uint32_t i = 0; i < lit; ++i) dst[opos + i] = ring[(litsrc + i) & kRingMask];
+                for (uint64_t lm = ballot(act && lit > 32); lm; lm &= lm - 1) {
+                    const int k = (int)__builtin_ctzll(lm);
+                    wave_copy(dst + lane_get(opos, k), src + lane_get(litsrc, k), lane_get(lit, k), lane);
+                }
+                // short copies of output produced before this window: one round of loads for all of them
+                const uint32_t spos = opos - off;
+                const bool indep = act && mlen && mlen <= 24 && spos + mlen <= op && (uint64_t)spos + 24 <= ulen;
+                if (indep) {
+                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
+                    uint8_t* d = dst + opos;
+                    if (mlen >= 8) {
+                        __builtin_memcpy(d, &v0, 8);
+                        if (mlen > 8) { const uint32_t o2 = mlen > 16 ? 8 : mlen - 8; const uint64_t x = ext64(v0, v1, v2, o2); __builtin_memcpy(d + o2, &x, 8); }
+                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); __builtin_memcpy(d + mlen - 8, &x, 8); }
+                    } else if (mlen >= 4) {
+                        const uint32_t lo = (uint32_t)v0; __builtin_memcpy(d, &lo, 4);
+                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); __builtin_memcpy(d + mlen - 4, &hi, 4);
+                    } else for (uint32_t i = 0; i < mlen; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
+                }
+                wave_fence();
+                // the other copies: in order, whole wave (elements are <= 64 bytes)
+                for (uint64_t dm = ballot(act && mlen && !indep); dm; dm &= dm - 1) {
+                    const int k = (int)__builtin_ctzll(dm);
+                    const uint32_t ms = lane_get(opos, k), ml = lane_get(mlen, k), of = lane_get(off, k);
+                    uint8_t* d = dst + ms; const uint8_t* sp = d - of;
+                    if ((uint32_t)lane < ml) { const uint8_t v = sp[of >= kWave ? (uint32_t)lane : (uint32_t)lane % of]; d[lane] = v; }
+                    wave_fence();
+                }
+                ip += cur; op += total;
+            }
+        }
+        if (!window) {
+            const int r = sn_decode_one(src, n, dst, ulen, ip, op, lane);
+            if (r < 0) return r;
         }
     }
     return op == ulen ? (int)op : -1;                                     // CheckLength :2146
@@ -340,8 +460,9 @@ __global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
 {
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const ChunkView v = decompress_view(b, c);
-    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap);
+    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, ring);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 

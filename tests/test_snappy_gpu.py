@@ -23,7 +23,7 @@ def test_known_answers(eng):
 
 
 @pytest.mark.parametrize("kind", list(a.corpus.KINDS))
-@pytest.mark.parametrize("chunk", [65536, 262144])
+@pytest.mark.parametrize("chunk", [1000, 4096, 65536, 262144])
 def test_compress_bit_exact(eng, oracle, kind, chunk):
     data = a.corpus.make(kind, (2 << 20) + 333, seed=12)
     src = torch.from_numpy(data).to(eng.device)
