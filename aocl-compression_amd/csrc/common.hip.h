@@ -19,15 +19,36 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
-__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
-__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ void st16(uint8_t* p, uint32_t v) { uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); }
-__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+// A byte of global memory.  Chunk pointers carry the address space in their type so that non-inlined device
+// functions still get global_* instructions: a generic ("flat") access counts against vmcnt AND lgkmcnt, which makes
+// every LDS wait also wait for the global loads in flight.
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+
+// unaligned little-endian loads/stores through any pointer type (generic, global or LDS)
+template <class P> __device__ __forceinline__ uint32_t ld8(P p) { return *p; }
+template <class P> __device__ __forceinline__ uint32_t ld16(P p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+template <class P> __device__ __forceinline__ uint32_t ld32(P p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+template <class P> __device__ __forceinline__ uint64_t ld64(P p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+template <class P> __device__ __forceinline__ void st16(P p, uint32_t v) { uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); }
+template <class P> __device__ __forceinline__ void st32(P p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+template <class P> __device__ __forceinline__ void st64(P p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 
 // wave-uniform broadcast of lane 0's value (also tells the compiler the value is an SGPR)
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// Arguments of a non-inlined device function arrive in VGPRs and count as divergent; a function whose control flow
+// hangs on them is compiled as divergent code (exec-mask loops, lane-mask booleans, 64-bit VALU address arithmetic).
+// uni_ptr / uni at the top of such a function restore scalar bases and scalar control flow.
+template <class P> __device__ __forceinline__ P uni_ptr(P p)
+{
+    if constexpr (sizeof(P) == 4) return (P)uni((uint32_t)p);
+    else {
+        const uint64_t v = (uint64_t)p;
+        return (P)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+    }
+}
+// a byte of this workgroup's LDS
+typedef __attribute__((address_space(3))) uint8_t lbyte;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // compiler-only ordering point between cross-lane LDS / global accesses of ONE wave
@@ -38,21 +59,21 @@ __device__ __forceinline__ int first_lane(uint64_t m) { return m ? (int)__builti
 
 // Chunk geometry of a batch (see aoclgpu_batch in include/aocl_gpu_codec.h)
 struct ChunkView {
-    const uint8_t* src; uint32_t src_len;
-    uint8_t* dst; uint32_t dst_cap;
+    const gbyte* src; uint32_t src_len;
+    gbyte* dst; uint32_t dst_cap;
 };
 
 __device__ __forceinline__ ChunkView compress_view(const aoclgpu_batch& b, uint32_t i)
 {
     ChunkView v;
     if (b.src_off) {
-        v.src = b.src + b.src_off[i]; v.src_len = b.src_len[i];
-        v.dst = b.dst + b.dst_off[i]; v.dst_cap = b.dst_cap[i];
+        v.src = (const gbyte*)b.src + b.src_off[i]; v.src_len = b.src_len[i];
+        v.dst = (gbyte*)b.dst + b.dst_off[i]; v.dst_cap = b.dst_cap[i];
     } else {
         const uint64_t o = (uint64_t)i * b.chunk_bytes;
         const uint64_t rem = b.total_bytes > o ? b.total_bytes - o : 0;
-        v.src = b.src + o; v.src_len = (uint32_t)(rem < b.chunk_bytes ? rem : b.chunk_bytes);
-        v.dst = b.dst + (uint64_t)i * b.slot_bytes;
+        v.src = (const gbyte*)b.src + o; v.src_len = (uint32_t)(rem < b.chunk_bytes ? rem : b.chunk_bytes);
+        v.dst = (gbyte*)b.dst + (uint64_t)i * b.slot_bytes;
         v.dst_cap = (uint32_t)(b.slot_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : b.slot_bytes);
     }
     return v;
@@ -62,20 +83,21 @@ __device__ __forceinline__ ChunkView decompress_view(const aoclgpu_batch& b, uin
 {
     ChunkView v;
     if (b.src_off) {
-        v.src = b.src + b.src_off[i]; v.src_len = b.src_len[i];
-        v.dst = b.dst + b.dst_off[i]; v.dst_cap = b.dst_cap[i];
+        v.src = (const gbyte*)b.src + b.src_off[i]; v.src_len = b.src_len[i];
+        v.dst = (gbyte*)b.dst + b.dst_off[i]; v.dst_cap = b.dst_cap[i];
     } else {
         const uint64_t o = (uint64_t)i * b.chunk_bytes;
         const uint64_t rem = b.total_bytes > o ? b.total_bytes - o : 0;
-        v.src = b.src + (uint64_t)i * b.slot_bytes; v.src_len = b.src_len[i];
-        v.dst = b.dst + o; v.dst_cap = (uint32_t)(rem < b.chunk_bytes ? rem : b.chunk_bytes);
+        v.src = (const gbyte*)b.src + (uint64_t)i * b.slot_bytes; v.src_len = b.src_len[i];
+        v.dst = (gbyte*)b.dst + o; v.dst_cap = (uint32_t)(rem < b.chunk_bytes ? rem : b.chunk_bytes);
     }
     return v;
 }
 
 // Cooperative forward copy of n bytes, non-overlapping, arbitrary alignment (global -> global).
 // All 64 lanes call it with uniform arguments.
-__device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t n, int lane)
+template <class D, class S>
+__device__ __forceinline__ void wave_copy(D* __restrict__ d, const S* __restrict__ s, uint32_t n, int lane)
 {
     if (n <= 64) {
         if ((uint32_t)lane < n) d[lane] = s[lane];
@@ -88,7 +110,7 @@ __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const uint8_t
     const uint32_t nvec = n >> 4;
     for (uint32_t i = (uint32_t)lane; i < nvec; i += kWave) {
         uint4 v; __builtin_memcpy(&v, s + ((size_t)i << 4), 16);
-        *reinterpret_cast<uint4*>(d + ((size_t)i << 4)) = v;
+        __builtin_memcpy(d + ((size_t)i << 4), &v, 16);
     }
     const uint32_t done = nvec << 4;
     if ((uint32_t)lane < n - done) d[done + lane] = s[done + lane];

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t lz4_hash(uint64_t seq)
 }
 
 // write the LZ4 "length - 15" continuation bytes (255,255,...,rem); returns bytes written
-__device__ __forceinline__ uint32_t put_len_bytes(uint8_t* d, uint32_t rem, int lane)
+__device__ __forceinline__ uint32_t put_len_bytes(gbyte* d, uint32_t rem, int lane)
 {
     const uint32_t nff = rem / 255;
     for (uint32_t i = (uint32_t)lane; i < nff; i += kWave) d[i] = 255;
@@ -60,7 +60,7 @@ __device__ unsigned long long g_lz4_prof[16];
 
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
 struct Win { uint64_t lo, hi; };
-__device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_t p)
+__device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t p)
 {
     Win w;
     w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
@@ -72,13 +72,19 @@ __device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_
 // slot (chunks <= 256 KiB): 9 KB of LDS instead of 16 KB, so 17 instead of 10 chunks are resident per CU.
 // MODE 2: byU32 table as u32[4096] whose spare high bits hold check bits (any chunk size).
 template <int MODE, bool PROF>
-__device__ __attribute__((noinline)) int lz4_compress_wave(const uint8_t* __restrict__ src, const uint32_t n,
-                                 uint8_t* __restrict__ dst, const uint32_t cap, void* lds, const uint32_t expf)
+__device__ __attribute__((noinline)) int lz4_compress_wave(const gbyte* __restrict__ src_, const uint32_t n_,
+                                 gbyte* __restrict__ dst_, const uint32_t cap_, lbyte* lds_, const uint32_t expf_)
 {
+    const gbyte* __restrict__ src = uni_ptr(src_);
+    gbyte* __restrict__ dst = uni_ptr(dst_);
+    lbyte* lds = uni_ptr(lds_);
+    const uint32_t n = uni(n_), cap = uni(cap_), expf = uni(expf_);
     constexpr bool U16 = (MODE == 0);
     using T = typename std::conditional<MODE == 2, uint32_t, uint16_t>::type;
-    T* table = reinterpret_cast<T*>(lds);
-    uint32_t* hib = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lds) + 8192);   // MODE 1: 256 words
+    typedef __attribute__((address_space(3))) T LT;
+    typedef __attribute__((address_space(3))) uint32_t L32;
+    LT* table = (LT*)lds;
+    L32* hib = (L32*)(lds + 8192);                        // MODE 1: 256 words
     auto tget = [&](uint32_t h) -> uint32_t {
         uint32_t v = table[h];
         if (MODE == 1) v |= ((hib[h >> 4] >> ((h & 15) * 2)) & 3u) << 16;
@@ -86,11 +92,11 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const uint8_t* __rest
     };
     auto tput = [&](uint32_t h, uint32_t v, uint32_t old) {           // `old` = entry this lane read from the slot
         table[h] = (T)v;
-        if (MODE == 1) { const uint32_t x = ((old ^ v) >> 16) & 3u; if (x) atomicXor(&hib[h >> 4], x << ((h & 15) * 2)); }
+        if (MODE == 1) { const uint32_t x = ((old ^ v) >> 16) & 3u; if (x) __hip_atomic_fetch_xor(&hib[h >> 4], x << ((h & 15) * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     };
     auto tput_blind = [&](uint32_t h, uint32_t v) {
         table[h] = (T)v;
-        if (MODE == 1) { const uint32_t sh = (h & 15) * 2; atomicAnd(&hib[h >> 4], ~(3u << sh)); atomicOr(&hib[h >> 4], ((v >> 16) & 3u) << sh); }
+        if (MODE == 1) { const uint32_t sh = (h & 15) * 2; __hip_atomic_fetch_and(&hib[h >> 4], ~(3u << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_or(&hib[h >> 4], ((v >> 16) & 3u) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     };
     const int lane = lane_id();
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -111,7 +117,7 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const uint8_t* __rest
         const uint32_t fill = (MODE == 2 && n >= 4) ? chk(ld32(src)) : 0u;
         const uint32_t bytes = MODE == 1 ? 8192u + 1024u : kTableBytes;
         for (uint32_t i = (uint32_t)lane; i < bytes / 16; i += kWave)
-            reinterpret_cast<uint4*>(lds)[i] = make_uint4(fill, fill, fill, fill);
+            ((__attribute__((address_space(3))) u32x4*)lds)[i] = u32x4{fill, fill, fill, fill};
     }
     wave_fence();
 
@@ -344,7 +350,7 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const uint8_t* __rest
 constexpr uint32_t kRing = 2048, kRingMask = kRing - 1;
 
 // one sequence, all rules of lz4.c:3563-3790.  returns 0 = continue, 1 = block finished, <0 = malformed
-__device__ int lz4_decode_one(const uint8_t* __restrict__ src, const int32_t iend, uint8_t* dst, const int32_t oend,
+__device__ int lz4_decode_one(const gbyte* __restrict__ src, const int32_t iend, gbyte* dst, const int32_t oend,
                               int32_t& ip, int32_t& op, int lane)
 {
     const uint32_t token = uni(src[ip]);
@@ -382,12 +388,12 @@ __device__ int lz4_decode_one(const uint8_t* __restrict__ src, const int32_t ien
     // match copy; every source byte lies before `op`, so (i mod offset) never reads a byte this
     // sequence has not produced yet within one 64-lane round
     wave_fence();
-    uint8_t* d = dst + op;
+    gbyte* d = dst + op;
     const uint32_t mlen = (uint32_t)ml;
     if (offset == 0) {                                    // lz4.c:3745-3753: run of zeros
         for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) d[i] = 0;
     } else if (offset >= kWave) {
-        const uint8_t* s = d - offset;
+        const gbyte* s = d - offset;
         for (uint32_t r = 0; r < mlen; r += kWave) {
             const uint32_t i = r + (uint32_t)lane;
             uint8_t v = 0;
@@ -396,7 +402,7 @@ __device__ int lz4_decode_one(const uint8_t* __restrict__ src, const int32_t ien
             wave_fence();
         }
     } else {
-        const uint8_t* s = d - offset;
+        const gbyte* s = d - offset;
         uint32_t k = (uint32_t)lane % offset;
         const uint32_t adv = kWave % offset;
         for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) {
@@ -417,7 +423,7 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
     return sh ? (a >> sh) | (b << (64 - sh)) : a;
 }
 
-__device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_t n, uint8_t* dst, const int32_t cap,
+__device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
                                    uint8_t* ring)
 {
     const int lane = lane_id();
@@ -494,7 +500,7 @@ __device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_
                 const bool indep = act && mlen <= 18 && spos + mlen <= (uint32_t)op;
                 if (indep) {
                     const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
-                    uint8_t* d = dst + mstart;
+                    gbyte* d = dst + mstart;
                     if (mlen >= 8) {
                         __builtin_memcpy(d, &v0, 8);
                         if (mlen > 8) { const uint64_t x = ext64(v0, v1, v2, mlen > 16 ? 8 : mlen - 8); __builtin_memcpy(d + (mlen > 16 ? 8 : mlen - 8), &x, 8); }
@@ -510,7 +516,7 @@ __device__ int lz4_decompress_wave(const uint8_t* __restrict__ src, const int32_
                 for (uint64_t dm = ballot(act && !indep); dm; dm &= dm - 1) {
                     const int k = (int)__builtin_ctzll(dm);
                     const uint32_t ms = lane_get(mstart, k), ml = lane_get(mlen, k), of = lane_get(off, k);
-                    uint8_t* d = dst + ms; const uint8_t* sp = d - of;
+                    gbyte* d = dst + ms; const gbyte* sp = d - of;
                     if (of >= kWave) {
                         for (uint32_t r = 0; r < ml; r += kWave) {
                             const uint32_t i = r + (uint32_t)lane;
@@ -556,12 +562,12 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
         if (v.dst_cap >= 1) { if (threadIdx.x == 0) v.dst[0] = 0; r = 1; }
     }
     else if (MODE == 3) {
-        if (n < k64KLimit) r = lz4_compress_wave<0, false>(v.src, n, v.dst, v.dst_cap, lds, b.reserved);
-        else if (n <= (1u << 18)) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, lds, b.reserved);
-        else r = lz4_compress_wave<2, false>(v.src, n, v.dst, v.dst_cap, lds, b.reserved);
+        if (n < k64KLimit) r = lz4_compress_wave<0, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
+        else if (n <= (1u << 18)) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
+        else r = lz4_compress_wave<2, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
     }
     else if ((MODE == 0) != (n < k64KLimit) || (MODE == 1 && n > (1u << 18))) r = 0;   // launcher picked the wrong mode
-    else r = lz4_compress_wave<MODE == 3 ? 2 : MODE, PROF>(v.src, n, v.dst, v.dst_cap, lds, b.reserved);
+    else r = lz4_compress_wave<MODE == 3 ? 2 : MODE, PROF>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 

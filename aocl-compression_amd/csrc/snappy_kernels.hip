@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t sn_hash(uint32_t bytes, int shift) { return 
 __device__ __forceinline__ int log2floor(uint32_t x) { return 31 - __builtin_clz(x); }
 
 // EmitLiteral (snappy.cc:435-476): tag + optional length bytes + data.  Returns bytes written.
-__device__ __forceinline__ uint32_t emit_literal(uint8_t* op, const uint8_t* lit, uint32_t len, int lane)
+__device__ __forceinline__ uint32_t emit_literal(gbyte* op, const gbyte* lit, uint32_t len, int lane)
 {
     const uint32_t n = len - 1;
     uint32_t hdr = 1;
@@ -58,13 +58,13 @@ __device__ __forceinline__ uint32_t emit_literal(uint8_t* op, const uint8_t* lit
 }
 
 // EmitCopy (snappy.cc:478-568).  Returns bytes written.
-__device__ __forceinline__ uint32_t emit_copy(uint8_t* op, uint32_t offset, uint32_t len, int lane)
+__device__ __forceinline__ uint32_t emit_copy(gbyte* op, uint32_t offset, uint32_t len, int lane)
 {
     uint32_t w = 0;
     if (len >= 12) {
         const uint32_t n64 = len >= 68 ? (len - 4) / 64 : 0;
         for (uint32_t e = (uint32_t)lane; e < n64; e += kWave) {
-            uint8_t* p = op + 3 * e;
+            gbyte* p = op + 3 * e;
             p[0] = (uint8_t)(2 | (63 << 2)); p[1] = (uint8_t)offset; p[2] = (uint8_t)(offset >> 8);
         }
         w = 3 * n64; len -= 64 * n64;
@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t emit_copy(uint8_t* op, uint32_t offset, uint
 // One <=64 KiB fragment (AOCL_CompressFragment).  Returns bytes written.
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the fragment start read as 0)
 struct Win { uint64_t lo, hi; };
-__device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_t p)
+__device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t p)
 {
     Win w;
     w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
@@ -95,8 +95,8 @@ __device__ __forceinline__ Win load_win(const uint8_t* __restrict__ src, uint32_
 // Same batch machinery as lz4_kernels.hip (windowed loads, in-register extension up to 28 bytes, several copies
 // resolved per batch, next windows requested early); Snappy specifics: the schedule is consecutive only for its
 // first 33 probes, the table has no spare bits for check bits, no catch-up, matches may run to the fragment end.
-__device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const uint8_t* __restrict__ in, const uint32_t n,
-                                                                   uint8_t* __restrict__ out, uint16_t* table, int lane)
+__device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in, const uint32_t n,
+                                                                   gbyte* __restrict__ out, uint16_t* table, int lane)
 {
     uint32_t tsize = n > kMaxTable ? kMaxTable : (n < kMinTable ? kMinTable : (2u << log2floor(n - 1)));   // :619-632
     const int shift = 32 - log2floor(tsize);
@@ -259,7 +259,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const uint8_t
     return op;
 }
 
-__device__ int sn_compress_wave(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* __restrict__ dst,
+__device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* __restrict__ dst,
                                 const uint32_t cap, uint16_t* table)
 {
     const int lane = lane_id();
@@ -281,7 +281,7 @@ constexpr uint32_t kRing = 2048, kRingMask = kRing - 1;
 
 // one element (literal or copy), all rules of DecompressAllTags / SnappyArrayWriter (:1466-1570, :2131-2209).
 // returns 0 = continue, <0 = malformed
-__device__ int sn_decode_one(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* dst, const uint32_t ulen,
+__device__ int sn_decode_one(const gbyte* __restrict__ src, const uint32_t n, gbyte* dst, const uint32_t ulen,
                              uint32_t& ip, uint32_t& op, int lane)
 {
     const uint32_t c = uni(src[ip]);
@@ -309,8 +309,8 @@ __device__ int sn_decode_one(const uint8_t* __restrict__ src, const uint32_t n, 
         ip += taglen;
         if (offset == 0 || offset > op || len > ulen - op) return -1;     // AppendFromSelf :2189-2207
         wave_fence();
-        uint8_t* d = dst + op;
-        const uint8_t* s = d - offset;
+        gbyte* d = dst + op;
+        const gbyte* s = d - offset;
         if ((uint32_t)lane < len) d[lane] = s[offset >= kWave ? (uint32_t)lane : (uint32_t)lane % offset];
         wave_fence();
         op += len;                                                         // copy elements are <= 64 bytes
@@ -330,7 +330,7 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // structure as the LZ4 decoder: elements far from the end of the input are parsed 64 byte positions at a time from an
 // LDS ring (lane k = "an element starts at ip+k", scalar walk over the real starts, prefix sum for the output
 // positions, all short literals and all short copies of earlier output at once); everything else one at a time.
-__device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_t n, uint8_t* dst, const uint32_t cap,
+__device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* dst, const uint32_t cap,
                                   uint8_t* ring)
 {
     const int lane = lane_id();
@@ -414,7 +414,7 @@ __device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_
                 const bool indep = act && mlen && mlen <= 24 && spos + mlen <= op && (uint64_t)spos + 24 <= ulen;
                 if (indep) {
                     const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
-                    uint8_t* d = dst + opos;
+                    gbyte* d = dst + opos;
                     if (mlen >= 8) {
                         __builtin_memcpy(d, &v0, 8);
                         if (mlen > 8) { const uint32_t o2 = mlen > 16 ? 8 : mlen - 8; const uint64_t x = ext64(v0, v1, v2, o2); __builtin_memcpy(d + o2, &x, 8); }
@@ -429,7 +429,7 @@ __device__ int sn_decompress_wave(const uint8_t* __restrict__ src, const uint32_
                 for (uint64_t dm = ballot(act && mlen && !indep); dm; dm &= dm - 1) {
                     const int k = (int)__builtin_ctzll(dm);
                     const uint32_t ms = lane_get(opos, k), ml = lane_get(mlen, k), of = lane_get(off, k);
-                    uint8_t* d = dst + ms; const uint8_t* sp = d - of;
+                    gbyte* d = dst + ms; const gbyte* sp = d - of;
                     if ((uint32_t)lane < ml) { const uint8_t v = sp[of >= kWave ? (uint32_t)lane : (uint32_t)lane % of]; d[lane] = v; }
                     wave_fence();
                 }

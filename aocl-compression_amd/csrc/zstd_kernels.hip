@@ -1062,7 +1062,7 @@ __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint
     const int lane = lane_id();
     for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = zstd_compress_wave(v.src, v.src_len, v.dst, v.dst_cap, lds, ldsBytes, ws, lane, b.reserved);
+        const int r = zstd_compress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, lane, b.reserved);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(64) zstd_decompress_kernel(aoclgpu_batch b, ui
     const int lane = lane_id();
     for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
         const ChunkView v = decompress_view(b, c);
-        const int r = zstd_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, &L, litBuf, lane);
+        const int r = zstd_decompress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, &L, litBuf, lane);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
