@@ -72,7 +72,7 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
 // slot (chunks <= 256 KiB): 9 KB of LDS instead of 16 KB, so 17 instead of 10 chunks are resident per CU.
 // MODE 2: byU32 table as u32[4096] whose spare high bits hold check bits (any chunk size).
 template <int MODE, bool PROF>
-__device__ __attribute__((noinline)) int lz4_compress_wave(const gbyte* __restrict__ src_, const uint32_t n_,
+__device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_, const uint32_t n_,
                                  gbyte* __restrict__ dst_, const uint32_t cap_, lbyte* lds_, const uint32_t expf_)
 {
     const gbyte* __restrict__ src = uni_ptr(src_);
@@ -209,46 +209,107 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const gbyte* __restri
             const uint32_t litbyte = (uint32_t)(pw.lo >> 32) & 0xFF;
 
             if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
-            asm volatile("; chain begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic from being sunk into the chain loop
-            // ---------------- resolve as many sequences as this batch holds ----------------
-            int start = 0;                                // first lane of the search being resolved
-            bool done = false, next_batch = false;
+            asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
+            // ---------------- resolve every sequence this batch holds ----------------
+            // Walk (scalar, a handful of instructions per sequence): first matching lane >= cur, end of that match, first
+            // matching lane at or after the end, ...  The next search (back-fill ip-2, probe ip, ip+1, ...) can be resolved
+            // from THIS batch because its probes are lanes of the batch whose table slots nobody before them touched
+            // (lanes < lim).  Sequences that need a loop (longer catch-up / extension than the windows hold), every
+            // sequence of a non-linear batch and of limitedOutput mode are "special": they end the walk and take the
+            // one-at-a-time path below.  Everything else is emitted for all sequences at once.
+            const uint64_t slowmask = limited ? ~0ull : ballot(!linear || mf || bk4 == 4);
+            uint64_t marks = 0, commit = 0;               // lanes that start a sequence / lanes whose table write the reference performs
+            uint32_t anchv = 0;                           // marked lane: its literal run starts at pos0 + (int32)anchv
+            int32_t arel = (int32_t)(anchor - pos0);      // running anchor, relative to pos0 (negative: literals carried in)
+            int cur = 0, special = -1, stop;              // stop: 0 no match in [cur, lim), 1 next search starts beyond lim, 2 end of input, 3 special
             for (;;) {
-                const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull);
-                const int m = first_lane(rem);
-                if (m >= 64) {                            // no match among lanes [start, lim): they were all probed
-                    if (lane >= start && lane < lim) tput(h, pos | mychk, ent);
-                    wave_fence();
-                    if (e < 64 && e <= f) { done = true; break; }          // next probe would pass mflimitPlusOne
-                    if (PROF) cnt[5]++;
-                    if (start == 0) i0 += (uint32_t)lim;
-                    else { i0 = (uint32_t)(lim - start); }                 // ip/extra already describe the chained search
-                    next_batch = true;
-                    break;
+                const uint64_t rem = okmask & (~0ull << cur);
+                if (rem == 0) { commit |= (~0ull << cur) & (lim >= 64 ? ~0ull : ~(~0ull << lim)); stop = 0; break; }
+                const int m = (int)__builtin_ctzll(rem);
+                commit |= (~0ull << cur) & ~(m >= 63 ? 0ull : (~0ull << (m + 1)));       // probes the reference executed
+                if ((slowmask >> m) & 1) { special = m; stop = 3; break; }
+                marks |= 1ull << m;
+                anchv = lane == m ? (uint32_t)arel : anchv;
+                const int endl = m + (int)kMinMatch + (int)lane_get(fw, m);
+                arel = endl;
+                if (pos0 + (uint32_t)endl >= mfl1) { stop = 2; break; }                   // lz4.c:1747
+                if (endl >= lim) { stop = 1; break; }
+                commit |= 1ull << (endl - 2);                                             // back-fill ip-2 (lz4.c:1750)
+                cur = endl;
+            }
+            if ((commit >> lane) & 1) tput(h, pos | mychk, ent);
+            wave_fence();
+            STAGE(3);
+            if (marks) {
+                // per-sequence quantities, in the lane that found the match (lz4.c:1611-1740)
+                const bool marked = (marks >> lane) & 1;
+                const int32_t la = (int32_t)anchv;
+                const uint32_t room = (uint32_t)((int32_t)lane - la);                    // m_pos - anchor
+                const uint32_t maxback = room < cand ? room : cand;
+                const uint32_t back = bk4 < maxback ? bk4 : maxback;
+                const uint32_t lit = room - back;
+                const uint32_t mcode = back + fw;                                         // <= 28: one length byte at most
+                const uint32_t lb = lit < 15 ? 0u : 1u + (lit - 15) / 255;
+                const uint32_t size = marked ? 1 + lb + lit + 2 + (mcode >= 15 ? 1u : 0u) : 0u;
+                uint32_t outv = 0;
+                for (uint64_t t = marks; t; t &= t - 1) {
+                    const int m = (int)__builtin_ctzll(t);
+                    outv = lane == m ? op : outv;
+                    op += lane_get(size, m);
                 }
-                if (lane >= start && lane <= m) tput(h, pos | mychk, ent);   // probes the reference executed
-                wave_fence();
+                if (PROF) cnt[1] += (uint32_t)__builtin_popcountll(marks);
+                if (do_st) {
+                    if (marked) {
+                        gbyte* o = dst + outv;
+                        o[0] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
+                        if (lit >= 15 && la >= 0) o[1] = (uint8_t)(lit - 15);            // in-batch literal runs are < 64 bytes
+                        st16(o + 1 + lb + lit, pos - cand);
+                        if (mcode >= 15) o[1 + lb + lit + 2] = (uint8_t)(mcode - 15);
+                    }
+                    // literals: lane L holds src[pos0+L]; its sequence is the first marked lane at or after it
+                    const uint64_t up = marks >> lane;
+                    const int owner = lane + (up ? (int)__builtin_ctzll(up) : 0);
+                    const uint32_t obase = outv + 1 + lb - (uint32_t)la;
+                    const uint32_t info = (uint32_t)(la < 0 ? 0 : la) | (((uint32_t)lane - back) << 8);
+                    const uint32_t ob = (uint32_t)__shfl((int)obase, owner), oi = (uint32_t)__shfl((int)info, owner);
+                    if (up != 0 && (uint32_t)lane >= (oi & 0xFF) && (uint32_t)lane < (oi >> 8)) dst[ob + (uint32_t)lane] = (uint8_t)litbyte;
+                    if ((int32_t)(anchor - pos0) < 0) {                                   // literals carried in from earlier batches
+                        const int m1 = (int)__builtin_ctzll(marks);
+                        const uint32_t o1 = lane_get(outv, m1), lit1 = lane_get(lit, m1), lb1 = lane_get(lb, m1);
+                        if (lit1 >= 15) put_len_bytes(dst + o1 + 1, lit1 - 15, lane);
+                        wave_copy(dst + o1 + 1 + lb1, src + anchor, pos0 - anchor, lane);
+                    }
+                }
+                ip = pos0 + (uint32_t)arel;
+                anchor = ip;
+                extra = true; i0 = 0;
+            }
+            STAGE(4);
+            bool done = false, prefetch = false;
+            if (stop == 2) done = true;
+            else if (stop == 1) prefetch = true;
+            else if (stop == 0) {
+                if (e < 64 && e <= f) done = true;                                        // next probe would pass mflimitPlusOne
+                else i0 += (uint32_t)(lim - cur);                                         // probes of the current search already examined
+            } else {
+                // ---------------- one special sequence, lane `special` (lz4.c:1611-1740) ----------------
+                const int m = special;
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
-                // catch-up (lz4.c:1611-1623): <= 4 bytes from the window, longer ones by the loop below
                 uint32_t back, fwd = lane_get(fw, m);
-                bool more_back, more_fwd = lane_get((uint32_t)mf, m) != 0;
+                const bool more_fwd = lane_get((uint32_t)mf, m) != 0;
                 {
                     const uint32_t a = m_pos - anchor, maxback = a < m_cand ? a : m_cand;
                     const uint32_t b4 = lane_get(bk4, m);
-                    more_back = b4 == 4 && maxback > 4;
                     back = b4 < maxback ? b4 : maxback;
-                }
-                STAGE(3);
-                if (more_back) {
-                    const uint32_t a = m_pos - anchor;
-                    const uint32_t maxback = a < m_cand ? a : m_cand;
-                    while (back < maxback) {
-                        const uint32_t k = back + (uint32_t)lane;
-                        bool eq = false;
-                        if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
-                        const int c = first_lane(ballot(!eq));
-                        back += (uint32_t)c;
-                        if (c < 64) break;
+                    if (b4 == 4 && maxback > 4) {
+                        while (back < maxback) {
+                            const uint32_t k = back + (uint32_t)lane;
+                            bool eq = false;
+                            if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
+                            const int c = first_lane(ballot(!eq));
+                            back += (uint32_t)c;
+                            if (c < 64) break;
+                        }
                     }
                 }
                 if (more_fwd) {
@@ -268,7 +329,6 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const gbyte* __restri
                         break;
                     }
                 }
-                // ---------------- emit sequence (lz4.c:1626-1740) ----------------
                 const uint32_t mstart = m_pos - back;
                 const uint32_t lit = mstart - anchor;
                 const uint32_t mcode = back + fwd;
@@ -287,37 +347,22 @@ __device__ __attribute__((noinline)) int lz4_compress_wave(const gbyte* __restri
                 if (limited && (uint64_t)op + (1 + kLastLiterals) + (mcode + 240) / 255 > cap) return 0;
                 if (mcode >= 15) { if (do_st) put_len_bytes(dst + op, mcode - 15, lane); op += (mcode - 15) / 255 + 1; }
                 if (do_st && lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
-                STAGE(4);
-                if (PROF) cnt[1]++;
+                if (PROF) { cnt[1]++; cnt[4]++; }
                 ip = mstart + kMinMatch + mcode;
                 anchor = ip;
-                if (ip >= mfl1) { done = true; break; }   // lz4.c:1747
-                extra = true; i0 = 0;
-                // The next search (back-fill ip-2, probe ip, ip+1, ...) can be resolved from THIS batch when its
-                // probes are lanes of the batch whose table slots nobody before them touched (lanes < lim).
-                const uint32_t Ln = ip - pos0;
-                if (linear && !more_fwd && Ln < (uint32_t)lim) {
-                    if ((uint32_t)lane == Ln - 2) tput(h, pos | mychk, ent);          // back-fill ip-2 (lz4.c:1750)
-                    wave_fence();
-                    start = (int)Ln;
-                    continue;
-                }
-                if (PROF) { if (more_fwd) cnt[4]++; else if (Ln >= 64) cnt[2]++; else cnt[3]++; }
-                // otherwise request the windows of the next batch now, ahead of everything else
-                {
-                    const uint32_t npos = ip + (uint32_t)lane;                         // probe -1 at ip, then ip+1+j
-                    const bool nvalid = lane == 0 || (ip + 1) + sched((uint32_t)lane) <= mfl1;
-                    pre.lo = 0; pre.hi = 0;
-                    if (nvalid) pre = load_win(src, npos);
-                    pre_fill = ld64(src + ip - 2);
-                    have_pre = true;
-                }
-                next_batch = true;
-                break;
+                if (ip >= mfl1) done = true;              // lz4.c:1747
+                else { extra = true; i0 = 0; prefetch = true; }
             }
-            asm volatile("; chain end" ::: "memory");
+            if (prefetch) {   // request the windows of the next search's first batch now, ahead of everything else
+                const uint32_t npos = ip + (uint32_t)lane;                             // probe -1 at ip, then ip+1+j
+                const bool nvalid = lane == 0 || (ip + 1) + sched((uint32_t)lane) <= mfl1;
+                pre.lo = 0; pre.hi = 0;
+                if (nvalid) pre = load_win(src, npos);
+                pre_fill = ld64(src + ip - 2);
+                have_pre = true;
+            }
+            asm volatile("; resolve end" ::: "memory");
             if (done) break;
-            (void)next_batch;
         }
     }
     // ---------------- last literals (lz4.c:1808-1834) ----------------
