@@ -49,6 +49,17 @@ template <class P> __device__ __forceinline__ P uni_ptr(P p)
 // a byte of this workgroup's LDS
 typedef __attribute__((address_space(3))) uint8_t lbyte;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// unaligned LDS reads (gfx950 handles any byte address in one ds_read)
+__device__ __forceinline__ u32x4 lds_ld128(const lbyte* p)
+{
+    typedef u32x4 __attribute__((aligned(1))) U;
+    return *(const __attribute__((address_space(3))) U*)p;
+}
+__device__ __forceinline__ uint64_t lds_ld64(const lbyte* p)
+{
+    typedef uint64_t __attribute__((aligned(1))) U;
+    return *(const __attribute__((address_space(3))) U*)p;
+}
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // compiler-only ordering point between cross-lane LDS / global accesses of ONE wave

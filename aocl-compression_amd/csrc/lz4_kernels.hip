@@ -29,6 +29,7 @@ namespace {
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMfLimit = 12, kMinLength = 13;
 constexpr uint32_t kDistMax = 65535, k64KLimit = 65536 + 11, kMaxInput = 0x7E000000u;
 constexpr uint32_t kTableBytes = 16384;   // LZ4_MEMORY_USAGE 14 (lz4.h:163)
+constexpr uint32_t kSrcRing = 544;        // compressor's source ring: 2 x 256 B + 32 B mirror
 
 __device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }   // lz4.h:261
 
@@ -129,7 +130,24 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     bool extra = false;                                   // next batch starts with the post-match probe
     // software pipeline: the probe windows of the NEXT search's first batch (and the ip-2 back-fill bytes) are
     // requested as soon as the current match length is known, ahead of the table commit and the emission
-    bool have_pre = false; Win pre = {0, 0}; uint64_t pre_fill = 0;
+    // Source ring: the bytes around the parse position are staged in LDS as two 256-byte blocks (block b of the
+    // chunk sits at ring offset (b & 1) * 256, the first 32 ring bytes are mirrored behind the end so that a 32-byte
+    // read never wraps).  The block after the newest one is always in flight in a register, requested ~256 bytes of
+    // parsing ahead of its use, so the 64 probe windows of a batch are LDS reads instead of a global round trip.
+    lbyte* ring = lds + (MODE == 1 ? 9216u : kTableBytes);
+    int32_t rb = -4;                                      // newest block in the ring (blocks rb-1 and rb are valid)
+    uint32_t pend = 0; bool have_pend = false;            // block rb+1, in flight
+    auto blk_load = [&](int32_t b) -> uint32_t {
+        const uint32_t a = 256u * (uint32_t)b + 4u * (uint32_t)lane;
+        uint32_t v = 0;
+        if (a + 4 <= n) v = ld32(src + a);
+        else if (a < n) for (uint32_t t = 0; t < n - a; ++t) v |= (uint32_t)src[a + t] << (8 * t);
+        return v;
+    };
+    auto blk_store = [&](int32_t b, uint32_t v) {
+        *(L32*)(ring + (((uint32_t)b & 1u) << 8) + 4u * (uint32_t)lane) = v;
+        if (!(b & 1) && lane < 8) *(L32*)(ring + 512u + 4u * (uint32_t)lane) = v;
+    };
 
     if (n >= kMinLength) {
         uint32_t i0 = 0;                                  // probes of the current search already examined
@@ -142,16 +160,40 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             const bool valid = base + sched((uint32_t)(j + 1)) <= mfl1;         // lz4.c:1513
             // 16-byte windows [p-4, p+12) around the probe and around its candidate: the 4 bytes of the match
             // test, 4 bytes of catch-up and 8 bytes of forward extension arrive in one round trip
-            Win pw = {0, 0};
-            if (i0 == 0 && have_pre) pw = pre;
-            else if (valid) pw = load_win(src, pos);
+            const uint32_t pos0 = lane_get(pos, 0);
+            // probe windows [p-4, p+28): from the source ring when the whole batch fits two blocks, else 16 bytes from memory
+            const uint32_t posmax = base + sched(i0 + 63u - (extra ? 1u : 0u));
+            const bool use_ring = posmax + 28 - (pos0 < 4 ? 0 : pos0 - 4) <= 256;
+            Win pw = {0, 0}; uint64_t p2 = 0, p3 = 0;
+            uint64_t fb = 0;                              // the 8 bytes at ip-2 (back-fill)
+            if (use_ring) {
+                const int32_t bl = pos0 < 4 ? 0 : (int32_t)((pos0 - 4) >> 8), bh = (int32_t)((posmax + 27) >> 8);
+                if (!(bh <= rb && rb <= bl + 1)) {
+                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
+                    else {
+                        const uint32_t v0 = blk_load(bl), v1 = blk_load(bh);
+                        blk_store(bl, v0);
+                        if (bh != bl) blk_store(bh, v1);
+                        rb = bh;
+                    }
+                    pend = blk_load(rb + 1); have_pend = true;
+                    wave_fence();
+                }
+                const uint32_t off = (pos - 4) & 511u;
+                const u32x4 a = lds_ld128(ring + off), b = lds_ld128(ring + off + 16);
+                pw.lo = a.x | ((uint64_t)a.y << 32); pw.hi = a.z | ((uint64_t)a.w << 32);
+                p2 = b.x | ((uint64_t)b.y << 32); p3 = b.z | ((uint64_t)b.w << 32);
+                if (pos0 < 4 && pos < 4) pw.lo &= ~0ull << (8 * (4 - pos));              // bytes before the chunk read as 0
+                if (extra && i0 == 0) fb = lds_ld64(ring + ((ip - 2) & 511u));
+            } else {
+                if (valid) pw = load_win(src, pos);
+                if (extra && i0 == 0) fb = ld64(src + ip - 2);
+            }
             if (extra && i0 == 0) {                       // back-fill ip-2 (lz4.c:1750) before the batch reads the table
-                const uint64_t fb = have_pre ? pre_fill : ld64(src + ip - 2);
                 const uint32_t h2 = lz4_hash<MODE == 0>(fb);
                 if (lane == 0) tput_blind(h2, (ip - 2) | chk((uint32_t)fb));
                 wave_fence();
             }
-            have_pre = false;
             STAGE(0);
             const uint64_t seq = (pw.lo >> 32) | (pw.hi << 32);
             const uint32_t h = lz4_hash<MODE == 0>(seq);
@@ -182,17 +224,14 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             const int e = first_lane(ballot(!valid));
             const int lim = f < e ? f : e;                // lanes < lim saw exactly the sequential candidates
             const uint64_t okmask = ballot(lane < lim && plausible && (uint32_t)(cw.lo >> 32) == (uint32_t)(pw.lo >> 32));
-            const uint32_t pos0 = lane_get(pos, 0);
             const bool linear = (i0 == 0);                // lane L probes pos0 + L (sched is the identity below 66)
             // in-lane forward extension (<= 24 bytes), LZ4_count lz4.c:656-679: the probe-side bytes beyond +12 sit in
             // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
             uint32_t fw; bool mf;
             {
-                const uint64_t p2 = __shfl_down(pw.hi, 8), p3 = __shfl_down(pw.hi, 16);
                 uint64_t c2 = 0, c3 = 0;
-                const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // those lanes hold real bytes
-                const bool have2 = plausible && linear && lane + 8 < 64 && v2 && cand + 20 <= n;
-                const bool have3 = have2 && lane + 16 < 64 && v3 && cand + 28 <= n;
+                const bool have2 = plausible && use_ring && cand + 20 <= n;
+                const bool have3 = have2 && cand + 28 <= n;
                 if (have2) c2 = ld64(src + cand + 12);
                 if (have3) c3 = ld64(src + cand + 20);
                 const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
@@ -211,52 +250,83 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
             asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
             // ---------------- resolve every sequence this batch holds ----------------
-            // Walk (scalar, a handful of instructions per sequence): first matching lane >= cur, end of that match, first
-            // matching lane at or after the end, ...  The next search (back-fill ip-2, probe ip, ip+1, ...) can be resolved
-            // from THIS batch because its probes are lanes of the batch whose table slots nobody before them touched
-            // (lanes < lim).  Sequences that need a loop (longer catch-up / extension than the windows hold), every
-            // sequence of a non-linear batch and of limitedOutput mode are "special": they end the walk and take the
-            // one-at-a-time path below.  Everything else is emitted for all sequences at once.
-            const uint64_t slowmask = limited ? ~0ull : ballot(!linear || mf || bk4 == 4);
-            uint64_t marks = 0, commit = 0;               // lanes that start a sequence / lanes whose table write the reference performs
-            uint32_t anchv = 0;                           // marked lane: its literal run starts at pos0 + (int32)anchv
-            int32_t arel = (int32_t)(anchor - pos0);      // running anchor, relative to pos0 (negative: literals carried in)
-            int cur = 0, special = -1, stop;              // stop: 0 no match in [cur, lim), 1 next search starts beyond lim, 2 end of input, 3 special
-            for (;;) {
-                const uint64_t rem = okmask & (~0ull << cur);
-                if (rem == 0) { commit |= (~0ull << cur) & (lim >= 64 ? ~0ull : ~(~0ull << lim)); stop = 0; break; }
-                const int m = (int)__builtin_ctzll(rem);
-                commit |= (~0ull << cur) & ~(m >= 63 ? 0ull : (~0ull << (m + 1)));       // probes the reference executed
-                if ((slowmask >> m) & 1) { special = m; stop = 3; break; }
-                marks |= 1ull << m;
-                anchv = lane == m ? (uint32_t)arel : anchv;
-                const int endl = m + (int)kMinMatch + (int)lane_get(fw, m);
-                arel = endl;
-                if (pos0 + (uint32_t)endl >= mfl1) { stop = 2; break; }                   // lz4.c:1747
-                if (endl >= lim) { stop = 1; break; }
-                commit |= 1ull << (endl - 2);                                             // back-fill ip-2 (lz4.c:1750)
-                cur = endl;
+            // The next search after a match (back-fill ip-2, probe ip, ip+1, ...) can be resolved from THIS batch because
+            // its probes are lanes of the batch whose table slots nobody before them touched (lanes < lim).  Every
+            // matching lane precomputes where the chain continues after its match (`nxt`), so the scalar walk is one
+            // readlane per sequence; everything else (table commit, token/length/offset/literal bytes of ALL sequences)
+            // is derived from 64-bit lane masks and done once per batch.  Sequences that need a loop (longer catch-up /
+            // extension than the windows hold), every sequence of a non-linear batch and of limitedOutput mode are
+            // "special": they end the walk and take the one-at-a-time path below.
+            const uint64_t slowmask = limited ? ~0ull : ballot(!linear || mf);
+            const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes
+            uint32_t nxt;                                 // next matching lane, or 64 + stop code
+            {
+                const uint64_t t = endl < 64 ? okmask >> endl : 0;
+                nxt = t ? endl + (uint32_t)__builtin_ctzll(t) : 64u;                      // 64: no match in [endl, lim)
+                if (endl >= (uint32_t)lim) nxt = 65;                                      // 65: next search starts beyond lim
+                if (pos0 + endl >= mfl1) nxt = 66;                                        // 66: end of input (lz4.c:1747)
             }
-            if ((commit >> lane) & 1) tput(h, pos | mychk, ent);
+            uint64_t marks = 0;                           // lanes that start a sequence
+            int special = -1;
+            uint32_t mw = okmask ? (uint32_t)__builtin_ctzll(okmask) : 64u;
+            while (mw < 64) {
+                if ((slowmask >> mw) & 1) { special = (int)mw; break; }
+                marks |= 1ull << mw;
+                mw = lane_get(nxt, (int)mw);
+            }
+            int stop = special >= 0 ? 3 : (int)mw - 64;   // 0 no match in [cur, lim), 1 beyond lim, 2 end of input, 3 special
+            const int32_t arel0 = (int32_t)(anchor - pos0);      // <= 0; negative: literals carried in from earlier batches
+            // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it
+            const uint64_t beloweq = ~0ull >> (63 - lane), below = beloweq >> 1;
+            const uint64_t mb_ = marks & below;
+            const int q = 63 - (int)__builtin_clzll(mb_ | 1);                             // highest marked lane strictly below
+            const uint32_t qend = (uint32_t)__shfl((int)endl, q);
+            const int32_t la = mb_ ? (int32_t)qend : arel0;
+            const uint32_t room = (uint32_t)((int32_t)lane - la);                        // m_pos - anchor
+            const uint32_t maxback = room < cand ? room : cand;
+            {   // a catch-up that runs past the 4 bytes of the window needs the loop: cut the chain in front of it
+                const uint64_t need = ballot(((marks >> lane) & 1) && bk4 == 4 && maxback > 4);
+                if (need) { special = (int)__builtin_ctzll(need); stop = 3; marks &= ~(~0ull << special); }
+            }
+            const int lastm = 63 - (int)__builtin_clzll(marks | 1);
+            const int cur = marks ? (int)lane_get(endl, lastm) : 0;                       // first lane of the unfinished search
+            const bool marked = (marks >> lane) & 1;
+            const bool covered = marked || (mb_ != 0 && (uint32_t)lane < qend);           // lanes inside a match [m, endl)
+            const uint64_t cover = ballot(covered);
+            {   // table writes the reference performs: every probed lane of every search, plus the ip-2 back-fills
+                const int R = stop == 0 ? lim : (stop == 3 ? special + 1 : cur);
+                const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
+                const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
+                const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
+                if ((commit >> lane) & 1) tput(h, pos | mychk, ent);
+            }
             wave_fence();
             STAGE(3);
             if (marks) {
                 // per-sequence quantities, in the lane that found the match (lz4.c:1611-1740)
-                const bool marked = (marks >> lane) & 1;
-                const int32_t la = (int32_t)anchv;
-                const uint32_t room = (uint32_t)((int32_t)lane - la);                    // m_pos - anchor
-                const uint32_t maxback = room < cand ? room : cand;
                 const uint32_t back = bk4 < maxback ? bk4 : maxback;
                 const uint32_t lit = room - back;
                 const uint32_t mcode = back + fw;                                         // <= 28: one length byte at most
                 const uint32_t lb = lit < 15 ? 0u : 1u + (lit - 15) / 255;
-                const uint32_t size = marked ? 1 + lb + lit + 2 + (mcode >= 15 ? 1u : 0u) : 0u;
-                uint32_t outv = 0;
-                for (uint64_t t = marks; t; t &= t - 1) {
-                    const int m = (int)__builtin_ctzll(t);
-                    outv = lane == m ? op : outv;
-                    op += lane_get(size, m);
+                const uint64_t lbmask = ballot(marked && lit >= 15), mbmask = ballot(marked && mcode >= 15);
+                const uint64_t backcover = (ballot(marked && back >= 1) >> 1) | (ballot(marked && back >= 2) >> 2) | (ballot(marked && back >= 3) >> 3) | (ballot(marked && back >= 4) >> 4);
+                const uint64_t litmask = (~0ull >> (63 - lastm)) & ~cover & ~backcover;   // lanes whose byte is a literal of some sequence
+                const int firstm = (int)__builtin_ctzll(marks);
+                // bytes that precede lane L's contribution: 3 per earlier sequence (token + offset), their length bytes,
+                // all earlier literal lanes, and (after the first sequence) its carried-in literals / extra length bytes
+                uint32_t adj = 0, lb1 = 0;
+                const uint32_t carry = (uint32_t)(-arel0);
+                if (arel0 < 0) {
+                    const uint32_t lit1 = lane_get(lit, firstm);
+                    lb1 = lit1 < 15 ? 0u : 1u + (lit1 - 15) / 255;
+                    adj = carry + lb1 - (lit1 >= 15 ? 1u : 0u);
                 }
+                auto cntbelow = [&](uint64_t mk) -> uint32_t {
+                    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                };
+                const uint32_t H = 3 * cntbelow(marks) + cntbelow(lbmask) + cntbelow(mbmask) + cntbelow(litmask) + (lane > firstm ? adj : 0u);
+                const uint32_t ownlit = lit - (lane == firstm ? carry : 0u);              // this sequence's literal lanes
+                const uint32_t outv = op + H - ownlit;                                    // marked lanes: where the token goes
                 if (PROF) cnt[1] += (uint32_t)__builtin_popcountll(marks);
                 if (do_st) {
                     if (marked) {
@@ -266,28 +336,26 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                         st16(o + 1 + lb + lit, pos - cand);
                         if (mcode >= 15) o[1 + lb + lit + 2] = (uint8_t)(mcode - 15);
                     }
-                    // literals: lane L holds src[pos0+L]; its sequence is the first marked lane at or after it
-                    const uint64_t up = marks >> lane;
-                    const int owner = lane + (up ? (int)__builtin_ctzll(up) : 0);
-                    const uint32_t obase = outv + 1 + lb - (uint32_t)la;
-                    const uint32_t info = (uint32_t)(la < 0 ? 0 : la) | (((uint32_t)lane - back) << 8);
-                    const uint32_t ob = (uint32_t)__shfl((int)obase, owner), oi = (uint32_t)__shfl((int)info, owner);
-                    if (up != 0 && (uint32_t)lane >= (oi & 0xFF) && (uint32_t)lane < (oi >> 8)) dst[ob + (uint32_t)lane] = (uint8_t)litbyte;
-                    if ((int32_t)(anchor - pos0) < 0) {                                   // literals carried in from earlier batches
-                        const int m1 = (int)__builtin_ctzll(marks);
-                        const uint32_t o1 = lane_get(outv, m1), lit1 = lane_get(lit, m1), lb1 = lane_get(lb, m1);
-                        if (lit1 >= 15) put_len_bytes(dst + o1 + 1, lit1 - 15, lane);
-                        wave_copy(dst + o1 + 1 + lb1, src + anchor, pos0 - anchor, lane);
+                    if ((litmask >> lane) & 1) {          // literals: lane L holds src[pos0+L]; its sequence is the first marked lane after it
+                        const uint64_t up = marks >> lane;
+                        const uint64_t iso = up & (0 - up);
+                        const uint32_t lbo = lane < firstm && arel0 < 0 ? lb1 : (((lbmask >> lane) & iso) ? 1u : 0u);
+                        dst[op + H + 1 + lbo + (lane < firstm ? carry : 0u)] = (uint8_t)litbyte;
+                    }
+                    if (arel0 < 0) {                      // the carried-in part of the first literal run
+                        if (lb1) put_len_bytes(dst + op + 1, lane_get(lit, firstm) - 15, lane);
+                        wave_copy(dst + op + 1 + lb1, src + anchor, carry, lane);
                     }
                 }
-                ip = pos0 + (uint32_t)arel;
+                op = lane_get(outv + 1 + lb + lit + 2 + (mcode >= 15 ? 1u : 0u), lastm);
+                ip = pos0 + (uint32_t)cur;
                 anchor = ip;
                 extra = true; i0 = 0;
             }
             STAGE(4);
-            bool done = false, prefetch = false;
+            bool done = false;
             if (stop == 2) done = true;
-            else if (stop == 1) prefetch = true;
+            else if (stop == 1) { /* next batch starts at ip */ }
             else if (stop == 0) {
                 if (e < 64 && e <= f) done = true;                                        // next probe would pass mflimitPlusOne
                 else i0 += (uint32_t)(lim - cur);                                         // probes of the current search already examined
@@ -351,16 +419,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 ip = mstart + kMinMatch + mcode;
                 anchor = ip;
                 if (ip >= mfl1) done = true;              // lz4.c:1747
-                else { extra = true; i0 = 0; prefetch = true; }
+                else { extra = true; i0 = 0; }
             }
-            if (prefetch) {   // request the windows of the next search's first batch now, ahead of everything else
-                const uint32_t npos = ip + (uint32_t)lane;                             // probe -1 at ip, then ip+1+j
-                const bool nvalid = lane == 0 || (ip + 1) + sched((uint32_t)lane) <= mfl1;
-                pre.lo = 0; pre.hi = 0;
-                if (nvalid) pre = load_win(src, npos);
-                pre_fill = ld64(src + ip - 2);
-                have_pre = true;
-            }
+            STAGE(5);
             asm volatile("; resolve end" ::: "memory");
             if (done) break;
         }
@@ -595,7 +656,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
 template <int MODE, bool PROF>
 __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint32_t first)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[MODE == 1 ? 9216 : kTableBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 : kTableBytes) + kSrcRing];
     const uint32_t c = first + blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = compress_view(b, c);

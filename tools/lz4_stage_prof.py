@@ -13,10 +13,10 @@ slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_lz4_prof(buf)
-names = ["emit-tail+probe loads+backfill", "hash+table lookup", "cand loads+slot-reuse", "decision+prefetch+commit", "extension+emit", "-"]
+names = ["ring + probe windows + backfill", "hash + table lookup", "cand loads + slot-reuse", "fw/bk + walk + commit", "vector emit", "special sequence path"]
 tot = sum(buf[:6]); nseq = src.numel() / 17.97
 for n, v in zip(names, buf[:6]):
-    print(f"{n:20s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
+    print(f"{n:34s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
 print("total cyc/seq", tot / nseq)
 
 c = list(buf[8:16])
