@@ -30,6 +30,9 @@ constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMfLimit = 12, kMinLength =
 constexpr uint32_t kDistMax = 65535, k64KLimit = 65536 + 11, kMaxInput = 0x7E000000u;
 constexpr uint32_t kTableBytes = 16384;   // LZ4_MEMORY_USAGE 14 (lz4.h:163)
 constexpr uint32_t kSrcRing = 544;        // compressor's source ring: 2 x 256 B + 32 B mirror
+#ifndef LZ4_LDS_PAD
+#define LZ4_LDS_PAD 0
+#endif
 
 __device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }   // lz4.h:261
 
@@ -154,15 +157,21 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         for (;;) {
             asm volatile("; batch begin" ::: "memory");
             // ---------------- one batch of 64 speculative probes (lz4.c:1483-1608, 1746-1804) ----------------
-            const uint32_t base = extra ? ip + 1 : ip;
-            const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-            const uint32_t pos = (j < 0) ? ip : base + sched((uint32_t)j);
-            const bool valid = base + sched((uint32_t)(j + 1)) <= mfl1;         // lz4.c:1513
+            uint32_t pos, posmax; bool valid;
+            if (i0 == 0) {                                // first 64 probes of a search: consecutive positions
+                pos = ip + (uint32_t)lane; posmax = ip + 63;
+                valid = pos + 1 <= mfl1;                                        // lz4.c:1513
+            } else {
+                const uint32_t base = extra ? ip + 1 : ip;
+                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
+                pos = base + sched((uint32_t)j);
+                posmax = base + sched(i0 + 63u - (extra ? 1u : 0u));
+                valid = base + sched((uint32_t)(j + 1)) <= mfl1;
+            }
             // 16-byte windows [p-4, p+12) around the probe and around its candidate: the 4 bytes of the match
             // test, 4 bytes of catch-up and 8 bytes of forward extension arrive in one round trip
             const uint32_t pos0 = lane_get(pos, 0);
             // probe windows [p-4, p+28): from the source ring when the whole batch fits two blocks, else 16 bytes from memory
-            const uint32_t posmax = base + sched(i0 + 63u - (extra ? 1u : 0u));
             const bool use_ring = posmax + 28 - (pos0 < 4 ? 0 : pos0 - 4) <= 256;
             Win pw = {0, 0}; uint64_t p2 = 0, p3 = 0;
             uint64_t fb = 0;                              // the 8 bytes at ip-2 (back-fill)
@@ -656,7 +665,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
 template <int MODE, bool PROF>
 __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint32_t first)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 : kTableBytes) + kSrcRing];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 + LZ4_LDS_PAD : kTableBytes) + kSrcRing];
     const uint32_t c = first + blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = compress_view(b, c);

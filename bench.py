@@ -246,6 +246,17 @@ def main():
                 "other_kernel_ms": round(ms_d if dom == "compress" else ms_c, 4),
             },
         }
+        # HBM-side traffic of the dominant kernel: not measurable from inside this process; taken from the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/traffic.json), raw counter
+        # bytes per launch, only when this run has the profiled shape.
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
+                t = json.load(f).get(args.codec)
+            if t and t["kernel"] == out["roofline"]["kernel"] and t["gib_per_gpu"] == args.gib and t["chunk_bytes"] == chunk:
+                out["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1000.0
+                out["roofline"]["traffic_source"] = t["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res = cpu_baseline(args.codec, base_np, total, chunk, slot, args.cpu_sample_gib)

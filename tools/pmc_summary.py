@@ -6,7 +6,7 @@ csv.field_size_limit(1 << 30)
 root, sub = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
-for f in sorted(glob.glob(root + "/*/**/*counter_collection.csv", recursive=True)):
+for f in sorted(set(glob.glob(root + "/**/*counter_collection.csv", recursive=True))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if sub not in k:

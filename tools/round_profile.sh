@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/round_profile.sh <tag>
+# Full bench lines (with cpu_baseline) for the three codecs, a rocprofv3 --kernel-trace --stats run of the default
+# bench command, and separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for HBM traffic.  Outputs: gpurun_out/<tag>/
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cd $R
+for c in lz4 snappy zstd; do
+  python3 bench.py --codec $c > $out/bench_$c.json 2> $out/bench_$c.err
+done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o lz4 -- python3 $R/bench.py --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o p -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_$ctr.json 2> $out/pmc_$ctr.err
+done
+ls -R $out | head -50
