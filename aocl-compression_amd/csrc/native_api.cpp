@@ -1,0 +1,198 @@
+// csrc/native_api.cpp -- the reference's per-codec native entry points on top of the GPU engine
+// (include/aocl_native_api.h).  Host buffers, one chunk per call, no CPU fallback.
+#include "../../include/aocl_native_api.h"
+#include "../../include/aocl_gpu_codec.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+const int kErrInvalidInput = -5;                          // api/aocl_compression.h:97 ERR_INVALID_INPUT
+
+// varint32 length prefix of a Snappy stream (snappy.cc:1202-1223, snappy-stubs-internal.h:440)
+bool sn_parse_len(const char* p, size_t n, uint32_t* out)
+{
+    uint32_t v = 0;
+    for (uint32_t shift = 0, i = 0; shift <= 28; shift += 7, ++i) {
+        if (i >= n) return false;
+        const uint32_t c = (uint8_t)p[i];
+        if (shift == 28 && (c & 0x7F) > 15) return false;  // LeftShiftOverflows
+        v |= (c & 0x7F) << shift;
+        if (c < 128) { *out = v; return true; }
+    }
+    return false;
+}
+
+size_t zerr(int code) { return (size_t)0 - (size_t)code; }
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- LZ4 ----------------------------------------
+int LZ4_versionNumber(void) { return 10903; }
+const char* LZ4_versionString(void) { return "1.9.3"; }
+int LZ4_compressBound(int isize) { return (unsigned)isize > 0x7E000000u ? 0 : isize + isize / 255 + 16; }   // lz4.h:261
+
+int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration)
+{   // lz4.c:2937-2975 (AOCL adds the NULL checks): only the default acceleration has a GPU backend
+    if ((!src && srcSize != 0) || !dst || srcSize < 0 || dstCapacity < 0) return 0;
+    if (acceleration > 1) return 0;
+    if ((unsigned)srcSize > 0x7E000000u) return 0;
+    const int64_t r = aoclgpu_compress_host(AOCLGPU_LZ4, src, (size_t)srcSize, dst, (size_t)dstCapacity);
+    return r > 0 && r <= 0x7FFFFFFF ? (int)r : 0;
+}
+int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)
+{
+    return LZ4_compress_fast(src, dst, srcSize, dstCapacity, 1);
+}
+int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity)
+{   // lz4.c:4898-4923
+    if (!src || !dst || compressedSize < 0 || dstCapacity < 0) return -1;
+    const int64_t r = aoclgpu_decompress_host(AOCLGPU_LZ4, src, (size_t)compressedSize, dst, (size_t)dstCapacity);
+    if (r >= 0) return (int)r;
+    return r > -0x7FFFFFFF ? (int)r : -1;
+}
+char* aocl_setup_lz4(int, int, size_t, size_t, size_t) { return nullptr; }
+void aocl_destroy_lz4(void) {}
+
+// ---------------------------------------------------------------- Snappy (C) ---------------------------------
+size_t snappy_max_compressed_length(size_t n) { return 32 + n + n / 6; }                 // snappy.cc:160-182
+snappy_status snappy_compress(const char* input, size_t input_length, char* compressed, size_t* compressed_length)
+{   // snappy-c.cc:37-49
+    if (!compressed_length || (!input && input_length) || !compressed) return SNAPPY_INVALID_INPUT;
+    if (*compressed_length < snappy_max_compressed_length(input_length)) return SNAPPY_BUFFER_TOO_SMALL;
+    const int64_t r = aoclgpu_compress_host(AOCLGPU_SNAPPY, input, input_length, compressed, *compressed_length);
+    if (r <= 0) return SNAPPY_INVALID_INPUT;
+    *compressed_length = (size_t)r;
+    return SNAPPY_OK;
+}
+snappy_status snappy_uncompressed_length(const char* compressed, size_t compressed_length, size_t* result)
+{
+    uint32_t v;
+    if (!compressed || !result || !sn_parse_len(compressed, compressed_length, &v)) return SNAPPY_INVALID_INPUT;
+    *result = v;
+    return SNAPPY_OK;
+}
+snappy_status snappy_uncompress(const char* compressed, size_t compressed_length, char* uncompressed, size_t* uncompressed_length)
+{   // snappy-c.cc:51-69
+    size_t real;
+    if (!uncompressed || !uncompressed_length) return SNAPPY_INVALID_INPUT;
+    if (snappy_uncompressed_length(compressed, compressed_length, &real) != SNAPPY_OK) return SNAPPY_INVALID_INPUT;
+    if (*uncompressed_length < real) return SNAPPY_BUFFER_TOO_SMALL;
+    const int64_t r = aoclgpu_decompress_host(AOCLGPU_SNAPPY, compressed, compressed_length, uncompressed, real);
+    if (r < 0 || (size_t)r != real) return SNAPPY_INVALID_INPUT;
+    *uncompressed_length = real;
+    return SNAPPY_OK;
+}
+snappy_status snappy_validate_compressed_buffer(const char* compressed, size_t compressed_length)
+{
+    size_t real;
+    if (snappy_uncompressed_length(compressed, compressed_length, &real) != SNAPPY_OK) return SNAPPY_INVALID_INPUT;
+    char* tmp = (char*)malloc(real ? real : 1);
+    if (!tmp) return SNAPPY_INVALID_INPUT;
+    const int64_t r = aoclgpu_decompress_host(AOCLGPU_SNAPPY, compressed, compressed_length, tmp, real);
+    free(tmp);
+    return r >= 0 && (size_t)r == real ? SNAPPY_OK : SNAPPY_INVALID_INPUT;
+}
+
+// ---------------------------------------------------------------- Zstd ---------------------------------------
+unsigned ZSTD_versionNumber(void) { return 10505; }
+const char* ZSTD_versionString(void) { return "1.5.5"; }
+size_t ZSTD_compressBound(size_t n)
+{   // zstd.h:228-230 ZSTD_COMPRESSBOUND
+    if (n >= (sizeof(size_t) == 8 ? 0xFF00FF00FF00FF00ull : 0xFF00FF00u)) return zerr(72);
+    return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
+}
+unsigned ZSTD_isError(size_t code) { return code > zerr(120); }                           // zstd_errors.h:100
+const char* ZSTD_getErrorName(size_t code)
+{
+    if (!ZSTD_isError(code)) return "No error detected";
+    switch ((int)((size_t)0 - code)) {
+    case 10: return "Unknown frame descriptor";
+    case 20: return "Data corruption detected";
+    case 40: return "Unsupported parameter";
+    case 70: return "Destination buffer is too small";
+    case 72: return "Src size is incorrect";
+    default: return "Error (generic)";
+    }
+}
+size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
+{   // zstd_compress.c:5534; only level 1 ("fast" strategy), one block per frame, has a GPU backend
+    if (!dst || (!src && srcSize)) return zerr(1);
+    if (level != 1) return zerr(40);
+    if (srcSize > (128u << 10)) return zerr(72);
+    const int64_t r = aoclgpu_compress_host(AOCLGPU_ZSTD, src, srcSize, dst, dstCapacity);
+    if (r > 0) return (size_t)r;
+    return zerr(dstCapacity < ZSTD_compressBound(srcSize) ? 70 : 1);
+}
+size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize)
+{   // zstd_decompress.c:1252
+    if ((!dst && dstCapacity) || !src) return zerr(1);
+    const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, src, compressedSize, dst ? dst : (void*)"", dstCapacity);
+    if (r >= 0) return (size_t)r;
+    return zerr(20);
+}
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
+{   // zstd_decompress.c:601-624 via ZSTD_getFrameHeader (zstd_decompress.c:440-560); zstd frames only
+    const unsigned long long kUnknown = 0ULL - 1, kError = 0ULL - 2;
+    const uint8_t* p = (const uint8_t*)src;
+    if (!p || srcSize < 5) return kError;
+    if ((p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)) != 0xFD2FB528u) return kError;
+    const uint32_t fhd = p[4], dictID = fhd & 3, single = (fhd >> 5) & 1, fcsID = fhd >> 6;
+    static const size_t did[4] = {0, 1, 2, 4}, fcs[4] = {0, 2, 4, 8};
+    size_t pos = 5 + (single ? 0 : 1) + did[dictID];
+    const size_t fl = (fcsID == 0) ? (single ? 1 : 0) : fcs[fcsID];
+    if (fhd & 0x08) return kError;                                    // reserved bit
+    if (srcSize < pos + fl) return kError;
+    if (fl == 0) return kUnknown;
+    unsigned long long v = 0;
+    for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
+    if (fl == 2) v += 256;
+    return v;
+}
+char* aocl_setup_zstd_encode(int, int, size_t, size_t, size_t) { return nullptr; }
+char* aocl_setup_zstd_decode(int, int, size_t, size_t, size_t) { return nullptr; }
+
+// ---------------------------------------------------------------- RAP frame ----------------------------------
+int32_t aocl_get_rap_frame_bound_mt(void)
+{   // threads/threads.c:315-318 with the thread count replaced by the GPU build's partition limit (the RAP
+    // header stores the partition count in 16 bits, threads/threads.h:82-83)
+    return 8 + 4 + 2 + 2 + 12 * 65535;
+}
+int32_t aocl_skip_rap_frame_mt(char* src, int32_t src_size)
+{   // threads/threads.c:320-336
+    if (!src) return kErrInvalidInput;
+    int64_t magic = 0;
+    if (src_size >= 8) memcpy(&magic, src, 8);
+    if (src_size < 8 || magic != 0x434C4C5F4C434F41ll) return 0;
+    if (src_size < 12) return 0;
+    uint32_t len; memcpy(&len, src + 8, 4);
+    return (int32_t)len;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- Snappy (C++) -------------------------------
+namespace snappy {
+size_t MaxCompressedLength(size_t n) { return snappy_max_compressed_length(n); }
+void RawCompress(const char* input, size_t input_length, char* compressed, size_t* compressed_length)
+{   // snappy.cc:2494-2503: NULL arguments -> silent return, *compressed_length untouched
+    if (!compressed || !compressed_length || (!input && input_length)) return;
+    const int64_t r = aoclgpu_compress_host(AOCLGPU_SNAPPY, input, input_length, compressed, MaxCompressedLength(input_length));
+    if (r > 0) *compressed_length = (size_t)r;
+}
+bool GetUncompressedLength(const char* compressed, size_t compressed_length, size_t* result)
+{
+    return snappy_uncompressed_length(compressed, compressed_length, result) == SNAPPY_OK;
+}
+bool RawUncompress(const char* compressed, size_t compressed_length, char* uncompressed)
+{   // snappy.cc:2271: the caller sized `uncompressed` from GetUncompressedLength
+    size_t real;
+    if (!uncompressed || !GetUncompressedLength(compressed, compressed_length, &real)) return false;
+    const int64_t r = aoclgpu_decompress_host(AOCLGPU_SNAPPY, compressed, compressed_length, uncompressed, real);
+    return r >= 0 && (size_t)r == real;
+}
+bool IsValidCompressedBuffer(const char* compressed, size_t compressed_length)
+{
+    return snappy_validate_compressed_buffer(compressed, compressed_length) == SNAPPY_OK;
+}
+}  // namespace snappy

@@ -1,0 +1,67 @@
+/* include/aocl_native_api.h -- the per-codec native entry points of amd/aocl-compression 4.2.0 that sit on the hot
+ * path, exported by libaocl_compression_gpu.so with the reference's names, argument meaning and return conventions
+ * (the reference .so is also linked as liblz4 / libsnappy / libzstd, CMakeLists.txt:616-635).
+ *
+ * Buffers are HOST buffers exactly as in the reference; one call = one chunk on the GPU (upload, one wavefront,
+ * download).  Bulk work should use the device-resident batch API of aocl_gpu_codec.h.  There is no CPU fallback:
+ * without a gfx950 device compression returns the codec's failure value.
+ *
+ * Scope is the north-star path only: LZ4 acceleration 1, Zstd level 1 with srcSize <= 128 KiB (one block);
+ * anything else fails loudly with the codec's error convention instead of silently doing something different.
+ */
+#ifndef AOCL_NATIVE_API_H
+#define AOCL_NATIVE_API_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- LZ4 1.9.3 (algos/lz4/lz4.h:128,137,203,232,287,309,464,470) ---- */
+int         LZ4_versionNumber(void);                       /* 10903 */
+const char* LZ4_versionString(void);                       /* "1.9.3" */
+int         LZ4_compressBound(int inputSize);              /* 0 if inputSize > 0x7E000000 */
+int         LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);   /* 0 = failure */
+int         LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration); /* acceleration <= 1 only */
+int         LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);    /* < 0 = malformed */
+char*       aocl_setup_lz4(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
+void        aocl_destroy_lz4(void);
+
+/* ---- Snappy C binding (algos/snappy/snappy-c.h:28-138) ---- */
+typedef enum { SNAPPY_OK = 0, SNAPPY_INVALID_INPUT = 1, SNAPPY_BUFFER_TOO_SMALL = 2 } snappy_status;
+snappy_status snappy_compress(const char* input, size_t input_length, char* compressed, size_t* compressed_length);
+snappy_status snappy_uncompress(const char* compressed, size_t compressed_length, char* uncompressed, size_t* uncompressed_length);
+size_t        snappy_max_compressed_length(size_t source_length);
+snappy_status snappy_uncompressed_length(const char* compressed, size_t compressed_length, size_t* result);
+snappy_status snappy_validate_compressed_buffer(const char* compressed, size_t compressed_length);
+
+/* ---- Zstd 1.5.5 (algos/zstd/lib/zstd.h:184,201,261,291,353,423,441,455) ---- */
+unsigned    ZSTD_versionNumber(void);                      /* 10505 */
+const char* ZSTD_versionString(void);                      /* "1.5.5" */
+size_t      ZSTD_compressBound(size_t srcSize);
+unsigned    ZSTD_isError(size_t code);
+const char* ZSTD_getErrorName(size_t code);
+size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
+char*       aocl_setup_zstd_encode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
+char*       aocl_setup_zstd_decode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
+
+/* ---- RAP frame helpers (api/aocl_threads.h:109,133; threads/threads.c:315-336) ---- */
+int32_t aocl_get_rap_frame_bound_mt(void);                 /* 16 + 12 * max partitions (65535 for the GPU build) */
+int32_t aocl_skip_rap_frame_mt(char* src, int32_t src_size); /* 0: no RAP frame; > 0: its length; ERR_INVALID_INPUT on NULL */
+
+#ifdef __cplusplus
+}
+
+/* ---- Snappy C++ binding (algos/snappy/snappy.h:255,280,369,391; snappy.cc:2271,2494) ---- */
+namespace snappy {
+void   RawCompress(const char* input, size_t input_length, char* compressed, size_t* compressed_length);
+bool   RawUncompress(const char* compressed, size_t compressed_length, char* uncompressed);
+size_t MaxCompressedLength(size_t source_bytes);
+bool   GetUncompressedLength(const char* compressed, size_t compressed_length, size_t* result);
+bool   IsValidCompressedBuffer(const char* compressed, size_t compressed_length);
+}
+#endif
+#endif
