@@ -65,10 +65,17 @@ __device__ unsigned long long g_lz4_prof[16];
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
 struct Win { uint64_t lo, hi; };
 __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t p)
-{
+{   // ONE 16-byte load per lane: scattered loads cost the address unit a cycle per lane and instruction, not per byte
+    typedef u32x4 __attribute__((aligned(1))) U;
+    const uint32_t q = p >= 4 ? p - 4 : 0;
+    const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + q);
     Win w;
-    w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
-    w.hi = ld64(src + p + 4);
+    w.lo = v.x | ((uint64_t)v.y << 32); w.hi = v.z | ((uint64_t)v.w << 32);
+    if (p < 4) {                                          // bytes before the chunk start read as 0
+        const uint32_t sh = 8 * (4 - p);
+        w.hi = (w.hi << sh) | (w.lo >> (64 - sh));
+        w.lo <<= sh;
+    }
     return w;
 }
 
@@ -241,8 +248,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 uint64_t c2 = 0, c3 = 0;
                 const bool have2 = plausible && use_ring && cand + 20 <= n;
                 const bool have3 = have2 && cand + 28 <= n;
-                if (have2) c2 = ld64(src + cand + 12);
-                if (have3) c3 = ld64(src + cand + 20);
+                if (have3) {                              // one 16-byte load
+                    typedef u32x4 __attribute__((aligned(1))) U;
+                    const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + cand + 12);
+                    c2 = v.x | ((uint64_t)v.y << 32); c3 = v.z | ((uint64_t)v.w << 32);
+                } else if (have2) c2 = ld64(src + cand + 12);
                 const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
                 uint32_t avail = 8;                       // bytes of forward data compared in registers
                 fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;

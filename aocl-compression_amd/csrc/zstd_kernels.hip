@@ -87,7 +87,7 @@ __device__ __forceinline__ u32 z_hash(u64 v, u32 hlog)
 }
 
 // common prefix of src[a..end) and src[b..], 256 bytes per step (ZSTD_count)
-__device__ u32 wave_count(const u8* __restrict__ src, u32 a, u32 b, u32 end, int lane)
+__device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, int lane)
 {
     u32 n = 0;
     for (;;) {
@@ -112,14 +112,17 @@ __device__ u32 wave_count(const u8* __restrict__ src, u32 a, u32 b, u32 end, int
 // slot in a packed word array (indices stay below 2^17 because nothing within 14 bytes of the chunk end is ever
 // inserted).  17 KB of LDS per chunk instead of 32 KB lets 9 instead of 5 chunks be resident per CU.
 template <int MLS, typename T>
-__device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlog, T* table, Workspace* ws,
+__device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
                           u32* litSizeOut, int lane)
 {
     static_assert(sizeof(T) == 2, "u16 slots");
+    typedef __attribute__((address_space(3))) T LT;
+    typedef __attribute__((address_space(3))) u32 L32;
     constexpr bool kHi = (MLS == 6);
     const u32 tsize = 1u << hlog;
-    u32* hib = reinterpret_cast<u32*>(table + tsize);                   // kHi: tsize/32 words
-    for (u32 i = (u32)lane; i < tsize / 2; i += kWave) reinterpret_cast<u32*>(table)[i] = 0;
+    LT* table = (LT*)lds;
+    L32* hib = (L32*)(lds + 2 * tsize);                                 // kHi: tsize/32 words
+    for (u32 i = (u32)lane; i < tsize / 2; i += kWave) ((L32*)lds)[i] = 0;
     if (kHi) for (u32 i = (u32)lane; i < tsize / 32; i += kWave) hib[i] = 0;
     wave_fence();
     auto tget = [&](u32 h) -> u32 {
@@ -129,7 +132,10 @@ __device__ u32 fast_block(const u8* __restrict__ src, const u32 n, const u32 hlo
     };
     auto tput = [&](u32 h, u32 v) {
         table[h] = (T)v;
-        if (kHi) { if (v >> 16) atomicOr(&hib[h >> 5], 1u << (h & 31)); else atomicAnd(&hib[h >> 5], ~(1u << (h & 31))); }
+        if (kHi) {
+            if (v >> 16) __hip_atomic_fetch_or(&hib[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_and(&hib[h >> 5], ~(1u << (h & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     // u32 entries: index (position + 2, 18 bits) plus 14 check bits of the 4 bytes at that position.  The check
     // bits never change a decision; they spare the speculative lanes a cache-line fetch for hopeless candidates.
@@ -578,8 +584,8 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         level1_params(n, &hlog, &mls);
         const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8);
         if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
-        if (mls == 5) nbSeq = fast_block<5, u16>(src, n, hlog, reinterpret_cast<u16*>(lds), ws, &litSize, lane);
-        else nbSeq = fast_block<6, u16>(src, n, hlog, reinterpret_cast<u16*>(lds), ws, &litSize, lane);
+        if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane);
+        else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane);
         wave_fence();
         if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
         else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
