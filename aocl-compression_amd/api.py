@@ -38,7 +38,11 @@ class Batch(C.Structure):
         ("out_len", C.c_void_p),
         ("nchunks", C.c_uint32), ("reserved", C.c_uint32),
         ("total_bytes", C.c_uint64), ("chunk_bytes", C.c_uint64), ("slot_bytes", C.c_uint64),
+        ("aux", C.c_void_p),
     ]
+
+
+FLAG_RAP_PARTITIONS = 0x100
 
 
 class LlcDesc(C.Structure):
@@ -58,6 +62,7 @@ EXPORTS = [
     "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
     "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks",
     "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_decompress_host",
+    "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
 ]
 
@@ -85,6 +90,12 @@ def load_library() -> C.CDLL:
         f = getattr(lib, n)
         f.restype = C.c_int64
         f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.aoclgpu_rap_pack.restype = C.c_int
+    lib.aoclgpu_rap_pack.argtypes = [C.c_int, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    lib.aoclgpu_rap_unpack.restype = C.c_int
+    lib.aoclgpu_rap_unpack.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_void_p]
+    lib.aoclgpu_rap_frame_bytes.restype = C.c_uint64
+    lib.aoclgpu_rap_frame_bytes.argtypes = [C.c_int, C.c_uint32]
     for n in ("aocl_llc_compress", "aocl_llc_decompress"):
         f = getattr(lib, n)
         f.restype = C.c_int64
@@ -170,6 +181,34 @@ class Engine:
         b = self.uniform_decompress_batch(slots, comp_u32, slot_bytes, dst, chunk_bytes, out_len)
         self._check(self._fn(codec, "decompress")(C.byref(b), self._stream()), f"{_NAMES[codec]} decompress")
         return dst, out_len
+
+    # ---- RAP streams (the reference's multi-threaded container) ----
+    def rap_compress(self, codec: int, src, chunk_bytes: int):
+        """Compress `src` in chunk_bytes partitions and join them into one RAP stream (aoclgpu_rap_pack).
+        Returns the stream as a uint8 tensor."""
+        t = self.torch
+        slot_bytes = (compress_bound(codec, chunk_bytes) + 15) & ~15
+        nchunks = max(1, -(-int(src.numel()) // chunk_bytes))
+        slots = t.empty(nchunks * slot_bytes, dtype=t.uint8, device=self.device)
+        out_len = t.zeros(nchunks, dtype=t.int32, device=self.device)
+        aux = t.zeros(nchunks, dtype=t.int32, device=self.device)
+        b = self.uniform_compress_batch(src, chunk_bytes, slots, out_len, slot_bytes)
+        b.aux = aux.data_ptr()
+        self._check(self._fn(codec, "compress")(C.byref(b), self._stream()), f"{_NAMES[codec]} compress")
+        cap = int(self.lib.aoclgpu_rap_frame_bytes(codec, nchunks)) + nchunks * slot_bytes + 16
+        out = t.empty(cap, dtype=t.uint8, device=self.device)
+        n = C.c_uint64(0)
+        self._check(self.lib.aoclgpu_rap_pack(codec, C.byref(b), out.data_ptr(), cap, C.byref(n), self._stream()), "rap_pack")
+        return out[:n.value]
+
+    def rap_decompress(self, codec: int, stream, max_bytes: int):
+        """Decode a RAP stream (or a plain one-shot stream).  Returns (dst tensor, decoded size or negative)."""
+        t = self.torch
+        dst = t.empty(max(max_bytes, 1), dtype=t.uint8, device=self.device)
+        r = C.c_int64(0)
+        self._check(self.lib.aoclgpu_rap_unpack(codec, stream.data_ptr(), int(stream.numel()), dst.data_ptr(), max_bytes,
+                                                C.byref(r), self._stream()), "rap_unpack")
+        return dst, r.value
 
     def compact(self, slots, slot_bytes: int, out_len):
         """Gather the used prefix of each slot into one stream; returns (packed, offsets uint64-as-int64[n+1])."""

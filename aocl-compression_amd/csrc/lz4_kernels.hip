@@ -84,7 +84,8 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
 // MODE 2: byU32 table as u32[4096] whose spare high bits hold check bits (any chunk size).
 template <int MODE, bool PROF>
 __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_, const uint32_t n_,
-                                 gbyte* __restrict__ dst_, const uint32_t cap_, lbyte* lds_, const uint32_t expf_)
+                                 gbyte* __restrict__ dst_, const uint32_t cap_, lbyte* lds_, const uint32_t expf_,
+                                 uint32_t* last_run)
 {
     const gbyte* __restrict__ src = uni_ptr(src_);
     gbyte* __restrict__ dst = uni_ptr(dst_);
@@ -448,6 +449,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     // ---------------- last literals (lz4.c:1808-1834) ----------------
     {
         const uint32_t lastRun = n - anchor;
+        *last_run = lastRun;
         if (limited && (uint64_t)op + lastRun + 1 + (lastRun + 255 - 15) / 255 > cap) return 0;
         if (lane == 0) dst[op] = (uint8_t)((lastRun < 15 ? lastRun : 15) << 4);
         op++;
@@ -540,6 +542,62 @@ __device__ int lz4_decode_one(const gbyte* __restrict__ src, const int32_t iend,
     return 0;
 }
 
+// One sequence of a RAP partition that is not the last one (AOCL_LZ4_decompress_generic_mt with is_last_thread == 0,
+// lz4.c:3807-4304): the partition holds whole sequences only, so it may end right after a match, a match may run up to
+// the very end of the partition's output, and the end-of-block literal rules do not apply.  Every access is bounds
+// checked against the partition.  returns 0 = continue, 1 = partition finished, <0 = malformed
+__device__ int lz4_decode_one_rap(const gbyte* __restrict__ src, const int32_t iend, gbyte* dst, const int32_t oend,
+                                  int32_t& ip, int32_t& op, int lane)
+{
+    const uint32_t token = uni(src[ip]);
+    ip++;
+    int64_t len = token >> 4;
+    if (len == 15) {
+        uint32_t s;
+        do {
+            if (ip >= iend) return -ip - 1;
+            s = uni(src[ip]); ip++; len += s;
+        } while (s == 255);
+    }
+    if (ip + len > (int64_t)iend || op + len > (int64_t)oend) return -ip - 1;
+    wave_copy(dst + op, src + ip, (uint32_t)len, lane);
+    ip += (int32_t)len; op += (int32_t)len;
+    if (ip == iend) return 1;                             // ended with literals
+    if (ip + 2 > iend) return -ip - 1;
+    const uint32_t offset = uni(ld16(src + ip));
+    ip += 2;
+    int64_t ml = token & 15;
+    if (ml == 15) {
+        uint32_t s;
+        do {
+            if (ip >= iend) return -ip - 1;
+            s = uni(src[ip]); ip++; ml += s;
+        } while (s == 255);
+    }
+    ml += kMinMatch;
+    if (offset == 0 || (int64_t)offset > op || op + ml > (int64_t)oend) return -ip - 1;
+    wave_fence();
+    gbyte* d = dst + op;
+    const gbyte* sp = d - offset;
+    const uint32_t mlen = (uint32_t)ml;
+    if (offset >= kWave) {
+        for (uint32_t r = 0; r < mlen; r += kWave) {
+            const uint32_t i = r + (uint32_t)lane;
+            uint8_t v = 0;
+            if (i < mlen) v = sp[i];
+            if (i < mlen) d[i] = v;
+            wave_fence();
+        }
+    } else {
+        uint32_t k = (uint32_t)lane % offset;
+        const uint32_t adv = kWave % offset;
+        for (uint32_t i = (uint32_t)lane; i < mlen; i += kWave) { d[i] = sp[k]; k += adv; if (k >= offset) k -= offset; }
+    }
+    wave_fence();
+    op += (int32_t)mlen;
+    return ip == iend ? 1 : 0;
+}
+
 // bytes [o, o+8) of the 24-byte little-endian string v0|v1|v2 (o <= 16)
 __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2, uint32_t o)
 {
@@ -549,7 +607,7 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 }
 
 __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
-                                   uint8_t* ring)
+                                   uint8_t* ring, const bool rap)
 {
     const int lane = lane_id();
     if (cap == 0) return (n == 1 && src[0] == 0) ? 0 : -1;   // lz4.c:3412-3416
@@ -660,7 +718,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
             }
         }
         if (!window) {
-            const int r = lz4_decode_one(src, iend, dst, oend, ip, op, lane);
+            const int r = rap ? lz4_decode_one_rap(src, iend, dst, oend, ip, op, lane) : lz4_decode_one(src, iend, dst, oend, ip, op, lane);
             if (r < 0) return r;
             if (r == 1) break;
         }
@@ -681,19 +739,20 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     const ChunkView v = compress_view(b, c);
     const uint32_t n = v.src_len;
     int r;
+    uint32_t lastrun = 0;
     if (n > kMaxInput) r = 0;                                               // lz4.c:2417
     else if (n == 0) {                                                      // lz4.c:2418-2429
         r = 0;
         if (v.dst_cap >= 1) { if (threadIdx.x == 0) v.dst[0] = 0; r = 1; }
     }
     else if (MODE == 3) {
-        if (n < k64KLimit) r = lz4_compress_wave<0, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
-        else if (n <= (1u << 18)) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
-        else r = lz4_compress_wave<2, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
+        if (n < k64KLimit) r = lz4_compress_wave<0, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
+        else if (n <= (1u << 18)) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
+        else r = lz4_compress_wave<2, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
     }
     else if ((MODE == 0) != (n < k64KLimit) || (MODE == 1 && n > (1u << 18))) r = 0;   // launcher picked the wrong mode
-    else r = lz4_compress_wave<MODE == 3 ? 2 : MODE, PROF>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved);
-    if (threadIdx.x == 0) b.out_len[c] = r;
+    else r = lz4_compress_wave<MODE == 3 ? 2 : MODE, PROF>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
+    if (threadIdx.x == 0) { b.out_len[c] = r; if (b.aux) b.aux[c] = lastrun; }
 }
 
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
@@ -704,7 +763,8 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
     const ChunkView v = decompress_view(b, c);
     int r;
     if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
-    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring);
+    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring,
+                                 (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) && c + 1 < b.nchunks);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 

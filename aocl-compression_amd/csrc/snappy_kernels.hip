@@ -331,11 +331,12 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // LDS ring (lane k = "an element starts at ip+k", scalar walk over the real starts, prefix sum for the output
 // positions, all short literals and all short copies of earlier output at once); everything else one at a time.
 __device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* dst, const uint32_t cap,
-                                  uint8_t* ring)
+                                  uint8_t* ring, const bool rap)
 {
     const int lane = lane_id();
     uint32_t ulen = 0, shift = 0, ip = 0;
-    for (;;) {                                                            // ReadUncompressedLength :1202-1223
+    if (rap) ulen = cap;                                                  // RAP partition: no prefix, exact size known (snappy.cc:2567-2654)
+    else for (;;) {                                                       // ReadUncompressedLength :1202-1223
         if (shift >= 32 || ip >= n) return -1;
         const uint32_t c = uni(src[ip]); ip++;
         const uint32_t val = c & 0x7f;
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
     if (c >= b.nchunks) return;
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const ChunkView v = decompress_view(b, c);
-    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, ring);
+    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, ring, (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) != 0);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 

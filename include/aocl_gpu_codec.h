@@ -55,11 +55,19 @@ typedef struct {
     const uint32_t* dst_cap;
     int32_t*        out_len;
     uint32_t        nchunks;
-    uint32_t        reserved;
+    uint32_t        reserved;     /* AOCLGPU_FLAG_* (bits below 0x100 are experiment switches of the test tools) */
     uint64_t        total_bytes;  /* uniform mode */
     uint64_t        chunk_bytes;  /* uniform mode */
     uint64_t        slot_bytes;   /* uniform mode */
+    uint32_t*       aux;          /* optional per-chunk side output (device, nchunks entries), may be NULL:
+                                     LZ4 compress -> length of the chunk's final literal run (what the reference's MT
+                                     compressor returns as last_bytes_len, lz4.c:2333-2337), needed by aoclgpu_rap_pack */
 } aoclgpu_batch;
+
+/* decompress: the chunks are partitions of a RAP stream (threads/threads.h:20-75).  LZ4: every chunk but the last
+ * may end right after a match (lz4.c:3935,4147-4181); Snappy: chunks carry no varint length prefix and dst_cap[i] is the
+ * exact decoded size (snappy.cc:2567-2654); Zstd: no effect (partitions are whole frames). */
+#define AOCLGPU_FLAG_RAP_PARTITIONS 0x100u
 
 /* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
  * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at
@@ -85,6 +93,28 @@ int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
  * out_off[i] (device, uint64, nchunks+1 entries) receives the exclusive prefix sum of out_len. */
 int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, const int32_t* out_len, uint32_t nchunks,
                           uint8_t* packed, uint64_t* out_off, void* stream);
+
+/* RAP ("random access point") streams, the reference's multi-threaded container (threads/threads.h:20-75):
+ *   [ 'AOCL_LLC' | u32 frame length | u16 partitions | u16 0 | partitions x { u32 offset, u32 length, u32 decoded length } ]
+ * followed by the partitions' payloads joined so that a legacy single-threaded decoder can decode the stream after
+ * skipping the frame (aocl_skip_rap_frame_mt): LZ4 -> the final literal run of partition k is merged into the first
+ * sequence of partition k+1 (lz4.c:2736-2906); Snappy -> one varint with the total length, partitions without their
+ * own (snappy.cc:2567-2654); Zstd -> the frame sits in a skippable frame, partitions are whole frames
+ * (zstd_compress.c:5343-5385,5499-5517).  With the reference's partition geometry the stream is byte-identical to
+ * the reference's AOCL_ENABLE_THREADS build.
+ *
+ * aoclgpu_rap_pack: `compressed` is the batch that was just given to aoclgpu_<codec>_compress_chunks on the same
+ * stream (uniform or explicit mode; LZ4 needs its aux[] output).  Writes the RAP stream to stream_out (device) and its
+ * size to *stream_bytes (HOST).  One chunk -> no frame, the plain one-shot stream (as the reference with one thread).
+ * The plan (12 bytes per partition) is made on the host: the call synchronises `stream`.
+ * aoclgpu_rap_unpack: decodes a RAP stream (or a plain single-partition stream) produced by aoclgpu_rap_pack or by the
+ * reference's MT build into dst (device); *decoded_bytes (HOST) = total size, negative = malformed.  Synchronous. */
+int aoclgpu_rap_pack(aoclgpu_codec codec, const aoclgpu_batch* compressed, uint8_t* stream_out, uint64_t stream_cap,
+                     uint64_t* stream_bytes, void* stream);
+int aoclgpu_rap_unpack(aoclgpu_codec codec, const uint8_t* rap_stream, uint64_t stream_bytes, uint8_t* dst,
+                       uint64_t dst_cap, int64_t* decoded_bytes, void* stream);
+/* bytes of RAP framing aoclgpu_rap_pack adds for nchunks partitions (0 for one chunk) */
+uint64_t aoclgpu_rap_frame_bytes(aoclgpu_codec codec, uint32_t nchunks);
 
 /* Timing helper used by bench.py: runs `iters` back-to-back launches of one batch op on `stream`
  * bracketed by HIP events recorded on that same stream; returns the average milliseconds per launch

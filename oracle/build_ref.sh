@@ -16,16 +16,32 @@ OUT="$HERE/_ref"; OBJ="$OUT/obj"
 if [ ! -f "$REF/api/api.cpp" ]; then
   echo "build_ref: reference tree $REF absent; keeping prebuilt $OUT/libaocl_ref.so (if any)"; exit 0
 fi
-if [ -f "$OUT/libaocl_ref.so" ] && [ "$OUT/libaocl_ref.so" -nt "$0" ]; then
+if [ -f "$OUT/libaocl_ref.so" ] && [ -f "$OUT/libaocl_ref_mt.so" ] && [ "$OUT/libaocl_ref_mt.so" -nt "$0" ]; then
   echo "build_ref: $OUT/libaocl_ref.so up to date"; exit 0
 fi
+build_variant() {  # $1 = output library, $2 = object dir, $3 = extra defines, $4 = extra C sources
+OUTLIB="$1"; OBJ="$2"; EXTRA="$3"
 mkdir -p "$OBJ"
-FLAGS="-O3 -DNDEBUG -fPIC -fomit-frame-pointer -fstrict-aliasing -ffast-math -fopenmp -w \
+FLAGS="-O3 -DNDEBUG -fPIC -fomit-frame-pointer -fstrict-aliasing -ffast-math -fopenmp -w $EXTRA \
  -DAOCL_DYNAMIC_DISPATCHER -DAOCL_EXCLUDE_BZIP2 -DAOCL_EXCLUDE_LZMA -DAOCL_EXCLUDE_ZLIB -DAOCL_EXCLUDE_LZ4HC \
  -I$REF -I$REF/api -I$REF/utils -I$REF/algos/common"
 VERS=(-DAOCL_BUILD_VERSION="\"Build_oracle\"" -DCFLAGS_SET1="\"-O3\"" -DCFLAGS_SET2="\"\"" -DCCompiler="\"gcc\"" -DCXXCompiler="\"g++\"")
 SNAP="-msse4.1 -DHAVE_BUILTIN_CTZ=1 -DHAVE_BUILTIN_EXPECT=1 -DHAVE_SYS_UIO_H"
 pids=()
+for f in utils/utils.cpp api/api.cpp api/codec.cpp; do cc1 g++ "$REF/$f" "${VERS[@]}"; done
+for f in snappy-sinksource snappy-stubs-internal snappy snappy-c; do cc1 g++ "$REF/algos/snappy/$f.cc" $SNAP "${VERS[@]}"; done
+waitall
+cc1 gcc "$REF/algos/lz4/lz4.c"; cc1 gcc "$REF/algos/lz4/xxhash.c"
+for f in $4; do cc1 gcc "$REF/$f"; done
+n=0
+for f in "$REF"/algos/zstd/lib/common/*.c "$REF"/algos/zstd/lib/compress/*.c "$REF"/algos/zstd/lib/decompress/*.c "$REF"/algos/zstd/lib/decompress/*.S; do
+  case "$f" in *code_alignment*) continue;; esac
+  cc1 gcc "$f"; n=$((n+1)); if [ $((n % 8)) -eq 0 ]; then waitall; fi
+done
+waitall
+g++ -shared -fopenmp -o "$OUTLIB" "$OBJ"/*.o
+echo "build_ref: built $OUTLIB"
+}
 cc1() { # $1 compiler, $2 src, rest flags
   local comp=$1 src=$2; shift 2
   local o="$OBJ/$(echo "${src#$REF/}" | tr '/' '_').o"
@@ -33,15 +49,8 @@ cc1() { # $1 compiler, $2 src, rest flags
   pids+=($!)
 }
 waitall() { for p in "${pids[@]}"; do wait "$p" || { echo "build_ref: compile failed"; exit 1; }; done; pids=(); }
-for f in utils/utils.cpp api/api.cpp api/codec.cpp; do cc1 g++ "$REF/$f" "${VERS[@]}"; done
-for f in snappy-sinksource snappy-stubs-internal snappy snappy-c; do cc1 g++ "$REF/algos/snappy/$f.cc" $SNAP "${VERS[@]}"; done
-waitall
-cc1 gcc "$REF/algos/lz4/lz4.c"; cc1 gcc "$REF/algos/lz4/xxhash.c"
-n=0
-for f in "$REF"/algos/zstd/lib/common/*.c "$REF"/algos/zstd/lib/compress/*.c "$REF"/algos/zstd/lib/decompress/*.c "$REF"/algos/zstd/lib/decompress/*.S; do
-  case "$f" in *code_alignment*) continue;; esac
-  cc1 gcc "$f"; n=$((n+1)); if [ $((n % 8)) -eq 0 ]; then waitall; fi
-done
-waitall
-g++ -shared -fopenmp -o "$OUT/libaocl_ref.so" "$OBJ"/*.o
-echo "build_ref: built $OUT/libaocl_ref.so"
+# default build (single-threaded codecs: the parity ground truth and the cpu_baseline functions)
+build_variant "$OUT/libaocl_ref.so" "$OUT/obj" "" ""
+# AOCL_ENABLE_THREADS build (CMakeLists.txt:81,256-273,473-474): the RAP-stream producer/consumer the GPU RAP
+# pack / unpack (csrc/rap.hip) is checked against
+build_variant "$OUT/libaocl_ref_mt.so" "$OUT/obj_mt" "-DAOCL_ENABLE_THREADS" "threads/threads.c"

@@ -27,6 +27,14 @@ def ref():
 
 
 @pytest.fixture(scope="session")
+def ref_mt():
+    import oracle_lib
+    if not oracle_lib.have_ref_mt():
+        pytest.skip("threaded reference build (oracle/_ref/libaocl_ref_mt.so) not available")
+    return oracle_lib.RefMT()
+
+
+@pytest.fixture(scope="session")
 def eng():
     """The GPU engine.  Fails (does not skip) when the HIP library or the GPU is missing: -m gpu tests
     must never pass on a fallback."""

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libaocl_ref.so")
+REF_MT_SO = os.path.join(ORACLE_DIR, "_ref", "libaocl_ref_mt.so")   # the same sources with AOCL_ENABLE_THREADS
 
 LZ4, SNAPPY, ZSTD = 0, 1, 2
 
@@ -84,14 +85,15 @@ class Oracle:
 
 class Ref:
     """The real reference (native one-shot APIs + aocl_llc_*)."""
+    SO = REF_SO
 
     def __init__(self):
-        if not os.path.exists(REF_SO):
+        if not os.path.exists(self.SO):
             if os.path.exists("/root/reference/api/api.cpp"):
                 subprocess.run(["bash", os.path.join(ORACLE_DIR, "build_ref.sh")], check=True)
             else:
-                raise FileNotFoundError(REF_SO)
-        L = self.L = C.CDLL(REF_SO)
+                raise FileNotFoundError(self.SO)
+        L = self.L = C.CDLL(self.SO)
         L.ZSTD_compress.restype = C.c_size_t
         L.ZSTD_decompress.restype = C.c_size_t
         L.ZSTD_isError.restype = C.c_uint
@@ -126,6 +128,38 @@ class Ref:
             return out.raw[:ln.value] if st == 0 else None
         r = self.L.ZSTD_decompress(out, cap, data, len(data))
         return None if self.L.ZSTD_isError(r) else out.raw[:r]
+
+
+class RefMT(Ref):
+    """The reference built with AOCL_ENABLE_THREADS: its one-shot functions write / read RAP streams
+    (threads/threads.c, lz4.c:2655-2909, snappy.cc:2505-2654, zstd_compress.c:5343-5534)."""
+    SO = REF_MT_SO
+
+    def __init__(self):
+        super().__init__()
+        self.L.aocl_skip_rap_frame_mt.argtypes = [C.c_void_p, C.c_int32]
+        self.gomp = C.CDLL("libgomp.so.1", mode=C.RTLD_GLOBAL)
+
+    def set_threads(self, n: int):
+        self.gomp.omp_set_num_threads(int(n))
+
+    def skip(self, stream: bytes) -> int:
+        return self.L.aocl_skip_rap_frame_mt(stream, len(stream))
+
+    def decompress(self, codec, data: bytes, cap: int):
+        if codec != SNAPPY:
+            return super().decompress(codec, data, cap)
+        # the C binding sizes the output from the first bytes of the stream, which in a RAP stream is the frame;
+        # the RAP-aware entry point is snappy::RawUncompress (snappy.cc:2271-2390)
+        f = getattr(self.L, "_ZN6snappy13RawUncompressEPKcmPc")
+        f.restype = C.c_bool
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        out = C.create_string_buffer(max(cap, 1))
+        return out.raw[:cap] if f(data, len(data), out) else None
+
+
+def have_ref_mt() -> bool:
+    return os.path.exists(REF_MT_SO) or os.path.exists("/root/reference/api/api.cpp")
 
 
 def have_ref() -> bool:

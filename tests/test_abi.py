@@ -42,7 +42,7 @@ def test_struct_layouts_match_the_reference_abi():
     assert C.sizeof(api.LlcDesc) == 128
     assert api.LlcDesc.inSize.offset == 24 and api.LlcDesc.measureStats.offset == 72 and api.LlcDesc.cSize.offset == 80
     assert api.LlcDesc.optOff.offset == 120
-    assert C.sizeof(api.Batch) == 88
+    assert C.sizeof(api.Batch) == 96
 
 
 def test_argument_checks_without_gpu():

@@ -1,0 +1,109 @@
+"""RAP streams: the GPU join of the per-chunk outputs into the reference's multi-threaded
+container (csrc/rap.hip) against the reference built with AOCL_ENABLE_THREADS (oracle/_ref/libaocl_ref_mt.so).
+
+ * with the reference's partition geometry (T threads -> T equal partitions) the LZ4 and Snappy streams are
+   byte-identical to the reference's MT output (lz4.c:2655-2909 last-literals join, snappy.cc:2567-2654 varint join);
+ * every stream decodes with a legacy single-threaded decoder after aocl_skip_rap_frame_mt (README.md:341-343,
+   zstd_gtest.cpp:589-603) and with the reference's MT decoder;
+ * the GPU decoder accepts the reference's MT streams and its own."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import aocl_compression_amd as a
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+CODECS = {"lz4": (a.LZ4, ol.LZ4), "snappy": (a.SNAPPY, ol.SNAPPY), "zstd": (a.ZSTD, ol.ZSTD)}
+
+
+def _mt_cap(n, parts):
+    return n + n // 6 + 64 + 16 + 12 * parts + 1024
+
+
+def _entries(stream: bytes, base=0):
+    magic, flen, cnt = struct.unpack_from("<qII", stream, base)
+    assert magic == 0x434C4C5F4C434F41
+    k = cnt & 0xFFFF
+    assert flen == 16 + 12 * k
+    return [struct.unpack_from("<III", stream, base + 16 + 12 * i) for i in range(k)]
+
+
+@pytest.mark.parametrize("kind", ["text", "jsonlog", "binary", "database", "random"])
+@pytest.mark.parametrize("codec", ["lz4", "snappy"])
+def test_stream_is_byte_identical_to_the_reference_mt_build(eng, ref, ref_mt, codec, kind):
+    gc, oc = CODECS[codec]
+    T, part = 4, 300000
+    data = a.corpus.make(kind, T * part, seed=11).tobytes()
+    ref_mt.set_threads(T)
+    want = ref_mt.compress(oc, data, _mt_cap(len(data), T))
+    assert want is not None and len(_entries(want)) == T            # the reference really used T partitions of `part` bytes
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+    got = bytes(eng.rap_compress(gc, src, part).cpu().numpy())
+    assert got == want
+    # legacy single-threaded decoder after skipping the frame
+    skip = ref_mt.skip(got)
+    assert skip == 16 + 12 * T
+    assert ref.decompress(oc, got[skip:], len(data)) == data
+    # GPU decoder on the stream
+    dst, r = eng.rap_decompress(gc, torch.frombuffer(bytearray(want), dtype=torch.uint8).to(eng.device), len(data))
+    assert r == len(data) and bytes(dst[:r].cpu().numpy()) == data
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+@pytest.mark.parametrize("chunk,total", [(65536, 1000003), (131072, 131072 * 9), (4096, 70000), (262144, 100)])
+def test_gpu_streams_decode_everywhere(eng, ref, ref_mt, codec, chunk, total):
+    gc, oc = CODECS[codec]
+    if codec == "zstd" and chunk > 131072:
+        chunk = 131072
+    data = a.corpus.silesia_mix(total, seed=5, segment=50000).tobytes()
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+    stream_t = eng.rap_compress(gc, src, chunk)
+    stream = bytes(stream_t.cpu().numpy())
+    nparts = -(-total // chunk)
+    skip = ref_mt.skip(stream)
+    if nparts == 1:
+        assert skip == 0 and stream == ol.Oracle().compress(oc, data)         # one partition: the plain one-shot stream
+    elif codec == "zstd":
+        assert skip == 0 and stream[:4] == bytes.fromhex("502a4d18")          # RAP frame inside a skippable frame
+        ents = _entries(stream, 8)
+        assert len(ents) == nparts and sum(e[2] for e in ents) == total
+    else:
+        ents = _entries(stream)
+        assert skip == 16 + 12 * nparts and sum(e[2] for e in ents) == total
+        assert ents[-1][0] + ents[-1][1] == len(stream)
+    # legacy single-threaded decoder (zstd: skippable frames are part of the format)
+    assert ref.decompress(oc, stream[skip:], total) == data
+    # the reference's own multi-threaded decoder
+    ref_mt.set_threads(3)
+    assert ref_mt.decompress(oc, stream, total) == data
+    # GPU decoder
+    dst, r = eng.rap_decompress(gc, stream_t, total)
+    assert r == total and torch.equal(dst[:total], src)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+def test_gpu_decodes_reference_mt_streams(eng, ref_mt, codec):
+    gc, oc = CODECS[codec]
+    for threads, total in ((2, 700001), (7, 3 << 20), (5, 2000000)):
+        data = a.corpus.silesia_mix(total, seed=threads, segment=100000).tobytes()
+        ref_mt.set_threads(threads)
+        stream = ref_mt.compress(oc, data, _mt_cap(total, 64))
+        assert stream is not None
+        dst, r = eng.rap_decompress(gc, torch.frombuffer(bytearray(stream), dtype=torch.uint8).to(eng.device), total)
+        assert r == total and bytes(dst[:total].cpu().numpy()) == data
+
+
+def test_malformed_rap_streams_are_rejected(eng, ref_mt):
+    data = a.corpus.make("text", 4 * 300000, seed=2).tobytes()
+    ref_mt.set_threads(4)
+    good = ref_mt.compress(ol.LZ4, data, _mt_cap(len(data), 4))
+    for mutate in (lambda b: b[:len(b) - 1000],                       # truncated payload
+                   lambda b: b[:20] + struct.pack("<I", 1 << 30) + b[24:],   # partition length out of range
+                   lambda b: b[:70000] + bytes(64) + b[70064:]):     # corrupted sequences
+        bad = mutate(good)
+        dst, r = eng.rap_decompress(a.LZ4, torch.frombuffer(bytearray(bad), dtype=torch.uint8).to(eng.device), len(data))
+        assert r < 0 or bytes(dst[:r].cpu().numpy()) != data
