@@ -62,7 +62,8 @@ EXPORTS = [
     "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
     "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks",
     "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_decompress_host",
-    "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes",
+    "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes", "aoclgpu_rap_default_chunk",
+    "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
 ]
 

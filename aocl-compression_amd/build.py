@@ -19,9 +19,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libaocl_compression_gpu.so")
+CLI = os.path.join(HERE, "aocl_compression_bench")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
+CLI_SOURCE = "bench_cli.cpp"
 SOURCES = ["capi.hip", "lz4_kernels.hip", "snappy_kernels.hip", "zstd_kernels.hip", "rap.hip", "aocl_api.cpp", "native_api.cpp"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
           *os.environ.get("AOCLGPU_CFLAGS", "").split()]
@@ -68,8 +70,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         _run(["gcc", "-shared", "-fPIC", stub_c, "-o", os.path.join(stubdir, "libamdhip64.so")])
         _run(["g++", "-shared", "-fPIC", *objs, "-o", LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
               "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    # the bench CLI (counterpart of the reference's aocl_compression_bench, test/codec_bench.c)
+    cli_src = os.path.join(CSRC, "bench_cli.cpp")
+    if force or not os.path.exists(CLI) or _newer(cli_src, CLI, headers + [LIB]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(HERE, "..", "include"), cli_src, "-o", CLI,
+              "-L" + HERE, "-laocl_compression_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+              "-Wl,--allow-shlib-undefined"])
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "and", CLI)
     return LIB
 
 

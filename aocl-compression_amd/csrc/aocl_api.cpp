@@ -38,6 +38,14 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
     aoclgpu_codec c;
     if (!gpu_codec(t, &c)) return kCodecError;
     if (!h->outBuf || (!h->inBuf && h->inSize != 0)) return kCodecError;
+    if (h->numThreads > 1) {
+        // The reference's AOCL_ENABLE_THREADS build partitions the input inside this call and returns a RAP stream
+        // (lz4.c:2655-2909, snappy.cc:2505-2654, zstd_compress.c:5388-5534; callers add aocl_get_rap_frame_bound_mt()
+        // to outSize).  Here `numThreads > 1` asks for the same with GPU chunks as the partitions.
+        if (h->inSize > 0x7FFFFFFFu || (t == ZSTD && h->level != 1 && h->level != 0)) return kCodecError;
+        int64_t r = aoclgpu_rap_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize, 0);
+        return r > 0 ? r : kCodecError;
+    }
     if (t == LZ4) {                                   // api/codec.cpp:126-134: LZ4_compress_default takes int sizes
         if (h->inSize > 0x7E000000u) return kCodecError;
         size_t cap = h->outSize > 0x7FFFFFFFu ? 0x7FFFFFFFu : h->outSize;
@@ -60,7 +68,13 @@ int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
     aoclgpu_codec c;
     if (!gpu_codec(t, &c)) return kCodecError;
     if (!h->inBuf || !h->outBuf) return kCodecError;
-    int64_t r = aoclgpu_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+    // RAP streams (threads/threads.c:183-300): split at the frame's partition table and decode the partitions as one batch
+    static const unsigned char kRap[8] = {'A', 'O', 'C', 'L', '_', 'L', 'L', 'C'}, kSkip[4] = {0x50, 0x2A, 0x4D, 0x18};
+    const unsigned char* p = (const unsigned char*)h->inBuf;
+    const bool rap = (h->inSize >= 16 && memcmp(p, kRap, 8) == 0) ||
+                     (t == ZSTD && h->inSize >= 24 && memcmp(p, kSkip, 4) == 0 && memcmp(p + 8, kRap, 8) == 0);
+    int64_t r = rap ? aoclgpu_rap_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize)
+                    : aoclgpu_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
     return r >= 0 ? r : kCodecError;                  // api/codec.cpp:143-151
 }
 

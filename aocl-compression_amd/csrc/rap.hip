@@ -300,3 +300,63 @@ extern "C" int aoclgpu_rap_unpack(aoclgpu_codec codec, const uint8_t* in, uint64
     *decoded = (int64_t)total;
     return AOCLGPU_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Host-buffer forms: what the reference's AOCL_ENABLE_THREADS build does inside its one-shot calls (partition,
+// compress the partitions in parallel, join into a RAP stream / split and decode in parallel), with GPU chunks
+// as the partitions.  Used by aocl_llc_compress / aocl_llc_decompress (csrc/aocl_api.cpp) when the caller asks for
+// more than one thread, and by the bench CLI.
+// ------------------------------------------------------------------------------------------------
+extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream);
+extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stream);
+extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
+
+extern "C" uint64_t aoclgpu_rap_default_chunk(aoclgpu_codec codec)
+{   // BASELINE configs 2-4: LZ4 256 KiB, Snappy 64 KiB, Zstd 128 KiB
+    return codec == AOCLGPU_LZ4 ? (256u << 10) : (codec == AOCLGPU_SNAPPY ? (64u << 10) : (128u << 10));
+}
+
+extern "C" int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap,
+                                             uint64_t chunk_bytes)
+{
+    if ((!hsrc && n) || !hdst || n > 0x7FFFFFFFull) { set_error_msg("rap_compress_host: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    if (chunk_bytes == 0) chunk_bytes = aoclgpu_rap_default_chunk(codec);
+    if (codec == AOCLGPU_ZSTD && chunk_bytes > (128u << 10)) chunk_bytes = 128u << 10;
+    uint64_t K = n ? (n + chunk_bytes - 1) / chunk_bytes : 1;
+    while (K > 65535) { chunk_bytes *= 2; K = (n + chunk_bytes - 1) / chunk_bytes; }   // 16-bit partition count
+    if (codec == AOCLGPU_ZSTD && chunk_bytes > (128u << 10)) { set_error_msg("rap_compress_host: zstd input needs more than 65535 partitions"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    const uint64_t slot = (aoclgpu_compress_bound(codec, chunk_bytes) + 15) & ~(uint64_t)15;
+    const uint64_t scap = aoclgpu_rap_frame_bytes(codec, (uint32_t)K) + K * slot + 16;
+    DevBuf dsrc, dslots, dlen, daux, dout;
+    if (!dsrc.alloc(n) || !dslots.alloc(K * slot) || !dlen.alloc(K * 4) || !daux.alloc(K * 4) || !dout.alloc(scap)) {
+        set_error_msg("rap_compress_host: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
+    }
+#define HCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(#call, e_); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; } } while (0)
+    if (n) HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    aoclgpu_batch b; memset(&b, 0, sizeof(b));
+    b.src = (const uint8_t*)dsrc.p; b.dst = (uint8_t*)dslots.p; b.out_len = (int32_t*)dlen.p; b.aux = (uint32_t*)daux.p;
+    b.nchunks = (uint32_t)K; b.total_bytes = n; b.chunk_bytes = chunk_bytes; b.slot_bytes = slot;
+    int rc = codec == AOCLGPU_LZ4 ? aoclgpu_lz4_compress_chunks(&b, nullptr)
+           : codec == AOCLGPU_SNAPPY ? aoclgpu_snappy_compress_chunks(&b, nullptr) : aoclgpu_zstd_compress_chunks(&b, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    uint64_t bytes = 0;
+    rc = aoclgpu_rap_pack(codec, &b, (uint8_t*)dout.p, scap, &bytes, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    if (bytes > cap) return 0;                                   // does not fit the caller's buffer
+    HCK(hipMemcpy(hdst, dout.p, bytes, hipMemcpyDeviceToHost));
+    return (int64_t)bytes;
+}
+
+extern "C" int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap)
+{
+    if (!hsrc || !hdst || n == 0) { set_error_msg("rap_decompress_host: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    DevBuf dsrc, ddst;
+    if (!dsrc.alloc(n) || !ddst.alloc(cap)) { set_error_msg("rap_decompress_host: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    int64_t r = -1;
+    const int rc = aoclgpu_rap_unpack(codec, (const uint8_t*)dsrc.p, n, (uint8_t*)ddst.p, cap, &r, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    if (r > 0) HCK(hipMemcpy(hdst, ddst.p, (size_t)r, hipMemcpyDeviceToHost));
+#undef HCK
+    return r;
+}

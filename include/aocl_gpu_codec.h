@@ -115,6 +115,14 @@ int aoclgpu_rap_unpack(aoclgpu_codec codec, const uint8_t* rap_stream, uint64_t 
                        uint64_t dst_cap, int64_t* decoded_bytes, void* stream);
 /* bytes of RAP framing aoclgpu_rap_pack adds for nchunks partitions (0 for one chunk) */
 uint64_t aoclgpu_rap_frame_bytes(aoclgpu_codec codec, uint32_t nchunks);
+/* Host-buffer forms (H2D, chunked compress + pack / unpack + chunked decompress, D2H): what the reference's
+ * AOCL_ENABLE_THREADS build does inside its one-shot calls, with GPU chunks as the partitions.  chunk_bytes 0 = the
+ * codec's default partition (aoclgpu_rap_default_chunk: LZ4 256 KiB, Snappy 64 KiB, Zstd 128 KiB).  Inputs up to 2 GiB.
+ * Return conventions of aoclgpu_compress_host / aoclgpu_decompress_host. */
+uint64_t aoclgpu_rap_default_chunk(aoclgpu_codec codec);
+int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap,
+                                  uint64_t chunk_bytes);
+int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
 
 /* Timing helper used by bench.py: runs `iters` back-to-back launches of one batch op on `stream`
  * bracketed by HIP events recorded on that same stream; returns the average milliseconds per launch

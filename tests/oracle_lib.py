@@ -139,6 +139,10 @@ class RefMT(Ref):
         super().__init__()
         self.L.aocl_skip_rap_frame_mt.argtypes = [C.c_void_p, C.c_int32]
         self.gomp = C.CDLL("libgomp.so.1", mode=C.RTLD_GLOBAL)
+        # the reference registers its threaded decoders in the codec's lazy native setup, which only the compress
+        # entry points trigger (lz4.c: LZ4_decompress_wrapper_mt_fp starts as the single-threaded wrapper)
+        for codec in (LZ4, SNAPPY, ZSTD):
+            self.compress(codec, b"warm-up " * 8)
 
     def set_threads(self, n: int):
         self.gomp.omp_set_num_threads(int(n))

@@ -77,9 +77,11 @@ def test_gpu_streams_decode_everywhere(eng, ref, ref_mt, codec, chunk, total):
         assert ents[-1][0] + ents[-1][1] == len(stream)
     # legacy single-threaded decoder (zstd: skippable frames are part of the format)
     assert ref.decompress(oc, stream[skip:], total) == data
-    # the reference's own multi-threaded decoder
-    ref_mt.set_threads(3)
-    assert ref_mt.decompress(oc, stream, total) == data
+    # the reference's own multi-threaded decoder: one thread per partition (threads/threads.c:217-232 falls back to the
+    # single-threaded decoder when there are fewer threads than partitions), and that fallback
+    for threads in ((nparts, 3) if 1 < nparts <= 32 else (3,)):
+        ref_mt.set_threads(threads)
+        assert ref_mt.decompress(oc, stream, total) == data
     # GPU decoder
     dst, r = eng.rap_decompress(gc, stream_t, total)
     assert r == total and torch.equal(dst[:total], src)
