@@ -111,6 +111,13 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 // Table layout: u16 per slot (low 16 bits of index = position + 2) and, for chunks above 16 KiB, one extra bit per
 // slot in a packed word array (indices stay below 2^17 because nothing within 14 bytes of the chunk end is ever
 // inserted).  17 KB of LDS per chunk instead of 32 KB lets 9 instead of 5 chunks be resident per CU.
+#ifdef ZSTD_PROF
+__device__ unsigned long long g_zstd_prof[16];
+#define ZSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); zacc[k] += t_ - zprev; zprev = t_; } while (0)
+#else
+#define ZSTAGE(k) do { } while (0)
+#endif
 template <int MLS, typename T>
 __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
                           u32* litSizeOut, int lane)
@@ -142,18 +149,27 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     constexpr bool kChk = false;
     constexpr u32 kPosMask = 0x3FFFFu;
     auto chk = [&](u32 v4) -> u32 { return kChk ? ((v4 * 2654435761u) & ~kPosMask) : 0u; };
-    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {       // one 4-lane store per sequence
-        if (lane < 4) {
-            u32* arr = lane == 0 ? ws->seqLL : (lane == 1 ? ws->seqOff : (lane == 2 ? ws->seqML : ws->seqSrc));
-            arr[idx] = lane == 0 ? ll : (lane == 1 ? off : (lane == 2 ? ml : srcpos));
-        }
+    // Sequence records are parked one per lane and written 64 at a time (four coalesced stores): a store in the search
+    // loop would sit in front of every following load in vmcnt order.
+    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;
+    auto flush_seq = [&](u32 first, u32 count) {
+        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
+    };
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
+        const bool me = (u32)lane == (idx & 63u);
+        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
+        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
     };
     u32 nbSeq = 0, litSize = 0, anchor = 0, s = 1, rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
+#ifdef ZSTD_PROF
+    unsigned long long zacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zprev = __builtin_amdgcn_s_memtime(), zbatches = 0;
+#endif
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
         for (;;) {                                                      // _start
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
-            u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
+            u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
+            bool e_ok1 = false, e_ok2 = false;
             for (;;) {
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
                 u32 am, sg, st;
@@ -162,8 +178,13 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 else { am = 0x40000000u; sg = 2; st = 2; }
                 const bool valid = (u64)s + am + sg + 1 < ilimit;       // ip3 < ilimit (:503, :631)
                 const u32 pos = s + am + half;
+                ZSTAGE(5);
                 u64 seq = 0;
                 if (valid) seq = ld64(src + pos);
+                ZSTAGE(0);
+#ifdef ZSTD_PROF
+                zbatches++;
+#endif
                 const u32 h = z_hash<MLS>(seq, hlog);
                 u32 ent = 0;
                 if (valid) ent = tget(h);
@@ -177,6 +198,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 u32 m4 = ~(u32)seq;
                 if (valid && cand >= 2 && ((ent ^ mychk) & ~kPosMask) == 0) m4 = ld32(src + cand - 2);
                 wave_fence();
+                ZSTAGE(1);
                 bool pending = valid; u32 w = (u32)lane;
                 do {
                     if (pending) table[h] = (T)lane;
@@ -185,6 +207,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                     wave_fence();
                     pending = valid && (u32)lane < w;
                 } while (ballot(pending) != 0);
+                ZSTAGE(2);
                 const int f = first_lane(ballot(valid && w != (u32)lane));
                 const int e = first_lane(ballot(!valid));
                 const int lim = f < e ? f : e;
@@ -199,44 +222,68 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                     ev = lane_get((u32)rep_hit, el) ? 2 : 1;
                     e_pos = lane_get(pos, el); e_cand = lane_get(cand, el);
                     e_sig = lane_get(sg, el); e_st = lane_get(st, el); e_half = lane_get(half, el);
+                    // the hashes of ip1 and current0+2 are already in the neighbouring lanes of the batch
+                    e_ok1 = el + 1 < 64 && lane_get((u32)valid, (el + 1) & 63) != 0;
+                    e_p1 = lane_get(pos, (el + 1) & 63); e_h1 = lane_get(h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64 && lane_get((u32)valid, (el + 2) & 63) != 0 && lane_get(pos, (el + 2) & 63) == e_pos + 2;
+                    e_h2 = lane_get(h, (el + 2) & 63);
                     break;
                 }
                 if (e < 64 && e <= f) break;
                 i0 += (u32)lim;
             }
             if (!ev) break;                                             // _cleanup
+            ZSTAGE(3);
             // table write of ip1 that accompanies the hit (:537, :557, :586-598)
             {
                 const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
                 if (e_half == 0 || e_st <= 4) {
-                    const u64 v1 = ld64(src + ip1);
-                    const u32 h1 = z_hash<MLS>(v1, hlog);
+                    const u32 h1 = (e_ok1 && e_p1 == ip1) ? e_h1 : z_hash<MLS>(ld64(src + ip1), hlog);
                     if (lane == 0) tput(h1, ip1 + 2);
                     wave_fence();
                 }
             }
             const u32 current0 = e_pos;
             u32 ip0, match0, offcode, mLength;
-            if (ev == 2) {
-                ip0 = e_pos + e_sig; match0 = ip0 - rep1;
-                const u32 back = uni(src[ip0 - 1] == src[match0 - 1] ? 1u : 0u);
-                ip0 -= back; match0 -= back; offcode = 1; mLength = 4 + back;
-            } else {                                                    // _offset (:651-665)
+            // Catch-up and forward extension: the first round of both compares (64 bytes back, 256 bytes forward) is
+            // issued together, one global round trip instead of two; longer runs continue with the loops.
+            u32 maxback;
+            if (ev == 2) { ip0 = e_pos + e_sig; match0 = ip0 - rep1; offcode = 1; maxback = 1; }       // :519-542
+            else {                                                      // _offset (:651-665)
                 ip0 = e_pos; match0 = e_cand - 2;
-                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3; mLength = 4;
-                const u32 a = ip0 - anchor, maxback = a < match0 ? a : match0;
-                u32 back = 0;
-                while (back < maxback) {
-                    const u32 k = back + (u32)lane;
-                    bool eq = false;
-                    if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
-                    const int c = first_lane(ballot(!eq));
-                    back += (u32)c;
-                    if (c < 64) break;
-                }
-                ip0 -= back; match0 -= back; mLength += back;
+                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
+                const u32 a = ip0 - anchor; maxback = a < match0 ? a : match0;
             }
-            mLength += wave_count(src, ip0 + mLength, match0 + mLength, n, lane);       // _match (:669)
+            u32 fwd;
+            {
+                const u32 fa = ip0 + 4, fb = match0 + 4;
+                bool eqb = false;
+                if ((u32)lane < maxback) eqb = src[ip0 - 1 - (u32)lane] == src[match0 - 1 - (u32)lane];
+                const u32 o = 4u * (u32)lane, pa = fa + o;
+                u32 x = 0xFFFFFFFFu;
+                if (pa + 4 <= n) x = ld32(src + pa) ^ ld32(src + fb + o);
+                else if (pa < n) {
+                    x = 0;
+                    for (u32 t = 0; t < n - pa; ++t) x |= (u32)(src[pa + t] ^ src[fb + o + t]) << (8 * t);
+                    x |= 0xFFFFFFFFu << (8 * (n - pa));
+                }
+                u32 back = (u32)first_lane(ballot(!eqb));               // <= maxback for maxback <= 64
+                if (back == 64) {
+                    while (back < maxback) {
+                        const u32 k = back + (u32)lane;
+                        bool eq = false;
+                        if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
+                        const int c = first_lane(ballot(!eq));
+                        back += (u32)c;
+                        if (c < 64) break;
+                    }
+                }
+                const int l = first_lane(ballot(x != 0));
+                if (l == 64) fwd = 256 + wave_count(src, fa + 256, fb + 256, n, lane);
+                else fwd = 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
+                ip0 -= back; match0 -= back; mLength = 4 + back + fwd;   // _match (:669)
+            }
+            ZSTAGE(4);
             {
                 const u32 ll = ip0 - anchor;
                 put_seq(nbSeq, ll, offcode, mLength, anchor);
@@ -244,12 +291,19 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
             }
             ip0 += mLength; anchor = ip0;
             if (ip0 <= ilimit) {                                        // :678-702
-                const u64 va = ld64(src + current0 + 2), vb = ld64(src + ip0 - 2);
-                const u32 ha = z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
+                // the two table writes and the immediate-repcode test read four places: one round of loads
+                const bool chk = rep2 > 0;
+                u64 va = 0;
+                if (!e_ok2) va = ld64(src + current0 + 2);
+                const u64 vb = ld64(src + ip0 - 2);
+                u32 r0 = 0, r1 = 1;
+                if (chk) { r0 = ld32(src + ip0); r1 = ld32(src + ip0 - rep2); }
+                const u32 ha = e_ok2 ? e_h2 : z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
                 if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
                 wave_fence();
-                if (rep2 > 0) {
-                    while (ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u)) {
+                if (chk) {
+                    bool hit = uni(r0 == r1 ? 1u : 0u) != 0;
+                    while (hit) {
                         const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
                         const u32 t = rep2; rep2 = rep1; rep1 = t;
                         const u64 vc = ld64(src + ip0);
@@ -259,12 +313,17 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                         wave_fence();
                         nbSeq++;
                         ip0 += rLength; anchor = ip0;
+                        hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
                     }
                 }
             }
             s = ip0;
         }
     }
+#ifdef ZSTD_PROF
+    if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq); }
+#endif
+    flush_seq(nbSeq & ~63u, nbSeq & 63u);
     // ---- literal buffer: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the
     //      search loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal
     //      lengths, short runs one per lane, long runs by the whole wave.
@@ -1123,6 +1182,15 @@ uint32_t lds_for_chunk(uint64_t n)
 }
 }  // namespace
 
+#ifdef ZSTD_PROF
+extern "C" int aoclgpu_debug_zstd_prof(unsigned long long* host16)
+{
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_prof), z, sizeof(z));
+    return 0;
+}
+#endif
 extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream)
 {
     if (int rc = aoclgpu::check_batch(b, false)) return rc;

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Experiment: per-stage cycle breakdown of the Zstd match finder (library built with AOCLGPU_CFLAGS=-DZSTD_PROF)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import aocl_compression_amd as a
+eng = a.engine(0)
+data = a.corpus.silesia_mix(64 << 20)
+src = torch.from_numpy(data).to(eng.device).repeat(8)
+os.environ["AOCLGPU_EXPERIMENT"] = "16"
+slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16)()
+eng.lib.aoclgpu_debug_zstd_prof(buf)
+names = ["probe loads (ld64 at pos)", "hash + table + cand/rep loads", "slot-reuse rounds", "decision + commit (+ no-hit batches)", "ip1 write + catch-up + extension", "store seq + post writes + rep2 / loop top"]
+tot = sum(buf[:6]); nseq = buf[9]
+for n, v in zip(names, buf[:6]):
+    print(f"{n:44s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
+print("total cyc/seq", tot / nseq, "batches", buf[8], "seqs", nseq, "batches/seq", buf[8] / nseq)
