@@ -701,11 +701,64 @@ struct BitR {                       // backward bit reader (bitstream.h:262-420)
     __device__ u32 read(int nb) { const u32 v = peek(nb); pos -= nb; return v; }
 };
 
+// Backward bit reader for the serial decode loops (one lane per stream).  A 128-bit register window over the stream
+// with two 8-byte blocks always in flight below it, so the loops never wait for memory in steady state; `grab`
+// left-aligns the next 64 unread bits in a container (BIT_reloadDStream), `take` consumes fields from its top with
+// three instructions (BIT_readBitsFast).  Bits below the start of the stream read as 0; bytes outside [p, p+n) are
+// never loaded.
+struct BitP {
+    const gbyte* p; u32 n; int pos;       // pos: bits of the stream still unread (may go negative: over-read)
+    int wq;                               // window = bytes [wq, wq+16): lo = [wq, wq+8), hi = [wq+8, wq+16)
+    u64 lo, hi, pre1, pre2;               // pre1 = bytes [wq-8, wq), pre2 = bytes [wq-16, wq-8)
+    u64 c;                                // container: unread bits, next one at bit 63
+    __device__ u64 ldwin(int q) const
+    {
+        if (q >= 0 && (u32)q + 8 <= n) return ld64(p + q);
+        u64 v = 0;
+        for (int i = 0; i < 8; ++i) { const int a = q + i; if (a >= 0 && (u32)a < n) v |= (u64)p[a] << (8 * i); }
+        return v;
+    }
+    __device__ bool init(const u8* s_, u32 len)
+    {
+        const gbyte* s = (const gbyte*)s_;                // the compressed stream lives in global memory
+        if (!len) return false;
+        const u32 last = s[len - 1];
+        if (!last) return false;
+        p = s; n = len; pos = (int)(len - 1) * 8 + hb(last);
+        wq = (int)((len + 7) & ~7u) - 16;
+        hi = ldwin(wq + 8); lo = ldwin(wq); pre1 = ldwin(wq - 8); pre2 = ldwin(wq - 16);
+        c = 0;
+        return true;
+    }
+    __device__ __forceinline__ void grab()  // c = bits [pos-64, pos) of the stream, left-aligned
+    {
+        int off = pos - 64 - 8 * wq;
+        for (int r = 0; r < 2; ++r)         // at most 64 bits are consumed between two grabs (+ the first grab of a stream)
+            if (off < 0 && wq > -16) {      // the upper half of the window is used up: move it 8 bytes down
+                hi = lo; lo = pre1; pre1 = pre2; wq -= 8; off += 64;
+                pre2 = ldwin(wq - 16);
+            }
+        if (off <= 0) c = off == 0 ? lo : (off > -64 ? lo << (-off) : 0);      // (off < 0 only below the start of the stream)
+        else c = off >= 64 ? hi >> (off - 64) : (lo >> off) | (hi << (64 - off));
+    }
+    __device__ __forceinline__ u32 take(u32 nb)   // nb <= 32 bits from the top of the container; nb == 0 -> 0
+    {
+        const u32 v = (u32)((c >> 1) >> (63 - nb));
+        c <<= nb; pos -= (int)nb;
+        return v;
+    }
+    __device__ __forceinline__ u32 top(u32 nb) const { return (u32)((c >> 1) >> (63 - nb)); }
+    __device__ __forceinline__ void skip(u32 nb) { c <<= nb; pos -= (int)nb; }
+};
+
+// sequence-table cell: everything one decode step needs in one 8-byte LDS read (ZSTD_seqSymbol, zstd_decompress_block.h)
+struct SeqD { u32 base; u16 newState; u8 nbBits; u8 addBits; };
+
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
 struct DecLds {
     u16 huf[4096];                  // symbol | nbBits << 8
-    FseD ll[512], of[256], ml[512];
+    SeqD ll[512], of[256], ml[512];
     u32 llLog, ofLog, mlLog, hufLog;
     u32 haveLL, haveOF, haveML, haveHuf;
     u32 rep[3];
@@ -840,34 +893,81 @@ __device__ u32 huf_read_table(DecLds* L, const u8* src, u32 n)
     return used;
 }
 // one Huffman stream, executed by ONE lane
-__device__ bool huf_decode_stream(u8* out, u32 nout, const u8* src, u32 n, const DecLds* L)
+// (kept inline: as a called function, under the 4-lane exec mask, this loop was miscompiled by ROCm 7.2's hipcc)
+__device__ __forceinline__ bool huf_decode_stream(u8* out_, u32 nout, const u8* src, u32 n, const DecLds* L_)
 {
-    BitR b; const int tl = (int)L->hufLog;
+    gbyte* out = (gbyte*)out_;                            // literal buffer: global; tables: LDS (no flat accesses in the loop)
+    const __attribute__((address_space(3))) DecLds* L = (const __attribute__((address_space(3))) DecLds*)L_;
+    BitP b; const u32 tl = L->hufLog;                     // <= 12: four symbols per 64-bit container (HUF_decodeStreamX1)
     if (!b.init(src, n)) return false;
-    for (u32 i = 0; i < nout; ++i) {
-        const u32 cell = L->huf[b.peek(tl)];
-        out[i] = (u8)cell; b.pos -= (int)(cell >> 8);
+    u32 i = 0;
+    for (; i + 8 <= nout; i += 8) {                       // 8 symbols per store
+        u64 acc = 0;
+        for (int g = 0; g < 2; ++g) {
+            b.grab();
+            for (int k = 0; k < 4; ++k) {
+                const u32 cell = L->huf[b.top(tl)];
+                acc |= (u64)(cell & 0xFF) << (8 * (4 * g + k)); b.skip(cell >> 8);
+            }
+        }
+        __builtin_memcpy(out + i, &acc, 8);
+    }
+    for (; i < nout; ++i) {
+        b.grab();
+        const u32 cell = L->huf[b.top(tl)];
+        out[i] = (u8)cell; b.skip(cell >> 8);
     }
     return b.pos == 0;
 }
 
+// ZSTD_buildFSETable (zstd_decompress_block.c:497-615) into fused cells; lane-serial.  bits == nullptr: offset codes
+// (base = 1 << code, code additional bits, codes above 31 are rejected here as ZSTD_decodeSequence would).
+__device__ bool seq_build_dtable(SeqD* dt, const s16* norm, u32 maxSym, u32 tableLog, u16* next, const u32* base, const u8* bits)
+{
+    const u32 size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    u32 high = size - 1, pos = 0;
+    for (u32 s = 0; s <= maxSym; ++s) {
+        if (norm[s] == -1) { dt[high--].addBits = (u8)s; next[s] = 1; }
+        else next[s] = (u16)norm[s];
+    }
+    for (u32 s = 0; s <= maxSym; ++s)
+        for (int i = 0; i < norm[s]; ++i) {
+            dt[pos].addBits = (u8)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    if (pos != 0) return false;
+    for (u32 u = 0; u < size; ++u) {
+        const u32 sym = dt[u].addBits; const u32 ns = next[sym]++;
+        const u32 nb = tableLog - (u32)hb(ns);
+        if (!bits && sym > 31) return false;
+        SeqD c; c.nbBits = (u8)nb; c.newState = (u16)((ns << nb) - size);
+        c.base = bits ? base[sym] : (1u << sym); c.addBits = bits ? bits[sym] : (u8)sym;
+        dt[u] = c;
+    }
+    return true;
+}
+
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705); lane-serial
-__device__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
-                          const s16* defNorm, u32 defMax, u32 defLog, DecLds* L)
+__device__ bool seq_table(SeqD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
+                          const s16* defNorm, u32 defMax, u32 defLog, DecLds* L, const u32* base, const u8* bits)
 {
     if (mode == 0) {
         for (u32 i = 0; i <= defMax; ++i) L->norm[i] = defNorm[i];
-        fse_build_dtable(dt, L->norm, defMax, defLog, L->next); *log = defLog; *have = 1; return true;
+        seq_build_dtable(dt, L->norm, defMax, defLog, L->next, base, bits); *log = defLog; *have = 1; return true;
     }
     if (mode == 1) {
         if (*ip >= iend || src[*ip] > maxSym) return false;
-        dt[0].symbol = src[*ip]; dt[0].nbBits = 0; dt[0].newState = 0; *log = 0; *have = 1; (*ip)++; return true;
+        const u32 sym = src[*ip];
+        if (!bits && sym > 31) return false;
+        SeqD c; c.nbBits = 0; c.newState = 0; c.base = bits ? base[sym] : (1u << sym); c.addBits = bits ? bits[sym] : (u8)sym;
+        dt[0] = c; *log = 0; *have = 1; (*ip)++; return true;
     }
     if (mode == 2) {
         u32 ms = maxSym, tl;
         const u32 h = fse_read_ncount(L->norm, &ms, &tl, src + *ip, iend - *ip, maxLog);
         if (h == 0xFFFFFFFFu) return false;
-        if (!fse_build_dtable(dt, L->norm, ms, tl, L->next)) return false;
+        if (!seq_build_dtable(dt, L->norm, ms, tl, L->next, base, bits)) return false;
         *log = tl; *have = 1; *ip += h; return true;
     }
     return *have != 0;
@@ -893,9 +993,20 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int 
 }
 
 // one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
+#ifdef ZSTD_PROF
+__device__ unsigned long long g_zstd_dprof[16];
+#define DSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dacc[k] += t_ - dprev; dprev = t_; } while (0)
+#else
+#define DSTAGE(k) do { } while (0)
+#endif
 __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
                             u8* litBuf, int lane)
 {
+#ifdef ZSTD_PROF
+    unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = __builtin_amdgcn_s_memtime();
+    struct Flush { unsigned long long* a; int lane; __device__ ~Flush() { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_dprof[k], a[k]); } } flush_{dacc, lane};
+#endif
     if (n < 1) return 0xFFFFFFFFu;
     u32 ip = 0, litSize = 0; const u8* litPtr = nullptr;
     {   // ---- literals (ZSTD_decodeLiteralsBlock :162-364) ----
@@ -950,6 +1061,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             litPtr = litBuf; ip = lh + csize;
         }
     }
+    DSTAGE(0);
     // ---- sequences header (ZSTD_decodeSeqHeaders :707-790) ----
     if (ip >= n) return 0xFFFFFFFFu;
     u32 nbSeq = src[ip++];
@@ -965,52 +1077,57 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (modes & 3) return 0xFFFFFFFFu;
         u32 okT = 1, ipT = ip;
         if (lane == 0) {
-            okT = seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ipT, n, 35, 9, kLLnorm, 35, 6, L)
-               && seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ipT, n, 31, 8, kOFnorm, 28, 5, L)
-               && seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ipT, n, 52, 9, kMLnorm, 52, 6, L);
+            okT = seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ipT, n, 35, 9, kLLnorm, 35, 6, L, kLLbase, kLLbits)
+               && seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ipT, n, 31, 8, kOFnorm, 28, 5, L, nullptr, nullptr)
+               && seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ipT, n, 52, 9, kMLnorm, 52, 6, L, kMLbase, kMLbits);
         }
         wave_fence();
         okT = uni(okT); ip = uni(ipT);
         if (!okT) return 0xFFFFFFFFu;
         // lane 0 decodes 64 sequences (ZSTD_decodeSequence :1339-1460), the wave executes them (:1007-1108)
-        BitR b; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
+        BitP b; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
+        u32 r0 = 0, r1 = 0, r2 = 0;                                              // repcodes live in lane 0's registers
         if (lane == 0) {
             okB = b.init(src + ip, n - ip) ? 1u : 0u;
-            if (okB) { sLL = b.read((int)L->llLog); sOF = b.read((int)L->ofLog); sML = b.read((int)L->mlLog); if (b.pos < 0) okB = 0; }
+            if (okB) { b.grab(); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0; }
+            r0 = L->rep[0]; r1 = L->rep[1]; r2 = L->rep[2];
         }
         if (!uni(okB)) return 0xFFFFFFFFu;
+        DSTAGE(1);
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
             u32 okS = 1;
             if (lane == 0) {
                 for (u32 k = 0; k < cnt; ++k) {
-                    const FseD dl = L->ll[sLL], dof = L->of[sOF], dm = L->ml[sML];
-                    const u32 llc = dl.symbol, ofc = dof.symbol, mlc = dm.symbol;
-                    if (ofc > 31) { okS = 0; break; }
-                    const u32 ofv = (1u << ofc) + b.read((int)ofc);
-                    const u32 ml = kMLbase[mlc] + b.read(kMLbits[mlc]);
-                    const u32 ll = kLLbase[llc] + b.read(kLLbits[llc]);
+                    const SeqD dl = L->ll[sLL], dof = L->of[sOF], dm = L->ml[sML];
+                    b.grab();                                                    // >= 64 bits: offset (<= 31) + lengths (<= 16 + 16)
+                    const u32 ofv = dof.base + b.take(dof.addBits);
+                    const u32 ml = dm.base + b.take(dm.addBits);
+                    const u32 ll = dl.base + b.take(dl.addBits);
                     u32 offset;
-                    if (ofv > 3) { offset = ofv - 3; L->rep[2] = L->rep[1]; L->rep[1] = L->rep[0]; L->rep[0] = offset; }
+                    if (ofv > 3) { offset = ofv - 3; r2 = r1; r1 = r0; r0 = offset; }
                     else {
                         const u32 idx = ofv - 1 + (ll == 0);
-                        if (idx == 0) offset = L->rep[0];
+                        if (idx == 0) offset = r0;
                         else {
-                            u32 t = (idx == 3) ? L->rep[0] - 1 : L->rep[idx];
+                            u32 t = (idx == 3) ? r0 - 1 : (idx == 1 ? r1 : r2);
                             t += !t;
-                            if (idx != 1) L->rep[2] = L->rep[1];
-                            L->rep[1] = L->rep[0]; L->rep[0] = t; offset = t;
+                            if (idx != 1) r2 = r1;
+                            r1 = r0; r0 = t; offset = t;
                         }
                     }
                     if (q0 + k + 1 < nbSeq) {
-                        sLL = dl.newState + b.read(dl.nbBits);
-                        sML = dm.newState + b.read(dm.nbBits);
-                        sOF = dof.newState + b.read(dof.nbBits);
+                        b.grab();                                                // the three state updates: <= 9 + 9 + 8 bits
+                        sLL = dl.newState + b.take(dl.nbBits);
+                        sML = dm.newState + b.take(dm.nbBits);
+                        sOF = dof.newState + b.take(dof.nbBits);
                     }
                     L->seqLL[k] = ll; L->seqML[k] = ml; L->seqOff[k] = offset;
                 }
+                if (q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
             }
             wave_fence();
+            DSTAGE(2);
             if (!uni(okS)) return 0xFFFFFFFFu;
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;
@@ -1026,13 +1143,52 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             const u32 myLit = litPos + incL - ll, myOut = out + incO - (ll + ml);
             // offsets must point inside what is already produced
             if (ballot((u32)lane < cnt && off > myOut + ll) != 0) return 0xFFFFFFFFu;
-            for (u32 i = 0; i < ll; ++i) dst[myOut + i] = litPtr[myLit + i];     // literals: one sequence per lane
+            {   // literals: short runs one sequence per lane (two 8-byte loads, exact-length stores), long runs by the wave
+                gbyte* gd = (gbyte*)dst; const gbyte* gl = (const gbyte*)litPtr;     // output and literal buffer are global memory
+                const bool shortl = ll <= 16 && (u64)myLit + 16 <= litSize + 0ull;   // the 16-byte read stays inside the literals
+                if (ll && shortl) {
+                    const u64 v0 = ld64(gl + myLit), v1 = ld64(gl + myLit + 8);
+                    gbyte* d = gd + myOut;
+                    if (ll >= 8) { st64(d, v0); if (ll > 8) { const u32 o2 = ll - 8; st64(d + o2, o2 == 8 ? v1 : (v0 >> (8 * o2)) | (v1 << (64 - 8 * o2))); } }
+                    else if (ll >= 4) { st32(d, (u32)v0); st32(d + ll - 4, (u32)(v0 >> (8 * (ll - 4)))); }
+                    else for (u32 i = 0; i < ll; ++i) d[i] = (u8)(v0 >> (8 * i));
+                }
+                for (u64 lm = ballot(ll && !shortl); lm; lm &= lm - 1) {
+                    const int k = (int)__builtin_ctzll(lm);
+                    wave_copy(gd + lane_get(myOut, k), gl + lane_get(myLit, k), lane_get(ll, k), lane);
+                }
+            }
             wave_fence();
-            for (u32 k = 0; k < cnt; ++k) {                                      // matches: in order, 64 lanes each
-                const u32 mo = lane_get(myOut, (int)k) + lane_get(ll, (int)k);
-                wave_match_copy(dst + mo, lane_get(off, (int)k), lane_get(ml, (int)k), lane);
+            DSTAGE(3);
+            {   // matches.  Those that copy from output produced before this tile (and are short) are independent of
+                // everything in the tile: all of them at once, one global round trip; the others in order, 64 lanes each.
+                gbyte* gd = (gbyte*)dst;
+                const u32 mo = myOut + ll, spos = mo - off;
+                const bool indep = (u32)lane < cnt && ml <= 32 && off >= ml && spos + ml <= out && (u64)spos + 32 <= cap;
+                if (indep) {
+                    const u64 v0 = ld64(gd + spos), v1 = ld64(gd + spos + 8), v2 = ld64(gd + spos + 16), v3 = ld64(gd + spos + 24);
+                    gbyte* d = gd + mo;
+                    auto ext = [&](u32 o) -> u64 {                                // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
+                        const u64 a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
+                        const u32 sh = (o & 7) * 8;
+                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
+                    };
+                    if (ml >= 8) {
+                        st64(d, v0);
+                        if (ml > 8) st64(d + (ml > 16 ? 8 : ml - 8), ext(ml > 16 ? 8 : ml - 8));
+                        if (ml > 16) st64(d + (ml > 24 ? 16 : ml - 8), ext(ml > 24 ? 16 : ml - 8));
+                        if (ml > 24) st64(d + ml - 8, ext(ml - 8));
+                    } else if (ml >= 4) { st32(d, (u32)v0); st32(d + ml - 4, (u32)(v0 >> (8 * (ml - 4)))); }
+                    else for (u32 i = 0; i < ml; ++i) d[i] = (u8)(v0 >> (8 * i));
+                }
+                wave_fence();
+                for (u64 dm = ballot((u32)lane < cnt && !indep); dm; dm &= dm - 1) {
+                    const int k = (int)__builtin_ctzll(dm);
+                    wave_match_copy(dst + lane_get(mo, k), lane_get(off, k), lane_get(ml, k), lane);
+                }
             }
             litPos += totL; out += totO;
+            DSTAGE(4);
         }
         u32 endOk = 1;
         if (lane == 0) endOk = b.pos <= 0 ? 1u : 0u;                             // bitstream fully consumed
@@ -1183,6 +1339,13 @@ uint32_t lds_for_chunk(uint64_t n)
 }  // namespace
 
 #ifdef ZSTD_PROF
+extern "C" int aoclgpu_debug_zstd_dprof(unsigned long long* host16)
+{
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_dprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_dprof), z, sizeof(z));
+    return 0;
+}
 extern "C" int aoclgpu_debug_zstd_prof(unsigned long long* host16)
 {
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
@@ -1230,7 +1393,17 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
 {
     if (int rc = aoclgpu::check_batch(b, true)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
-    uint32_t grid = 256u * 8u;
+    // persistent blocks: exactly as many as are resident at once (LDS / VGPR limited), asked from the runtime
+    static int perCU = 0, nCU = 0;
+    if (!perCU) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::zstd_decompress_kernel, 64, 0) != hipSuccess || perCU < 1) {
+            aoclgpu::set_error_msg("zstd: occupancy query failed"); perCU = 0; return AOCLGPU_ERR_HIP;
+        }
+        nCU = prop.multiProcessorCount;
+    }
+    uint32_t grid = (uint32_t)(perCU * nCU);
     if (grid > b->nchunks) grid = b->nchunks;
     // the decoder's literal buffers share the workspace pool with the compressor's (same stream order)
     void* ws = get_workspace((size_t)grid * ((128u << 10) + 64));
