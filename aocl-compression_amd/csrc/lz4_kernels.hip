@@ -606,6 +606,7 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
     return sh ? (a >> sh) | (b << (64 - sh)) : a;
 }
 
+template <bool RAP>
 __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
                                    uint8_t* ring, const bool rap)
 {
@@ -624,7 +625,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
             rend += 1024; have_pend = false;
         }
         if (rend - ip < 640 && rend + 1024 <= iend) {
-            __builtin_memcpy(&pend, src + rend + 16 * lane, 16);
+            { typedef u32x4 __attribute__((aligned(1))) U; const u32x4 t_ = *(const __attribute__((address_space(1))) U*)(src + rend + 16 * lane); pend = make_uint4(t_.x, t_.y, t_.z, t_.w); }
             have_pend = true;
             if (rend - ip < 160) {
                 *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
@@ -685,12 +686,12 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
                     const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
                     gbyte* d = dst + mstart;
                     if (mlen >= 8) {
-                        __builtin_memcpy(d, &v0, 8);
-                        if (mlen > 8) { const uint64_t x = ext64(v0, v1, v2, mlen > 16 ? 8 : mlen - 8); __builtin_memcpy(d + (mlen > 16 ? 8 : mlen - 8), &x, 8); }
-                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); __builtin_memcpy(d + mlen - 8, &x, 8); }
+                        st64(d, v0);
+                        if (mlen > 8) { const uint64_t x = ext64(v0, v1, v2, mlen > 16 ? 8 : mlen - 8); st64(d + (mlen > 16 ? 8 : mlen - 8), x); }
+                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); st64(d + mlen - 8, x); }
                     } else {
-                        const uint32_t lo = (uint32_t)v0; __builtin_memcpy(d, &lo, 4);
-                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); __builtin_memcpy(d + mlen - 4, &hi, 4);
+                        const uint32_t lo = (uint32_t)v0; st32(d, lo);
+                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); st32(d + mlen - 4, hi);
                     }
                 }
                 wave_fence();
@@ -718,7 +719,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
             }
         }
         if (!window) {
-            const int r = rap ? lz4_decode_one_rap(src, iend, dst, oend, ip, op, lane) : lz4_decode_one(src, iend, dst, oend, ip, op, lane);
+            const int r = (RAP && rap) ? lz4_decode_one_rap(src, iend, dst, oend, ip, op, lane) : lz4_decode_one(src, iend, dst, oend, ip, op, lane);
             if (r < 0) return r;
             if (r == 1) break;
         }
@@ -755,6 +756,7 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     if (threadIdx.x == 0) { b.out_len[c] = r; if (b.aux) b.aux[c] = lastrun; }
 }
 
+template <bool RAP>
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
@@ -763,8 +765,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
     const ChunkView v = decompress_view(b, c);
     int r;
     if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
-    else r = lz4_decompress_wave(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring,
-                                 (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) && c + 1 < b.nchunks);
+    else r = lz4_decompress_wave<RAP>(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring, RAP && c + 1 < b.nchunks);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 
@@ -823,6 +824,9 @@ extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* strea
 {
     if (int rc = aoclgpu::check_batch(b, /*decompress=*/true)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
-    hipLaunchKernelGGL(aoclgpu::lz4_decompress_kernel, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
+    if (b->reserved & AOCLGPU_FLAG_RAP_PARTITIONS)
+        hipLaunchKernelGGL(aoclgpu::lz4_decompress_kernel<true>, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
+    else
+        hipLaunchKernelGGL(aoclgpu::lz4_decompress_kernel<false>, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
     return aoclgpu::check_launch("lz4_decompress_kernel");
 }
