@@ -223,6 +223,15 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             STAGE(1);
             Win cw = {~pw.lo, 0};
             if (plausible) cw = load_win(src, cand);
+            // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
+            uint64_t c2 = 0, c3 = 0;
+            const bool have2 = plausible && use_ring && cand + 20 <= n;
+            const bool have3 = have2 && cand + 28 <= n;
+            if (have3) {                                  // one 16-byte load
+                typedef u32x4 __attribute__((aligned(1))) U;
+                const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + cand + 12);
+                c2 = v.x | ((uint64_t)v.y << 32); c3 = v.z | ((uint64_t)v.w << 32);
+            } else if (have2) c2 = ld64(src + cand + 12);
             // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
             wave_fence();
             bool pending = valid;
@@ -246,14 +255,6 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
             uint32_t fw; bool mf;
             {
-                uint64_t c2 = 0, c3 = 0;
-                const bool have2 = plausible && use_ring && cand + 20 <= n;
-                const bool have3 = have2 && cand + 28 <= n;
-                if (have3) {                              // one 16-byte load
-                    typedef u32x4 __attribute__((aligned(1))) U;
-                    const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + cand + 12);
-                    c2 = v.x | ((uint64_t)v.y << 32); c3 = v.z | ((uint64_t)v.w << 32);
-                } else if (have2) c2 = ld64(src + cand + 12);
                 const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
                 uint32_t avail = 8;                       // bytes of forward data compared in registers
                 fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
@@ -385,36 +386,48 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
                 uint32_t back, fwd = lane_get(fw, m);
                 const bool more_fwd = lane_get((uint32_t)mf, m) != 0;
-                {
+                {   // the first round of the longer catch-up (64 bytes back) and of the longer extension (256 bytes forward)
+                    // is issued together: one global round trip instead of two
                     const uint32_t a = m_pos - anchor, maxback = a < m_cand ? a : m_cand;
                     const uint32_t b4 = lane_get(bk4, m);
                     back = b4 < maxback ? b4 : maxback;
-                    if (b4 == 4 && maxback > 4) {
-                        while (back < maxback) {
-                            const uint32_t k = back + (uint32_t)lane;
-                            bool eq = false;
-                            if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
-                            const int c = first_lane(ballot(!eq));
-                            back += (uint32_t)c;
-                            if (c < 64) break;
-                        }
-                    }
-                }
-                if (more_fwd) {
-                    const uint32_t a = m_pos + kMinMatch, b = m_cand + kMinMatch;
-                    for (;;) {
-                        const uint32_t o = fwd + 4u * (uint32_t)lane;
-                        const uint32_t pa = a + o;
-                        uint32_t x = 0xFFFFFFFFu;
+                    const bool more_back = b4 == 4 && maxback > 4;
+                    bool eqb = false;
+                    if (more_back && back + (uint32_t)lane < maxback) eqb = src[m_pos - 1 - back - (uint32_t)lane] == src[m_cand - 1 - back - (uint32_t)lane];
+                    uint32_t x = 0xFFFFFFFFu;
+                    const uint32_t fa = m_pos + kMinMatch, fb = m_cand + kMinMatch;
+                    if (more_fwd) {
+                        const uint32_t o = fwd + 4u * (uint32_t)lane, pa = fa + o;
                         if (pa < matchlimit) {
-                            x = ld32(src + pa) ^ ld32(src + b + o);
+                            x = ld32(src + pa) ^ ld32(src + fb + o);
                             const uint32_t avail = matchlimit - pa;
                             if (avail < 4) x |= 0xFFFFFFFFu << (8 * avail);
                         }
-                        const int l = first_lane(ballot(x != 0));
-                        if (l == 64) { fwd += 256; continue; }
-                        fwd += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
-                        break;
+                    }
+                    if (more_back) {
+                        int c = first_lane(ballot(!eqb));
+                        back += (uint32_t)c;
+                        while (c == 64 && back < maxback) {
+                            const uint32_t k = back + (uint32_t)lane;
+                            bool eq = false;
+                            if (k < maxback) eq = src[m_pos - 1 - k] == src[m_cand - 1 - k];
+                            c = first_lane(ballot(!eq));
+                            back += (uint32_t)c;
+                        }
+                    }
+                    if (more_fwd) {
+                        for (;;) {
+                            const int l = first_lane(ballot(x != 0));
+                            if (l < 64) { fwd += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3); break; }
+                            fwd += 256;
+                            const uint32_t o = fwd + 4u * (uint32_t)lane, pa = fa + o;
+                            x = 0xFFFFFFFFu;
+                            if (pa < matchlimit) {
+                                x = ld32(src + pa) ^ ld32(src + fb + o);
+                                const uint32_t avail = matchlimit - pa;
+                                if (avail < 4) x |= 0xFFFFFFFFu << (8 * avail);
+                            }
+                        }
                     }
                 }
                 const uint32_t mstart = m_pos - back;
