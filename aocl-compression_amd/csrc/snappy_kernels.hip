@@ -132,6 +132,14 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             if (valid) cand = table[h];
             Win cw = {~pw.lo, 0};
             if (valid) cw = load_win(in, cand);
+            // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
+            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;        // lanes [0, linlim) probe consecutive positions
+            uint64_t c2 = 0, c3 = 0;
+            const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
+            const bool have2 = valid && lane + 8 < linlim && v2 && cand + 20 <= n;
+            const bool have3 = have2 && lane + 16 < linlim && v3 && cand + 28 <= n;
+            if (have2) c2 = ld64(in + cand + 12);
+            if (have3) c3 = ld64(in + cand + 20);
             wave_fence();
             bool pending = valid;
             uint32_t w = (uint32_t)lane;
@@ -150,18 +158,10 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const uint64_t okmask = ballot(lane < lim && (uint32_t)(cw.lo >> 32) == seq);
             const uint32_t pos0 = lane_get(pos, 0);
             // lanes [0, linlim) probe consecutive positions pos0 + lane (the schedule's first 33 steps are 1 byte)
-            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;
             // in-lane forward extension (<= 24 bytes beyond the 4 tested), FindMatchLength snappy-internal.h:228-352
             uint32_t fw; bool mf;
             {
                 const uint64_t p2 = __shfl_down(pw.hi, 8), p3 = __shfl_down(pw.hi, 16);
-                uint64_t c2 = 0, c3 = 0;
-                const bool cm = valid && (uint32_t)(cw.lo >> 32) == seq;
-                const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
-                const bool have2 = cm && lane + 8 < linlim && v2 && cand + 20 <= n;
-                const bool have3 = have2 && lane + 16 < linlim && v3 && cand + 28 <= n;
-                if (have2) c2 = ld64(in + cand + 12);
-                if (have3) c3 = ld64(in + cand + 20);
                 const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
                 uint32_t avail = 8;
                 fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
