@@ -109,3 +109,21 @@ def test_malformed_rap_streams_are_rejected(eng, ref_mt):
         bad = mutate(good)
         dst, r = eng.rap_decompress(a.LZ4, torch.frombuffer(bytearray(bad), dtype=torch.uint8).to(eng.device), len(data))
         assert r < 0 or bytes(dst[:r].cpu().numpy()) != data
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+@pytest.mark.parametrize("kind,chunk,total", [("text", 4096, 100001), ("random", 1000, 40000), ("jsonlog", 65536, 65536 * 5 + 17),
+                                              ("binary", 13, 700), ("database", 100, 5000), ("image16", 30000, 400000)])
+def test_gpu_pack_equals_the_join_model(eng, oracle, ref, ref_mt, codec, kind, chunk, total):
+    """Geometries the threaded reference cannot be steered into (tiny / ragged / all-literal partitions): the GPU join
+    against the Python restatement of the reference's join (tests/rap_model.py, itself pinned to the threaded build)."""
+    import rap_model
+    gc, oc = CODECS[codec]
+    data = a.corpus.make(kind, total, seed=chunk).tobytes()
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+    stream_t = eng.rap_compress(gc, src, chunk)
+    stream = bytes(stream_t.cpu().numpy())
+    assert stream == rap_model.pack(oracle, oc, data, chunk)
+    assert ref.decompress(oc, stream[ref_mt.skip(stream):], total) == data
+    dst, r = eng.rap_decompress(gc, stream_t, total)
+    assert r == total and torch.equal(dst[:total], src)
