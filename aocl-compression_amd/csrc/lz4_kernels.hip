@@ -634,6 +634,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
         if (ip > rend) { rend = ip & ~15; have_pend = false; }
         if (have_pend) {
             *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
+            if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *reinterpret_cast<uint4*>(ring + kRing) = pend;   // mirror: 16-byte reads never wrap
             wave_fence();
             rend += 1024; have_pend = false;
         }
@@ -642,6 +643,7 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
             have_pend = true;
             if (rend - ip < 160) {
                 *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
+                if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *reinterpret_cast<uint4*>(ring + kRing) = pend;
                 wave_fence();
                 rend += 1024; have_pend = false;
             }
@@ -686,7 +688,14 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
             else {
                 const bool act = (mask >> lane) & 1;
                 // short literal runs: straight from the ring, one sequence per lane
-                if (act && lit < 15) for (uint32_t i = 0; i < lit; ++i) dst[opos + i] = ring[(litsrc + i) & kRingMask];
+                if (act && lit && lit < 15) {             // one 16-byte LDS read, exact-length overlapping stores
+                    uint4 q4; __builtin_memcpy(&q4, ring + (litsrc & kRingMask), 16);
+                    const uint64_t v0 = q4.x | ((uint64_t)q4.y << 32), v1 = q4.z | ((uint64_t)q4.w << 32);
+                    gbyte* d = dst + opos;
+                    if (lit >= 8) { st64(d, v0); if (lit > 8) { const uint32_t o2 = lit - 8; st64(d + o2, (v0 >> (8 * o2)) | (v1 << (64 - 8 * o2))); } }
+                    else if (lit >= 4) { st32(d, (uint32_t)v0); st32(d + lit - 4, (uint32_t)(v0 >> (8 * (lit - 4)))); }
+                    else for (uint32_t i = 0; i < lit; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
+                }
                 // long literal runs: whole wave, from the compressed stream
                 for (uint64_t lm = ballot(act && lit >= 15); lm; lm &= lm - 1) {
                     const int k = (int)__builtin_ctzll(lm);
@@ -772,7 +781,7 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
 template <bool RAP>
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 16];
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = decompress_view(b, c);

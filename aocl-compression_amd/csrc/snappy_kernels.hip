@@ -352,6 +352,7 @@ __device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t 
         if (ip > rend) { rend = ip & ~15u; have_pend = false; }
         if (have_pend) {
             *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
+            if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
             wave_fence();
             rend += 1024; have_pend = false;
         }
@@ -360,6 +361,8 @@ __device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t 
             have_pend = true;
             if ((int32_t)(rend - ip) < 352) {
                 *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
+                if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
+            if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
                 wave_fence();
                 rend += 1024; have_pend = false;
             }
@@ -405,7 +408,24 @@ __device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t 
             else {
                 const bool act = (mask >> lane) & 1;
                 // short literals from the ring, long ones by the whole wave from the compressed stream
-                if (act && lit && lit <= 32) for (uint32_t i = 0; i < lit; ++i) dst[opos + i] = ring[(litsrc + i) & kRingMask];
+                if (act && lit && lit <= 32) {            // two 16-byte LDS reads, exact-length overlapping stores
+                    uint4 qa, qb; __builtin_memcpy(&qa, ring + (litsrc & kRingMask), 16); __builtin_memcpy(&qb, ring + (litsrc & kRingMask) + 16, 16);
+                    const uint64_t v0 = qa.x | ((uint64_t)qa.y << 32), v1 = qa.z | ((uint64_t)qa.w << 32);
+                    const uint64_t v2 = qb.x | ((uint64_t)qb.y << 32), v3 = qb.z | ((uint64_t)qb.w << 32);
+                    auto ext = [&](uint32_t o) -> uint64_t {  // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
+                        const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
+                        const uint32_t sh = (o & 7) * 8;
+                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
+                    };
+                    gbyte* d = dst + opos;
+                    if (lit >= 8) {
+                        st64(d, v0);
+                        if (lit > 8) st64(d + (lit > 16 ? 8 : lit - 8), ext(lit > 16 ? 8 : lit - 8));
+                        if (lit > 16) st64(d + (lit > 24 ? 16 : lit - 8), ext(lit > 24 ? 16 : lit - 8));
+                        if (lit > 24) st64(d + lit - 8, ext(lit - 8));
+                    } else if (lit >= 4) { st32(d, (uint32_t)v0); st32(d + lit - 4, (uint32_t)(v0 >> (8 * (lit - 4)))); }
+                    else for (uint32_t i = 0; i < lit; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
+                }
                 for (uint64_t lm = ballot(act && lit > 32); lm; lm &= lm - 1) {
                     const int k = (int)__builtin_ctzll(lm);
                     wave_copy(dst + lane_get(opos, k), src + lane_get(litsrc, k), lane_get(lit, k), lane);
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
 {
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 32];
     const ChunkView v = decompress_view(b, c);
     const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, ring, (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) != 0);
     if (threadIdx.x == 0) b.out_len[c] = r;
