@@ -702,45 +702,20 @@ struct BitR {                       // backward bit reader (bitstream.h:262-420)
     __device__ u32 read(int nb) { const u32 v = peek(nb); pos -= nb; return v; }
 };
 
-// Backward bit reader for the serial decode loops (one lane per stream).  A 128-bit register window over the stream
-// with two 8-byte blocks always in flight below it, so the loops never wait for memory in steady state; `grab`
-// left-aligns the next 64 unread bits in a container (BIT_reloadDStream), `take` consumes fields from its top with
-// three instructions (BIT_readBitsFast).  Bits below the start of the stream read as 0; bytes outside [p, p+n) are
-// never loaded.
-struct BitP {
-    const gbyte* p; u32 n; int pos;       // pos: bits of the stream still unread (may go negative: over-read)
-    int wq;                               // window = bytes [wq, wq+16): lo = [wq, wq+8), hi = [wq+8, wq+16)
-    u64 lo, hi, pre1, pre2;               // pre1 = bytes [wq-8, wq), pre2 = bytes [wq-16, wq-8)
+// Backward bit reader for the serial decode loops (one lane per stream).  The stream is staged through a window in
+// LDS that the whole wavefront refills with coalesced loads between rounds of the serial loop (bytes outside the
+// stream are stored as 0), so the loop itself never touches global memory: `grab` is one 8-byte LDS read that
+// left-aligns the next >= 57 unread bits in a container (BIT_reloadDStream), `take` consumes fields from its top with
+// three instructions (BIT_readBitsFast).
+struct BitL {
+    int pos;                              // bits of the stream still unread (may go negative: over-read)
+    int wb;                               // stream byte offset of window byte 0
     u64 c;                                // container: unread bits, next one at bit 63
-    __device__ u64 ldwin(int q) const
+    __device__ __forceinline__ void grab(const lbyte* win)
     {
-        if (q >= 0 && (u32)q + 8 <= n) return ld64(p + q);
-        u64 v = 0;
-        for (int i = 0; i < 8; ++i) { const int a = q + i; if (a >= 0 && (u32)a < n) v |= (u64)p[a] << (8 * i); }
-        return v;
-    }
-    __device__ bool init(const u8* s_, u32 len)
-    {
-        const gbyte* s = (const gbyte*)s_;                // the compressed stream lives in global memory
-        if (!len) return false;
-        const u32 last = s[len - 1];
-        if (!last) return false;
-        p = s; n = len; pos = (int)(len - 1) * 8 + hb(last);
-        wq = (int)((len + 7) & ~7u) - 16;
-        hi = ldwin(wq + 8); lo = ldwin(wq); pre1 = ldwin(wq - 8); pre2 = ldwin(wq - 16);
-        c = 0;
-        return true;
-    }
-    __device__ __forceinline__ void grab()  // c = bits [pos-64, pos) of the stream, left-aligned
-    {
-        int off = pos - 64 - 8 * wq;
-        for (int r = 0; r < 2; ++r)         // at most 64 bits are consumed between two grabs (+ the first grab of a stream)
-            if (off < 0 && wq > -16) {      // the upper half of the window is used up: move it 8 bytes down
-                hi = lo; lo = pre1; pre1 = pre2; wq -= 8; off += 64;
-                pre2 = ldwin(wq - 16);
-            }
-        if (off <= 0) c = off == 0 ? lo : (off > -64 ? lo << (-off) : 0);      // (off < 0 only below the start of the stream)
-        else c = off >= 64 ? hi >> (off - 64) : (lo >> off) | (hi << (64 - off));
+        if (pos <= 0) { c = 0; return; }
+        const int e = (pos + 7) >> 3;      // the 8 bytes that end with the byte holding bit pos-1
+        c = lds_ld64(win + (e - 8 - wb)) << (8 * e - pos);
     }
     __device__ __forceinline__ u32 take(u32 nb)   // nb <= 32 bits from the top of the container; nb == 0 -> 0
     {
@@ -751,7 +726,22 @@ struct BitP {
     __device__ __forceinline__ u32 top(u32 nb) const { return (u32)((c >> 1) >> (63 - nb)); }
     __device__ __forceinline__ void skip(u32 nb) { c <<= nb; pos -= (int)nb; }
 };
-
+// position of the last set bit of a stream's final byte: unread bit count, or -1 for an invalid stream
+__device__ __forceinline__ int bit_stream_bits(const u8* s, u32 len)
+{
+    if (!len) return -1;
+    const u32 last = s[len - 1];
+    if (!last) return -1;
+    return (int)(len - 1) * 8 + hb(last);
+}
+// 16 stream bytes at offset `off` (bytes outside [0, n) read as 0)
+__device__ __forceinline__ u32x4 stream16(const gbyte* p, u32 n, int off)
+{
+    if (off >= 0 && (u32)off + 16 <= n) { typedef u32x4 __attribute__((aligned(1))) U; return *(const __attribute__((address_space(1))) U*)(p + off); }
+    u32 w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; ++i) { const int a = off + i; if (a >= 0 && (u32)a < n) w[i >> 2] |= (u32)p[a] << (8 * (i & 3)); }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
 
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
@@ -770,6 +760,8 @@ struct DecLds {                     // 11.6 KB: 13-14 blocks resident per CU (th
     FseD wdt[64];
     u32 seqLL[64], seqML[64], seqOff[64];
     u32 streamOk[4];
+    u8 bswin[1024 + 16] __attribute__((aligned(16)));       // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes)
+    u8 hwin[4][512 + 16] __attribute__((aligned(16)));      // windows of the four Huffman streams (256 symbols need <= 384 bytes)
 };
 
 // FSE_readNCount (entropy_common.c:40-186), lane-serial; bytes consumed or 0xFFFFFFFF
@@ -896,38 +888,68 @@ __device__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big)
     return used;
 }
 // one Huffman stream, executed by ONE lane
-// (kept inline: as a called function, under the 4-lane exec mask, this loop was miscompiled by ROCm 7.2's hipcc)
+// Lanes 0..3 (nstreams of them) decode one Huffman stream each: rounds of up to 256 symbols (HUF_decodeStreamX1, four
+// symbols per container), the whole wave refilling the LDS windows in between.  All 64 lanes call it; returns false
+// on a lane whose stream is malformed.  (Kept inline: as a called function under a partial exec mask this loop was
+// miscompiled by ROCm 7.2's hipcc.)
 template <class TAB>
-__device__ __forceinline__ bool huf_decode_stream_t(gbyte* out, u32 nout, const u8* src, u32 n, TAB tab, const u32 tl)
+__device__ __forceinline__ bool huf_decode_streams_t(DecLds* L, u8* out_, u32 nout, const u8* src_, u32 n, TAB tab, const u32 tl,
+                                                     const bool mine, int lane)
 {
-    BitP b;                                               // tl <= 12: four symbols per 64-bit container (HUF_decodeStreamX1)
-    if (!b.init(src, n)) return false;
+    gbyte* out = (gbyte*)out_; const gbyte* src = (const gbyte*)src_;
+    BitL b; b.pos = mine ? bit_stream_bits(src_, n) : 0; b.wb = 0; b.c = 0;
+    bool ok = !mine || b.pos >= 0;
     u32 i = 0;
-    for (; i + 8 <= nout; i += 8) {                       // 8 symbols per store
-        u64 acc = 0;
-        for (int g = 0; g < 2; ++g) {
-            b.grab();
-            for (int k = 0; k < 4; ++k) {
+    const u32 todo = (mine && ok) ? nout : 0;
+    while (ballot(i < todo) != 0) {
+        {   // refill: 16 lanes x 32 bytes per stream, window = the 512 bytes that end with the byte holding bit pos-1
+            const int j = lane >> 4, k = lane & 15;
+            const int e = (__shfl(b.pos, j) + 7) >> 3;
+            const u64 sp = ((u64)(u32)__shfl((int)(u32)((u64)src >> 32), j) << 32) | (u32)__shfl((int)(u32)(u64)src, j);
+            const u32 sn = (u32)__shfl((int)n, j);
+            const bool act = __shfl((int)(i < todo), j) != 0;
+            if (act) {
+                const gbyte* p = (const gbyte*)sp;
+                const int wb = e - 512;
+                typedef __attribute__((address_space(3))) u32x4 LV;
+                lbyte* w = (lbyte*)&L->hwin[j][0];
+                *(LV*)(w + 32 * k) = stream16(p, sn, wb + 32 * k);
+                *(LV*)(w + 32 * k + 16) = stream16(p, sn, wb + 32 * k + 16);
+            }
+            b.wb = ((b.pos + 7) >> 3) - 512;
+            wave_fence();
+        }
+        if (i < todo) {
+            const lbyte* win = (const lbyte*)&L->hwin[lane & 3][0];
+            const u32 stop = i + 256 < todo ? i + 256 : todo;
+            for (; i + 8 <= stop; i += 8) {               // 8 symbols per store
+                u64 acc = 0;
+                for (int g = 0; g < 2; ++g) {
+                    b.grab(win);
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 cell = tab[b.top(tl)];
+                        acc |= (u64)(cell & 0xFF) << (8 * (4 * g + k)); b.skip(cell >> 8);
+                    }
+                }
+                st64(out + i, acc);
+            }
+            if (stop == todo) for (; i < todo; ++i) {
+                b.grab(win);
                 const u32 cell = tab[b.top(tl)];
-                acc |= (u64)(cell & 0xFF) << (8 * (4 * g + k)); b.skip(cell >> 8);
+                out[i] = (u8)cell; b.skip(cell >> 8);
             }
         }
-        st64(out + i, acc);
+        wave_fence();
     }
-    for (; i < nout; ++i) {
-        b.grab();
-        const u32 cell = tab[b.top(tl)];
-        out[i] = (u8)cell; b.skip(cell >> 8);
-    }
-    return b.pos == 0;
+    return ok && (!mine || b.pos == 0);
 }
-__device__ __forceinline__ bool huf_decode_stream(u8* out, u32 nout, const u8* src, u32 n, const DecLds* L, const u16* big)
+__device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout, const u8* src, u32 n, const u16* big, const bool mine, int lane)
 {
     typedef __attribute__((address_space(3))) const u16 LT;
     typedef __attribute__((address_space(1))) const u16 GT;
-    const u32 tl = L->hufLog;
-    if (tl == 12) return huf_decode_stream_t((gbyte*)out, nout, src, n, (GT*)big, tl);
-    return huf_decode_stream_t((gbyte*)out, nout, src, n, (LT*)L->huf, tl);
+    const u32 tl = uni(L->hufLog);
+    if (tl == 12) return huf_decode_streams_t(L, out, nout, src, n, (GT*)big, tl, mine, lane);
+    return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane);
 }
 
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705); lane-serial
@@ -1022,18 +1044,18 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             } else if (!uni(L->haveHuf)) return 0xFFFFFFFFu;
             wave_fence();
             bool ok = true;
-            if (!streams4) { if (lane == 0) ok = huf_decode_stream(litBuf, litSize, src + hoff, hsz, L, (u16*)(litBuf + kBlockMax + 64)); }
+            const u16* big = (const u16*)(litBuf + kBlockMax + 64);
+            if (!streams4) ok = huf_decode_streams(L, litBuf, litSize, src + hoff, hsz, big, lane == 0, lane);
             else {
                 if (litSize < 6 || hsz < 10) return 0xFFFFFFFFu;
                 const u32 s1 = ld16(src + hoff), s2 = ld16(src + hoff + 2), s3 = ld16(src + hoff + 4), seg = (litSize + 3) / 4;
                 if (6 + s1 + s2 + s3 > hsz || 3 * seg > litSize) return 0xFFFFFFFFu;
                 const u32 s4 = hsz - 6 - s1 - s2 - s3;
-                if (lane < 4) {
-                    const u32 so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
-                    const u32 sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
-                    const u32 no = lane < 3 ? seg : litSize - 3 * seg;
-                    ok = huf_decode_stream(litBuf + (u32)lane * seg, no, src + hoff + 6 + so, sl, L, (u16*)(litBuf + kBlockMax + 64));
-                }
+                const u32 j = (u32)lane & 3;
+                const u32 so = j == 0 ? 0 : (j == 1 ? s1 : (j == 2 ? s1 + s2 : s1 + s2 + s3));
+                const u32 sl = j == 0 ? s1 : (j == 1 ? s2 : (j == 2 ? s3 : s4));
+                const u32 no = j < 3 ? seg : litSize - 3 * seg;
+                ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane);
             }
             if (ballot(!ok) != 0) return 0xFFFFFFFFu;
             wave_fence();
@@ -1064,11 +1086,25 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         okT = uni(okT); ip = uni(ipT);
         if (!okT) return 0xFFFFFFFFu;
         // lane 0 decodes 64 sequences (ZSTD_decodeSequence :1339-1460), the wave executes them (:1007-1108)
-        BitP b; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
+        BitL b; b.pos = 0; b.wb = 0; b.c = 0; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
         u32 r0 = 0, r1 = 0, r2 = 0;                                              // repcodes live in lane 0's registers
+        const gbyte* bsp = (const gbyte*)(src + ip); const u32 bsn = n - ip;      // the sequence bitstream
+        const lbyte* win = (const lbyte*)&L->bswin[0];
+        auto refill = [&]() {                                                    // whole wave: the 1024 bytes that end with the byte holding bit pos-1
+            const int e = ((int)lane_get((u32)b.pos, 0) + 7) >> 3, wb = e - 1024;
+            typedef __attribute__((address_space(3))) u32x4 LV;
+            *(LV*)((lbyte*)&L->bswin[0] + 16 * lane) = stream16(bsp, bsn, wb + 16 * lane);
+            b.wb = wb;
+            wave_fence();
+        };
+        {
+            const int bits = bit_stream_bits(src + ip, n - ip);
+            if (bits < 0) return 0xFFFFFFFFu;
+            b.pos = bits;
+            refill();
+        }
         if (lane == 0) {
-            okB = b.init(src + ip, n - ip) ? 1u : 0u;
-            if (okB) { b.grab(); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0; }
+            b.grab(win); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0;
             r0 = L->rep[0]; r1 = L->rep[1]; r2 = L->rep[2];
         }
         if (!uni(okB)) return 0xFFFFFFFFu;
@@ -1076,12 +1112,14 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
             u32 okS = 1;
+            if (q0) refill();
             if (lane == 0) {
                 for (u32 k = 0; k < cnt; ++k) {
                     const FseD dl = L->ll[sLL], dof = L->of[sOF], dm = L->ml[sML];
                     const u32 tLL = L->llTab[dl.symbol], tML = L->mlTab[dm.symbol], ofc = dof.symbol;
-                    b.grab();                                                    // >= 64 bits: offset (<= 31) + lengths (<= 16 + 16)
+                    b.grab(win);                                                 // >= 57 bits
                     const u32 ofv = (1u << ofc) + b.take(ofc);
+                    if (ofc > 24) b.grab(win);                                   // offset (<= 31) + lengths (<= 16 + 16) may exceed one container
                     const u32 ml = (tML & 0xFFFFFFu) + b.take(tML >> 24);
                     const u32 ll = (tLL & 0xFFFFFFu) + b.take(tLL >> 24);
                     u32 offset;
@@ -1097,7 +1135,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                         }
                     }
                     if (q0 + k + 1 < nbSeq) {
-                        b.grab();                                                // the three state updates: <= 9 + 9 + 8 bits
+                        b.grab(win);                                             // the three state updates: <= 9 + 9 + 8 bits
                         sLL = dl.newState + b.take(dl.nbBits);
                         sML = dm.newState + b.take(dm.nbBits);
                         sOF = dof.newState + b.take(dof.nbBits);
