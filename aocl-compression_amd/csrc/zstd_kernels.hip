@@ -1396,10 +1396,14 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail) };
     }
     for (int i = 0; i < nl; ++i) {
-        const uint32_t perCU = 160u * 1024u / L[i].lds;
-        uint32_t grid = 256u * (perCU ? perCU : 1u);
+        // persistent blocks: exactly as many as are resident at once for this LDS size (LDS is allocated in 512-byte granules)
+        int perCU = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::zstd_compress_kernel, 64, L[i].lds) != hipSuccess || perCU < 1) {
+            aoclgpu::set_error_msg("zstd: occupancy query failed"); return AOCLGPU_ERR_HIP;
+        }
+        uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
-        if (grid > 2304) grid = 2304;
         void* ws = get_workspace((size_t)grid * aoclgpu::zstd_workspace_bytes());
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         if (L[i].lds > 65536u) {
