@@ -24,6 +24,7 @@
 // (inherently serial) run on three lanes, one per symbol stream, 64 sequences per tile.
 #include "zstd_entropy.hip.h"
 #include "host_util.h"
+#include <mutex>
 
 namespace aoclgpu {
 namespace {
@@ -1334,18 +1335,30 @@ size_t zstd_entropy_lds_bytes() { return sizeof(EntropyLds); }
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct WsPool { void* p = nullptr; size_t bytes = 0; int dev = -1; };
-WsPool g_pool;
+// Zstd launches need per-resident-block scratch in HBM (compressor: sequence store + staged block; decoder: literal
+// buffer).  One pool entry per (device, stream): launches on the same stream are ordered, launches on different
+// streams never share scratch.  A pool that has to grow is freed first (hipFree waits for the device).
+struct WsPool { void* p = nullptr; size_t bytes = 0; int dev = -1; void* stream = nullptr; };
+WsPool g_pool[16];
+std::mutex g_pool_mu;
 
-void* get_workspace(size_t bytes)
+void* get_workspace(size_t bytes, void* stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (g_pool.p && g_pool.dev == dev && g_pool.bytes >= bytes) return g_pool.p;
-    if (g_pool.p) { (void)hipFree(g_pool.p); g_pool.p = nullptr; }
-    if (hipMalloc(&g_pool.p, bytes) != hipSuccess) { g_pool.p = nullptr; return nullptr; }
-    g_pool.bytes = bytes; g_pool.dev = dev;
-    return g_pool.p;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    WsPool* e = nullptr;
+    for (WsPool& q : g_pool) if (q.p && q.dev == dev && q.stream == stream) { e = &q; break; }
+    if (!e) for (WsPool& q : g_pool) if (!q.p) { e = &q; break; }
+    if (!e) {                                             // more than 16 (device, stream) pairs: recycle the first entry
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        e = &g_pool[0];
+    }
+    if (e->p && e->dev == dev && e->stream == stream && e->bytes >= bytes) return e->p;
+    if (e->p) { (void)hipFree(e->p); e->p = nullptr; }
+    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return nullptr; }
+    e->bytes = bytes; e->dev = dev; e->stream = stream;
+    return e->p;
 }
 uint32_t lds_for_chunk(uint64_t n)
 {   // hash table bytes of the level-1 parameters for an n-byte chunk, never less than the entropy-stage LDS
@@ -1404,7 +1417,7 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         }
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
-        void* ws = get_workspace((size_t)grid * aoclgpu::zstd_workspace_bytes());
+        void* ws = get_workspace((size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         if (L[i].lds > 65536u) {
             hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
@@ -1432,8 +1445,8 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
     }
     uint32_t grid = (uint32_t)(perCU * nCU);
     if (grid > b->nchunks) grid = b->nchunks;
-    // the decoder's literal buffers share the workspace pool with the compressor's (same stream order)
-    void* ws = get_workspace((size_t)grid * aoclgpu::kDecWs);
+    // the decoder's literal buffers share the stream's workspace with the compressor's (same stream order)
+    void* ws = get_workspace((size_t)grid * aoclgpu::kDecWs, stream);
     if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
     hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws);
     return aoclgpu::check_launch("zstd_decompress_kernel");
