@@ -703,14 +703,20 @@ __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t 
                 }
                 // short matches whose source was produced before this window: one round of loads for all of them
                 const uint32_t spos = mstart - off;
-                const bool indep = act && mlen <= 18 && spos + mlen <= (uint32_t)op;
+                const bool indep = act && mlen <= 32 && spos + mlen <= (uint32_t)op;
                 if (indep) {
-                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
+                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16), v3 = ld64(dst + spos + 24);
                     gbyte* d = dst + mstart;
+                    auto ext = [&](uint32_t o) -> uint64_t {          // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
+                        const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
+                        const uint32_t sh = (o & 7) * 8;
+                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
+                    };
                     if (mlen >= 8) {
                         st64(d, v0);
-                        if (mlen > 8) { const uint64_t x = ext64(v0, v1, v2, mlen > 16 ? 8 : mlen - 8); st64(d + (mlen > 16 ? 8 : mlen - 8), x); }
-                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); st64(d + mlen - 8, x); }
+                        if (mlen > 8) st64(d + (mlen > 16 ? 8 : mlen - 8), ext(mlen > 16 ? 8 : mlen - 8));
+                        if (mlen > 16) st64(d + (mlen > 24 ? 16 : mlen - 8), ext(mlen > 24 ? 16 : mlen - 8));
+                        if (mlen > 24) st64(d + mlen - 8, ext(mlen - 8));
                     } else {
                         const uint32_t lo = (uint32_t)v0; st32(d, lo);
                         const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); st32(d + mlen - 4, hi);
