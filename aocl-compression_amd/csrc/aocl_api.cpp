@@ -27,6 +27,7 @@ bool gpu_codec(aocl_compression_type t, aoclgpu_codec* out)
 {
     switch (t) {
     case LZ4: *out = AOCLGPU_LZ4; return true;
+    case LZ4HC: *out = AOCLGPU_LZ4; return true;      // decode only: LZ4HC streams are LZ4 blocks (api/codec.cpp:179-188)
     case SNAPPY: *out = AOCLGPU_SNAPPY; return true;
     case ZSTD: *out = AOCLGPU_ZSTD; return true;
     default: return false;
@@ -37,6 +38,7 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
 {
     aoclgpu_codec c;
     if (!gpu_codec(t, &c)) return kCodecError;
+    if (t == LZ4HC) return kCodecError;               // no GPU match finder for the HC levels (api/codec.cpp:169-177)
     if (!h->outBuf || (!h->inBuf && h->inSize != 0)) return kCodecError;
     if (h->numThreads > 1) {
         // The reference's AOCL_ENABLE_THREADS build partitions the input inside this call and returns a RAP stream

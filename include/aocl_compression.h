@@ -4,6 +4,7 @@
  * values, same LP64 struct layout, same five functions with the same argument meaning and error
  * behaviour (api/api.cpp:45-189), so a program written against the reference header can be relinked
  * against this library.  Only LZ4, SNAPPY and ZSTD (level 1 "fast" strategy) have a GPU backend; the
+ * (LZ4HC: decompression only - its streams are LZ4 blocks, api/codec.cpp:179-188; compression fails);
  * other enumerators report ERR_EXCLUDED_METHOD from aocl_llc_setup exactly as a reference build
  * configured with -DAOCL_EXCLUDE_<codec>=ON does (api/api.cpp:133-162).
  */

@@ -23,7 +23,7 @@ build_variant() {  # $1 = output library, $2 = object dir, $3 = extra defines, $
 OUTLIB="$1"; OBJ="$2"; EXTRA="$3"
 mkdir -p "$OBJ"
 FLAGS="-O3 -DNDEBUG -fPIC -fomit-frame-pointer -fstrict-aliasing -ffast-math -fopenmp -w $EXTRA \
- -DAOCL_DYNAMIC_DISPATCHER -DAOCL_EXCLUDE_BZIP2 -DAOCL_EXCLUDE_LZMA -DAOCL_EXCLUDE_ZLIB -DAOCL_EXCLUDE_LZ4HC \
+ -DAOCL_DYNAMIC_DISPATCHER -DAOCL_EXCLUDE_BZIP2 -DAOCL_EXCLUDE_LZMA -DAOCL_EXCLUDE_ZLIB \
  -I$REF -I$REF/api -I$REF/utils -I$REF/algos/common"
 VERS=(-DAOCL_BUILD_VERSION="\"Build_oracle\"" -DCFLAGS_SET1="\"-O3\"" -DCFLAGS_SET2="\"\"" -DCCompiler="\"gcc\"" -DCXXCompiler="\"g++\"")
 SNAP="-msse4.1 -DHAVE_BUILTIN_CTZ=1 -DHAVE_BUILTIN_EXPECT=1 -DHAVE_SYS_UIO_H"
@@ -31,7 +31,7 @@ pids=()
 for f in utils/utils.cpp api/api.cpp api/codec.cpp; do cc1 g++ "$REF/$f" "${VERS[@]}"; done
 for f in snappy-sinksource snappy-stubs-internal snappy snappy-c; do cc1 g++ "$REF/algos/snappy/$f.cc" $SNAP "${VERS[@]}"; done
 waitall
-cc1 gcc "$REF/algos/lz4/lz4.c"; cc1 gcc "$REF/algos/lz4/xxhash.c"
+cc1 gcc "$REF/algos/lz4/lz4.c"; cc1 gcc "$REF/algos/lz4/lz4hc.c"; cc1 gcc "$REF/algos/lz4/xxhash.c"   # lz4hc: producer of LZ4HC streams for the decoder tests
 for f in $4; do cc1 gcc "$REF/$f"; done
 n=0
 for f in "$REF"/algos/zstd/lib/common/*.c "$REF"/algos/zstd/lib/compress/*.c "$REF"/algos/zstd/lib/decompress/*.c "$REF"/algos/zstd/lib/decompress/*.S; do

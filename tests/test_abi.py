@@ -53,7 +53,7 @@ def test_argument_checks_without_gpu():
     assert b"NULL" in lib.aoclgpu_last_error()
     d = api.LlcDesc()
     assert lib.aocl_llc_setup(C.byref(d), 99) == -4                    # ERR_UNSUPPORTED_METHOD (api/api.cpp:133-138)
-    assert lib.aocl_llc_setup(C.byref(d), 1) == -3                     # LZ4HC: ERR_EXCLUDED_METHOD (no backend)
+    assert lib.aocl_llc_setup(C.byref(d), 2) == -3                     # LZMA: ERR_EXCLUDED_METHOD (no backend)
 
 
 def test_no_cpu_fallback():

@@ -175,3 +175,26 @@ def test_full_size_round_trip(eng):
     # identical chunks (the base repeats every 48 MiB = 192 chunks) must compress identically
     per = (48 << 20) // chunk
     assert torch.equal(out_len[:per], out_len[per:2 * per])
+
+
+def test_lz4hc_streams_decode(eng, ref):
+    """LZ4HC: its streams are LZ4 blocks decoded by LZ4_decompress_safe (api/codec.cpp:179-188).  Streams
+    from the reference's LZ4_compress_HC at several levels decode on the GPU; the unified API decodes them under the
+    LZ4HC method and refuses to compress with it (no GPU match finder for the HC levels)."""
+    import ctypes as C
+    from aocl_compression_amd import api
+    lib = api.load_library()
+    ref.L.LZ4_compress_HC.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    for kind, size, level in (("text", 300000, 9), ("jsonlog", 65536, 1), ("binary", 1 << 20, 12), ("database", 5000, 4)):
+        raw = a.corpus.make(kind, size, seed=level).tobytes()
+        out = C.create_string_buffer(size + size // 255 + 16)
+        r = ref.L.LZ4_compress_HC(raw, out, size, len(out), level)
+        assert r > 0
+        assert eng.decompress_host(a.LZ4, out.raw[:r], size) == raw
+        d = api.LlcDesc()
+        back = C.create_string_buffer(size)
+        d.inBuf = C.cast(out, C.c_void_p); d.inSize = r; d.outBuf = C.cast(back, C.c_void_p); d.outSize = size
+        assert lib.aocl_llc_setup(C.byref(d), 1) == 0
+        assert lib.aocl_llc_decompress(C.byref(d), 1) == size and back.raw == raw
+        d.inBuf = C.cast(back, C.c_void_p); d.inSize = size; d.outBuf = C.cast(out, C.c_void_p); d.outSize = len(out)
+        assert lib.aocl_llc_compress(C.byref(d), 1) == -2                 # ERR_COMPRESSION_FAILED
