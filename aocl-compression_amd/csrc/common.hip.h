@@ -67,6 +67,38 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_A
 
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int first_lane(uint64_t m) { return m ? (int)__builtin_ctzll(m) : 64; }
+// "some lane has p", as an opaque wave-uniform value.  LLVM folds `ballot(p) != 0` in a branch condition to a divergent
+// branch on p itself: a loop written as `do { ... } while (ballot(pending) != 0)` then lets every lane leave as soon as
+// ITS OWN pending is false, which is wrong whenever the lanes that stay change what the others would have read.
+__device__ __forceinline__ bool any_lane(bool p)
+{
+    uint64_t b = __ballot(p);
+    asm volatile("" : "+s"(b));
+    return b != 0;
+}
+
+// First lane per LDS slot.  Every lane names a 16-bit LDS slot (byte address `slot`); on return w is the smallest lane
+// id among the lanes that named the same slot (w == lane: nobody before this lane uses the slot).  Rounds of "lanes that
+// have not seen an id <= their own write their id, everybody reads back" - which of several writers of one ds_write
+// lands is up to the hardware, but a lane keeps writing only while the slot holds a larger id, so the minimum sticks.
+// One asm block per round: the compiler must not split it per lane (it threads `if (pending) store` into a nested
+// loop in which the lanes that are done stop re-reading, and then miss the smaller id a later round brings).
+__device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint32_t lane)
+{
+    uint64_t pend = ~0ull, saved;
+    uint32_t w;
+    do {
+        asm volatile("s_and_saveexec_b64 %1, %3\n\t"
+                     "ds_write_b16 %2, %4\n\t"
+                     "s_mov_b64 exec, %1\n\t"
+                     "ds_read_u16 %0, %2\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(w), "=&s"(saved) : "v"(slot), "s"(pend), "v"(lane) : "memory");
+        pend = __ballot(lane < w);
+        asm volatile("" : "+s"(pend));
+    } while (pend != 0);
+    return w;
+}
 
 // Chunk geometry of a batch (see aoclgpu_batch in include/aocl_gpu_codec.h)
 struct ChunkView {

@@ -23,6 +23,7 @@
 // sequence bitstream are emitted by all 64 lanes through a prefix-sum bit packer; the FSE state chains
 // (inherently serial) run on three lanes, one per symbol stream, 64 sequences per tile.
 #include "zstd_entropy.hip.h"
+#include "zstd_chain.h"
 #include "host_util.h"
 #include <mutex>
 
@@ -113,6 +114,10 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 // Table layout: u16 per slot (low 16 bits of index = position + 2) and, for chunks above 16 KiB, one extra bit per
 // slot in a packed word array (indices stay below 2^17 because nothing within 14 bytes of the chunk end is ever
 // inserted).  17 KB of LDS per chunk instead of 32 KB lets 9 instead of 5 chunks be resident per CU.
+#ifdef ZSTD_TRACE
+__device__ unsigned long long g_ztrace[8 * 4096];
+__device__ unsigned int g_ztrace_n;
+#endif
 #ifdef ZSTD_PROF
 __device__ unsigned long long g_zstd_prof[16];
 #define ZSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -122,7 +127,7 @@ __device__ unsigned long long g_zstd_prof[16];
 #endif
 template <int MLS, typename T>
 __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
-                          u32* litSizeOut, int lane)
+                          u32* litSizeOut, int lane, const u32 expf)
 {
     static_assert(sizeof(T) == 2, "u16 slots");
     typedef __attribute__((address_space(3))) T LT;
@@ -168,11 +173,108 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
 #endif
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
+        const bool chain = !(expf & 32);                                // experiment 32: one match per batch everywhere
+        // immediate rep2 matches behind a sequence that ends at ip0 (:690-702); returns where the next search starts
+        auto rep_loop = [&](u32 ip0) -> u32 {
+            bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            while (hit) {
+                const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
+                const u32 t = rep2; rep2 = rep1; rep1 = t;
+                const u64 vc = ld64(src + ip0);
+                const u32 hc = z_hash<MLS>(vc, hlog);
+                if (lane == 0) tput(hc, ip0 + 2);
+                put_seq(nbSeq, 0, 1, rLength, ip0);
+                wave_fence();
+                nbSeq++;
+                ip0 += rLength;
+                hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            }
+            return ip0;
+        };
         for (;;) {                                                      // _start
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
             u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
             bool e_ok1 = false, e_ok2 = false;
-            for (;;) {
+            if (chain && s >= 4 && (u64)s + 100 < ilimit) {
+                // ---------------- chain batch: the 64 consecutive probes a search starts with; every sequence they
+                //                  hold is resolved from registers by the scalar walk of zstd_chain.h ----------------
+                const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
+                typedef u32x4 __attribute__((aligned(1))) U4;
+                typedef const __attribute__((address_space(1))) U4* GP4;
+                const u32x4 pa = *(GP4)(src + pos - 4), pb = *(GP4)(src + pos + 12);      // probe window [pos-4, pos+28)
+                // byte equality at the two repcode distances over [pos0+1, pos0+93): two byte loads per lane each
+                const u32 b1 = src[pos + 1 - rep1];
+                u32 b1h = 0, p65 = 0, b2 = 0, b2h = 0;
+                if (lane < 28) { b1h = src[pos + 65 - rep1]; p65 = src[pos + 65]; }
+                if (rep2) { b2 = src[pos + 1 - rep2]; if (lane < 28) b2h = src[pos + 65 - rep2]; }
+                ZSTAGE(0);
+#ifdef ZSTD_PROF
+                zbatches++;
+#endif
+                const u64 seq = pa.y | ((u64)pa.z << 32);
+                const u32 h = z_hash<MLS>(seq, hlog);
+                const u32 ent = tget(h);
+                const bool has = ent >= 2;
+                const u32 c = ent - 2;
+                const bool near0 = c < 4;                               // candidate within 4 bytes of the chunk start: exact path
+                u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+                if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }   // candidate window [c-4, c+28)
+                wave_fence();
+                ZSTAGE(1);
+                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
+                wave_fence();
+                table[h] = (T)ent;                                        // low halves only: the extra bits were not touched
+                wave_fence();
+                ZSTAGE(2);
+                const int lim = first_lane(ballot(w != (u32)lane));
+                using zchain::zero_bytes;
+                const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
+                                (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
+                const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
+                const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
+                const u32 infoV = near0 ? zchain::pack_info(c, 0, 7) : zchain::pack_info(c, fw, bk4);
+                const u64 okmask = ballot(lane < lim && ok);
+                const u32 pb1 = (pa.y >> 8) & 0xFFu;                    // the byte at pos+1
+                const zchain::Desc D1 = zchain::desc_from_ballots(ballot(pb1 == b1), ballot(lane < 28 && p65 == b1h));
+                const zchain::Desc D2 = zchain::desc_from_ballots(ballot(rep2 != 0 && pb1 == b2), ballot(rep2 != 0 && lane < 28 && p65 == b2h));
+                const zchain::WalkOut wo = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, D1, D2,
+                    [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
+                    [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; });
+                if ((wo.commit >> lane) & 1) tput(h, pos + 2);
+                wave_fence();
+#ifdef ZSTD_TRACE
+                if (lane == 0 && g_ztrace_n < 4096) {
+                    unsigned long long* t = g_ztrace + 8 * g_ztrace_n++;
+                    t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = wo.commit; t[4] = (u32)wo.outcome | ((u64)(u32)wo.S << 8) | ((u64)(u32)wo.ev << 16) | ((u64)(u32)wo.el << 24) | ((u64)(u32)wo.ntail << 32) | ((u64)wo.post << 40);
+                    t[5] = D1.eq.lo; t[6] = D1.eq.hi; t[7] = ((u64)rep1 << 32) | rep2;
+                }
+#endif
+                anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
+                ZSTAGE(3);
+                if (wo.outcome == zchain::ZC_RESTART) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {                       // the chain's last table writes, one by one
+                        if (t >= 3 - wo.ntail) {
+                            const int idx = wo.tail[t];
+                            const u32 hh = idx < 64 ? lane_get(h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
+                            if (lane == 0) tput(hh, pos0 + (u32)idx + 2);
+                            wave_fence();
+                        }
+                    }
+                    if (wo.post) { s = rep_loop(s); anchor = s; }
+                    ZSTAGE(4);
+                    continue;
+                }
+                if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(lim - wo.S);
+                else {
+                    const int el = wo.el;
+                    ev = wo.ev;
+                    e_pos = pos0 + (u32)el; e_cand = lane_get(ent, el); e_sig = 2; e_st = 2; e_half = (u32)(el - wo.S) & 1u;
+                    e_ok1 = el + 1 < 64; e_p1 = e_pos + 1; e_h1 = lane_get(h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64; e_h2 = lane_get(h, (el + 2) & 63);
+                }
+            }
+            if (!ev) for (;;) {
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
                 u32 am, sg, st;
                 if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
@@ -303,21 +405,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u32 ha = e_ok2 ? e_h2 : z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
                 if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
                 wave_fence();
-                if (chk) {
-                    bool hit = uni(r0 == r1 ? 1u : 0u) != 0;
-                    while (hit) {
-                        const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
-                        const u32 t = rep2; rep2 = rep1; rep1 = t;
-                        const u64 vc = ld64(src + ip0);
-                        const u32 hc = z_hash<MLS>(vc, hlog);
-                        if (lane == 0) tput(hc, ip0 + 2);
-                        put_seq(nbSeq, 0, 1, rLength, ip0);
-                        wave_fence();
-                        nbSeq++;
-                        ip0 += rLength; anchor = ip0;
-                        hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
-                    }
-                }
+                if (chk && uni(r0 == r1 ? 1u : 0u) != 0) { ip0 = rep_loop(ip0); anchor = ip0; }
             }
             s = ip0;
         }
@@ -645,8 +733,8 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         level1_params(n, &hlog, &mls);
         const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8);
         if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
-        if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane);
-        else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane);
+        if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
         wave_fence();
         if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
         else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
@@ -1374,6 +1462,48 @@ uint32_t lds_for_chunk(uint64_t n)
 }
 }  // namespace
 
+// Debug hook (tests only): the match finder's sequences for ONE chunk already in device memory:
+// out_host[0] = nbSeq, out_host[1] = litSize, then {litLength, offBase, matchLength} per sequence.
+namespace aoclgpu {
+__global__ void __launch_bounds__(64) zstd_debug_seq_kernel(const uint8_t* src, uint32_t n, uint8_t* wsBase, uint32_t* out, uint32_t maxSeq, uint32_t expf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    Workspace* ws = reinterpret_cast<Workspace*>(wsBase);
+    const int lane = lane_id();
+    u32 hlog, mls, litSize = 0, nbSeq;
+    level1_params(n, &hlog, &mls);
+    if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+    else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+    wave_fence();
+    if (lane == 0) { out[0] = nbSeq; out[1] = litSize; }
+    for (u32 i = (u32)lane; i < nbSeq && i < maxSeq; i += kWave) { out[2 + 3 * i] = ws->seqLL[i]; out[3 + 3 * i] = ws->seqOff[i]; out[4 + 3 * i] = ws->seqML[i]; }
+}
+}  // namespace aoclgpu
+extern "C" int aoclgpu_debug_zstd_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t maxSeq, uint32_t expf)
+{
+    if (n < 7 || n > (128u << 10)) return AOCLGPU_ERR_ARG;
+    void* ws = get_workspace(aoclgpu::zstd_workspace_bytes(), nullptr);
+    uint32_t* out = nullptr;
+    const size_t bytes = (2 + 3 * (size_t)maxSeq) * sizeof(uint32_t);
+    if (!ws || hipMalloc((void**)&out, bytes) != hipSuccess) return AOCLGPU_ERR_HIP;
+    const uint32_t lds = lds_for_chunk(n);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)aoclgpu::zstd_debug_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(aoclgpu::zstd_debug_seq_kernel, dim3(1), dim3(64), lds, nullptr, (const uint8_t*)src_dev, n, (uint8_t*)ws, out, maxSeq, expf);
+    const hipError_t e = hipMemcpy(out_host, out, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(out);
+    return e == hipSuccess ? AOCLGPU_OK : AOCLGPU_ERR_HIP;
+}
+
+#ifdef ZSTD_TRACE
+extern "C" int aoclgpu_debug_zstd_trace(unsigned long long* host, unsigned int* count)
+{
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(aoclgpu::g_ztrace), 8 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(aoclgpu::g_ztrace_n), sizeof(unsigned int)) != hipSuccess) return -1;
+    unsigned int z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_ztrace_n), &z, sizeof(z));
+    return 0;
+}
+#endif
 #ifdef ZSTD_PROF
 extern "C" int aoclgpu_debug_zstd_dprof(unsigned long long* host16)
 {

@@ -1,0 +1,116 @@
+"""CPU check of the Zstd match finder's batch/chain logic: tests/zstd_chain_model.cpp (a lane-by-lane model of the
+kernel's batch that runs the kernel's own scalar walk, csrc/zstd_chain.h) must produce exactly the oracle's sequences."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from aocl_compression_amd import corpus
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "_build", "libzchain_model.so")
+
+
+@pytest.fixture(scope="module")
+def model():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "aocl-compression_amd", "csrc"),
+                    os.path.join(HERE, "zstd_chain_model.cpp"), "-o", SO], check=True)
+    L = C.CDLL(SO)
+    L.zchain_model_sequences.restype = C.c_size_t
+    L.zchain_model_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_int]
+    return L
+
+
+@pytest.fixture(scope="module")
+def orc():
+    ol.build_oracle()
+    L = C.CDLL(ol.ORACLE_SO)
+    L.orc_dbg_zstd_sequences.restype = C.c_size_t
+    L.orc_dbg_zstd_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    return L
+
+
+def sequences(fn, data: bytes, *extra):
+    n = len(data)
+    out = np.zeros(4 * (n // 3 + 16), dtype=np.uint32)
+    lit = C.c_size_t(0)
+    buf = C.create_string_buffer(data, n + 1)
+    nb = fn(buf, n, out.ctypes.data, C.byref(lit), *extra)
+    return out[:4 * nb].reshape(-1, 4)[:, :3].copy(), lit.value
+
+
+def check(model, orc, data: bytes, stats_acc=None):
+    want, wl = sequences(orc.orc_dbg_zstd_sequences, data)
+    st = np.zeros(8, dtype=np.uint64)
+    got, gl = sequences(model.zchain_model_sequences, data, st.ctypes.data, 1)
+    if stats_acc is not None:
+        stats_acc += st
+    if got.shape != want.shape or not np.array_equal(got, want) or gl != wl:
+        k = 0
+        while k < min(len(got), len(want)) and np.array_equal(got[k], want[k]):
+            k += 1
+        raise AssertionError(f"first difference at sequence {k}: model {got[k:k+3].tolist()} oracle {want[k:k+3].tolist()} (n={len(data)})")
+    seq0, l0 = sequences(model.zchain_model_sequences, data, None, 0)          # the model's sequential path alone
+    assert np.array_equal(seq0, want) and l0 == wl
+
+
+@pytest.mark.parametrize("kind", sorted(corpus.KINDS))
+def test_corpus_kinds(model, orc, kind):
+    data = corpus.make(kind, 3 << 20).tobytes()
+    acc = np.zeros(8, dtype=np.uint64)
+    for i in range(0, len(data), 131072):
+        check(model, orc, data[i:i + 131072], acc)
+    assert acc[1] > 0 or kind == "random"            # the chain path is exercised
+
+
+def test_mix_and_sizes(model, orc):
+    data = corpus.silesia_mix(8 << 20).tobytes()
+    for i in range(0, len(data), 131072):
+        check(model, orc, data[i:i + 131072])
+    for n in [0, 1, 19, 20, 21, 99, 119, 120, 121, 130, 200, 1000, 4095, 16384, 16385, 65536, 100000, 131071]:
+        check(model, orc, data[12345:12345 + n])
+
+
+def lz_grammar(rng, nbytes, alphabet):
+    out = bytearray()
+    while len(out) < nbytes:
+        r = rng.integers(0, 10)
+        if r < 4 or not out:
+            out += bytes(rng.integers(0, alphabet, int(rng.integers(1, 24)), dtype=np.uint8))
+        elif r < 8:
+            d = int(rng.integers(1, min(len(out), 70000) + 1)); ln = int(rng.integers(3, 60))
+            for _ in range(ln):
+                out.append(out[-d])
+        elif r < 9:
+            out += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 80))
+        else:
+            p = int(rng.integers(1, 10))
+            if len(out) >= p:
+                for _ in range(int(rng.integers(4, 120))):
+                    out.append(out[-p])
+    return bytes(out[:nbytes])
+
+
+@pytest.mark.parametrize("alphabet", [2, 4, 16, 256])
+def test_grammar_inputs(model, orc, alphabet):
+    rng = np.random.default_rng(1234 + alphabet)
+    for it in range(40):
+        n = int(rng.integers(100, 60000))
+        check(model, orc, lz_grammar(rng, n, alphabet))
+
+
+def test_record_like_inputs(model, orc):
+    """fixed-size records with a few changing bytes: repcode after repcode, immediate rep2 matches"""
+    rng = np.random.default_rng(7)
+    for rec in [8, 12, 16, 24, 37, 64]:
+        base = rng.integers(0, 256, rec, dtype=np.uint8)
+        rows = np.tile(base, (131072 // rec, 1))
+        for k in range(rows.shape[0]):
+            for _ in range(int(rng.integers(0, 3))):
+                rows[k, int(rng.integers(0, rec))] = int(rng.integers(0, 256))
+        check(model, orc, rows.tobytes())

@@ -1,0 +1,205 @@
+// tests/zstd_chain_model.cpp -- TEST INFRASTRUCTURE: lane-by-lane CPU model of the Zstd match-finder kernel
+// (aocl-compression_amd/csrc/zstd_kernels.hip, fast_block) that runs the kernel's own scalar chain walk
+// (csrc/zstd_chain.h) on the host.  tests/test_zstd_chain_model.py compares its sequences with the oracle's sequential
+// parser (oracle/zstd_oracle.c, fast_block) on many inputs, so the batching logic - which lanes are trustworthy, which
+// table writes are committed, when a chain has to stop - is validated without a GPU.
+//
+// Build: g++ -O2 -shared -fPIC -I aocl-compression_amd/csrc tests/zstd_chain_model.cpp -o tests/_build/libzchain_model.so
+#include "zstd_chain.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+typedef uint8_t u8; typedef uint32_t u32; typedef uint64_t u64;
+u32 rd32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
+u64 rd64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+u32 zhash(const u8* p, u32 hlog, u32 mls)
+{
+    const u64 v = rd64(p);
+    if (mls == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
+    return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+}
+u32 zcount(const u8* s, u32 a, u32 b, u32 end) { u32 n = 0; while (a + n < end && s[a + n] == s[b + n]) n++; return n; }
+int hb(u32 v) { int r = 0; while (v >>= 1) r++; return r; }
+
+// pair schedule (same construction as FastSched in zstd_kernels.hip)
+struct Sched {
+    enum { N = 70000 };
+    std::vector<u32> a, sigma, st;
+    Sched() : a(N), sigma(N), st(N) {
+        u32 step = 2, nextStep = 128, A = 0, sig = 2;
+        for (u32 m = 0; m < N; ++m) {
+            a[m] = A; sigma[m] = sig; st[m] = step;
+            const u32 A2 = A + sig; sig = step;
+            if (A2 + step >= nextStep) { step++; nextStep += 128; }
+            A = A2;
+        }
+    }
+};
+const Sched g_sched;
+u64* g_trace = nullptr; u32 g_trace_n = 0;      // optional per-batch trace (debugging the kernel against the model)
+
+struct Seq { u32 ll, off, ml; };
+
+struct Model {
+    const u8* src; u32 n, hlog, mls;
+    std::vector<u32> table;
+    std::vector<Seq> seqs;
+    u64 litSize = 0;
+    u64 stat[40] = {0};   // batches, fast sequences, specials, restarts, continues, sequential searches, tails, post checks; [8+why] specials by reason
+    void put(u32 pos) { table[zhash(src + pos, hlog, mls)] = pos + 2; }
+};
+
+}  // namespace
+
+extern "C" void zchain_model_trace(u64* buf) { g_trace = buf; g_trace_n = 0; }
+extern "C" u32 zchain_model_trace_count(void) { return g_trace_n; }
+
+extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, size_t* litSizeOut, u64* stats, int useChain)
+{
+    Model M; M.src = src; M.n = (u32)n_;
+    const u32 n = M.n;
+    {   // level1_params (oracle/zstd_oracle.c)
+        const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
+        if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; M.hlog = (15 < w + 1) ? 15 : w + 1; M.mls = 5; }
+        else { const u32 w = srcLog < 17 ? srcLog : 17; M.hlog = (13 < w + 1) ? 13 : w + 1; M.mls = 6; }
+    }
+    M.table.assign((size_t)1 << M.hlog, 0);
+    u32 anchor = 0, s = 1, rep1 = 1, rep2 = 0, i0 = 0;
+    if (n >= 20) {
+        const u32 ilimit = n - 16;
+        // immediate rep2 matches after a sequence that ends at ip0 (oracle fast_block :713-722)
+        auto rep_loop = [&](u32 ip0) -> u32 {
+            if (rep2 > 0) {
+                while (ip0 <= ilimit && rd32(src + ip0) == rd32(src + ip0 - rep2)) {
+                    const u32 rLength = zcount(src, ip0 + 4, ip0 + 4 - rep2, n) + 4;
+                    const u32 t = rep2; rep2 = rep1; rep1 = t;
+                    M.put(ip0);
+                    ip0 += rLength;
+                    M.seqs.push_back({0, 1, rLength});
+                }
+            }
+            return ip0;
+        };
+        for (;;) {
+            int ev = 0; u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
+            if (useChain && i0 == 0 && s >= 4 && (u64)s + 100 < ilimit) {
+                // ---------------- chain batch: 64 consecutive probes ----------------
+                M.stat[0]++;
+                const u32 pos0 = s;
+                u32 h[64], ent[64], eqbv[64], infov[64]; bool ok[64];
+                for (int j = 0; j < 64; ++j) {
+                    const u32 p = pos0 + (u32)j;
+                    h[j] = zhash(src + p, M.hlog, M.mls);
+                    ent[j] = M.table[h[j]];
+                    ok[j] = false; eqbv[j] = 0; infov[j] = 0;
+                    if (ent[j] >= 2) {
+                        const u32 c = ent[j] - 2;
+                        if (c >= 4) {
+                            u32 e = 0;
+                            for (int i = 0; i < 32; ++i) if (src[p - 4 + i] == src[c - 4 + i]) e |= 1u << i;
+                            const u32 fwm = ~(e >> 8);
+                            const u32 fw = (u32)__builtin_ctz(fwm);                       // <= 24
+                            const u32 bkm = ~(e << 28);
+                            const u32 bk4 = (u32)__builtin_clz(bkm);                      // <= 4
+                            eqbv[j] = e; infov[j] = zchain::pack_info(c, fw, bk4);
+                            ok[j] = ((e >> 4) & 15u) == 15u;
+                        } else {
+                            ok[j] = rd32(src + c) == rd32(src + p);
+                            infov[j] = zchain::pack_info(c, 0, 7);
+                        }
+                    }
+                }
+                int lim = 64;
+                for (int j = 1; j < 64 && lim == 64; ++j) for (int i = 0; i < j; ++i) if (h[i] == h[j]) { lim = j; break; }
+                u64 okmask = 0;
+                for (int j = 0; j < lim; ++j) if (ok[j]) okmask |= 1ull << j;
+                u64 B1 = 0, B1h = 0, B2 = 0, B2h = 0;
+                for (int j = 0; j < 64; ++j) {
+                    const u32 p = pos0 + (u32)j;
+                    if (src[p + 1] == src[p + 1 - rep1]) B1 |= 1ull << j;
+                    if (j < 28 && src[p + 65] == src[p + 65 - rep1]) B1h |= 1ull << j;
+                    if (rep2) {
+                        if (src[p + 1] == src[p + 1 - rep2]) B2 |= 1ull << j;
+                        if (j < 28 && src[p + 65] == src[p + 65 - rep2]) B2h |= 1ull << j;
+                    }
+                }
+                const zchain::Desc D1 = zchain::desc_from_ballots(B1, B1h), D2 = zchain::desc_from_ballots(B2, B2h);
+                const zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, D1, D2,
+                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; },
+                    [&](u32 ll, u32 off, u32 ml, u32 apos) {
+                        (void)apos;
+                        M.seqs.push_back({ll, off, ml}); M.litSize += ll; M.stat[1]++;
+                    });
+                for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
+                if (g_trace && g_trace_n < 4096) {
+                    u64* t = g_trace + 8 * g_trace_n++;
+                    t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = w.commit; t[4] = (u32)w.outcome | ((u64)(u32)w.S << 8) | ((u64)(u32)w.ev << 16) | ((u64)(u32)w.el << 24) | ((u64)(u32)w.ntail << 32) | ((u64)w.post << 40);
+                    t[5] = D1.eq.lo; t[6] = D1.eq.hi; t[7] = ((u64)rep1 << 32) | rep2;
+                }
+                anchor = (u32)((int32_t)pos0 + w.arel); rep1 = w.rep1; rep2 = w.rep2; s = pos0 + (u32)w.S;
+                if (w.outcome == zchain::ZC_RESTART) {
+                    M.stat[3]++;
+                    for (int t = 3 - w.ntail; t < 3; ++t) M.put(pos0 + (u32)w.tail[t]);
+                    if (w.ntail) M.stat[6]++;
+                    if (w.post) { M.stat[7]++; s = rep_loop(s); anchor = s; }
+                    continue;
+                }
+                if (w.outcome == zchain::ZC_CONTINUE) { M.stat[4]++; i0 = (u32)(lim - w.S); }
+                else {
+                    M.stat[2]++; M.stat[8 + (w.why & 31)]++;
+                    ev = w.ev; e_pos = pos0 + (u32)w.el; e_cand = ent[w.el]; e_sig = 2; e_st = 2; e_half = (u32)(w.el - w.S) & 1u;
+                }
+            }
+            if (!ev) {
+                // ---------------- sequential search from probe i0 of the search that starts at s ----------------
+                M.stat[5]++;
+                for (u32 K = i0;; ++K) {
+                    const u32 m = K >> 1, half = K & 1;
+                    const u32 am = g_sched.a[m], sg = g_sched.sigma[m], st = g_sched.st[m];
+                    if (!((u64)s + am + sg + 1 < ilimit)) break;
+                    const u32 pos = s + am + half;
+                    const u32 hh = zhash(src + pos, M.hlog, M.mls);
+                    const u32 idx = M.table[hh];
+                    M.table[hh] = pos + 2;
+                    if (half == 0 && rd32(src + pos + sg) == rd32(src + pos + sg - rep1)) { ev = 2; e_pos = pos; e_sig = sg; e_st = st; e_half = 0; break; }
+                    if (idx >= 2 && rd32(src + idx - 2) == rd32(src + pos)) { ev = 1; e_pos = pos; e_cand = idx; e_sig = sg; e_st = st; e_half = half; break; }
+                }
+                i0 = 0;
+                if (!ev) break;
+            }
+            // ---------------- one sequence the exact way (oracle fast_block :701-723) ----------------
+            {
+                const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
+                if (e_half == 0 || e_st <= 4) M.put(ip1);
+            }
+            const u32 current0 = e_pos;
+            u32 ip0, match0, offcode, mLength;
+            if (ev == 2) {
+                ip0 = e_pos + e_sig; match0 = ip0 - rep1;
+                const u32 back = src[ip0 - 1] == src[match0 - 1];
+                ip0 -= back; match0 -= back; offcode = 1; mLength = back + 4;
+            } else {
+                ip0 = e_pos; match0 = e_cand - 2;
+                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3; mLength = 4;
+                while (ip0 > anchor && match0 > 0 && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+            }
+            mLength += zcount(src, ip0 + mLength, match0 + mLength, n);
+            M.seqs.push_back({ip0 - anchor, offcode, mLength}); M.litSize += ip0 - anchor;
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {
+                M.put(current0 + 2);
+                M.put(ip0 - 2);
+                ip0 = rep_loop(ip0); anchor = ip0;
+            }
+            s = ip0;
+        }
+    }
+    M.litSize += n - anchor;
+    for (size_t i = 0; i < M.seqs.size(); ++i) { out[4 * i] = M.seqs[i].ll; out[4 * i + 1] = M.seqs[i].off; out[4 * i + 2] = M.seqs[i].ml; out[4 * i + 3] = 0; }
+    *litSizeOut = (size_t)M.litSize;
+    if (stats) memcpy(stats, M.stat, 8 * sizeof(u64));
+    if (stats && useChain == 2) memcpy(stats, M.stat, sizeof(M.stat));
+    return M.seqs.size();
+}
