@@ -10,10 +10,11 @@
 // the repcode at k+2 (:519-542), then the table candidate of probe k, then the candidate of probe k+1 (:546-598).
 //   M event  lane j holds a table candidate whose 4 bytes match (okmask bit j; only lanes < lim are trustworthy).
 //   R event  even probe k whose bytes at k+2 repeat at distance rep1.
-// Byte equality at a fixed distance is kept as a 128-bit map (bit i <-> src[pos0+i] == src[pos0+i-dist], bits outside
-// the known range are 0): for the two repcodes the batch starts with, the maps come from two coalesced loads; after an
-// M event the new rep1 is that match's offset and its map is the equality mask of the lane's own 32-byte probe /
-// candidate windows - the same bytes the forward extension compared - known up to 28 bytes past the probe.
+// Byte equality at a fixed distance is kept as a 64-bit map over the batch's lanes (bit i <-> src[pos0+i] ==
+// src[pos0+i-dist], bits outside the known range are 0): for the two repcodes the batch starts with, the map is one
+// ballot over a coalesced byte load; after an M event the new rep1 is that match's offset and its map is the equality
+// mask of the lane's own 32-byte probe / candidate windows - the same bytes the forward extension compared - known up
+// to 28 bytes past the probe.
 // The walk stops as soon as anything is not decidable from registers:
 //   ZC_SPECIAL   the next event is known (ev, el) but needs the one-at-a-time path (long extension or catch-up,
 //                immediate rep2 match, table writes beyond the trustworthy lanes);
@@ -31,54 +32,17 @@
 
 namespace zchain {
 
-struct M128 { uint64_t lo, hi; };
-
-ZC_FN M128 shr(M128 m, uint32_t s)
-{
-    M128 r;
-    if (s == 0) return m;
-    if (s < 64) { r.lo = (m.lo >> s) | (m.hi << (64 - s)); r.hi = m.hi >> s; }
-    else if (s < 128) { r.lo = m.hi >> (s - 64); r.hi = 0; }
-    else { r.lo = 0; r.hi = 0; }
-    return r;
-}
-ZC_FN M128 shl(M128 m, uint32_t s)
-{
-    M128 r;
-    if (s == 0) return m;
-    if (s < 64) { r.hi = (m.hi << s) | (m.lo >> (64 - s)); r.lo = m.lo << s; }
-    else if (s < 128) { r.hi = m.lo << (s - 64); r.lo = 0; }
-    else { r.lo = 0; r.hi = 0; }
-    return r;
-}
-ZC_FN M128 band(M128 a, M128 b) { M128 r; r.lo = a.lo & b.lo; r.hi = a.hi & b.hi; return r; }
-ZC_FN uint64_t bits_at(M128 m, uint32_t i) { return shr(m, i).lo; }
+ZC_FN uint64_t shr64(uint64_t m, int s) { return s < 64 ? m >> s : 0; }     // s >= 0
 ZC_FN int ctz64(uint64_t v) { return v ? (int)__builtin_ctzll(v) : 64; }
+// "4 equal bytes start here"
+ZC_FN uint64_t quad(uint64_t eq) { const uint64_t a = eq & (eq >> 1); return a & (a >> 2); }
 
-// equality map at one distance: eq = byte equality, q = "4 equal bytes start here", known for indices < end
-struct Desc { M128 eq, q; int32_t end; };
-
-ZC_FN Desc make_desc(M128 eq, int32_t end)
+// equality map of lane j's match offset: eqb bit i <-> byte (pos0 + j - 4 + i) equals its candidate byte; known for
+// lanes [j, min(j + 28, 64))
+ZC_FN uint64_t map_from_window(uint32_t eqb, int j)
 {
-    Desc d; d.eq = eq;
-    const M128 a = band(eq, shr(eq, 1));
-    d.q = band(a, shr(a, 2));
-    d.end = end;
-    return d;
-}
-// map of the batch's initial repcodes: B bit j <-> byte pos0+1+j is equal (lanes 0..63), Bh bit j <-> byte pos0+65+j (lanes 0..27)
-constexpr int32_t kRepEnd = 93;
-ZC_FN Desc desc_from_ballots(uint64_t B, uint64_t Bh)
-{
-    M128 eq; eq.lo = B << 1; eq.hi = (B >> 63) | ((Bh & 0xFFFFFFFull) << 1);
-    return make_desc(eq, kRepEnd);
-}
-// map of the offset of the match found by lane j: eqb bit i <-> byte (pos0 + j - 4 + i) equals its candidate byte
-ZC_FN Desc desc_from_window(uint32_t eqb, int j)
-{
-    M128 eq; eq.lo = eqb & ~0xFull; eq.hi = 0;
-    eq = j >= 4 ? shl(eq, (uint32_t)(j - 4)) : shr(eq, (uint32_t)(4 - j));
-    return make_desc(eq, j + 28);
+    const uint64_t e = eqb & ~0xFu;
+    return j >= 4 ? e << (j - 4) : e >> (4 - j);
 }
 
 // per-lane record of a table candidate, packed for one readlane: candidate position (17 bits) | forward length beyond
@@ -90,6 +54,7 @@ enum { ZC_RESTART = 0, ZC_SPECIAL = 1, ZC_CONTINUE = 2 };
 struct WalkOut {
     int outcome;
     int S;              // lane where the unfinished search starts
+    int R;              // ZC_CONTINUE: lanes [S, R) of the unfinished search hold no event
     int ev, el;         // ZC_SPECIAL: 1 = table match at lane el, 2 = repcode found by even probe el
     int32_t arel;       // anchor - pos0
     uint32_t rep1, rep2;
@@ -98,14 +63,14 @@ struct WalkOut {
                         // by one, in order, after the commit
     bool post;          // ZC_RESTART: the immediate rep2 test at S (:690) is still to be made, with loads
     int why;            // ZC_SPECIAL, statistics only: 1 long extension, 2 long catch-up / candidate at the chunk start,
-                        // 4 table writes beyond lim, 8 immediate rep2 test not decidable, 16 immediate rep2 match
+                        // 4 table writes beyond the batch, 16 immediate rep2 match
 };
 
-ZC_FN uint64_t lane_range(int a, int b)   // bits [a, b), 0 <= a, b <= 64
+ZC_FN uint64_t lane_range(int a, int b)   // bits [a, b), 0 <= a < 64, b <= 64
 {
     if (b <= a) return 0;
     const uint64_t hi = b >= 64 ? ~0ull : ((1ull << b) - 1);
-    return hi & ~((1ull << a) - 1);       // a < 64 here
+    return hi & ~((1ull << a) - 1);
 }
 ZC_FN uint64_t lane_bit(int i) { return (i >= 0 && i < 64) ? 1ull << i : 0; }
 
@@ -122,43 +87,47 @@ ZC_FN void finish(WalkOut& o, uint64_t& commit, int w1, int w2, int w3, int lim,
     o.outcome = ZC_RESTART;
 }
 
-// info(j), eqb(j): per-lane inputs of lane j; emit(litLength, offBase, matchLength, anchorPosition) stores one sequence.
+// okmask: lanes below lim with a matching table candidate.  eq1 / eq2: equality maps at distance rep1 / rep2 over all 64
+// lanes (eq2 is ignored while rep2 == 0).  info(j), eqb(j): per-lane inputs of lane j;
+// emit(litLength, offBase, matchLength, anchorPosition) stores one sequence.
 template <class Info, class Eqb, class Emit>
 ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, int32_t arel, uint32_t rep1, uint32_t rep2,
-                   Desc D1, Desc D2, Info info, Eqb eqb, Emit emit)
+                   uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit)
 {
     WalkOut o;
     int S = 0;
     uint64_t commit = 0;
-    o.ev = 0; o.el = 0; o.why = 0; o.ntail = 0; o.post = false; o.tail[0] = o.tail[1] = o.tail[2] = 0;
+    uint64_t q1 = quad(eq1), q2 = quad(eq2);
+    int end1 = 64, end2 = 64;                            // the maps are known for lanes below end
+    o.ev = 0; o.el = 0; o.R = 0; o.why = 0; o.ntail = 0; o.post = false; o.tail[0] = o.tail[1] = o.tail[2] = 0;
     for (;;) {
         if (S >= lim) { o.outcome = ZC_RESTART; break; }
-        const uint64_t mm = okmask & (~0ull << S);
-        const int jm = ctz64(mm);
-        const uint64_t t = bits_at(D1.q, (uint32_t)S + 2) & 0x5555555555555555ull;
-        const int kr = t ? S + (int)__builtin_ctzll(t) : 1000;
-        const int KL = D1.end - 6;                       // even probes <= KL have a known repcode test
+        const int jm = S + ctz64(okmask >> S);                                                   // first M event, >= 64: none
+        const uint64_t t = shr64(q1, S + 2) & 0x5555555555555555ull;
+        const int kr = S + ctz64(t);                                                             // first R event
+        const int U = t ? 1000 : end1 - 5;               // even probes below U have a known repcode test (k + 6 <= end1)
         int ev;
-        if (kr <= jm) ev = kr < lim ? 2 : 0;             // (kr found: every earlier repcode test is known negative)
-        else if (jm < 64) { if (!t && jm > KL) { o.outcome = ZC_RESTART; break; } ev = 1; }
-        else ev = 0;
-        if (ev == 0) {
-            if (!t && lim - 1 > KL) { o.outcome = ZC_RESTART; break; }
-            commit |= lane_range(S, lim);
-            o.outcome = ZC_CONTINUE; break;
+        if (t && kr <= jm) {
+            if (kr >= lim) { commit |= lane_range(S, lim); o.R = lim; o.outcome = ZC_CONTINUE; break; }
+            ev = 2;
+        } else if (jm < 64 && jm < U) ev = 1;
+        else {
+            const int R = lim < U ? lim : U;             // no event in [S, R)
+            if (R < lim && S > 0) { o.outcome = ZC_RESTART; break; }                             // a fresh batch sees further
+            commit |= lane_range(S, R); o.R = R; o.outcome = ZC_CONTINUE; break;
         }
         if (ev == 2) {
             const int k = kr, q = k + 2;
-            const uint32_t back1 = (uint32_t)(bits_at(D1.eq, (uint32_t)q - 1) & 1);          // :533
-            const int f = ctz64(~bits_at(D1.eq, (uint32_t)q + 4));
+            const uint32_t back1 = (uint32_t)(eq1 >> (q - 1)) & 1u;                              // :533
+            const int f = ctz64(~shr64(eq1, q + 4));
             const int E = q + 4 + f;
             // table writes at k+1, k+2 and E-2 (:537, :680-681): lanes below lim join the batch commit; from the first one
             // at or beyond lim on they follow one by one (`tail`, in order) and the chain ends with this sequence
             const bool tails = E - 2 >= lim;
-            int why = (E < D1.end && f < 64 ? 0 : 1) | (tails && k + 2 >= 64 ? 4 : 0);   // f == 64: bits_at holds 64 bits
+            int why = E < end1 ? 0 : 1;                  // the comparison ran into the end of what is known
             bool post = false;                                                                    // :690 immediate rep2 test
             if (!why && rep2) {
-                if (E + 4 <= D2.end) why = (bits_at(D2.q, (uint32_t)E) & 1) ? 16 : 0;
+                if (E + 4 <= end2) why = ((q2 >> E) & 1) ? 16 : 0;
                 else post = true;                                                                 // by two loads after the walk
             }
             commit |= lane_range(S, k + 1);
@@ -179,7 +148,7 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             int why = (fw < 24 ? 0 : 1) | (bk4 != 7 && !(bk4 == 4 && maxback > 4) ? 0 : 2) | (tails && j + 2 >= 64 ? 4 : 0);
             bool post = false;                                                                    // rep2 becomes the old rep1
             if (!why) {
-                if (E + 4 <= D1.end) why = (bits_at(D1.q, (uint32_t)E) & 1) ? 16 : 0;
+                if (E + 4 <= end1) why = ((q1 >> E) & 1) ? 16 : 0;
                 else post = true;
             }
             commit |= lane_range(S, j + 1);
@@ -190,7 +159,8 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             arel = E; S = E;
             if (tails || post) { finish(o, commit, j + 1, j + 2, E - 2, lim, post); break; }
             commit |= lane_bit(j + 1) | lane_bit(j + 2) | lane_bit(E - 2);
-            D2 = D1; D1 = desc_from_window(eqb(j), j);
+            q2 = q1; end2 = end1;
+            eq1 = map_from_window(eqb(j), j); q1 = quad(eq1); end1 = j + 28 < 64 ? j + 28 : 64;
         }
     }
     o.S = S; o.arel = arel; o.rep1 = rep1; o.rep2 = rep2; o.commit = commit;

@@ -202,11 +202,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 typedef u32x4 __attribute__((aligned(1))) U4;
                 typedef const __attribute__((address_space(1))) U4* GP4;
                 const u32x4 pa = *(GP4)(src + pos - 4), pb = *(GP4)(src + pos + 12);      // probe window [pos-4, pos+28)
-                // byte equality at the two repcode distances over [pos0+1, pos0+93): two byte loads per lane each
-                const u32 b1 = src[pos + 1 - rep1];
-                u32 b1h = 0, p65 = 0, b2 = 0, b2h = 0;
-                if (lane < 28) { b1h = src[pos + 65 - rep1]; p65 = src[pos + 65]; }
-                if (rep2) { b2 = src[pos + 1 - rep2]; if (lane < 28) b2h = src[pos + 65 - rep2]; }
+                // byte equality at the two repcode distances over the 64 lanes: one byte load per lane each
+                const u32 b1 = src[pos - rep1];
+                u32 b2 = 0x100;
+                if (rep2) b2 = src[pos - rep2];
                 ZSTAGE(0);
 #ifdef ZSTD_PROF
                 zbatches++;
@@ -234,10 +233,8 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
                 const u32 infoV = near0 ? zchain::pack_info(c, 0, 7) : zchain::pack_info(c, fw, bk4);
                 const u64 okmask = ballot(lane < lim && ok);
-                const u32 pb1 = (pa.y >> 8) & 0xFFu;                    // the byte at pos+1
-                const zchain::Desc D1 = zchain::desc_from_ballots(ballot(pb1 == b1), ballot(lane < 28 && p65 == b1h));
-                const zchain::Desc D2 = zchain::desc_from_ballots(ballot(rep2 != 0 && pb1 == b2), ballot(rep2 != 0 && lane < 28 && p65 == b2h));
-                const zchain::WalkOut wo = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, D1, D2,
+                const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
+                const zchain::WalkOut wo = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, ballot(pb0 == b1), ballot(pb0 == b2),
                     [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
                     [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; });
                 if ((wo.commit >> lane) & 1) tput(h, pos + 2);
@@ -246,7 +243,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 if (lane == 0 && g_ztrace_n < 4096) {
                     unsigned long long* t = g_ztrace + 8 * g_ztrace_n++;
                     t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = wo.commit; t[4] = (u32)wo.outcome | ((u64)(u32)wo.S << 8) | ((u64)(u32)wo.ev << 16) | ((u64)(u32)wo.el << 24) | ((u64)(u32)wo.ntail << 32) | ((u64)wo.post << 40);
-                    t[5] = D1.eq.lo; t[6] = D1.eq.hi; t[7] = ((u64)rep1 << 32) | rep2;
+                    t[5] = ballot(pb0 == b1); t[6] = ballot(pb0 == b2); t[7] = ((u64)rep1 << 32) | rep2;
                 }
 #endif
                 anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
@@ -265,7 +262,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                     ZSTAGE(4);
                     continue;
                 }
-                if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(lim - wo.S);
+                if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(wo.R - wo.S);
                 else {
                     const int el = wo.el;
                     ev = wo.ev;

@@ -115,18 +115,13 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                 for (int j = 1; j < 64 && lim == 64; ++j) for (int i = 0; i < j; ++i) if (h[i] == h[j]) { lim = j; break; }
                 u64 okmask = 0;
                 for (int j = 0; j < lim; ++j) if (ok[j]) okmask |= 1ull << j;
-                u64 B1 = 0, B1h = 0, B2 = 0, B2h = 0;
+                u64 eq1 = 0, eq2 = 0;
                 for (int j = 0; j < 64; ++j) {
                     const u32 p = pos0 + (u32)j;
-                    if (src[p + 1] == src[p + 1 - rep1]) B1 |= 1ull << j;
-                    if (j < 28 && src[p + 65] == src[p + 65 - rep1]) B1h |= 1ull << j;
-                    if (rep2) {
-                        if (src[p + 1] == src[p + 1 - rep2]) B2 |= 1ull << j;
-                        if (j < 28 && src[p + 65] == src[p + 65 - rep2]) B2h |= 1ull << j;
-                    }
+                    if (src[p] == src[p - rep1]) eq1 |= 1ull << j;
+                    if (rep2 && src[p] == src[p - rep2]) eq2 |= 1ull << j;
                 }
-                const zchain::Desc D1 = zchain::desc_from_ballots(B1, B1h), D2 = zchain::desc_from_ballots(B2, B2h);
-                const zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, D1, D2,
+                const zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
                     [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; },
                     [&](u32 ll, u32 off, u32 ml, u32 apos) {
                         (void)apos;
@@ -136,7 +131,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                 if (g_trace && g_trace_n < 4096) {
                     u64* t = g_trace + 8 * g_trace_n++;
                     t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = w.commit; t[4] = (u32)w.outcome | ((u64)(u32)w.S << 8) | ((u64)(u32)w.ev << 16) | ((u64)(u32)w.el << 24) | ((u64)(u32)w.ntail << 32) | ((u64)w.post << 40);
-                    t[5] = D1.eq.lo; t[6] = D1.eq.hi; t[7] = ((u64)rep1 << 32) | rep2;
+                    t[5] = eq1; t[6] = eq2; t[7] = ((u64)rep1 << 32) | rep2;
                 }
                 anchor = (u32)((int32_t)pos0 + w.arel); rep1 = w.rep1; rep2 = w.rep2; s = pos0 + (u32)w.S;
                 if (w.outcome == zchain::ZC_RESTART) {
@@ -146,7 +141,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                     if (w.post) { M.stat[7]++; s = rep_loop(s); anchor = s; }
                     continue;
                 }
-                if (w.outcome == zchain::ZC_CONTINUE) { M.stat[4]++; i0 = (u32)(lim - w.S); }
+                if (w.outcome == zchain::ZC_CONTINUE) { M.stat[4]++; i0 = (u32)(w.R - w.S); }
                 else {
                     M.stat[2]++; M.stat[8 + (w.why & 31)]++;
                     ev = w.ev; e_pos = pos0 + (u32)w.el; e_cand = ent[w.el]; e_sig = 2; e_st = 2; e_half = (u32)(w.el - w.S) & 1u;

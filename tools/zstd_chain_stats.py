@@ -15,4 +15,4 @@ for kind in kinds:
         tot += L.zchain_model_sequences(d, len(d), out.ctypes.data, C.byref(lit), s.ctypes.data, 2); st += s
     b, f, sp, rs, co, sq = [int(x) for x in st[:6]]
     print(f"{kind:9s} seqs {tot} batches {b} fast {f} ({f/max(tot,1):.2f}) special {sp} restart {rs} cont {co} seqsearch {sq} seq/batch {tot/max(b,1):.2f}")
-    print("   special reasons (1 long ext, 2 catch-up, 4 writes>=lim, 8 rep2 unknown, 16 rep2 hit):", {k: int(st[8 + k]) for k in range(32) if st[8 + k]})
+    print("   special reasons (1 long ext, 2 catch-up, 4 writes beyond the batch, 16 rep2 hit):", {k: int(st[8 + k]) for k in range(32) if st[8 + k]})
