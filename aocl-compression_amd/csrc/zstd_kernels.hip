@@ -35,6 +35,10 @@ constexpr u32 kBlockMax = 128u << 10;
 constexpr u32 kMaxSeq = kBlockMax / 4 + 8;
 constexpr u32 kDecWs = kBlockMax + 64 + 8192;   // decoder workspace per resident block: literal buffer + a 12-bit Huffman table
 constexpr u32 kSchedLen = 960;
+constexpr u32 kRingBlk = 240;                   // source ring of the chain batches: two 240-byte blocks + a 32-byte mirror
+}
+constexpr uint32_t kSrcRingBytes = 512;
+namespace {
 
 // ---- pair schedule of the fast match finder (zstd_fast.c:491-631): offset of pair m from the search
 //      start, gap to the repcode probe (sigma) and the value of `step` while the pair is examined ----
@@ -174,6 +178,23 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
         const bool chain = !(expf & 32);                                // experiment 32: one match per batch everywhere
+        // Source ring of the chain batches.  Block b of the chunk (240 bytes) sits at ring offset (b & 1) * 240, the first
+        // 32 bytes of the even block are mirrored behind the odd one so that a 32-byte read never wraps; the block after
+        // the newest one is always in flight in a register (requested a block of parsing ahead of its use), so the 64
+        // probe windows of a batch are LDS reads instead of a global round trip.
+        lbyte* ring = lds + 2 * tsize + (kHi ? tsize / 8 : 0);
+        int32_t rb = -4;                                                // newest block in the ring (rb-1 and rb are valid)
+        u32 pend = 0; bool have_pend = false;                           // block rb+1, in flight
+        auto blk_load = [&](int32_t b) -> u32 {
+            const u32 a = kRingBlk * (u32)b + 4u * (u32)lane;
+            u32 v = 0;
+            if (lane < 60 && a + 4 <= n) v = ld32(src + a);             // (the chain never looks at the chunk's last 25 bytes)
+            return v;
+        };
+        auto blk_store = [&](int32_t b, u32 v) {
+            if (lane < 60) *(L32*)(ring + ((u32)b & 1u) * kRingBlk + 4u * (u32)lane) = v;
+            if (!(b & 1) && lane < 8) *(L32*)(ring + 2 * kRingBlk + 4u * (u32)lane) = v;
+        };
         // immediate rep2 matches behind a sequence that ends at ip0 (:690-702); returns where the next search starts
         auto rep_loop = [&](u32 ip0) -> u32 {
             bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
@@ -201,7 +222,22 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
                 typedef u32x4 __attribute__((aligned(1))) U4;
                 typedef const __attribute__((address_space(1))) U4* GP4;
-                const u32x4 pa = *(GP4)(src + pos - 4), pb = *(GP4)(src + pos + 12);      // probe window [pos-4, pos+28)
+                // probe windows [pos-4, pos+28) from the source ring
+                const int32_t bl = (int32_t)(((u64)(pos0 - 4) * 17895698ull) >> 32), bh = (int32_t)(((u64)(pos0 + 90) * 17895698ull) >> 32);   // / 240
+                if (!(bh <= rb && rb <= bl + 1)) {
+                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
+                    else {
+                        const u32 v0 = blk_load(bl), v1 = blk_load(bh);
+                        blk_store(bl, v0);
+                        if (bh != bl) blk_store(bh, v1);
+                        rb = bh;
+                    }
+                    pend = blk_load(rb + 1); have_pend = true;
+                    wave_fence();
+                }
+                u32 ro = (pos0 - 4) - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
+                if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
+                const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
                 // byte equality at the two repcode distances over the 64 lanes: one byte load per lane each
                 const u32 b1 = src[pos - rep1];
                 u32 b2 = 0x100;
@@ -728,7 +764,7 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 hlog, mls, litSize = 0, nbSeq;
         level1_params(n, &hlog, &mls);
-        const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8);
+        const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8) + kSrcRingBytes;
         if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
         if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
         else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
@@ -1451,8 +1487,8 @@ uint32_t lds_for_chunk(uint64_t n)
     if (n <= 16384) {
         uint32_t srcLog = 6; if (n >= 64) { srcLog = 0; uint64_t t = n - 1; while (t) { srcLog++; t >>= 1; } }
         const uint32_t w = srcLog < 14 ? srcLog : 14, hl = (15 < w + 1) ? 15 : w + 1;
-        need = 2u << hl;
-    } else need = (2u << 13) + (1u << 13) / 8;
+        need = (2u << hl) + aoclgpu::kSrcRingBytes;
+    } else need = (2u << 13) + (1u << 13) / 8 + aoclgpu::kSrcRingBytes;
     const uint32_t ent = (uint32_t)aoclgpu::zstd_entropy_lds_bytes();
     need = need > ent ? need : ent;
     return (need + 255u) & ~255u;
