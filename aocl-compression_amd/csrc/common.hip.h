@@ -83,9 +83,9 @@ __device__ __forceinline__ bool any_lane(bool p)
 // lands is up to the hardware, but a lane keeps writing only while the slot holds a larger id, so the minimum sticks.
 // One asm block per round: the compiler must not split it per lane (it threads `if (pending) store` into a nested
 // loop in which the lanes that are done stop re-reading, and then miss the smaller id a later round brings).
-__device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint32_t lane)
-{
-    uint64_t pend = ~0ull, saved;
+__device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint32_t lane, bool valid = true)
+{   // lanes with !valid name no slot: they neither write nor count (their w is meaningless)
+    uint64_t pend = __ballot(valid), saved;
     uint32_t w;
     do {
         asm volatile("s_and_saveexec_b64 %1, %3\n\t"
@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint3
                      "ds_read_u16 %0, %2\n\t"
                      "s_waitcnt lgkmcnt(0)"
                      : "=&v"(w), "=&s"(saved) : "v"(slot), "s"(pend), "v"(lane) : "memory");
-        pend = __ballot(lane < w);
+        pend = __ballot(valid && lane < w);
         asm volatile("" : "+s"(pend));
     } while (pend != 0);
     return w;

@@ -234,15 +234,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             } else if (have2) c2 = ld64(src + cand + 12);
             // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
             wave_fence();
-            bool pending = valid;
-            uint32_t w = (uint32_t)lane;
-            do {
-                if (pending) table[h] = (T)lane;
-                wave_fence();
-                if (valid) w = table[h];
-                wave_fence();
-                pending = valid && (uint32_t)lane < w;
-            } while (ballot(pending) != 0);
+            const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane, valid);
+            wave_fence();
             if (valid) table[h] = (T)ent;                 // undo the lane ids (the low halves; extra bits were not touched)
             wave_fence();
             STAGE(2);

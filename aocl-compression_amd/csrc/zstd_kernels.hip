@@ -336,14 +336,8 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 if (valid && cand >= 2 && ((ent ^ mychk) & ~kPosMask) == 0) m4 = ld32(src + cand - 2);
                 wave_fence();
                 ZSTAGE(1);
-                bool pending = valid; u32 w = (u32)lane;
-                do {
-                    if (pending) table[h] = (T)lane;
-                    wave_fence();
-                    if (valid) w = table[h];
-                    wave_fence();
-                    pending = valid && (u32)lane < w;
-                } while (ballot(pending) != 0);
+                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane, valid);
+                wave_fence();
                 ZSTAGE(2);
                 const int f = first_lane(ballot(valid && w != (u32)lane));
                 const int e = first_lane(ballot(!valid));
