@@ -11,6 +11,8 @@
 // first 16 steps), the u16 table of 256..16384 entries (32 KB of LDS), the ip-1 back-fill + immediate
 // re-probe after every copy (:1016-1021), and the tag-byte output format.
 #include "common.hip.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace aoclgpu {
 namespace {
@@ -95,13 +97,36 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
 // Same batch machinery as lz4_kernels.hip (windowed loads, in-register extension up to 28 bytes, several copies
 // resolved per batch, next windows requested early); Snappy specifics: the schedule is consecutive only for its
 // first 33 probes, the table has no spare bits for check bits, no catch-up, matches may run to the fragment end.
+// GT = false: the table lives in LDS (32 KB: 5 fragments resident per CU).  GT = true: the table lives in global memory
+// (one 32 KB slice of a workspace per resident workgroup, served by L2 / Infinity Cache) and LDS only holds a 2 KB scratch
+// for the slot-reuse rounds (indexed by the low 10 hash bits: a false alarm only cuts a batch short) - the number of
+// resident fragments is then bounded by registers (20 per CU) instead of LDS, which is what a latency-bound parser needs.
+// Table accesses in global memory are relaxed agent-scope atomics (served by L2, never by a stale L1 line); a wave's
+// vector memory operations reach L2 in order, so the next batch's reads see this batch's commits.
+typedef __attribute__((address_space(3))) uint16_t lu16;
+typedef __attribute__((address_space(1))) uint16_t gu16;
+constexpr uint32_t kScratch = 1024;
+
+template <bool GT>
 __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in, const uint32_t n,
-                                                                   gbyte* __restrict__ out, uint16_t* table, int lane)
+                                                                   gbyte* __restrict__ out, uint16_t* table_, lu16* scr, int lane)
 {
+    using TP = typename std::conditional<GT, gu16*, lu16*>::type;
+    TP table = (TP)uni_ptr(table_);
+    auto tget = [&](uint32_t h) -> uint32_t {
+        if (GT) return __hip_atomic_load((uint16_t*)(table + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return table[h];
+    };
+    auto tput = [&](uint32_t h, uint32_t v) {
+        if (GT) __hip_atomic_store((uint16_t*)(table + h), (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else table[h] = (uint16_t)v;
+    };
     uint32_t tsize = n > kMaxTable ? kMaxTable : (n < kMinTable ? kMinTable : (2u << log2floor(n - 1)));   // :619-632
     const int shift = 32 - log2floor(tsize);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     for (uint32_t i = (uint32_t)lane; i < tsize / 8; i += kWave)         // memset, snappy.cc:651-657
-        reinterpret_cast<uint4*>(table)[i] = make_uint4(0, 0, 0, 0);
+        ((typename std::conditional<GT, __attribute__((address_space(1))) u4*, __attribute__((address_space(3))) u4*>::type)table)[i] = u4{0, 0, 0, 0};
+    if (GT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     wave_fence();
 
     uint32_t ip = 0, op = 0, anchor = 0;                                  // anchor = next_emit
@@ -122,14 +147,14 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
                 const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
                 const uint32_t h1 = sn_hash(fb, shift);
-                if (lane == 0) table[h1] = (uint16_t)(ip - 1);
+                if (lane == 0) tput(h1, ip - 1);
                 wave_fence();
             }
             have_pre = false;
             const uint32_t seq = (uint32_t)(pw.lo >> 32);
             const uint32_t h = sn_hash(seq, shift);
             uint32_t cand = 0;
-            if (valid) cand = table[h];
+            if (valid) cand = tget(h);
             Win cw = {~pw.lo, 0};
             if (valid) cw = load_win(in, cand);
             // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
@@ -141,16 +166,19 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             if (have2) c2 = ld64(in + cand + 12);
             if (have3) c3 = ld64(in + cand + 20);
             wave_fence();
-            bool pending = valid;
             uint32_t w = (uint32_t)lane;
-            do {                                                          // exact per-slot minimum lane
-                if (pending) table[h] = (uint16_t)lane;
-                wave_fence();
-                if (valid) w = table[h];
-                wave_fence();
-                pending = valid && (uint32_t)lane < w;
-            } while (ballot(pending) != 0);
-            if (valid) table[h] = (uint16_t)cand;                         // undo the lane ids
+            if (GT) w = lds_first_lane_per_slot((uint32_t)(uintptr_t)(scr + (h & (kScratch - 1))), (uint32_t)lane, valid);
+            else {
+                bool pending = valid;
+                do {                                                      // exact per-slot minimum lane
+                    if (pending) table[h] = (uint16_t)lane;
+                    wave_fence();
+                    if (valid) w = table[h];
+                    wave_fence();
+                    pending = valid && (uint32_t)lane < w;
+                } while (ballot(pending) != 0);
+                if (valid) table[h] = (uint16_t)cand;                     // undo the lane ids
+            }
             wave_fence();
             const int f = first_lane(ballot(valid && w != (uint32_t)lane));
             const int e = first_lane(ballot(!valid));
@@ -182,7 +210,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
                 const int m = first_lane(rem);
                 if (m >= 64) {                                            // lanes [start, hi) were probed without a match
-                    if (lane >= start && lane < hi) table[h] = (uint16_t)pos;
+                    if (lane >= start && lane < hi) tput(h, pos);
                     wave_fence();
                     // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
                     // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
@@ -193,7 +221,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     else i0 = (uint32_t)(hi - start);
                     break;
                 }
-                if (lane >= start && lane <= m) table[h] = (uint16_t)pos;            // probes the reference executed
+                if (lane >= start && lane <= m) tput(h, pos);                        // probes the reference executed
                 wave_fence();
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
                 uint32_t matched = 4 + lane_get(fw, m);
@@ -235,7 +263,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint32_t Ln = ip - pos0;
                 const int hi2 = lim < linlim ? lim : linlim;
                 if (!more_fwd && (int)Ln < hi2) {
-                    if ((uint32_t)lane == Ln - 1) table[h] = (uint16_t)pos;           // back-fill ip-1 (:1016-1017)
+                    if ((uint32_t)lane == Ln - 1) tput(h, pos);                       // back-fill ip-1 (:1016-1017)
                     wave_fence();
                     start = (int)Ln;
                     continue;
@@ -259,8 +287,9 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
     return op;
 }
 
+template <bool GT>
 __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* __restrict__ dst,
-                                const uint32_t cap, uint16_t* table)
+                                const uint32_t cap, uint16_t* table, lu16* scr)
 {
     const int lane = lane_id();
     if ((uint64_t)cap < 32ull + n + n / 6) return 0;                      // api/codec.cpp:271-274
@@ -270,7 +299,7 @@ __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n,
     op++;
     for (uint32_t pos = 0; pos < n; pos += kBlock) {                      // snappy.cc:1761-1816
         const uint32_t frag = n - pos < kBlock ? n - pos : kBlock;
-        op += sn_compress_fragment(src + pos, frag, dst + op, table, lane);
+        op += sn_compress_fragment<GT>(src + pos, frag, dst + op, table, scr, lane);
         wave_fence();
     }
     return (int)op;
@@ -473,8 +502,21 @@ __global__ void __launch_bounds__(64) snappy_compress_kernel(aoclgpu_batch b)
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = compress_view(b, c);
-    const int r = sn_compress_wave(v.src, v.src_len, v.dst, v.dst_cap, table);
+    const int r = sn_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
     if (threadIdx.x == 0) b.out_len[c] = r;
+}
+
+// persistent grid, hash tables in a global workspace (tables + blockIdx.x * kMaxTable)
+__global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b, uint16_t* tables)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t scr[kScratch];
+    uint16_t* table = tables + (size_t)blockIdx.x * kMaxTable;
+    for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
+        const ChunkView v = compress_view(b, c);
+        const int r = sn_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr);
+        if (threadIdx.x == 0) b.out_len[c] = r;
+        wave_fence();
+    }
 }
 
 __global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
@@ -495,6 +537,25 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
 {
     if (int rc = aoclgpu::check_batch(b, false)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
+    // Batches that LDS can hold at once (5 tables per CU) use the LDS-table kernel; larger ones the persistent
+    // global-table kernel with 12 workgroups per CU (the measured optimum: 10 -> 20.3, 12 -> 21.8, 14 -> 21.2, 16 -> 20.3 GiB/s
+    // against 14.0 for the LDS kernel).  Experiment 64 forces the LDS kernel.
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("snappy: device query failed"); return AOCLGPU_ERR_HIP; }
+    if (!(b->reserved & 64u) && b->nchunks > 5u * (uint32_t)prop.multiProcessorCount) {
+        int perCU = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::snappy_compress_gt_kernel, 64, 0) != hipSuccess || perCU < 1) {
+            aoclgpu::set_error_msg("snappy: occupancy query failed"); return AOCLGPU_ERR_HIP;
+        }
+        if (perCU > 12) perCU = 12;
+        if (const char* g = getenv("AOCLGPU_SNAPPY_GT_PER_CU")) perCU = atoi(g) > 0 ? atoi(g) : perCU;      // tuning hook
+        uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
+        if (grid > b->nchunks) grid = b->nchunks;
+        void* tables = aoclgpu::get_workspace((size_t)grid * aoclgpu::kMaxTable * sizeof(uint16_t), stream);
+        if (!tables) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+        hipLaunchKernelGGL(aoclgpu::snappy_compress_gt_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint16_t*)tables);
+        return aoclgpu::check_launch("snappy_compress_gt_kernel");
+    }
     hipLaunchKernelGGL(aoclgpu::snappy_compress_kernel, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
     return aoclgpu::check_launch("snappy_compress_kernel");
 }

@@ -1450,31 +1450,7 @@ size_t zstd_entropy_lds_bytes() { return sizeof(EntropyLds); }
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------------
 namespace {
-// Zstd launches need per-resident-block scratch in HBM (compressor: sequence store + staged block; decoder: literal
-// buffer).  One pool entry per (device, stream): launches on the same stream are ordered, launches on different
-// streams never share scratch.  A pool that has to grow is freed first (hipFree waits for the device).
-struct WsPool { void* p = nullptr; size_t bytes = 0; int dev = -1; void* stream = nullptr; };
-WsPool g_pool[16];
-std::mutex g_pool_mu;
-
-void* get_workspace(size_t bytes, void* stream)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    WsPool* e = nullptr;
-    for (WsPool& q : g_pool) if (q.p && q.dev == dev && q.stream == stream) { e = &q; break; }
-    if (!e) for (WsPool& q : g_pool) if (!q.p) { e = &q; break; }
-    if (!e) {                                             // more than 16 (device, stream) pairs: recycle the first entry
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-        e = &g_pool[0];
-    }
-    if (e->p && e->dev == dev && e->stream == stream && e->bytes >= bytes) return e->p;
-    if (e->p) { (void)hipFree(e->p); e->p = nullptr; }
-    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return nullptr; }
-    e->bytes = bytes; e->dev = dev; e->stream = stream;
-    return e->p;
-}
+using aoclgpu::get_workspace;
 uint32_t lds_for_chunk(uint64_t n)
 {   // hash table bytes of the level-1 parameters for an n-byte chunk, never less than the entropy-stage LDS
     uint32_t need;
