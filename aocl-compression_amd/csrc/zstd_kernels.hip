@@ -26,6 +26,7 @@
 #include "zstd_chain.h"
 #include "host_util.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace aoclgpu {
 namespace {
@@ -1495,6 +1496,48 @@ extern "C" int aoclgpu_debug_zstd_sequences(const void* src_dev, uint32_t n, uin
     const hipError_t e = hipMemcpy(out_host, out, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(out);
     return e == hipSuccess ? AOCLGPU_OK : AOCLGPU_ERR_HIP;
+}
+
+// Block-level external sequence producer for libzstd (ZSTD_sequenceProducer_F, /root/reference algos/zstd/lib/zstd.h:4065-4098;
+// consumed by ZSTD_registerSequenceProducer, zstd_compress.c:3346-3406, 7370-7386): the GPU match finder parses the block,
+// libzstd on the host does the entropy stage.  offBase values are resolved to real offsets with the format's repcode
+// rules (history {1, 4, 8} per block, as each block is parsed without history); the parse ends with a block delimiter
+// that carries the last literals.  Any failure returns ZSTD_SEQUENCE_PRODUCER_ERROR so that zstd can fall back.
+extern "C" size_t aoclgpu_zstd_sequence_producer(void* state, void* outSeqs, size_t outSeqsCapacity, const void* src, size_t srcSize,
+                                                 const void* dict, size_t dictSize, int compressionLevel, size_t windowSize)
+{
+    (void)state; (void)dict; (void)compressionLevel; (void)windowSize;
+    struct Seq { unsigned offset, litLength, matchLength, rep; };
+    const size_t kErr = (size_t)-1;
+    Seq* o = (Seq*)outSeqs;
+    if (dictSize != 0 || srcSize > (128u << 10) || !o || outSeqsCapacity < 1) return kErr;
+    if (srcSize < 7) { o[0] = Seq{0, (unsigned)srcSize, 0, 0}; return 1; }          // below the match finder's minimum
+    static std::mutex mu;
+    static void* dsrc = nullptr; static uint32_t* hout = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint32_t maxSeq = (128u << 10) / 3 + 16;
+    if (!dsrc && hipMalloc(&dsrc, (128u << 10) + 64) != hipSuccess) { dsrc = nullptr; return kErr; }
+    if (!hout) hout = (uint32_t*)malloc((2 + 3 * (size_t)maxSeq) * sizeof(uint32_t));
+    if (!hout || hipMemcpy(dsrc, src, srcSize, hipMemcpyHostToDevice) != hipSuccess) return kErr;
+    if (aoclgpu_debug_zstd_sequences(dsrc, (uint32_t)srcSize, hout, maxSeq, 0) != AOCLGPU_OK) return kErr;
+    const uint32_t nb = hout[0];
+    if ((size_t)nb + 1 > outSeqsCapacity || nb > maxSeq) return kErr;
+    uint32_t rep1 = 1, rep2 = 4, rep3 = 8;
+    size_t consumed = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t ll = hout[2 + 3 * i], ob = hout[3 + 3 * i], ml = hout[4 + 3 * i];
+        uint32_t off;
+        if (ob > 3) { off = ob - 3; rep3 = rep2; rep2 = rep1; rep1 = off; }
+        else if (ob == 1 && ll > 0) off = rep1;                                       // the fast strategy only emits repcode 1
+        else if (ob == 1) { off = rep2; rep2 = rep1; rep1 = off; }                    // litLength == 0 shifts the repcodes by one
+        else return kErr;
+        o[i] = Seq{off, ll, ml, 0};
+        consumed += (size_t)ll + ml;
+    }
+    (void)rep3;
+    if (consumed > srcSize) return kErr;
+    o[nb] = Seq{0, (unsigned)(srcSize - consumed), 0, 0};
+    return (size_t)nb + 1;
 }
 
 #ifdef ZSTD_TRACE

@@ -48,6 +48,14 @@ unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
 char*       aocl_setup_zstd_encode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
 char*       aocl_setup_zstd_decode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
 
+/* ---- Block-level external sequence producer for libzstd (algos/zstd/lib/zstd.h:4065-4098): has the ZSTD_sequenceProducer_F
+ *      signature (outSeqs is a ZSTD_Sequence*); a user of upstream / reference libzstd registers it with
+ *      ZSTD_registerSequenceProducer(cctx, NULL, (ZSTD_sequenceProducer_F*)aoclgpu_zstd_sequence_producer)
+ *      and the GPU match finder (level-1 "fast" parse, one block at a time, no history) feeds zstd's own entropy stage.
+ *      Returns the number of sequences incl. the closing block delimiter, or ZSTD_SEQUENCE_PRODUCER_ERROR ((size_t)-1). ---- */
+size_t aoclgpu_zstd_sequence_producer(void* state, void* outSeqs, size_t outSeqsCapacity, const void* src, size_t srcSize,
+                                      const void* dict, size_t dictSize, int compressionLevel, size_t windowSize);
+
 /* ---- RAP frame helpers (api/aocl_threads.h:109,133; threads/threads.c:315-336) ---- */
 int32_t aocl_get_rap_frame_bound_mt(void);                 /* 16 + 12 * max partitions (65535 for the GPU build) */
 int32_t aocl_skip_rap_frame_mt(char* src, int32_t src_size); /* 0: no RAP frame; > 0: its length; ERR_INVALID_INPUT on NULL */

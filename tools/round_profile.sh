@@ -12,6 +12,9 @@ for c in lz4 snappy zstd; do
 done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o lz4 -- python3 $R/bench.py --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
+for c in snappy zstd; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$c -o $c -- python3 $R/bench.py --codec $c --no-cpu-baseline > $out/trace_bench_$c.json 2> $out/trace_$c.err
+done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -o p -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_$ctr.json 2> $out/pmc_$ctr.err
 done
