@@ -52,6 +52,8 @@ char*       aocl_setup_zstd_decode(int optOff, int optLevel, size_t insize, size
  *      signature (outSeqs is a ZSTD_Sequence*); a user of upstream / reference libzstd registers it with
  *      ZSTD_registerSequenceProducer(cctx, NULL, (ZSTD_sequenceProducer_F*)aoclgpu_zstd_sequence_producer)
  *      and the GPU match finder (level-1 "fast" parse, one block at a time, no history) feeds zstd's own entropy stage.
+ *      Offsets are real offsets: set ZSTD_c_searchForExternalRepcodes = ZSTD_ps_enable so that zstd turns them back into repcodes
+ *      (it only does so by default from level 10 on).
  *      Returns the number of sequences incl. the closing block delimiter, or ZSTD_SEQUENCE_PRODUCER_ERROR ((size_t)-1). ---- */
 size_t aoclgpu_zstd_sequence_producer(void* state, void* outSeqs, size_t outSeqsCapacity, const void* src, size_t srcSize,
                                       const void* dict, size_t dictSize, int compressionLevel, size_t windowSize);
