@@ -612,15 +612,18 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
     return sh ? (a >> sh) | (b << (64 - sh)) : a;
 }
 
+// op0 > 0: dst[0, op0) is history the block may copy from (linked blocks of an LZ4 frame, LZ4_decompress_safe_usingDict
+// with the dictionary in front of the output, lz4.c:4985-5010); the block's own output is dst[op0, op0 + cap) and the
+// return value is the end position op0 + decoded size.
 template <bool RAP>
 __device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
-                                   uint8_t* ring, const bool rap)
+                                   uint8_t* ring, const bool rap, const int32_t op0 = 0)
 {
     const int lane = lane_id();
-    if (cap == 0) return (n == 1 && src[0] == 0) ? 0 : -1;   // lz4.c:3412-3416
+    if (cap == 0) return (n == 1 && src[0] == 0) ? op0 : -1;  // lz4.c:3412-3416
     if (n <= 0) return -1;                                    // lz4.c:3418
-    const int32_t iend = n, oend = cap;
-    int32_t ip = 0, op = 0, rend = 0;                         // ring holds compressed bytes [.., rend)
+    const int32_t iend = n, oend = op0 + cap;
+    int32_t ip = 0, op = op0, rend = 0;                       // ring holds compressed bytes [.., rend)
     uint4 pend = make_uint4(0, 0, 0, 0); bool have_pend = false;
     for (;;) {
         // ---- keep >= 160 staged bytes ahead of ip (requested one iteration early) ----
@@ -777,6 +780,32 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     if (threadIdx.x == 0) { b.out_len[c] = r; if (b.aux) b.aux[c] = lastrun; }
 }
 
+// The blocks of ONE stream with linked blocks (LZ4 frame format, blockMode LZ4F_blockLinked): explicit batch, decoded in
+// order by a single wavefront into b.dst back to back; every block may copy from everything decoded before it (offsets are
+// 16-bit, so from the previous 64 KB).  src_len[i] bit 31 marks a stored (uncompressed) block.  out_len[i] = decoded size
+// of block i or < 0 (then every later block is < 0 as well); dst_cap[i] bounds block i, dst_off is ignored.
+__global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch b, uint64_t dst_total)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 32];
+    const int lane = lane_id();
+    int32_t op = 0; bool bad = false;
+    for (uint32_t c = 0; c < b.nchunks; ++c) {
+        int32_t r = -1;
+        if (!bad) {
+            const gbyte* src = (const gbyte*)b.src + b.src_off[c];
+            const uint32_t sl = b.src_len[c], n = sl & 0x7FFFFFFFu;
+            uint32_t cap = b.dst_cap[c];
+            if ((uint64_t)op + cap > dst_total) cap = (uint32_t)(dst_total - (uint64_t)op);
+            if (sl >> 31) {
+                if (n <= cap) { wave_copy((gbyte*)b.dst + op, src, n, lane); r = op + (int32_t)n; }
+            } else r = lz4_decompress_wave<false>(src, (int32_t)n, (gbyte*)b.dst, (int32_t)cap, ring, false, op);
+            wave_fence();
+        }
+        if (r < 0) { bad = true; if (lane == 0) b.out_len[c] = -1; }
+        else { if (lane == 0) b.out_len[c] = r - op; op = r; }
+    }
+}
+
 template <bool RAP>
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 {
@@ -845,6 +874,11 @@ extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* strea
 {
     if (int rc = aoclgpu::check_batch(b, /*decompress=*/true)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
+    if (b->reserved & AOCLGPU_FLAG_LZ4_LINKED) {
+        if (!b->src_off) { aoclgpu::set_error_msg("lz4: linked blocks need an explicit batch"); return AOCLGPU_ERR_ARG; }
+        hipLaunchKernelGGL(aoclgpu::lz4_decompress_linked_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *b, (uint64_t)b->total_bytes);
+        return aoclgpu::check_launch("lz4_decompress_linked_kernel");
+    }
     if (b->reserved & AOCLGPU_FLAG_RAP_PARTITIONS)
         hipLaunchKernelGGL(aoclgpu::lz4_decompress_kernel<true>, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
     else

@@ -1,0 +1,340 @@
+// csrc/lz4frame_api.cpp -- LZ4 frame format (reference: algos/lz4/lz4frame.c, lz4frame.h, built with LZ4_FRAME_FORMAT_SUPPORT,
+// CMakeLists.txt:311-325) on top of the GPU block codec.  Host buffers in, host buffers out, no CPU codec anywhere:
+// the blocks of a frame are LZ4 blocks compressed / decoded by lz4_kernels.hip, this file only does the framing
+// (header, block sizes, end mark) and the xxHash32 checksums of lz4frame.c:259-266, 758-761, 1004-1010.
+//
+//  * LZ4F_compressFrame (lz4frame.c:373-460): every block is compressed on its own, all blocks of the frame in one
+//    launch, with the reference's `srcSize - 1` output limit (LZ4F_makeBlock :740-763: a block that does not shrink is
+//    stored).  For blockMode LZ4F_blockIndependent - and for any input that fits one block, which the reference switches
+//    to independent itself (:394-395) - the frame is byte-identical to the reference's.  A multi-block frame requested
+//    with LZ4F_blockLinked (the default) is ALSO written with independent blocks and says so in its FLG byte: linked
+//    blocks chain every block to the hash table of the one before (LZ4_compress_fast_continue), i.e. a frame would be
+//    one sequential stream; the result is a valid frame every LZ4F decoder reads, a little larger than the reference's.
+//    Levels: the fast compressor at default acceleration only (compressionLevel 0..2; LZ4HC levels and negative
+//    "acceleration" levels return LZ4F_ERROR_compressionLevel_invalid).
+//  * LZ4F_decompress (lz4frame.c:1398-1860): takes a WHOLE frame per call (the reference also accepts it in pieces;
+//    here an incomplete frame is LZ4F_ERROR_frameSize_wrong).  Independent blocks are decoded in one launch, one
+//    wavefront per block; linked blocks by one wavefront in order, each block copying from what was decoded before it.
+//    Header, block and content checksums are verified.  Skippable frames are skipped.
+#include "../../include/aocl_native_api.h"
+#include "../../include/aocl_gpu_codec.h"
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+enum {   // lz4frame.h:511-533
+    E_OK = 0, E_GENERIC, E_maxBlockSize_invalid, E_blockMode_invalid, E_contentChecksumFlag_invalid, E_compressionLevel_invalid,
+    E_headerVersion_wrong, E_blockChecksum_invalid, E_reservedFlag_set, E_allocation_failed, E_srcSize_tooLarge,
+    E_dstMaxSize_tooSmall, E_frameHeader_incomplete, E_frameType_unknown, E_frameSize_wrong, E_srcPtr_wrong,
+    E_decompressionFailed, E_headerChecksum_invalid, E_contentChecksum_invalid, E_frameDecoding_alreadyStarted, E_maxCode
+};
+const char* const kErrNames[] = {
+    "OK_NoError", "ERROR_GENERIC", "ERROR_maxBlockSize_invalid", "ERROR_blockMode_invalid", "ERROR_contentChecksumFlag_invalid",
+    "ERROR_compressionLevel_invalid", "ERROR_headerVersion_wrong", "ERROR_blockChecksum_invalid", "ERROR_reservedFlag_set",
+    "ERROR_allocation_failed", "ERROR_srcSize_tooLarge", "ERROR_dstMaxSize_tooSmall", "ERROR_frameHeader_incomplete",
+    "ERROR_frameType_unknown", "ERROR_frameSize_wrong", "ERROR_srcPtr_wrong", "ERROR_decompressionFailed",
+    "ERROR_headerChecksum_invalid", "ERROR_contentChecksum_invalid", "ERROR_frameDecoding_alreadyStarted", "ERROR_maxCode" };
+size_t err(int code) { return (size_t)0 - (size_t)code; }                    // lz4frame.c:283-288
+
+const uint32_t kMagic = 0x184D2204u, kSkipMagic = 0x184D2A50u;              // lz4frame.c:225-226
+const size_t kMaxHeader = 19, kBH = 4, kBF = 4;                              // maxFHSize, BHSize, BFSize (:228-232)
+const uint32_t kStored = 0x80000000u;                                        // LZ4F_BLOCKUNCOMPRESSED_FLAG
+
+uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t rd64(const uint8_t* p) { return rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+void wr64(uint8_t* p, uint64_t v) { wr32(p, (uint32_t)v); wr32(p + 4, (uint32_t)(v >> 32)); }
+
+// xxHash32 (the published algorithm; the reference's copy is algos/lz4/xxhash.c) - checksums only, host side
+uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+uint32_t xxh32(const void* data, size_t len, uint32_t seed)
+{
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const uint8_t* p = (const uint8_t*)data; const uint8_t* const end = p + len;
+    uint32_t h;
+    if (len >= 16) {
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t* const limit = end - 16;
+        do {
+            v1 = rotl(v1 + rd32(p) * P2, 13) * P1; v2 = rotl(v2 + rd32(p + 4) * P2, 13) * P1;
+            v3 = rotl(v3 + rd32(p + 8) * P2, 13) * P1; v4 = rotl(v4 + rd32(p + 12) * P2, 13) * P1;
+            p += 16;
+        } while (p <= limit);
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+    } else h = seed + P5;
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl(h + rd32(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl(h + *p * P5, 11) * P1; p++; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
+size_t block_size(int id)
+{   // LZ4F_getBlockSize (lz4frame.c:290-298): 0 = default = 64 KB
+    if (id == 0) id = 4;
+    if (id < 4 || id > 7) return 0;
+    return (size_t)1 << (8 + 2 * id);
+}
+int optimal_bsid(int requested, size_t srcSize)
+{   // LZ4F_optimalBSID (lz4frame.c:304-316)
+    int proposed = 4; size_t maxBlock = 64u << 10;
+    while (requested > proposed) {
+        if (srcSize <= maxBlock) return proposed;
+        proposed++; maxBlock <<= 2;
+    }
+    return requested;
+}
+
+struct DevBuf {   // device allocations released on scope exit
+    std::vector<void*> p;
+    ~DevBuf() { for (void* q : p) if (q) (void)hipFree(q); }
+    void* get(size_t bytes) { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr; p.push_back(q); return q; }
+};
+
+// upload the explicit-mode geometry arrays of a batch; returns false on failure
+bool upload_geometry(DevBuf& D, aoclgpu_batch& b, const std::vector<uint64_t>& so, const std::vector<uint32_t>& sl,
+                     const std::vector<uint64_t>& dofs, const std::vector<uint32_t>& dc)
+{
+    const size_t n = so.size();
+    uint64_t* d_so = (uint64_t*)D.get(n * 8); uint32_t* d_sl = (uint32_t*)D.get(n * 4);
+    uint64_t* d_do = (uint64_t*)D.get(n * 8); uint32_t* d_dc = (uint32_t*)D.get(n * 4);
+    int32_t* d_ol = (int32_t*)D.get(n * 4);
+    if (!d_so || !d_sl || !d_do || !d_dc || !d_ol) return false;
+    if (hipMemcpy(d_so, so.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_sl, sl.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_do, dofs.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_dc, dc.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+    b.src_off = d_so; b.src_len = d_sl; b.dst_off = d_do; b.dst_cap = d_dc; b.out_len = d_ol; b.nchunks = (uint32_t)n;
+    return true;
+}
+
+struct FrameHeader { int bsid; bool independent, blockChecksum, contentChecksum, hasSize, hasDict; uint64_t contentSize; uint32_t dictID; size_t bytes; };
+
+// LZ4F_decodeHeader (lz4frame.c:1190-1290) for a regular frame; returns 0 or an error code
+size_t parse_header(const uint8_t* p, size_t n, FrameHeader* h)
+{
+    if (n < 7) return err(E_frameHeader_incomplete);
+    if (rd32(p) != kMagic) return err(E_frameType_unknown);
+    const uint32_t flg = p[4], bd = p[5];
+    if (((flg >> 6) & 3) != 1) return err(E_headerVersion_wrong);
+    if ((flg >> 1) & 1) return err(E_reservedFlag_set);
+    h->independent = (flg >> 5) & 1; h->blockChecksum = (flg >> 4) & 1; h->hasSize = (flg >> 3) & 1;
+    h->contentChecksum = (flg >> 2) & 1; h->hasDict = flg & 1;
+    h->bytes = 7 + (h->hasSize ? 8 : 0) + (h->hasDict ? 4 : 0);
+    if (n < h->bytes) return err(E_frameHeader_incomplete);
+    if ((bd >> 7) & 1) return err(E_reservedFlag_set);
+    h->bsid = (bd >> 4) & 7;
+    if (h->bsid < 4) return err(E_maxBlockSize_invalid);
+    if (bd & 15) return err(E_reservedFlag_set);
+    if (((xxh32(p + 4, h->bytes - 5, 0) >> 8) & 0xFF) != p[h->bytes - 1]) return err(E_headerChecksum_invalid);
+    h->contentSize = h->hasSize ? rd64(p + 6) : 0;
+    h->dictID = h->hasDict ? rd32(p + 6 + (h->hasSize ? 8 : 0)) : 0;
+    return 0;
+}
+
+}  // namespace
+
+struct LZ4F_dctx_s { unsigned version; LZ4F_frameInfo_t info; bool haveInfo; };
+
+extern "C" {
+
+unsigned LZ4F_isError(size_t code) { return code > err(E_maxCode); }          // lz4frame.c:270-273
+const char* LZ4F_getErrorName(size_t code)
+{
+    if (LZ4F_isError(code)) return kErrNames[(size_t)0 - code];
+    return "Unspecified error code";
+}
+unsigned LZ4F_getVersion(void) { return 100; }                                // LZ4F_VERSION
+int LZ4F_compressionLevel_max(void) { return 12; }                            // LZ4HC_CLEVEL_MAX
+
+size_t LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs)
+{   // lz4frame.c:324-361 with autoFlush = 1
+    const int bsid = prefs ? (int)prefs->frameInfo.blockSizeID : 0;
+    const size_t bs = block_size(bsid);
+    if (!bs) return err(E_maxBlockSize_invalid);
+    const size_t full = srcSize / bs, last = srcSize & (bs - 1), nb = full + (last > 0);
+    const size_t blockCrc = (prefs && prefs->frameInfo.blockChecksumFlag) ? kBF : 0;
+    const size_t frameEnd = kBH + ((prefs && prefs->frameInfo.contentChecksumFlag) ? kBF : 0);
+    return kMaxHeader + (kBH + blockCrc) * nb + bs * full + last + frameEnd;
+}
+
+size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* prefsPtr)
+{
+    LZ4F_preferences_t prefs;
+    if (prefsPtr) prefs = *prefsPtr; else memset(&prefs, 0, sizeof(prefs));
+    if (!dstBuffer || (!srcBuffer && srcSize)) return err(E_GENERIC);
+    if (prefs.compressionLevel < 0 || prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);   // only the fast compressor
+    if (prefs.frameInfo.contentSize != 0) prefs.frameInfo.contentSize = srcSize;                              // :389-390
+    prefs.frameInfo.blockSizeID = (LZ4F_blockSizeID_t)optimal_bsid((int)prefs.frameInfo.blockSizeID, srcSize);
+    if (!block_size((int)prefs.frameInfo.blockSizeID)) return err(E_maxBlockSize_invalid);
+    if (dstCapacity < LZ4F_compressFrameBound(srcSize, &prefs)) return err(E_dstMaxSize_tooSmall);           // :400-401
+    if (prefs.frameInfo.blockSizeID == 0) prefs.frameInfo.blockSizeID = LZ4F_max64KB;                         // :612
+    const size_t bs = block_size((int)prefs.frameInfo.blockSizeID);
+    if (srcSize > ((size_t)0xFFFFFFFFu - 64) * 1) return err(E_srcSize_tooLarge);
+    uint8_t* const dst = (uint8_t*)dstBuffer; uint8_t* op = dst;
+    // ---- frame header (lz4frame.c:670-699); blocks are always independent here ----
+    wr32(op, kMagic); op += 4;
+    uint8_t* const hs = op;
+    *op++ = (uint8_t)((1 << 6) | (1 << 5) | ((prefs.frameInfo.blockChecksumFlag & 1) << 4) | ((prefs.frameInfo.contentSize > 0) << 3) |
+                      ((prefs.frameInfo.contentChecksumFlag & 1) << 2) | (prefs.frameInfo.dictID > 0));
+    *op++ = (uint8_t)(((int)prefs.frameInfo.blockSizeID & 7) << 4);
+    if (prefs.frameInfo.contentSize) { wr64(op, prefs.frameInfo.contentSize); op += 8; }
+    if (prefs.frameInfo.dictID) { wr32(op, prefs.frameInfo.dictID); op += 4; }
+    *op = (uint8_t)(xxh32(hs, (size_t)(op - hs), 0) >> 8); op++;
+    // ---- blocks: one launch for the whole frame ----
+    const size_t nb = (srcSize + bs - 1) / bs;
+    if (nb) {
+        DevBuf D;
+        const size_t slot = (bs + 15) & ~(size_t)15;
+        uint8_t* d_src = (uint8_t*)D.get(srcSize); uint8_t* d_dst = (uint8_t*)D.get(nb * slot);
+        if (!d_src || !d_dst) return err(E_allocation_failed);
+        std::vector<uint64_t> so(nb), dofs(nb); std::vector<uint32_t> sl(nb), dc(nb);
+        for (size_t i = 0; i < nb; ++i) {
+            so[i] = i * bs; sl[i] = (uint32_t)(srcSize - i * bs < bs ? srcSize - i * bs : bs);
+            dofs[i] = i * slot; dc[i] = sl[i] - 1;                                                             // LZ4F_makeBlock :747-749
+        }
+        aoclgpu_batch b; memset(&b, 0, sizeof(b));
+        b.src = d_src; b.dst = d_dst;
+        if (hipMemcpy(d_src, srcBuffer, srcSize, hipMemcpyHostToDevice) != hipSuccess || !upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
+        if (aoclgpu_lz4_compress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+        std::vector<int32_t> ol(nb);
+        std::vector<uint8_t> slots(nb * slot);
+        if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(slots.data(), d_dst, nb * slot, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+        for (size_t i = 0; i < nb; ++i) {
+            uint32_t c = ol[i] > 0 ? (uint32_t)ol[i] : 0;
+            if (c == 0) {                                                                                       // stored block
+                c = sl[i]; wr32(op, c | kStored); memcpy(op + kBH, (const uint8_t*)srcBuffer + so[i], c);
+            } else { wr32(op, c); memcpy(op + kBH, slots.data() + i * slot, c); }
+            if (prefs.frameInfo.blockChecksumFlag) wr32(op + kBH + c, xxh32(op + kBH, c, 0));
+            op += kBH + c + (prefs.frameInfo.blockChecksumFlag ? kBF : 0);
+        }
+    }
+    wr32(op, 0); op += 4;                                                                                     // end mark (:1002)
+    if (prefs.frameInfo.contentChecksumFlag) { wr32(op, xxh32(srcBuffer, srcSize, 0)); op += 4; }
+    return (size_t)(op - dst);
+}
+
+size_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version)
+{
+    if (!dctxPtr) return err(E_GENERIC);
+    LZ4F_dctx* d = (LZ4F_dctx*)calloc(1, sizeof(LZ4F_dctx));
+    if (!d) { *dctxPtr = nullptr; return err(E_allocation_failed); }
+    d->version = version; *dctxPtr = d;
+    return 0;
+}
+size_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx) { free(dctx); return 0; }
+void LZ4F_resetDecompressionContext(LZ4F_dctx* dctx) { if (dctx) dctx->haveInfo = false; }
+
+size_t LZ4F_headerSize(const void* src, size_t srcSize)
+{   // lz4frame.c:1150-1180
+    if (!src) return err(E_srcPtr_wrong);
+    if (srcSize < 5) return err(E_frameHeader_incomplete);
+    const uint8_t* p = (const uint8_t*)src;
+    if ((rd32(p) & 0xFFFFFFF0u) == kSkipMagic) return 8;
+    if (rd32(p) != kMagic) return err(E_frameType_unknown);
+    return 7 + ((p[4] >> 3) & 1 ? 8 : 0) + (p[4] & 1 ? 4 : 0);
+}
+
+size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* src, size_t* srcSizePtr)
+{   // lz4frame.c:1310-1360: decodes the header, consumes it, hints at the next block header
+    if (!dctx || !info || !src || !srcSizePtr) return err(E_GENERIC);
+    FrameHeader h;
+    const size_t r = parse_header((const uint8_t*)src, *srcSizePtr, &h);
+    if (LZ4F_isError(r)) { *srcSizePtr = 0; return r; }
+    memset(info, 0, sizeof(*info));
+    info->blockSizeID = (LZ4F_blockSizeID_t)h.bsid; info->blockMode = h.independent ? LZ4F_blockIndependent : LZ4F_blockLinked;
+    info->contentChecksumFlag = h.contentChecksum ? LZ4F_contentChecksumEnabled : LZ4F_noContentChecksum;
+    info->frameType = LZ4F_frame; info->contentSize = h.contentSize; info->dictID = h.dictID;
+    info->blockChecksumFlag = h.blockChecksum ? LZ4F_blockChecksumEnabled : LZ4F_noBlockChecksum;
+    dctx->info = *info; dctx->haveInfo = true;
+    *srcSizePtr = h.bytes;
+    return kBH;
+}
+
+size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                       const LZ4F_decompressOptions_t* opts)
+{
+    (void)opts;
+    if (!dctx || !dstSizePtr || !srcSizePtr || (!srcBuffer && *srcSizePtr)) return err(E_GENERIC);
+    const uint8_t* const src = (const uint8_t*)srcBuffer; const size_t n = *srcSizePtr, cap = *dstSizePtr;
+    *srcSizePtr = 0; *dstSizePtr = 0;
+    if (n >= 8 && (rd32(src) & 0xFFFFFFF0u) == kSkipMagic) {                                                  // skippable frame (:1236-1246)
+        const size_t sz = rd32(src + 4);
+        if (n < 8 + sz) return err(E_frameSize_wrong);
+        *srcSizePtr = 8 + sz; return 0;
+    }
+    FrameHeader h;
+    { const size_t r = parse_header(src, n, &h); if (LZ4F_isError(r)) return r; }
+    const size_t bs = block_size(h.bsid);
+    // ---- walk the block headers up to the end mark ----
+    struct Blk { size_t off; uint32_t len; bool stored; };
+    std::vector<Blk> blks;
+    size_t ip = h.bytes;
+    for (;;) {
+        if (n - ip < kBH) return err(E_frameSize_wrong);
+        const uint32_t v = rd32(src + ip); ip += kBH;
+        if (v == 0) break;
+        const uint32_t len = v & 0x7FFFFFFFu;
+        if (len > bs) return err(E_maxBlockSize_invalid);                                                       // :1541-1542
+        if (n - ip < (size_t)len + (h.blockChecksum ? kBF : 0)) return err(E_frameSize_wrong);
+        if (h.blockChecksum && xxh32(src + ip, len, 0) != rd32(src + ip + len)) return err(E_blockChecksum_invalid);
+        blks.push_back(Blk{ip, len, (v & kStored) != 0});
+        ip += len + (h.blockChecksum ? kBF : 0);
+    }
+    uint32_t wantCrc = 0;
+    if (h.contentChecksum) { if (n - ip < kBF) return err(E_frameSize_wrong); wantCrc = rd32(src + ip); ip += kBF; }
+    const size_t nb = blks.size();
+    size_t produced = 0;
+    if (nb) {
+        if (!dstBuffer) return err(E_dstMaxSize_tooSmall);
+        DevBuf D;
+        const size_t payload = ip - h.bytes;
+        uint8_t* d_src = (uint8_t*)D.get(payload);
+        if (!d_src || hipMemcpy(d_src, src + h.bytes, payload, hipMemcpyHostToDevice) != hipSuccess) return err(E_allocation_failed);
+        std::vector<uint64_t> so(nb), dofs(nb); std::vector<uint32_t> sl(nb), dc(nb);
+        std::vector<int32_t> ol(nb);
+        aoclgpu_batch b; memset(&b, 0, sizeof(b));
+        b.src = d_src;
+        if (h.independent) {
+            // every block into its own slot, then the slots are joined in order (blocks need not be full)
+            uint8_t* d_slots = (uint8_t*)D.get(nb * bs);
+            if (!d_slots) return err(E_allocation_failed);
+            for (size_t i = 0; i < nb; ++i) { so[i] = blks[i].off - h.bytes; sl[i] = blks[i].stored ? 1 : blks[i].len; dofs[i] = i * bs; dc[i] = (uint32_t)bs; }
+            // stored blocks: a one-byte dummy block for the launch (decodes to nothing useful), overwritten below
+            b.dst = d_slots;
+            if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
+            if (aoclgpu_lz4_decompress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+            if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+            for (size_t i = 0; i < nb; ++i) {
+                if (blks[i].stored) ol[i] = (int32_t)blks[i].len;
+                else if (ol[i] < 0) return err(E_decompressionFailed);
+                if (produced + (size_t)ol[i] > cap) return err(E_dstMaxSize_tooSmall);
+                if (blks[i].stored) memcpy((uint8_t*)dstBuffer + produced, src + blks[i].off, blks[i].len);
+                else if (hipMemcpy((uint8_t*)dstBuffer + produced, d_slots + i * bs, (size_t)ol[i], hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+                produced += (size_t)ol[i];
+            }
+        } else {
+            // linked blocks: one wavefront, in order, into one contiguous device buffer
+            const size_t total = nb * bs < cap ? nb * bs : cap;
+            if (total > 0x7FFFFFFFu) return err(E_srcSize_tooLarge);
+            uint8_t* d_out = (uint8_t*)D.get(total);
+            if (!d_out) return err(E_allocation_failed);
+            for (size_t i = 0; i < nb; ++i) { so[i] = blks[i].off - h.bytes; sl[i] = blks[i].len | (blks[i].stored ? kStored : 0u); dofs[i] = 0; dc[i] = (uint32_t)bs; }
+            b.dst = d_out; b.reserved = AOCLGPU_FLAG_LZ4_LINKED; b.total_bytes = total;
+            if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
+            if (aoclgpu_lz4_decompress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+            if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+            for (size_t i = 0; i < nb; ++i) { if (ol[i] < 0) return err(nb * bs > cap ? E_dstMaxSize_tooSmall : E_decompressionFailed); produced += (size_t)ol[i]; }
+            if (produced > cap) return err(E_dstMaxSize_tooSmall);
+            if (hipMemcpy(dstBuffer, d_out, produced, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+        }
+    }
+    if (h.hasSize && h.contentSize != produced) return err(E_frameSize_wrong);                                 // :1722-1723
+    if (h.contentChecksum && xxh32(dstBuffer, produced, 0) != wantCrc) return err(E_contentChecksum_invalid);
+    *srcSizePtr = ip; *dstSizePtr = produced;
+    return 0;
+}
+
+}  // extern "C"

@@ -68,6 +68,10 @@ typedef struct {
  * may end right after a match (lz4.c:3935,4147-4181); Snappy: chunks carry no varint length prefix and dst_cap[i] is the
  * exact decoded size (snappy.cc:2567-2654); Zstd: no effect (partitions are whole frames). */
 #define AOCLGPU_FLAG_RAP_PARTITIONS 0x100u
+/* LZ4 decompress, explicit batch: the chunks are the blocks of ONE stream with linked blocks (LZ4 frame format, lz4frame.h
+ * LZ4F_blockLinked): decoded in order into dst back to back (dst_off is ignored, total_bytes = capacity of dst), every block
+ * may copy from what was decoded before it; src_len[i] bit 31 marks a stored block. */
+#define AOCLGPU_FLAG_LZ4_LINKED 0x200u
 
 /* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
  * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at

@@ -28,6 +28,37 @@ int         LZ4_decompress_safe(const char* src, char* dst, int compressedSize, 
 char*       aocl_setup_lz4(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
 void        aocl_destroy_lz4(void);
 
+/* ---- LZ4 frame format (algos/lz4/lz4frame.h:100-260, 380-470; lz4frame.c:373-460, 1398-1860) on the GPU block codec.
+ *      Types mirror lz4frame.h.  LZ4F_compressFrame: the fast compressor only (compressionLevel 0..2), blocks always
+ *      independent (byte-identical to the reference for LZ4F_blockIndependent and for single-block inputs);
+ *      LZ4F_decompress: one whole frame per call, independent and linked blocks, all checksums verified. ---- */
+typedef size_t LZ4F_errorCode_t;
+typedef enum { LZ4F_default = 0, LZ4F_max64KB = 4, LZ4F_max256KB = 5, LZ4F_max1MB = 6, LZ4F_max4MB = 7 } LZ4F_blockSizeID_t;
+typedef enum { LZ4F_blockLinked = 0, LZ4F_blockIndependent } LZ4F_blockMode_t;
+typedef enum { LZ4F_noContentChecksum = 0, LZ4F_contentChecksumEnabled } LZ4F_contentChecksum_t;
+typedef enum { LZ4F_noBlockChecksum = 0, LZ4F_blockChecksumEnabled } LZ4F_blockChecksum_t;
+typedef enum { LZ4F_frame = 0, LZ4F_skippableFrame } LZ4F_frameType_t;
+typedef struct {
+    LZ4F_blockSizeID_t blockSizeID; LZ4F_blockMode_t blockMode; LZ4F_contentChecksum_t contentChecksumFlag; LZ4F_frameType_t frameType;
+    unsigned long long contentSize; unsigned dictID; LZ4F_blockChecksum_t blockChecksumFlag;
+} LZ4F_frameInfo_t;
+typedef struct { LZ4F_frameInfo_t frameInfo; int compressionLevel; unsigned autoFlush; unsigned favorDecSpeed; unsigned reserved[3]; } LZ4F_preferences_t;
+typedef struct { unsigned stableDst; unsigned reserved[3]; } LZ4F_decompressOptions_t;
+typedef struct LZ4F_dctx_s LZ4F_dctx;
+unsigned    LZ4F_isError(LZ4F_errorCode_t code);
+const char* LZ4F_getErrorName(LZ4F_errorCode_t code);
+unsigned    LZ4F_getVersion(void);
+int         LZ4F_compressionLevel_max(void);
+size_t      LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
+size_t      LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
+LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version);
+LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);
+void        LZ4F_resetDecompressionContext(LZ4F_dctx* dctx);
+size_t      LZ4F_headerSize(const void* src, size_t srcSize);
+size_t      LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* frameInfoPtr, const void* srcBuffer, size_t* srcSizePtr);
+size_t      LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                            const LZ4F_decompressOptions_t* dOptPtr);
+
 /* ---- Snappy C binding (algos/snappy/snappy-c.h:28-138) ---- */
 typedef enum { SNAPPY_OK = 0, SNAPPY_INVALID_INPUT = 1, SNAPPY_BUFFER_TOO_SMALL = 2 } snappy_status;
 snappy_status snappy_compress(const char* input, size_t input_length, char* compressed, size_t* compressed_length);

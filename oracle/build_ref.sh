@@ -32,6 +32,7 @@ for f in utils/utils.cpp api/api.cpp api/codec.cpp; do cc1 g++ "$REF/$f" "${VERS
 for f in snappy-sinksource snappy-stubs-internal snappy snappy-c; do cc1 g++ "$REF/algos/snappy/$f.cc" $SNAP "${VERS[@]}"; done
 waitall
 cc1 gcc "$REF/algos/lz4/lz4.c"; cc1 gcc "$REF/algos/lz4/lz4hc.c"; cc1 gcc "$REF/algos/lz4/xxhash.c"   # lz4hc: producer of LZ4HC streams for the decoder tests
+cc1 gcc "$REF/algos/lz4/lz4frame.c"                        # LZ4 frame format (LZ4_FRAME_FORMAT_SUPPORT, CMakeLists.txt:311-325): ground truth of csrc/lz4frame_api.cpp
 for f in $4; do cc1 gcc "$REF/$f"; done
 n=0
 for f in "$REF"/algos/zstd/lib/common/*.c "$REF"/algos/zstd/lib/compress/*.c "$REF"/algos/zstd/lib/decompress/*.c "$REF"/algos/zstd/lib/decompress/*.S; do

@@ -1,0 +1,122 @@
+"""LZ4 frame format on the GPU block codec (csrc/lz4frame_api.cpp) against the reference's lz4frame.c (oracle/_ref):
+SURVEY 8f row 3.  CPU part: bounds, header parsing, error codes (no codec call).  GPU part: frames byte-identical to
+LZ4F_compressFrame for independent blocks, every frame readable by the reference, reference frames (linked and independent
+blocks, stored blocks, all checksum options) decoded on the GPU, corrupted frames rejected."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import aocl_compression_amd as a
+from aocl_compression_amd import api
+import oracle_lib as ol
+import lz4f_lib as lf
+
+
+@pytest.fixture(scope="module")
+def G():
+    return lf.bind(api.load_library())
+
+
+@pytest.fixture(scope="module")
+def R():
+    if not os.path.exists(ol.REF_SO):
+        pytest.skip("reference build not present")
+    L = C.CDLL(ol.REF_SO)
+    if not hasattr(L, "LZ4F_compressFrame"):
+        pytest.skip("reference build without lz4frame.c")
+    return lf.bind(L)
+
+
+SIZES = [0, 1, 12, 13, 100, 65535, 65536, 65537, 200000, 262144, 262145, 1 << 20, (1 << 20) + 7, 5 << 20]
+OPTS = [dict(), dict(independent=True), dict(bsid=5, independent=True, content_checksum=True),
+        dict(bsid=6, independent=True, block_checksum=True, content_size=True), dict(bsid=7, independent=True, content_checksum=True, block_checksum=True),
+        dict(bsid=7), dict(bsid=5, content_size=True)]
+
+
+def test_bounds_and_errors_match_reference(G, R):
+    for n in SIZES + [4 << 20, (4 << 20) + 1, 123456789]:
+        assert G.LZ4F_compressFrameBound(n, None) == R.LZ4F_compressFrameBound(n, None)
+        for o in OPTS:
+            p = lf.prefs(**o)
+            assert G.LZ4F_compressFrameBound(n, C.byref(p)) == R.LZ4F_compressFrameBound(n, C.byref(p)), (n, o)
+    for code in range(1, 20):
+        e = (1 << 64) - code
+        assert G.LZ4F_isError(e) == R.LZ4F_isError(e) == 1
+        assert G.LZ4F_getErrorName(e) == R.LZ4F_getErrorName(e)
+    assert not G.LZ4F_isError(0) and not G.LZ4F_isError(12345)
+
+
+def test_header_parsing_matches_reference(G, R):
+    data = a.corpus.make("text", 300000).tobytes()
+    for o in OPTS:
+        frame = lf.compress(R, data, lf.prefs(**o))
+        assert G.LZ4F_headerSize(frame, len(frame)) == R.LZ4F_headerSize(frame, len(frame))
+        gi, ri = lf.FrameInfo(), lf.FrameInfo()
+        for L, info in ((G, gi), (R, ri)):
+            ctx = C.c_void_p(); L.LZ4F_createDecompressionContext(C.byref(ctx), 100)
+            n = C.c_size_t(len(frame))
+            hint = L.LZ4F_getFrameInfo(ctx, C.byref(info), frame, C.byref(n))
+            assert not L.LZ4F_isError(hint)
+            info.consumed = n.value
+            L.LZ4F_freeDecompressionContext(ctx)
+        assert bytes(gi) == bytes(ri) and gi.consumed == ri.consumed
+    bad = bytearray(lf.compress(R, data, lf.prefs(content_size=True)))
+    bad[6] ^= 1                                                      # content size changed: header checksum no longer fits
+    ctx = C.c_void_p(); G.LZ4F_createDecompressionContext(C.byref(ctx), 100)
+    n = C.c_size_t(len(bad)); info = lf.FrameInfo()
+    assert G.LZ4F_getErrorName(G.LZ4F_getFrameInfo(ctx, C.byref(info), bytes(bad), C.byref(n))) == b"ERROR_headerChecksum_invalid"
+    G.LZ4F_freeDecompressionContext(ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text", "binary", "random"])
+def test_compress_frames(eng, G, R, kind):
+    base = a.corpus.make(kind, 6 << 20).tobytes()
+    for n in SIZES:
+        data = base[1000:1000 + n]
+        for o in OPTS:
+            p = lf.prefs(**o)
+            got = lf.compress(G, data, p)
+            assert isinstance(got, bytes), (n, o, got)
+            back = lf.decompress(R, got, n)
+            assert back == (data, len(got)), (n, o, back if isinstance(back, str) else "bytes differ")
+            bs = 1 << (8 + 2 * max(p.frameInfo.blockSizeID, 4))
+            if o.get("independent") or n <= 65536 or (o.get("bsid", 0) >= 5 and n <= 262144) or (o.get("bsid", 0) >= 6 and n <= (1 << 20)) or (o.get("bsid", 0) >= 7 and n <= (4 << 20)):
+                assert got == lf.compress(R, data, p), (n, o)        # independent blocks / one block: the reference's bytes
+    assert lf.compress(G, base[:1000], lf.prefs(level=5)) == "ERROR_compressionLevel_invalid"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text", "binary", "random", "database"])
+def test_decompress_reference_frames(eng, G, R, kind):
+    base = a.corpus.make(kind, 6 << 20).tobytes()
+    for n in SIZES:
+        data = base[777:777 + n]
+        for o in OPTS:
+            frame = lf.compress(R, data, lf.prefs(**o))
+            assert lf.decompress(G, frame, n) == (data, len(frame)), (n, o)
+            assert lf.decompress(G, frame + b"tail", n + 10) == (data, len(frame))           # stops at the end of the frame
+
+
+@pytest.mark.gpu
+def test_malformed_frames(eng, G, R):
+    data = a.corpus.make("text", 400000).tobytes()
+    rng = np.random.default_rng(5)
+    for o in OPTS:
+        frame = lf.compress(R, data, lf.prefs(**o))
+        assert lf.decompress(G, frame[:-1], len(data)) == "ERROR_frameSize_wrong"
+        assert isinstance(lf.decompress(G, frame, len(data) - 1), str)                       # output too small
+        for _ in range(12):
+            bad = bytearray(frame)
+            k = int(rng.integers(4, len(bad)))
+            bad[k] ^= 1 << int(rng.integers(0, 8))
+            want = lf.decompress(R, bytes(bad), len(data) + 65536)
+            got = lf.decompress(G, bytes(bad), len(data) + 65536)
+            if isinstance(want, tuple) and want[1] == len(bad):
+                assert got == want, (o, k)                                                   # a harmless flip (no checksum covers it)
+            else:
+                assert isinstance(got, str) or got == want, (o, k, want if isinstance(want, str) else "ok")
+    skip = b"\x52\x2A\x4D\x18" + (5).to_bytes(4, "little") + b"hello"
+    assert lf.decompress(G, skip + lf.compress(R, data[:100], None), 100) == (b"", 13)
