@@ -3,6 +3,7 @@
 #include "common.hip.h"
 #include "host_util.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -220,6 +221,7 @@ static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_
     {
         aoclgpu_batch b; std::memset(&b, 0, sizeof(b));
         b.src = dsrc; b.dst = ddst; b.out_len = dlen; b.nchunks = 1;
+        if (const char* ex = getenv("AOCLGPU_EXPERIMENT")) b.reserved = (uint32_t)atoi(ex) & 0xFFu;   // experiment switches of the test tools
         if (op == 0) { b.total_bytes = n; b.chunk_bytes = n ? n : 1; b.slot_bytes = cap; }
         else {
             uint32_t sl = (uint32_t)n;

@@ -539,10 +539,10 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     if (b->nchunks == 0) return AOCLGPU_OK;
     // Batches that LDS can hold at once (5 tables per CU) use the LDS-table kernel; larger ones the persistent
     // global-table kernel with 12 workgroups per CU (the measured optimum: 10 -> 20.3, 12 -> 21.8, 14 -> 21.2, 16 -> 20.3 GiB/s
-    // against 14.0 for the LDS kernel).  Experiment 64 forces the LDS kernel.
+    // against 14.0 for the LDS kernel).  Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests).
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("snappy: device query failed"); return AOCLGPU_ERR_HIP; }
-    if (!(b->reserved & 64u) && b->nchunks > 5u * (uint32_t)prop.multiProcessorCount) {
+    if (!(b->reserved & 64u) && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || (b->reserved & 128u))) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::snappy_compress_gt_kernel, 64, 0) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("snappy: occupancy query failed"); return AOCLGPU_ERR_HIP;

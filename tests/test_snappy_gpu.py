@@ -16,6 +16,15 @@ def _chunks(raw, chunk):
     return [raw[i:i + chunk] for i in range(0, max(len(raw), 1), chunk)]
 
 
+@pytest.fixture(params=["auto", "hbm-tables"], autouse=True)
+def table_placement(request, monkeypatch):
+    """every test runs twice: with the launcher's own choice (LDS tables for these small batches) and with the global-table
+    kernel forced (experiment switch 128), which otherwise only large batches reach"""
+    if request.param == "hbm-tables":
+        monkeypatch.setenv("AOCLGPU_EXPERIMENT", "128")
+    return request.param
+
+
 def test_known_answers(eng):
     for inp, hexout in KNOWN:
         assert eng.compress_host(a.SNAPPY, inp).hex() == hexout
