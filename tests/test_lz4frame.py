@@ -120,3 +120,49 @@ def test_malformed_frames(eng, G, R):
                 assert isinstance(got, str) or got == want, (o, k, want if isinstance(want, str) else "ok")
     skip = b"\x52\x2A\x4D\x18" + (5).to_bytes(4, "little") + b"hello"
     assert lf.decompress(G, skip + lf.compress(R, data[:100], None), 100) == (b"", 13)
+
+
+# ---- committed vectors (tests/golden/lz4f_golden.json, produced by tests/golden/make_lz4f_golden.py from the reference) ----
+import hashlib
+import json
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lz4f_golden.json")))["cases"]
+
+
+def _golden_data(c):
+    return a.corpus.make(c["kind"], max(c["n"], 4096), seed=c["seed"]).tobytes()[:c["n"]]
+
+
+def test_golden_headers(G):
+    """host-only part of the API on the committed reference frames: header size, frame info, bound >= frame size"""
+    for c in GOLDEN:
+        data = _golden_data(c)
+        assert hashlib.sha256(data).hexdigest() == c["data_sha256"]
+        p = lf.prefs(**c["prefs"])
+        assert G.LZ4F_compressFrameBound(c["n"], C.byref(p)) >= c["frame_bytes"]
+        if "frame_hex" not in c:
+            continue
+        frame = bytes.fromhex(c["frame_hex"])
+        info = lf.FrameInfo(); ctx = C.c_void_p(); G.LZ4F_createDecompressionContext(C.byref(ctx), 100)
+        n = C.c_size_t(len(frame))
+        assert not G.LZ4F_isError(G.LZ4F_getFrameInfo(ctx, C.byref(info), frame, C.byref(n)))
+        G.LZ4F_freeDecompressionContext(ctx)
+        assert n.value == G.LZ4F_headerSize(frame, len(frame))
+        assert info.contentChecksumFlag == int(c["prefs"].get("content_checksum", False))
+        assert info.blockChecksumFlag == int(c["prefs"].get("block_checksum", False))
+        assert info.contentSize == (c["n"] if c["prefs"].get("content_size") else 0)
+
+
+@pytest.mark.gpu
+def test_golden_frames(eng, G):
+    for c in GOLDEN:
+        data = _golden_data(c)
+        p = lf.prefs(**c["prefs"])
+        got = lf.compress(G, data, p)
+        assert isinstance(got, bytes), got
+        bs = 1 << (8 + 2 * max(c["prefs"].get("bsid", 0), 4))
+        one_block = c["n"] <= (65536 if c["prefs"].get("bsid", 0) == 0 else bs) or (c["prefs"].get("bsid", 0) >= 5 and c["n"] <= 65536)
+        if c["prefs"].get("independent") or one_block:
+            assert hashlib.sha256(got).hexdigest() == c["frame_sha256"], (c["kind"], c["n"], c["prefs"])
+        if "frame_hex" in c:
+            assert lf.decompress(G, bytes.fromhex(c["frame_hex"]), c["n"]) == (data, c["frame_bytes"])
