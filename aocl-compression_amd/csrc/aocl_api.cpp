@@ -44,7 +44,7 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
         // The reference's AOCL_ENABLE_THREADS build partitions the input inside this call and returns a RAP stream
         // (lz4.c:2655-2909, snappy.cc:2505-2654, zstd_compress.c:5388-5534; callers add aocl_get_rap_frame_bound_mt()
         // to outSize).  Here `numThreads > 1` asks for the same with GPU chunks as the partitions.
-        if (h->inSize > 0x7FFFFFFFu || (t == ZSTD && h->level != 1 && h->level != 0)) return kCodecError;
+        if (h->inSize > 0x7FFFFFFFu || (t == ZSTD && h->level != 1)) return kCodecError;
         int64_t r = aoclgpu_rap_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize, 0);
         return r > 0 ? r : kCodecError;
     }
@@ -59,8 +59,9 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
         int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
         return r > 0 ? r : kCodecError;
     }
-    // ZSTD (api/codec.cpp:396-422): only the level-1 "fast" strategy has a GPU backend
-    if (h->level != 1 && h->level != 0) return kCodecError;
+    // ZSTD (api/codec.cpp:396-422): only the level-1 "fast" strategy has a GPU backend (level 0 is ZSTD_CLEVEL_DEFAULT = 3
+    // in the reference, a double-fast parse: refused rather than answered with different bytes)
+    if (h->level != 1) return kCodecError;
     int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
     return r > 0 ? r : kCodecError;
 }

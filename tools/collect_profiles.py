@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (tools/round_profile.sh) into the files kept under profiles/:
+bench_r01_<codec>_<ver>.json, r01_<codec>_<ver>_kernel_trace_and_pmc.txt, traffic.json.
+usage: tools/collect_profiles.py <tag> <ver>   e.g.  r01_v7 v7"""
+import csv, glob, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, ver = sys.argv[1], sys.argv[2]
+O = os.path.join(ROOT, "gpurun_out", tag)
+P = os.path.join(ROOT, "profiles")
+traffic = {}
+for c in ("lz4", "snappy", "zstd"):
+    line = [l for l in open(os.path.join(O, f"bench_{c}.json")) if l.startswith("{")][-1]
+    open(os.path.join(P, f"bench_r01_{c}_{ver}.json"), "w").write(line)
+    bench = json.loads(line)
+    dom = bench["roofline"]["kernel"]
+    name = f"r01_{c}_{ver}_kernel_trace_and_pmc.txt"
+    with open(os.path.join(P, name), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --codec {c} --no-cpu-baseline  (round 1, {ver} kernels, 1x MI355X, 8 GiB)\n")
+        rows = list(csv.reader(open(os.path.join(O, f"trace_{c}", f"{c}_kernel_stats.csv"))))
+        f.write(",".join(f'"{x}"' for x in rows[0]) + "\n")
+        for r in rows[1:]:
+            if "aoclgpu" in r[0]:
+                f.write(",".join(f'"{x}"' if i == 0 else x for i, x in enumerate(r)) + "\n")
+        f.write("# (kernels of the bench harness itself - torch copies, compares, reductions - left out)\n\n# bench.py line of the same (profiled) run\n")
+        f.write([l for l in open(os.path.join(O, f"trace_bench_{c}.json")) if l.startswith("{")][-1])
+        f.write(f"\n# separate --pmc passes (one counter per pass, kernel-trace only), python3 bench.py --codec {c} --no-cpu-baseline --steps 1 --warmup 0; raw counter values (KB) per launch\n")
+        kb = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, f"pmc_{c}_{ctr}"), c + "_"], capture_output=True, text=True).stdout
+            f.write(txt)
+            cur = None
+            for l in txt.splitlines():
+                if not l.startswith(" "):
+                    cur = l.strip()
+                elif ctr in l and cur and dom.split("_kernel")[0] in cur:
+                    kb[ctr] = int(float(l.split()[1]))
+    if len(kb) == 2:
+        traffic[c] = {"kernel": dom, "gib_per_gpu": bench["config"]["gib_per_gpu"], "chunk_bytes": bench["config"]["chunk_bytes"],
+                      "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
+                      "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, raw KB per launch)"}
+json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=2)
+print(json.dumps(traffic, indent=1))
