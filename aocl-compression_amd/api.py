@@ -43,6 +43,7 @@ class Batch(C.Structure):
 
 
 FLAG_RAP_PARTITIONS = 0x100
+FLAG_ZSTD_LEVEL2 = 0x400      # Zstd level 2 instead of 1 (include/aocl_gpu_codec.h)
 
 
 class LlcDesc(C.Structure):
@@ -61,7 +62,7 @@ EXPORTS = [
     "aoclgpu_lz4_compress_chunks", "aoclgpu_lz4_decompress_chunks",
     "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
     "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks",
-    "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_decompress_host",
+    "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_compress_host_ex", "aoclgpu_decompress_host",
     "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes", "aoclgpu_rap_default_chunk",
     "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
@@ -91,6 +92,8 @@ def load_library() -> C.CDLL:
         f = getattr(lib, n)
         f.restype = C.c_int64
         f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.aoclgpu_compress_host_ex.restype = C.c_int64
+    lib.aoclgpu_compress_host_ex.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32]
     lib.aoclgpu_rap_pack.restype = C.c_int
     lib.aoclgpu_rap_pack.argtypes = [C.c_int, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     lib.aoclgpu_rap_unpack.restype = C.c_int
@@ -159,8 +162,8 @@ class Engine:
                      nchunks=nchunks, total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes)
 
     # ---- batch API on device tensors ----
-    def compress_chunks(self, codec: int, src, chunk_bytes: int, slot_bytes: int | None = None):
-        """Compress every chunk_bytes-sized chunk of `src` independently.
+    def compress_chunks(self, codec: int, src, chunk_bytes: int, slot_bytes: int | None = None, flags: int = 0):
+        """Compress every chunk_bytes-sized chunk of `src` independently (flags: AOCLGPU_FLAG_*, e.g. FLAG_ZSTD_LEVEL2).
         Returns (slots uint8[nchunks*slot_bytes], out_len int32[nchunks], slot_bytes)."""
         t = self.torch
         if slot_bytes is None:
@@ -169,6 +172,7 @@ class Engine:
         slots = t.empty(nchunks * slot_bytes, dtype=t.uint8, device=self.device)
         out_len = t.zeros(nchunks, dtype=t.int32, device=self.device)
         b = self.uniform_compress_batch(src, chunk_bytes, slots, out_len, slot_bytes)
+        b.reserved |= flags
         self._check(self._fn(codec, "compress")(C.byref(b), self._stream()), f"{_NAMES[codec]} compress")
         return slots, out_len, slot_bytes
 
@@ -229,10 +233,10 @@ class Engine:
         return ms
 
     # ---- host one-shot (native-API contract) ----
-    def compress_host(self, codec: int, data: bytes, cap: int | None = None) -> bytes | None:
+    def compress_host(self, codec: int, data: bytes, cap: int | None = None, flags: int = 0) -> bytes | None:
         cap = compress_bound(codec, len(data)) if cap is None else cap
         out = C.create_string_buffer(max(cap, 1))
-        r = self.lib.aoclgpu_compress_host(codec, data, len(data), out, cap)
+        r = self.lib.aoclgpu_compress_host_ex(codec, data, len(data), out, cap, flags)
         if r < 0:
             raise EngineError(f"compress_host failed ({r}): {self.lib.aoclgpu_last_error().decode()}")
         return out.raw[:r] if r > 0 else None

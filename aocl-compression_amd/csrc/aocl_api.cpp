@@ -59,10 +59,10 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
         int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
         return r > 0 ? r : kCodecError;
     }
-    // ZSTD (api/codec.cpp:396-422): only the level-1 "fast" strategy has a GPU backend (level 0 is ZSTD_CLEVEL_DEFAULT = 3
-    // in the reference, a double-fast parse: refused rather than answered with different bytes)
-    if (h->level != 1) return kCodecError;
-    int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+    // ZSTD (api/codec.cpp:396-422): the "fast" strategy has a GPU backend, i.e. levels 1 and 2 for inputs of at most 128 KiB
+    // (level 0 is ZSTD_CLEVEL_DEFAULT = 3 in the reference, a double-fast parse: refused rather than answered with different bytes)
+    if (h->level != 1 && h->level != 2) return kCodecError;
+    int64_t r = aoclgpu_compress_host_ex(c, h->inBuf, h->inSize, h->outBuf, h->outSize, h->level == 2 ? AOCLGPU_FLAG_ZSTD_LEVEL2 : 0u);
     return r > 0 ? r : kCodecError;
 }
 

@@ -203,7 +203,7 @@ extern "C" double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_
 }
 
 // ---------------- host-buffer one-shot path ----------------
-static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_t n, void* hdst, size_t cap)
+static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_t n, void* hdst, size_t cap, uint32_t flags = 0)
 {
     batch_fn fn = pick(codec, op);
     if (!fn) { set_error_msg("bad codec"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
@@ -222,6 +222,7 @@ static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_
         aoclgpu_batch b; std::memset(&b, 0, sizeof(b));
         b.src = dsrc; b.dst = ddst; b.out_len = dlen; b.nchunks = 1;
         if (const char* ex = getenv("AOCLGPU_EXPERIMENT")) b.reserved = (uint32_t)atoi(ex) & 0xFFu;   // experiment switches of the test tools
+        b.reserved |= flags & ~0xFFu;
         if (op == 0) { b.total_bytes = n; b.chunk_bytes = n ? n : 1; b.slot_bytes = cap; }
         else {
             uint32_t sl = (uint32_t)n;
@@ -245,6 +246,10 @@ done:
     return result;
 }
 
+extern "C" int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags)
+{
+    return host_oneshot(codec, 0, host_src, n, host_dst, cap, flags);
+}
 extern "C" int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap)
 {
     return host_oneshot(codec, 0, host_src, n, host_dst, cap);

@@ -615,10 +615,13 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // op0 > 0: dst[0, op0) is history the block may copy from (linked blocks of an LZ4 frame, LZ4_decompress_safe_usingDict
 // with the dictionary in front of the output, lz4.c:4985-5010); the block's own output is dst[op0, op0 + cap) and the
 // return value is the end position op0 + decoded size.
-template <bool RAP>
-__device__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
-                                   uint8_t* ring, const bool rap, const int32_t op0 = 0)
+// (HIST is a template parameter and the function is inlined into each kernel: a shared, non-inlined copy receives its
+//  arguments in VGPRs, loses its scalar control flow, and the plain decoder drops from 250 to 156 GiB/s.)
+template <bool RAP, bool HIST = false>
+__device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
+                                                   uint8_t* ring, const bool rap, const int32_t op0_ = 0)
 {
+    const int32_t op0 = HIST ? op0_ : 0;
     const int lane = lane_id();
     if (cap == 0) return (n == 1 && src[0] == 0) ? op0 : -1;  // lz4.c:3412-3416
     if (n <= 0) return -1;                                    // lz4.c:3418
@@ -798,7 +801,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch
             if ((uint64_t)op + cap > dst_total) cap = (uint32_t)(dst_total - (uint64_t)op);
             if (sl >> 31) {
                 if (n <= cap) { wave_copy((gbyte*)b.dst + op, src, n, lane); r = op + (int32_t)n; }
-            } else r = lz4_decompress_wave<false>(src, (int32_t)n, (gbyte*)b.dst, (int32_t)cap, ring, false, op);
+            } else r = lz4_decompress_wave<false, true>(src, (int32_t)n, (gbyte*)b.dst, (int32_t)cap, ring, false, op);
             wave_fence();
         }
         if (r < 0) { bad = true; if (lane == 0) b.out_len[c] = -1; }

@@ -116,11 +116,11 @@ const char* ZSTD_getErrorName(size_t code)
     }
 }
 size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
-{   // zstd_compress.c:5534; only level 1 ("fast" strategy), one block per frame, has a GPU backend
+{   // zstd_compress.c:5534; the "fast" strategy (levels 1 and 2 at these sizes), one block per frame, has a GPU backend
     if (!dst || (!src && srcSize)) return zerr(1);
-    if (level != 1) return zerr(40);
+    if (level != 1 && level != 2) return zerr(40);
     if (srcSize > (128u << 10)) return zerr(72);
-    const int64_t r = aoclgpu_compress_host(AOCLGPU_ZSTD, src, srcSize, dst, dstCapacity);
+    const int64_t r = aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, srcSize, dst, dstCapacity, level == 2 ? AOCLGPU_FLAG_ZSTD_LEVEL2 : 0u);
     if (r > 0) return (size_t)r;
     return zerr(dstCapacity < ZSTD_compressBound(srcSize) ? 70 : 1);
 }

@@ -89,7 +89,8 @@ struct EntropyLds {
 
 template <int MLS>
 __device__ __forceinline__ u32 z_hash(u64 v, u32 hlog)
-{   // ZSTD_hash5Ptr / ZSTD_hash6Ptr (zstd_compress_internal.h:843-875)
+{   // ZSTD_hash4Ptr / ZSTD_hash5Ptr / ZSTD_hash6Ptr (zstd_compress_internal.h:836-875)
+    if (MLS == 4) return ((u32)v * 2654435761u) >> (32 - hlog);
     if (MLS == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
     return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
 }
@@ -130,14 +131,14 @@ __device__ unsigned long long g_zstd_prof[16];
 #else
 #define ZSTAGE(k) do { } while (0)
 #endif
-template <int MLS, typename T>
+template <int MLS, typename T, bool HI>
 __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
                           u32* litSizeOut, int lane, const u32 expf)
 {
     static_assert(sizeof(T) == 2, "u16 slots");
     typedef __attribute__((address_space(3))) T LT;
     typedef __attribute__((address_space(3))) u32 L32;
-    constexpr bool kHi = (MLS == 6);
+    constexpr bool kHi = HI;                                            // positions need 17 bits (chunks above 16 KiB)
     const u32 tsize = 1u << hlog;
     LT* table = (LT*)lds;
     L32* hib = (L32*)(lds + 2 * tsize);                                 // kHi: tsize/32 words
@@ -731,13 +732,16 @@ __device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, 
     return op;
 }
 
-// cParams for level 1 and a known size (clevels.h:80,107 + ZSTD_adjustCParams_internal zstd_compress.c:1575-1595)
-__device__ __forceinline__ void level1_params(u32 n, u32* hlog, u32* mls)
+// cParams for levels 1 and 2 and a known size (clevels.h:80-82,107-108 + ZSTD_adjustCParams_internal zstd_compress.c:1575-1595):
+// both are the "fast" strategy with step 2 for chunks of at most 128 KiB; level 2 has a 2^15-slot table and minMatch 5
+// (4 for chunks of at most 16 KiB)
+__device__ __forceinline__ void level_params(u32 level, u32 n, u32* hlog, u32* mls)
 {
     const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
-    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = 5; }
-    else { const u32 w = srcLog < 17 ? srcLog : 17; *hlog = (13 < w + 1) ? 13 : w + 1; *mls = 6; }
+    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = level == 2 ? 4 : 5; }
+    else { const u32 w = srcLog < 17 ? srcLog : 17, hl = level == 2 ? 15 : 13; *hlog = (hl < w + 1) ? hl : w + 1; *mls = level == 2 ? 5 : 6; }
 }
+__device__ __forceinline__ void level1_params(u32 n, u32* hlog, u32* mls) { level_params(1, n, hlog, mls); }
 
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
                                   void* lds, u32 ldsBytes, Workspace* ws, int lane, u32 expf)
@@ -758,11 +762,15 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     u32 cSize = 0;
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 hlog, mls, litSize = 0, nbSeq;
-        level1_params(n, &hlog, &mls);
-        const u32 need = (2u << hlog) + (mls == 5 ? 0u : (1u << hlog) / 8) + kSrcRingBytes;
+        const u32 level = (expf & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2u : 1u;
+        level_params(level, n, &hlog, &mls);
+        const bool hi = n > 16384;
+        const u32 need = (2u << hlog) + (hi ? (1u << hlog) / 8 : 0u) + kSrcRingBytes;
         if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
-        if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
-        else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        if (mls == 4) nbSeq = fast_block<4, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        else if (mls == 6) nbSeq = fast_block<6, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        else if (hi) nbSeq = fast_block<5, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        else nbSeq = fast_block<5, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
         wave_fence();
         if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
         else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
@@ -1452,14 +1460,17 @@ size_t zstd_entropy_lds_bytes() { return sizeof(EntropyLds); }
 // ------------------------------------------------------------------------------------------------
 namespace {
 using aoclgpu::get_workspace;
-uint32_t lds_for_chunk(uint64_t n)
-{   // hash table bytes of the level-1 parameters for an n-byte chunk, never less than the entropy-stage LDS
+uint32_t lds_for_chunk(uint64_t n, int level = 1)
+{   // hash table bytes of the level's parameters for an n-byte chunk, never less than the entropy-stage LDS
     uint32_t need;
     if (n <= 16384) {
         uint32_t srcLog = 6; if (n >= 64) { srcLog = 0; uint64_t t = n - 1; while (t) { srcLog++; t >>= 1; } }
         const uint32_t w = srcLog < 14 ? srcLog : 14, hl = (15 < w + 1) ? 15 : w + 1;
         need = (2u << hl) + aoclgpu::kSrcRingBytes;
-    } else need = (2u << 13) + (1u << 13) / 8 + aoclgpu::kSrcRingBytes;
+    } else {
+        const uint32_t hl = level == 2 ? 15 : 13;
+        need = (2u << hl) + (1u << hl) / 8 + aoclgpu::kSrcRingBytes;
+    }
     const uint32_t ent = (uint32_t)aoclgpu::zstd_entropy_lds_bytes();
     need = need > ent ? need : ent;
     return (need + 255u) & ~255u;
@@ -1476,8 +1487,8 @@ __global__ void __launch_bounds__(64) zstd_debug_seq_kernel(const uint8_t* src, 
     const int lane = lane_id();
     u32 hlog, mls, litSize = 0, nbSeq;
     level1_params(n, &hlog, &mls);
-    if (mls == 5) nbSeq = fast_block<5, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
-    else nbSeq = fast_block<6, u16>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+    if (mls == 5) nbSeq = fast_block<5, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+    else nbSeq = fast_block<6, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
     wave_fence();
     if (lane == 0) { out[0] = nbSeq; out[1] = litSize; }
     for (u32 i = (u32)lane; i < nbSeq && i < maxSeq; i += kWave) { out[2 + 3 * i] = ws->seqLL[i]; out[3 + 3 * i] = ws->seqOff[i]; out[4 + 3 * i] = ws->seqML[i]; }
@@ -1574,15 +1585,16 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
     // launch classes: uniform mode -> body chunks share one LDS size, the ragged tail chunk gets its own launch;
     // explicit mode -> sizes live on the device, so every block gets the largest table (64 KiB)
     struct Launch { uint32_t first, count, lds; } L[2]; int nl = 0;
-    if (b->src_off) { L[nl++] = { 0, b->nchunks, 65536u }; }
+    const int level = (b->reserved & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2 : 1;
+    if (b->src_off) { L[nl++] = { 0, b->nchunks, level == 2 ? lds_for_chunk(128u << 10, 2) : 65536u }; }
     else {
         const uint64_t tail = b->total_bytes - (uint64_t)(b->nchunks - 1) * b->chunk_bytes;
         if (b->chunk_bytes > (128u << 10) && b->nchunks > 1) { aoclgpu::set_error_msg("zstd: chunk_bytes > 128 KiB"); return AOCLGPU_ERR_ARG; }
         // a separate launch for the ragged tail chunk only when it needs more LDS than the body (a lone chunk is slow)
-        if (b->nchunks > 1 && lds_for_chunk(tail) > lds_for_chunk(b->chunk_bytes)) {
-            L[nl++] = { b->nchunks - 1, 1, lds_for_chunk(tail) };
-            L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes) };
-        } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail) };
+        if (b->nchunks > 1 && lds_for_chunk(tail, level) > lds_for_chunk(b->chunk_bytes, level)) {
+            L[nl++] = { b->nchunks - 1, 1, lds_for_chunk(tail, level) };
+            L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes, level) };
+        } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail, level) };
     }
     for (int i = 0; i < nl; ++i) {
         // persistent blocks: exactly as many as are resident at once for this LDS size (LDS is allocated in 512-byte granules)

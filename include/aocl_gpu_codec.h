@@ -72,6 +72,9 @@ typedef struct {
  * LZ4F_blockLinked): decoded in order into dst back to back (dst_off is ignored, total_bytes = capacity of dst), every block
  * may copy from what was decoded before it; src_len[i] bit 31 marks a stored block. */
 #define AOCLGPU_FLAG_LZ4_LINKED 0x200u
+/* Zstd compress: level 2 instead of level 1 (clevels.h:82,108: still the "fast" strategy for chunks <= 128 KiB, with a 2^15-slot
+ * table - 68 KB of LDS, 2 chunks per CU - and minMatch 5 / 4); frames byte-identical to ZSTD_compress(.., 2). */
+#define AOCLGPU_FLAG_ZSTD_LEVEL2 0x400u
 
 /* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
  * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at
@@ -137,6 +140,8 @@ double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, i
  * native one-shot API (compress: size, 0 = does not fit; decompress: size, small negative = malformed),
  * or a value <= AOCLGPU_HOST_FAIL/2 when the GPU path itself failed (AOCLGPU_HOST_FAIL + AOCLGPU_ERR_*). */
 #define AOCLGPU_HOST_FAIL (-(1LL << 40))
+/* flags: AOCLGPU_FLAG_* of the codec (e.g. AOCLGPU_FLAG_ZSTD_LEVEL2) */
+int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
 int64_t aoclgpu_decompress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
 

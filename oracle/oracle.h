@@ -39,6 +39,7 @@ size_t orc_zstd_compress_bound(size_t n);                              /* zstd.h
 /* == ZSTD_compress(dst,cap,src,n,1) through the AOCL fast path for n <= 128 KiB blocks per frame.
  * returns compressed size, 0 on failure */
 size_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
+size_t orc_zstd_compress_level(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, int level);   /* level 1 or 2 */
 /* == ZSTD_decompress: returns decoded size, (size_t)-1 on error */
 size_t orc_zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
 

@@ -649,6 +649,7 @@ static size_t entropy_compress(u8* dst, const u8* lits, size_t litSize, const zs
 static u32 z_hash(const u8* p, u32 hlog, u32 mls)
 {
     const u64 v = z_rd64(p);
+    if (mls == 4) return ((u32)v * 2654435761u) >> (32 - hlog);                   /* ZSTD_hash4 (zstd_compress_internal.h:836-841) */
     if (mls == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
     return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
 }
@@ -730,15 +731,21 @@ cleanup:
     return nbSeq;
 }
 
-/* cParams for level 1 and a known source size (clevels.h:80,107 + zstd_compress.c:1575-1595) */
-static void level1_params(size_t n, u32* hlog, u32* mls)
+/* cParams for levels 1 and 2 and a known source size <= 128 KiB (clevels.h:80-82,107-108 + ZSTD_adjustCParams_internal
+ * zstd_compress.c:1575-1595): both levels use the "fast" strategy with step 2 there; level 2 has a 2^15 table and minMatch
+ * 5 (4 for inputs of at most 16 KiB) */
+static void level_params(int level, size_t n, u32* hlog, u32* mls)
 {
     const u32 srcLog = (n < 64) ? 6 : (u32)z_hb((u32)n - 1) + 1;
-    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = 5; }
-    else { const u32 w = srcLog < 17 ? srcLog : 17; *hlog = (13 < w + 1) ? 13 : w + 1; *mls = 6; }
+    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = level == 2 ? 4 : 5; }
+    else { const u32 w = srcLog < 17 ? srcLog : 17, hl = level == 2 ? 15 : 13; *hlog = (hl < w + 1) ? hl : w + 1; *mls = level == 2 ? 5 : 6; }
 }
+static void level1_params(size_t n, u32* hlog, u32* mls) { level_params(1, n, hlog, mls); }
 
-size_t orc_zstd_compress(const u8* src, size_t n, u8* dst, size_t dstCap)
+size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, int level);
+size_t orc_zstd_compress(const u8* src, size_t n, u8* dst, size_t dstCap) { return orc_zstd_compress_level(src, n, dst, dstCap, 1); }
+/* level 1 or 2 */
+size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, int level)
 {
     u8* op = dst;
     if (n > (128u << 10) || dstCap < orc_zstd_compress_bound(n) || dstCap < 9) return 0;
@@ -757,7 +764,8 @@ size_t orc_zstd_compress(const u8* src, size_t n, u8* dst, size_t dstCap)
             zseq* seqs = (zseq*)malloc(sizeof(zseq) * (n / 3 + 8));
             u8* lits = (u8*)malloc(n + 8);
             u8* tmp = (u8*)malloc(2 * n + 1024);
-            level1_params(n, &hlog, &mls);
+            if (level != 1 && level != 2) { free(seqs); free(lits); free(tmp); return 0; }
+            level_params(level, n, &hlog, &mls);
             nbSeq = fast_block(src, (u32)n, hlog, mls, seqs, lits, &litSize);
             cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq);
             if (cSize >= n - ((n >> 6) + 2)) cSize = 0;               /* ZSTD_minGain, zstd_compress.c:3055-3057 */

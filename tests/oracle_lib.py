@@ -47,14 +47,15 @@ class Oracle:
         sig("orc_snappy_uncompressed_length", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)])
         sig("orc_zstd_compress_bound", C.c_size_t, [C.c_size_t])
         sig("orc_zstd_compress", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
+        sig("orc_zstd_compress_level", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int])
         sig("orc_zstd_decompress", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
         sig("orc_compress_chunks", C.c_int,
             [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int])
         sig("orc_decompress_chunks", C.c_int,
             [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int])
 
-    def compress(self, codec, data: bytes, cap=None):
-        """bytes or None (failure)"""
+    def compress(self, codec, data: bytes, cap=None, level=1):
+        """bytes or None (failure); level: Zstd only (1 or 2)"""
         n = len(data)
         cap = bound(codec, n) if cap is None else cap
         out = C.create_string_buffer(max(cap, 1))
@@ -64,7 +65,7 @@ class Oracle:
             assert cap >= bound(SNAPPY, n)
             r = self.L.orc_snappy_compress(data, n, out)
         else:
-            r = self.L.orc_zstd_compress(data, n, out, cap)
+            r = self.L.orc_zstd_compress_level(data, n, out, cap, level)
         return out.raw[:r] if r > 0 else None
 
     def decompress(self, codec, data: bytes, cap: int):
@@ -103,7 +104,7 @@ class Ref:
         L.snappy_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         L.snappy_uncompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
 
-    def compress(self, codec, data: bytes, cap=None):
+    def compress(self, codec, data: bytes, cap=None, level=1):
         n = len(data)
         cap = bound(codec, n) if cap is None else cap
         out = C.create_string_buffer(max(cap, 1))
@@ -114,7 +115,7 @@ class Ref:
             ln = C.c_size_t(cap)
             st = self.L.snappy_compress(data, n, out, C.byref(ln))
             return out.raw[:ln.value] if st == 0 else None
-        r = self.L.ZSTD_compress(out, cap, data, n, 1)
+        r = self.L.ZSTD_compress(out, cap, data, n, level)
         return None if self.L.ZSTD_isError(r) else out.raw[:r]
 
     def decompress(self, codec, data: bytes, cap: int):

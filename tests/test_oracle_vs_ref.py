@@ -25,6 +25,18 @@ def test_compress_bit_exact(oracle, ref, kind):
                 assert oracle.decompress(codec, got, max(len(raw), 1)) == raw
 
 
+@pytest.mark.parametrize("kind", list(a.corpus.KINDS))
+def test_zstd_level2_bit_exact(oracle, ref, kind):
+    """level 2 is still the "fast" strategy for inputs of at most 128 KiB (2^15-slot table, minMatch 5 / 4)"""
+    d = a.corpus.make(kind, 1 << 20, seed=37).tobytes()
+    for size in SIZES:
+        for off in (0, 4321, 777777):
+            raw = d[off:off + size]
+            got, want = oracle.compress(ol.ZSTD, raw, level=2), ref.compress(ol.ZSTD, raw, level=2)
+            assert got == want, (size, off)
+            assert oracle.decompress(ol.ZSTD, got, max(len(raw), 1)) == raw
+
+
 def test_special_inputs(oracle, ref):
     rng = np.random.default_rng(5)
     cases = [bytes(131072), b"\xff" * 70000, bytes(range(256)) * 512, b"ab" * 50000, b"abc" * 40000,

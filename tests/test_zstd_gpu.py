@@ -1,4 +1,6 @@
 """GPU parity: HIP Zstd level-1 kernels (through the C-ABI) vs the CPU oracle -- bit-exact frames."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -135,3 +137,40 @@ def test_full_size_round_trip(eng):
     dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, total, chunk)
     assert int((dl != chunk).sum().item()) == 0
     assert torch.equal(dst, src)
+
+
+# ---- level 2 (the levels above 1 that still use the "fast" strategy at these sizes) ----
+@pytest.mark.parametrize("kind", ["text", "jsonlog", "binary", "database", "random"])
+@pytest.mark.parametrize("chunk", [131072, 50000, 16384, 4096])
+def test_level2_bit_exact(eng, oracle, kind, chunk):
+    data = a.corpus.make(kind, (1 << 19) + 777, seed=17)
+    src = torch.from_numpy(data).to(eng.device)
+    slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.FLAG_ZSTD_LEVEL2)
+    lens = out_len.cpu().tolist()
+    host = slots.cpu().numpy()
+    parts = _chunks(data.tobytes(), chunk)
+    bad = []
+    for i, part in enumerate(parts):
+        want = oracle.compress(ol.ZSTD, part, level=2)
+        if host[i * slot:i * slot + lens[i]].tobytes() != want:
+            bad.append((i, len(part), lens[i], len(want)))
+    assert not bad, bad[:5]
+    dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, len(data), chunk)
+    assert torch.equal(dst, src)
+
+
+@pytest.mark.parametrize("size", [1, 7, 20, 21, 255, 1000, 4096, 16384, 16385, 65536, 100001, 131072])
+def test_level2_sizes_and_native_api(eng, oracle, ref, size):
+    raw = a.corpus.make("text", size, seed=size + 1).tobytes()
+    want = oracle.compress(ol.ZSTD, raw, level=2)
+    assert eng.compress_host(a.ZSTD, raw, flags=a.api.FLAG_ZSTD_LEVEL2) == want
+    cap = len(raw) + (len(raw) >> 8) + 1024
+    out = C.create_string_buffer(cap)
+    r = ref.L.ZSTD_compress(out, cap, raw, len(raw), 2)                  # the reference itself
+    assert out.raw[:r] == want
+    L = a.api.load_library()
+    L.ZSTD_compress.restype = C.c_size_t
+    L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    out2 = C.create_string_buffer(cap)
+    r2 = L.ZSTD_compress(out2, cap, raw, len(raw), 2)                    # the GPU library under the reference's name
+    assert out2.raw[:r2] == want
