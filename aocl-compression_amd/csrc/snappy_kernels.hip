@@ -104,29 +104,40 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
 // Table accesses in global memory are relaxed agent-scope atomics (served by L2, never by a stale L1 line); a wave's
 // vector memory operations reach L2 in order, so the next batch's reads see this batch's commits.
 typedef __attribute__((address_space(3))) uint16_t lu16;
-typedef __attribute__((address_space(1))) uint16_t gu16;
+typedef __attribute__((address_space(1))) uint32_t gu32;
 constexpr uint32_t kScratch = 1024;
 
 template <bool GT>
 __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in, const uint32_t n,
                                                                    gbyte* __restrict__ out, uint16_t* table_, lu16* scr, int lane)
 {
-    using TP = typename std::conditional<GT, gu16*, lu16*>::type;
-    TP table = (TP)uni_ptr(table_);
+    // GT: a slot is a u32 = position | check bits of the 4 bytes at that position << 16.  The check bits never change a
+    // decision (a probe whose check bits differ cannot pass the 4-byte test); they spare the speculative lanes the fetch
+    // of a candidate window that cannot match - most of the kernel's memory traffic.  An empty slot aliases position 0
+    // as in the reference's zero-filled table, so the table is filled with entry(0).
+    using TP = typename std::conditional<GT, gu32*, lu16*>::type;
+    TP table = (TP)uni_ptr((typename std::conditional<GT, uint32_t*, uint16_t*>::type)table_);
+    auto chk = [&](uint32_t v4) -> uint32_t { return GT ? ((v4 * 2654435761u) & 0xFFFF0000u) : 0u; };
     auto tget = [&](uint32_t h) -> uint32_t {
-        if (GT) return __hip_atomic_load((uint16_t*)(table + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (GT) return __hip_atomic_load((uint32_t*)(table + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return table[h];
     };
-    auto tput = [&](uint32_t h, uint32_t v) {
-        if (GT) __hip_atomic_store((uint16_t*)(table + h), (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto tput = [&](uint32_t h, uint32_t v, uint32_t bytes4) {          // bytes4 = the 4 bytes at position v
+        if (GT) __hip_atomic_store((uint32_t*)(table + h), (v & 0xFFFFu) | chk(bytes4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else table[h] = (uint16_t)v;
     };
     uint32_t tsize = n > kMaxTable ? kMaxTable : (n < kMinTable ? kMinTable : (2u << log2floor(n - 1)));   // :619-632
     const int shift = 32 - log2floor(tsize);
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    for (uint32_t i = (uint32_t)lane; i < tsize / 8; i += kWave)         // memset, snappy.cc:651-657
-        ((typename std::conditional<GT, __attribute__((address_space(1))) u4*, __attribute__((address_space(3))) u4*>::type)table)[i] = u4{0, 0, 0, 0};
-    if (GT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (GT) {
+        const uint32_t fill = n >= 4 ? chk(ld32(in)) : 0u;
+        for (uint32_t i = (uint32_t)lane; i < tsize / 4; i += kWave)
+            ((__attribute__((address_space(1))) u4*)table)[i] = u4{fill, fill, fill, fill};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    } else {
+        for (uint32_t i = (uint32_t)lane; i < tsize / 8; i += kWave)     // memset, snappy.cc:651-657
+            ((__attribute__((address_space(3))) u4*)table)[i] = u4{0, 0, 0, 0};
+    }
     wave_fence();
 
     uint32_t ip = 0, op = 0, anchor = 0;                                  // anchor = next_emit
@@ -147,21 +158,23 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
                 const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
                 const uint32_t h1 = sn_hash(fb, shift);
-                if (lane == 0) tput(h1, ip - 1);
+                if (lane == 0) tput(h1, ip - 1, fb);
                 wave_fence();
             }
             have_pre = false;
             const uint32_t seq = (uint32_t)(pw.lo >> 32);
             const uint32_t h = sn_hash(seq, shift);
-            uint32_t cand = 0;
-            if (valid) cand = tget(h);
+            uint32_t ent = 0;
+            if (valid) ent = tget(h);
+            const uint32_t cand = ent & 0xFFFFu;
+            const bool plausible = valid && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
             Win cw = {~pw.lo, 0};
-            if (valid) cw = load_win(in, cand);
+            if (plausible) cw = load_win(in, cand);
             // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
             const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;        // lanes [0, linlim) probe consecutive positions
             uint64_t c2 = 0, c3 = 0;
             const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
-            const bool have2 = valid && lane + 8 < linlim && v2 && cand + 20 <= n;
+            const bool have2 = plausible && lane + 8 < linlim && v2 && cand + 20 <= n;
             const bool have3 = have2 && lane + 16 < linlim && v3 && cand + 28 <= n;
             if (have2) c2 = ld64(in + cand + 12);
             if (have3) c3 = ld64(in + cand + 20);
@@ -210,7 +223,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
                 const int m = first_lane(rem);
                 if (m >= 64) {                                            // lanes [start, hi) were probed without a match
-                    if (lane >= start && lane < hi) tput(h, pos);
+                    if (lane >= start && lane < hi) tput(h, pos, seq);
                     wave_fence();
                     // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
                     // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
@@ -221,7 +234,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     else i0 = (uint32_t)(hi - start);
                     break;
                 }
-                if (lane >= start && lane <= m) tput(h, pos);                        // probes the reference executed
+                if (lane >= start && lane <= m) tput(h, pos, seq);                   // probes the reference executed
                 wave_fence();
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
                 uint32_t matched = 4 + lane_get(fw, m);
@@ -263,7 +276,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint32_t Ln = ip - pos0;
                 const int hi2 = lim < linlim ? lim : linlim;
                 if (!more_fwd && (int)Ln < hi2) {
-                    if ((uint32_t)lane == Ln - 1) tput(h, pos);                       // back-fill ip-1 (:1016-1017)
+                    if ((uint32_t)lane == Ln - 1) tput(h, pos, seq);                  // back-fill ip-1 (:1016-1017)
                     wave_fence();
                     start = (int)Ln;
                     continue;
@@ -510,7 +523,7 @@ __global__ void __launch_bounds__(64) snappy_compress_kernel(aoclgpu_batch b)
 __global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b, uint16_t* tables)
 {
     __shared__ __attribute__((aligned(16))) uint16_t scr[kScratch];
-    uint16_t* table = tables + (size_t)blockIdx.x * kMaxTable;
+    uint16_t* table = tables + (size_t)blockIdx.x * kMaxTable * 2;       // u32[kMaxTable] per workgroup
     for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
         const int r = sn_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr);
@@ -538,8 +551,9 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     if (int rc = aoclgpu::check_batch(b, false)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
     // Batches that LDS can hold at once (5 tables per CU) use the LDS-table kernel; larger ones the persistent
-    // global-table kernel with 12 workgroups per CU (the measured optimum: 10 -> 20.3, 12 -> 21.8, 14 -> 21.2, 16 -> 20.3 GiB/s
-    // against 14.0 for the LDS kernel).  Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests).
+    // global-table kernel with 14 workgroups per CU (the measured optimum with check bits in the slots: 10 -> 21.7,
+    // 12 -> 22.9, 14 -> 24.3, 16 -> 23.6, 20 -> 19.7 GiB/s; without check bits 12 -> 21.8; LDS kernel 14.0).
+    // Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests).
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("snappy: device query failed"); return AOCLGPU_ERR_HIP; }
     if (!(b->reserved & 64u) && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || (b->reserved & 128u))) {
@@ -547,11 +561,11 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::snappy_compress_gt_kernel, 64, 0) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("snappy: occupancy query failed"); return AOCLGPU_ERR_HIP;
         }
-        if (perCU > 12) perCU = 12;
+        if (perCU > 14) perCU = 14;
         if (const char* g = getenv("AOCLGPU_SNAPPY_GT_PER_CU")) perCU = atoi(g) > 0 ? atoi(g) : perCU;      // tuning hook
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > b->nchunks) grid = b->nchunks;
-        void* tables = aoclgpu::get_workspace((size_t)grid * aoclgpu::kMaxTable * sizeof(uint16_t), stream);
+        void* tables = aoclgpu::get_workspace((size_t)grid * aoclgpu::kMaxTable * sizeof(uint32_t), stream);
         if (!tables) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         hipLaunchKernelGGL(aoclgpu::snappy_compress_gt_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint16_t*)tables);
         return aoclgpu::check_launch("snappy_compress_gt_kernel");
