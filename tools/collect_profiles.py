@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (tools/round_profile.sh) into the files kept under profiles/:
 bench_r01_<codec>_<ver>.json, r01_<codec>_<ver>_kernel_trace_and_pmc.txt, traffic.json.
-usage: tools/collect_profiles.py <tag> <ver>   e.g.  r01_v7 v7"""
+usage: tools/collect_profiles.py <tag> <ver> [codec ...]   e.g.  r01_v7 v7"""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ver = sys.argv[1], sys.argv[2]
 O = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(ROOT, "profiles")
-traffic = {}
-for c in ("lz4", "snappy", "zstd"):
+tpath = os.path.join(P, "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
     line = [l for l in open(os.path.join(O, f"bench_{c}.json")) if l.startswith("{")][-1]
     open(os.path.join(P, f"bench_r01_{c}_{ver}.json"), "w").write(line)
     bench = json.loads(line)
@@ -38,5 +39,5 @@ for c in ("lz4", "snappy", "zstd"):
         traffic[c] = {"kernel": dom, "gib_per_gpu": bench["config"]["gib_per_gpu"], "chunk_bytes": bench["config"]["chunk_bytes"],
                       "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
                       "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, raw KB per launch)"}
-json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=2)
+json.dump(traffic, open(tpath, "w"), indent=2)
 print(json.dumps(traffic, indent=1))
