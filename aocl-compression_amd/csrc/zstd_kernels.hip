@@ -870,8 +870,7 @@ __device__ __forceinline__ u32x4 stream16(const gbyte* p, u32 n, int off)
 
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
-struct DecLds {                     // 11.6 KB: 13-14 blocks resident per CU (the serial entropy loops are latency chains,
-                                    // so throughput is proportional to resident blocks)
+struct DecLds {                     // 14.7 KB: 10 blocks resident per CU (the serial entropy loops are latency chains)
     u16 huf[2048];                  // symbol | nbBits << 8, table logs <= 11; a 12-bit table (accepted by the reference,
                                     // never produced by zstd) lives in the block's global workspace instead
     FseD ll[512], of[256], ml[512];
@@ -962,7 +961,9 @@ __device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tabl
 }
 
 // HUF_readStats + X1 table (entropy_common.c:234-310, huf_decompress.c:380-470); lane-serial; bytes used or 0xFFFFFFFF
-__device__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big)
+// (noinline: the table builders run once per block on lane 0 but need ~200 VGPRs when inlined, which held the whole decoder
+//  at 2 waves per SIMD = 8 blocks per CU; as separate functions the kernel needs 103 and LDS bounds it at 10 per CU)
+__device__ __attribute__((noinline)) u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big)
 {
     u8* w = L->weights; u32 nsym, total = 0, used, rank[14];
     for (int i = 0; i < 14; ++i) rank[i] = 0;
@@ -1078,7 +1079,7 @@ __device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout,
 }
 
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705); lane-serial
-__device__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
+__device__ __attribute__((noinline)) bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
                           const s16* defNorm, u32 defMax, u32 defLog, DecLds* L)
 {
     if (mode == 0) {
