@@ -1603,11 +1603,16 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail, level) };
     }
     for (int i = 0; i < nl; ++i) {
-        // persistent blocks: exactly as many as are resident at once for this LDS size (LDS is allocated in 512-byte granules)
+        // persistent blocks: exactly as many as are resident at once for this LDS size (gfx950 allocates LDS in 1280-byte
+        // granules, the occupancy query counts bytes: the smaller of the two, see aoclgpu_zstd_decompress_chunks)
         int perCU = 0, dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::zstd_compress_kernel, 64, L[i].lds) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("zstd: occupancy query failed"); return AOCLGPU_ERR_HIP;
+        }
+        {
+            const int byLds = (int)((160u << 10) / (((L[i].lds + 1279u) / 1280u) * 1280u));
+            if (byLds >= 1 && byLds < perCU) perCU = byLds;
         }
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
