@@ -870,7 +870,8 @@ __device__ __forceinline__ u32x4 stream16(const gbyte* p, u32 n, int off)
 
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
-struct DecLds {                     // 14.7 KB: 10 blocks resident per CU (the serial entropy loops are latency chains)
+struct DecLds {                     // 12.4 KB = 10 LDS granules of 1280 bytes: 12 blocks resident per CU (the serial entropy loops are
+                                    // latency chains: throughput follows residency)
     u16 huf[2048];                  // symbol | nbBits << 8, table logs <= 11; a 12-bit table (accepted by the reference,
                                     // never produced by zstd) lives in the block's global workspace instead
     FseD ll[512], of[256], ml[512];
@@ -879,9 +880,9 @@ struct DecLds {                     // 14.7 KB: 10 blocks resident per CU (the s
     u32 rep[3];
     u32 seqLL[64], seqML[64], seqOff[64];
     u32 streamOk[4];
-    u8 bswin[1024 + 16] __attribute__((aligned(16)));       // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes)
+    u8 bswin[768] __attribute__((aligned(16)));             // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes + the 8-byte container)
     union {                                                  // never live at the same time
-        u8 hwin[4][512 + 16] __attribute__((aligned(16)));  // decoding the literals: windows of the four Huffman streams (256 symbols need <= 384 bytes)
+        u8 hwin[4][480] __attribute__((aligned(16)));       // decoding the literals: windows of the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
         struct {                                             // reading a table description (Huffman weights before the streams, FSE tables after them)
             s16 norm[256];
             u16 next[256];
@@ -1032,21 +1033,21 @@ __device__ __forceinline__ bool huf_decode_streams_t(DecLds* L, u8* out_, u32 no
     u32 i = 0;
     const u32 todo = (mine && ok) ? nout : 0;
     while (ballot(i < todo) != 0) {
-        {   // refill: 16 lanes x 32 bytes per stream, window = the 512 bytes that end with the byte holding bit pos-1
+        {   // refill: 15 lanes x 32 bytes per stream, window = the 480 bytes that end with the byte holding bit pos-1
             const int j = lane >> 4, k = lane & 15;
             const int e = (__shfl(b.pos, j) + 7) >> 3;
             const u64 sp = ((u64)(u32)__shfl((int)(u32)((u64)src >> 32), j) << 32) | (u32)__shfl((int)(u32)(u64)src, j);
             const u32 sn = (u32)__shfl((int)n, j);
             const bool act = __shfl((int)(i < todo), j) != 0;
-            if (act) {
+            if (act && k < 15) {
                 const gbyte* p = (const gbyte*)sp;
-                const int wb = e - 512;
+                const int wb = e - 480;
                 typedef __attribute__((address_space(3))) u32x4 LV;
                 lbyte* w = (lbyte*)&L->hwin[j][0];
                 *(LV*)(w + 32 * k) = stream16(p, sn, wb + 32 * k);
                 *(LV*)(w + 32 * k + 16) = stream16(p, sn, wb + 32 * k + 16);
             }
-            b.wb = ((b.pos + 7) >> 3) - 512;
+            b.wb = ((b.pos + 7) >> 3) - 480;
             wave_fence();
         }
         if (i < todo) {
@@ -1225,10 +1226,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         u32 r0 = 0, r1 = 0, r2 = 0;                                              // repcodes live in lane 0's registers
         const gbyte* bsp = (const gbyte*)(src + ip); const u32 bsn = n - ip;      // the sequence bitstream
         const lbyte* win = (const lbyte*)&L->bswin[0];
-        auto refill = [&]() {                                                    // whole wave: the 1024 bytes that end with the byte holding bit pos-1
-            const int e = ((int)lane_get((u32)b.pos, 0) + 7) >> 3, wb = e - 1024;
+        auto refill = [&]() {                                                    // 48 lanes: the 768 bytes that end with the byte holding bit pos-1
+            const int e = ((int)lane_get((u32)b.pos, 0) + 7) >> 3, wb = e - 768;
             typedef __attribute__((address_space(3))) u32x4 LV;
-            *(LV*)((lbyte*)&L->bswin[0] + 16 * lane) = stream16(bsp, bsn, wb + 16 * lane);
+            if (lane < 48) *(LV*)((lbyte*)&L->bswin[0] + 16 * lane) = stream16(bsp, bsn, wb + 16 * lane);
             b.wb = wb;
             wave_fence();
         };
