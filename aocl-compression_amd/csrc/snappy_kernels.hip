@@ -532,6 +532,31 @@ __global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b,
     }
 }
 
+// Mixed residency: one workgroup = four independent wavefronts (no barrier anywhere): wave 0 keeps its hash table in this
+// workgroup's LDS, waves 1-3 keep theirs in HBM (check-bit slots, 2 KB LDS scratch each).  38 KB of LDS per workgroup = 31 of
+// the CU's 128 LDS granules: 4 workgroups per CU = 4 LDS-table waves (the fast ones, no table traffic) + 12 HBM-table waves,
+// which is also what the registers allow (4 waves per SIMD).  Chunks are handed out through an atomic counter, so the faster
+// waves simply take more of them.
+__global__ void __launch_bounds__(256) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
+    __shared__ __attribute__((aligned(16))) uint16_t scr[3][kScratch];
+    const uint32_t w = threadIdx.x >> 6;
+    uint32_t* gt = tables + ((size_t)blockIdx.x * 3 + (w ? w - 1 : 0)) * kMaxTable;
+    for (;;) {
+        uint32_t c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(counter, 1u);
+        c = uni(c);
+        if (c >= b.nchunks) break;
+        const ChunkView v = compress_view(b, c);
+        int r;
+        if (w == 0) r = sn_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
+        else r = sn_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, (uint16_t*)gt, (lu16*)scr[w - 1]);
+        if ((threadIdx.x & 63) == 0) b.out_len[c] = r;
+        wave_fence();
+    }
+}
+
 __global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
 {
     const uint32_t c = blockIdx.x;
@@ -553,9 +578,24 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     // Batches that LDS can hold at once (5 tables per CU) use the LDS-table kernel; larger ones the persistent
     // global-table kernel with 14 workgroups per CU (the measured optimum with check bits in the slots: 10 -> 21.7,
     // 12 -> 22.9, 14 -> 24.3, 16 -> 23.6, 20 -> 19.7 GiB/s; without check bits 12 -> 21.8; LDS kernel 14.0).
-    // Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests).
+    // Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests); the largest batches take the
+    // mixed kernel below.
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("snappy: device query failed"); return AOCLGPU_ERR_HIP; }
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    if ((!(b->reserved & (64u | 128u)) && b->nchunks > 16u * cus) || (b->reserved & 32u)) {     // experiment 32 forces it (tests)
+        // large batches: the mixed kernel, 4 workgroups of 4 waves per CU (see snappy_compress_mix_kernel)
+        uint32_t grid = 4u * cus;
+        if (grid > (b->nchunks + 3) / 4) grid = (b->nchunks + 3) / 4;
+        if (const char* g = getenv("AOCLGPU_SNAPPY_MIX_PER_CU")) grid = (uint32_t)(atoi(g) > 0 ? atoi(g) : 4) * cus;   // tuning hook
+        const size_t tbytes = (size_t)grid * 3 * aoclgpu::kMaxTable * sizeof(uint32_t);
+        uint8_t* ws = (uint8_t*)aoclgpu::get_workspace(tbytes + 256, stream);
+        if (!ws) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+        uint32_t* counter = (uint32_t*)(ws + tbytes);
+        if (hipMemsetAsync(counter, 0, 4, (hipStream_t)stream) != hipSuccess) { aoclgpu::set_error_msg("snappy: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
+        hipLaunchKernelGGL(aoclgpu::snappy_compress_mix_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *b, (uint32_t*)ws, counter);
+        return aoclgpu::check_launch("snappy_compress_mix_kernel");
+    }
     if (!(b->reserved & 64u) && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || (b->reserved & 128u))) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::snappy_compress_gt_kernel, 64, 0) != hipSuccess || perCU < 1) {

@@ -243,7 +243,7 @@ def main():
             "decompress_GiBps": round(unc_total / GIB / (ms_d * 1e-3), 3),
             "ratio": round(unc_total / comp_total, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "snappy_compress_gt_kernel" if (args.codec, dom) == ("snappy", "compress") and nchunks > 5 * 256
+                "bound": "hbm", "kernel": "snappy_compress_mix_kernel" if (args.codec, dom) == ("snappy", "compress") and nchunks > 16 * 256
                                           else f"{args.codec}_{dom}_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_c if dom == "compress" else ms_d, 4),

@@ -16,12 +16,14 @@ def _chunks(raw, chunk):
     return [raw[i:i + chunk] for i in range(0, max(len(raw), 1), chunk)]
 
 
-@pytest.fixture(params=["auto", "hbm-tables"], autouse=True)
+@pytest.fixture(params=["auto", "hbm-tables", "mixed"], autouse=True)
 def table_placement(request, monkeypatch):
-    """every test runs twice: with the launcher's own choice (LDS tables for these small batches) and with the global-table
-    kernel forced (experiment switch 128), which otherwise only large batches reach"""
+    """every test runs three times: with the launcher's own choice (LDS tables for these small batches), with the global-table
+    kernel forced (experiment switch 128) and with the mixed kernel forced (32), which otherwise only large batches reach"""
     if request.param == "hbm-tables":
         monkeypatch.setenv("AOCLGPU_EXPERIMENT", "128")
+    if request.param == "mixed":                     # four-wave workgroups: one LDS-table wave + three HBM-table waves
+        monkeypatch.setenv("AOCLGPU_EXPERIMENT", "32")
     return request.param
 
 
