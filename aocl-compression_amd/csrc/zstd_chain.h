@@ -20,7 +20,10 @@
 //                immediate rep2 match, table writes beyond the trustworthy lanes);
 //   ZC_CONTINUE  no event below lim: the search goes on in the next batch, `lim - S` probes already examined;
 //   ZC_RESTART   a fresh batch has to start at lane S (S is the start of a search; never returned before at least
-//                one sequence was resolved, so the parse always advances).
+//                one sequence was resolved, so the parse always advances);
+//   ZC_REFRESH   the equality map of the current rep1 (taken from a match's 32-byte window) does not reach far enough to
+//                decide the search that starts at lane S: the caller loads fresh full-width maps for (rep1, rep2) and calls
+//                walk() again with S0 = S and the commit mask so far - one load round instead of a whole new batch.
 #pragma once
 #include <stdint.h>
 
@@ -49,7 +52,7 @@ ZC_FN uint64_t map_from_window(uint32_t eqb, int j)
 // the 4 match bytes, 0..24 (24 = runs out of the window) << 17 | catch-up bytes 0..4 (7 = needs the exact path) << 22
 ZC_FN uint32_t pack_info(uint32_t c, uint32_t fw, uint32_t bk4) { return c | (fw << 17) | (bk4 << 22); }
 
-enum { ZC_RESTART = 0, ZC_SPECIAL = 1, ZC_CONTINUE = 2 };
+enum { ZC_RESTART = 0, ZC_SPECIAL = 1, ZC_CONTINUE = 2, ZC_REFRESH = 3 };
 
 struct WalkOut {
     int outcome;
@@ -92,11 +95,11 @@ ZC_FN void finish(WalkOut& o, uint64_t& commit, int w1, int w2, int w3, int lim,
 // emit(litLength, offBase, matchLength, anchorPosition) stores one sequence.
 template <class Info, class Eqb, class Emit>
 ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, int32_t arel, uint32_t rep1, uint32_t rep2,
-                   uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit)
+                   uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit, const int S0 = 0, const uint64_t commit0 = 0)
 {
     WalkOut o;
-    int S = 0;
-    uint64_t commit = 0;
+    int S = S0;
+    uint64_t commit = commit0;
     uint64_t q1 = quad(eq1), q2 = quad(eq2);
     int end1 = 64, end2 = 64;                            // the maps are known for lanes below end
     o.ev = 0; o.el = 0; o.R = 0; o.why = 0; o.ntail = 0; o.post = false; o.tail[0] = o.tail[1] = o.tail[2] = 0;
@@ -113,7 +116,7 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
         } else if (jm < 64 && jm < U) ev = 1;
         else {
             const int R = lim < U ? lim : U;             // no event in [S, R)
-            if (R < lim && S > 0) { o.outcome = ZC_RESTART; break; }                             // a fresh batch sees further
+            if (R < lim && S > 0) { o.outcome = end1 < 64 ? ZC_REFRESH : ZC_RESTART; break; }   // fresh maps / a fresh batch see further
             commit |= lane_range(S, R); o.R = R; o.outcome = ZC_CONTINUE; break;
         }
         if (ev == 2) {

@@ -272,9 +272,24 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u32 infoV = near0 ? zchain::pack_info(c, 0, 7) : zchain::pack_info(c, fw, bk4);
                 const u64 okmask = ballot(lane < lim && ok);
                 const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
-                const zchain::WalkOut wo = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, ballot(pb0 == b1), ballot(pb0 == b2),
-                    [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
-                    [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; });
+                zchain::WalkOut wo;
+                {
+                    u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
+                    int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
+                    for (;;) {
+                        wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
+                            [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
+                            [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0);
+                        if (wo.outcome != zchain::ZC_REFRESH) break;
+                        // the map of the current rep1 came from a match's window and ends too early: one load round for full-width
+                        // maps of both repcodes instead of a whole new batch (lanes below the repcode's reach are not needed)
+                        u32 nb1 = 0x100, nb2 = 0x100;
+                        if (pos >= wo.rep1) nb1 = src[pos - wo.rep1];
+                        if (wo.rep2 && pos >= wo.rep2) nb2 = src[pos - wo.rep2];
+                        e1 = ballot(pb0 == nb1); e2 = ballot(pb0 == nb2);
+                        S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
+                    }
+                }
                 if ((wo.commit >> lane) & 1) tput(h, pos + 2);
                 wave_fence();
 #ifdef ZSTD_TRACE

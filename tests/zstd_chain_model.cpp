@@ -121,12 +121,23 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                     if (src[p] == src[p - rep1]) eq1 |= 1ull << j;
                     if (rep2 && src[p] == src[p - rep2]) eq2 |= 1ull << j;
                 }
-                const zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
-                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; },
-                    [&](u32 ll, u32 off, u32 ml, u32 apos) {
-                        (void)apos;
-                        M.seqs.push_back({ll, off, ml}); M.litSize += ll; M.stat[1]++;
-                    });
+                auto emit = [&](u32 ll, u32 off, u32 ml, u32 apos) {
+                    (void)apos;
+                    M.seqs.push_back({ll, off, ml}); M.litSize += ll; M.stat[1]++;
+                };
+                zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
+                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit);
+                while (w.outcome == zchain::ZC_REFRESH) {                                 // fresh full-width maps for the current repcodes
+                    M.stat[33]++;
+                    u64 e1 = 0, e2 = 0;
+                    for (int j = 0; j < 64; ++j) {
+                        const u32 p = pos0 + (u32)j;
+                        if (p >= w.rep1 && src[p] == src[p - w.rep1]) e1 |= 1ull << j;           // (lanes below S may lie before the offset's reach)
+                        if (w.rep2 && p >= w.rep2 && src[p] == src[p - w.rep2]) e2 |= 1ull << j;
+                    }
+                    w = zchain::walk(okmask, lim, pos0, w.arel, w.rep1, w.rep2, e1, e2,
+                        [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit);
+                }
                 for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
                 if (g_trace && g_trace_n < 4096) {
                     u64* t = g_trace + 8 * g_trace_n++;
