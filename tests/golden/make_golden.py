@@ -48,6 +48,9 @@ def main():
                 continue        # the GPU engine's Zstd chunk contract is one block (<= 128 KiB)
             c = ref.compress(codec, raw)
             v["out"][name] = {"size": len(c), "sha256": hashlib.sha256(c).hexdigest()}
+            if codec == ol.ZSTD:     # level 2: still the "fast" strategy at these sizes (separate key, older readers ignore it)
+                c2 = ref.compress(codec, raw, level=2)
+                v.setdefault("zstd_level2", {}).update({"size": len(c2), "sha256": hashlib.sha256(c2).hexdigest()})
         out["vectors"].append(v)
     for raw in TINY:
         t = {"input_hex": raw.hex(), "out": {}}

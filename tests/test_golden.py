@@ -31,6 +31,15 @@ def test_oracle_matches_golden(oracle, idx):
         assert oracle.decompress(CODECS[name], c, len(raw)) == raw
 
 
+@pytest.mark.parametrize("idx", [i for i, v in enumerate(GOLD["vectors"]) if "zstd_level2" in v])
+def test_oracle_matches_golden_zstd_level2(oracle, idx):
+    v = GOLD["vectors"][idx]
+    raw = _data(v)
+    c = oracle.compress(2, raw, level=2)
+    assert len(c) == v["zstd_level2"]["size"] and hashlib.sha256(c).hexdigest() == v["zstd_level2"]["sha256"]
+    assert oracle.decompress(2, c, len(raw)) == raw
+
+
 def test_oracle_tiny(oracle):
     for t in GOLD["tiny"]:
         raw = bytes.fromhex(t["input_hex"])
@@ -48,6 +57,16 @@ def test_gpu_matches_golden(eng, idx):
         c = eng.compress_host(CODECS[name], raw)
         assert len(c) == exp["size"] and hashlib.sha256(c).hexdigest() == exp["sha256"], name
         assert eng.decompress_host(CODECS[name], c, len(raw)) == raw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [i for i, v in enumerate(GOLD["vectors"]) if "zstd_level2" in v])
+def test_gpu_matches_golden_zstd_level2(eng, idx):
+    v = GOLD["vectors"][idx]
+    raw = _data(v)
+    c = eng.compress_host(2, raw, flags=a.api.FLAG_ZSTD_LEVEL2)
+    assert len(c) == v["zstd_level2"]["size"] and hashlib.sha256(c).hexdigest() == v["zstd_level2"]["sha256"]
+    assert eng.decompress_host(2, c, len(raw)) == raw
 
 
 @pytest.mark.gpu
