@@ -12,15 +12,18 @@
 //    one sequential stream; the result is a valid frame every LZ4F decoder reads, a little larger than the reference's.
 //    Levels: the fast compressor at default acceleration only (compressionLevel 0..2; LZ4HC levels and negative
 //    "acceleration" levels return LZ4F_ERROR_compressionLevel_invalid).
-//  * LZ4F_decompress (lz4frame.c:1398-1860): takes a WHOLE frame per call (the reference also accepts it in pieces;
-//    here an incomplete frame is LZ4F_ERROR_frameSize_wrong).  Independent blocks are decoded in one launch, one
-//    wavefront per block; linked blocks by one wavefront in order, each block copying from what was decoded before it.
-//    Header, block and content checksums are verified.  Skippable frames are skipped.
+//  * LZ4F_decompress (lz4frame.c:1398-1860): a whole frame per call is decoded straight into the caller's buffer;
+//    a frame that arrives in pieces (or a destination too small for all of it) is collected in the context, decoded when
+//    its end mark has arrived, and handed out over the following calls - same calling convention as the reference (0 when
+//    a frame is done, otherwise a hint > 0), but output only starts once the frame is complete.  Independent blocks are
+//    decoded in one launch, one wavefront per block; linked blocks by one wavefront in order, each block copying from what
+//    was decoded before it.  Header, block and content checksums are verified.  Skippable frames are skipped.
 #include "../../include/aocl_native_api.h"
 #include "../../include/aocl_gpu_codec.h"
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <vector>
 
 namespace {
@@ -135,7 +138,13 @@ size_t parse_header(const uint8_t* p, size_t n, FrameHeader* h)
 
 }  // namespace
 
-struct LZ4F_dctx_s { unsigned version; LZ4F_frameInfo_t info; bool haveInfo; };
+struct LZ4F_dctx_s {
+    unsigned version; LZ4F_frameInfo_t info; bool haveInfo;
+    // piecewise decoding: the frame is collected here until its end mark (and checksum) has arrived, decoded in one go,
+    // and handed out as the caller's buffers allow
+    std::vector<uint8_t> in, out;
+    size_t outPos;
+};
 
 extern "C" {
 
@@ -219,13 +228,13 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
 size_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version)
 {
     if (!dctxPtr) return err(E_GENERIC);
-    LZ4F_dctx* d = (LZ4F_dctx*)calloc(1, sizeof(LZ4F_dctx));
+    LZ4F_dctx* d = new (std::nothrow) LZ4F_dctx();
     if (!d) { *dctxPtr = nullptr; return err(E_allocation_failed); }
-    d->version = version; *dctxPtr = d;
+    d->version = version; d->haveInfo = false; d->outPos = 0; memset(&d->info, 0, sizeof(d->info)); *dctxPtr = d;
     return 0;
 }
-size_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx) { free(dctx); return 0; }
-void LZ4F_resetDecompressionContext(LZ4F_dctx* dctx) { if (dctx) dctx->haveInfo = false; }
+size_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx) { delete dctx; return 0; }
+void LZ4F_resetDecompressionContext(LZ4F_dctx* dctx) { if (dctx) { dctx->haveInfo = false; dctx->in.clear(); dctx->out.clear(); dctx->outPos = 0; } }
 
 size_t LZ4F_headerSize(const void* src, size_t srcSize)
 {   // lz4frame.c:1150-1180
@@ -249,15 +258,15 @@ size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* sr
     info->frameType = LZ4F_frame; info->contentSize = h.contentSize; info->dictID = h.dictID;
     info->blockChecksumFlag = h.blockChecksum ? LZ4F_blockChecksumEnabled : LZ4F_noBlockChecksum;
     dctx->info = *info; dctx->haveInfo = true;
+    dctx->in.assign((const uint8_t*)src, (const uint8_t*)src + h.bytes);      // the header is consumed here: LZ4F_decompress continues behind it
+    dctx->out.clear(); dctx->outPos = 0;
     *srcSizePtr = h.bytes;
     return kBH;
 }
 
-size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
-                       const LZ4F_decompressOptions_t* opts)
+// one whole frame (or skippable frame) at srcBuffer -> dstBuffer; 0 and the consumed / produced sizes, or an error code
+static size_t decode_whole(void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr)
 {
-    (void)opts;
-    if (!dctx || !dstSizePtr || !srcSizePtr || (!srcBuffer && *srcSizePtr)) return err(E_GENERIC);
     const uint8_t* const src = (const uint8_t*)srcBuffer; const size_t n = *srcSizePtr, cap = *dstSizePtr;
     *srcSizePtr = 0; *dstSizePtr = 0;
     if (n >= 8 && (rd32(src) & 0xFFFFFFF0u) == kSkipMagic) {                                                  // skippable frame (:1236-1246)
@@ -338,3 +347,81 @@ size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, con
 }
 
 }  // extern "C"
+
+// Length of the frame that starts at p, if all of it is within the n bytes given: 0 = not complete yet (*need = bytes
+// still missing for the next header / block, at least 1), or an error code.  *upper = upper bound of the decoded size.
+static size_t frame_extent(const uint8_t* p, size_t n, size_t* need, size_t* upper)
+{
+    *need = 1; *upper = 0;
+    if (n < 4) { *need = 4 - n; return 0; }
+    if ((rd32(p) & 0xFFFFFFF0u) == kSkipMagic) {
+        if (n < 8) { *need = 8 - n; return 0; }
+        const size_t tot = 8 + (size_t)rd32(p + 4);
+        if (n < tot) { *need = tot - n; return 0; }
+        return tot;
+    }
+    if (rd32(p) != kMagic) return err(E_frameType_unknown);
+    if (n < 7) { *need = 7 - n; return 0; }
+    const size_t hb = 7 + ((p[4] >> 3) & 1 ? 8 : 0) + (p[4] & 1 ? 4 : 0);
+    if (n < hb) { *need = hb - n; return 0; }
+    FrameHeader h;
+    { const size_t r = parse_header(p, n, &h); if (LZ4F_isError(r)) return r; }
+    const size_t bs = block_size(h.bsid);
+    size_t ip = h.bytes;
+    for (;;) {
+        if (n - ip < kBH) { *need = kBH - (n - ip); return 0; }
+        const uint32_t v = rd32(p + ip); ip += kBH;
+        if (v == 0) break;
+        const size_t len = (v & 0x7FFFFFFFu) + (h.blockChecksum ? kBF : 0);
+        if ((v & 0x7FFFFFFFu) > bs) return err(E_maxBlockSize_invalid);
+        if (n - ip < len) { *need = len - (n - ip); return 0; }
+        ip += len; *upper += bs;
+    }
+    if (h.contentChecksum) { if (n - ip < kBF) { *need = kBF - (n - ip); return 0; } ip += kBF; }
+    return ip;
+}
+
+extern "C" size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                                  const LZ4F_decompressOptions_t* opts)
+{   // lz4frame.c:1398-1860.  Returns 0 when a frame is completely decoded and delivered, otherwise a hint (> 0) of how many
+    // source bytes the next call should bring (output still pending: 1), or an error code.
+    (void)opts;
+    if (!dctx || !dstSizePtr || !srcSizePtr || (!srcBuffer && *srcSizePtr)) return err(E_GENERIC);
+    const size_t n = *srcSizePtr, cap = *dstSizePtr;
+    size_t consumed = 0;
+    if (dctx->outPos >= dctx->out.size()) {                                  // nothing decoded is waiting: collect / decode
+        dctx->out.clear(); dctx->outPos = 0;
+        size_t need = 1, upper = 0;
+        if (dctx->in.empty()) {
+            // the usual call: a whole frame in srcBuffer, room for all of its content in dstBuffer
+            const size_t ext = frame_extent((const uint8_t*)srcBuffer, n, &need, &upper);
+            if (LZ4F_isError(ext)) { *srcSizePtr = 0; *dstSizePtr = 0; return ext; }
+            if (ext) {
+                size_t sn = n, dn = cap;
+                const size_t r = decode_whole(dstBuffer, &dn, srcBuffer, &sn);
+                if (r == 0) { *srcSizePtr = sn; *dstSizePtr = dn; return 0; }
+                if (r != err(E_dstMaxSize_tooSmall)) { *srcSizePtr = 0; *dstSizePtr = 0; return r; }
+            }
+        }
+        // piecewise: append, and decode into the context once the frame is complete
+        const size_t before = dctx->in.size();
+        if (n) dctx->in.insert(dctx->in.end(), (const uint8_t*)srcBuffer, (const uint8_t*)srcBuffer + n);
+        const size_t ext = frame_extent(dctx->in.data(), dctx->in.size(), &need, &upper);
+        if (LZ4F_isError(ext)) { dctx->in.clear(); *srcSizePtr = 0; *dstSizePtr = 0; return ext; }
+        if (!ext) { *srcSizePtr = n; *dstSizePtr = 0; return need; }
+        consumed = ext - before;                                             // bytes behind the frame stay with the caller
+        dctx->in.resize(ext);
+        dctx->out.resize(upper ? upper : 1);
+        size_t sn = ext, dn = upper;
+        const size_t r = decode_whole(dctx->out.data(), &dn, dctx->in.data(), &sn);
+        dctx->in.clear();
+        if (r != 0) { dctx->out.clear(); *srcSizePtr = 0; *dstSizePtr = 0; return r; }
+        dctx->out.resize(dn); dctx->outPos = 0; dctx->haveInfo = false;
+    }
+    const size_t left = dctx->out.size() - dctx->outPos, give = left < cap ? left : cap;
+    if (give) memcpy(dstBuffer, dctx->out.data() + dctx->outPos, give);
+    dctx->outPos += give;
+    *srcSizePtr = consumed; *dstSizePtr = give;
+    if (dctx->outPos >= dctx->out.size()) { dctx->out.clear(); dctx->outPos = 0; return 0; }
+    return 1;
+}

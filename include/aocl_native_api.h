@@ -31,7 +31,8 @@ void        aocl_destroy_lz4(void);
 /* ---- LZ4 frame format (algos/lz4/lz4frame.h:100-260, 380-470; lz4frame.c:373-460, 1398-1860) on the GPU block codec.
  *      Types mirror lz4frame.h.  LZ4F_compressFrame: the fast compressor only (compressionLevel 0..2), blocks always
  *      independent (byte-identical to the reference for LZ4F_blockIndependent and for single-block inputs);
- *      LZ4F_decompress: one whole frame per call, independent and linked blocks, all checksums verified. ---- */
+ *      LZ4F_decompress: independent and linked blocks, all checksums verified; whole frames are decoded in place, frames fed in
+ *      pieces are collected and decoded once complete. ---- */
 typedef size_t LZ4F_errorCode_t;
 typedef enum { LZ4F_default = 0, LZ4F_max64KB = 4, LZ4F_max256KB = 5, LZ4F_max1MB = 6, LZ4F_max4MB = 7 } LZ4F_blockSizeID_t;
 typedef enum { LZ4F_blockLinked = 0, LZ4F_blockIndependent } LZ4F_blockMode_t;
