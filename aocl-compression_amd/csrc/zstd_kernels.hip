@@ -1499,10 +1499,11 @@ uint32_t lds_for_chunk(uint64_t n, int level = 1)
 }
 }  // namespace
 
-// Debug hook (tests only): the match finder's sequences for ONE chunk already in device memory:
+// The match finder's sequences for ONE chunk already in device memory (used by the sequence producer below and by the
+// debugging tools):
 // out_host[0] = nbSeq, out_host[1] = litSize, then {litLength, offBase, matchLength} per sequence.
 namespace aoclgpu {
-__global__ void __launch_bounds__(64) zstd_debug_seq_kernel(const uint8_t* src, uint32_t n, uint8_t* wsBase, uint32_t* out, uint32_t maxSeq, uint32_t expf)
+__global__ void __launch_bounds__(64) zstd_block_sequences_kernel(const uint8_t* src, uint32_t n, uint8_t* wsBase, uint32_t* out, uint32_t maxSeq, uint32_t expf)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase);
@@ -1516,7 +1517,7 @@ __global__ void __launch_bounds__(64) zstd_debug_seq_kernel(const uint8_t* src, 
     for (u32 i = (u32)lane; i < nbSeq && i < maxSeq; i += kWave) { out[2 + 3 * i] = ws->seqLL[i]; out[3 + 3 * i] = ws->seqOff[i]; out[4 + 3 * i] = ws->seqML[i]; }
 }
 }  // namespace aoclgpu
-extern "C" int aoclgpu_debug_zstd_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t maxSeq, uint32_t expf)
+extern "C" int aoclgpu_zstd_block_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t maxSeq, uint32_t expf)
 {
     if (n < 7 || n > (128u << 10)) return AOCLGPU_ERR_ARG;
     void* ws = get_workspace(aoclgpu::zstd_workspace_bytes(), nullptr);
@@ -1524,8 +1525,8 @@ extern "C" int aoclgpu_debug_zstd_sequences(const void* src_dev, uint32_t n, uin
     const size_t bytes = (2 + 3 * (size_t)maxSeq) * sizeof(uint32_t);
     if (!ws || hipMalloc((void**)&out, bytes) != hipSuccess) return AOCLGPU_ERR_HIP;
     const uint32_t lds = lds_for_chunk(n);
-    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)aoclgpu::zstd_debug_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(aoclgpu::zstd_debug_seq_kernel, dim3(1), dim3(64), lds, nullptr, (const uint8_t*)src_dev, n, (uint8_t*)ws, out, maxSeq, expf);
+    if (lds > 65536u) (void)hipFuncSetAttribute((const void*)aoclgpu::zstd_block_sequences_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(aoclgpu::zstd_block_sequences_kernel, dim3(1), dim3(64), lds, nullptr, (const uint8_t*)src_dev, n, (uint8_t*)ws, out, maxSeq, expf);
     const hipError_t e = hipMemcpy(out_host, out, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(out);
     return e == hipSuccess ? AOCLGPU_OK : AOCLGPU_ERR_HIP;
@@ -1552,7 +1553,7 @@ extern "C" size_t aoclgpu_zstd_sequence_producer(void* state, void* outSeqs, siz
     if (!dsrc && hipMalloc(&dsrc, (128u << 10) + 64) != hipSuccess) { dsrc = nullptr; return kErr; }
     if (!hout) hout = (uint32_t*)malloc((2 + 3 * (size_t)maxSeq) * sizeof(uint32_t));
     if (!hout || hipMemcpy(dsrc, src, srcSize, hipMemcpyHostToDevice) != hipSuccess) return kErr;
-    if (aoclgpu_debug_zstd_sequences(dsrc, (uint32_t)srcSize, hout, maxSeq, 0) != AOCLGPU_OK) return kErr;
+    if (aoclgpu_zstd_block_sequences(dsrc, (uint32_t)srcSize, hout, maxSeq, 0) != AOCLGPU_OK) return kErr;
     const uint32_t nb = hout[0];
     if ((size_t)nb + 1 > outSeqsCapacity || nb > maxSeq) return kErr;
     uint32_t rep1 = 1, rep2 = 4, rep3 = 8;

@@ -141,6 +141,11 @@ double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, i
  * or a value <= AOCLGPU_HOST_FAIL/2 when the GPU path itself failed (AOCLGPU_HOST_FAIL + AOCLGPU_ERR_*). */
 #define AOCLGPU_HOST_FAIL (-(1LL << 40))
 /* flags: AOCLGPU_FLAG_* of the codec (e.g. AOCLGPU_FLAG_ZSTD_LEVEL2) */
+/* The Zstd match finder alone ("fast" parse of level 1, no history): sequences of ONE chunk (7 .. 131072 bytes, device memory).
+ * out_host[0] = number of sequences, out_host[1] = total literal bytes, then {litLength, offBase, matchLength} per sequence
+ * (offBase as in zstd: 1 = repcode, offset + 3 otherwise).  Synchronous; flags: 0. */
+int aoclgpu_zstd_block_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t max_sequences, uint32_t flags);
+
 int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
 int64_t aoclgpu_decompress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);

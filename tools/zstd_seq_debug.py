@@ -11,7 +11,7 @@ ol.build_oracle()
 O = C.CDLL(ol.ORACLE_SO)
 O.orc_dbg_zstd_sequences.restype = C.c_size_t
 O.orc_dbg_zstd_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
-eng.lib.aoclgpu_debug_zstd_sequences.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+eng.lib.aoclgpu_zstd_block_sequences.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
 expf = int(os.environ.get("ZEXP", "0"))
 kinds = sys.argv[1:] or ["text", "jsonlog", "binary", "database"]
 nbad = 0
@@ -25,7 +25,7 @@ for kind in kinds:
         dev = torch.frombuffer(bytearray(d), dtype=torch.uint8).to(eng.device)
         maxs = n // 3 + 16
         out = np.zeros(2 + 3 * maxs, dtype=np.uint32)
-        rc = eng.lib.aoclgpu_debug_zstd_sequences(dev.data_ptr(), n, out.ctypes.data, maxs, expf)
+        rc = eng.lib.aoclgpu_zstd_block_sequences(dev.data_ptr(), n, out.ctypes.data, maxs, expf)
         assert rc == 0, rc
         got = out[2:2 + 3 * int(out[0])].reshape(-1, 3)
         if got.shape == want.shape and np.array_equal(got, want) and out[1] == lit.value:
@@ -54,7 +54,7 @@ if hasattr(eng.lib, "aoclgpu_debug_zstd_trace"):
     Mo.zchain_model_trace.argtypes = [C.c_void_p]
     eng.lib.aoclgpu_debug_zstd_trace(gt.ctypes.data, C.byref(cnt))          # reset
     out = np.zeros(2 + 3 * (n // 3 + 16), dtype=np.uint32)
-    eng.lib.aoclgpu_debug_zstd_sequences(dev.data_ptr(), n, out.ctypes.data, n // 3 + 16, expf)
+    eng.lib.aoclgpu_zstd_block_sequences(dev.data_ptr(), n, out.ctypes.data, n // 3 + 16, expf)
     eng.lib.aoclgpu_debug_zstd_trace(gt.ctypes.data, C.byref(cnt))
     mt = np.zeros(8 * 4096, dtype=np.uint64)
     Mo.zchain_model_trace(mt.ctypes.data)
