@@ -12,6 +12,7 @@
 //    one sequential stream; the result is a valid frame every LZ4F decoder reads, a little larger than the reference's.
 //    Levels: the fast compressor at default acceleration only (compressionLevel 0..2; LZ4HC levels and negative
 //    "acceleration" levels return LZ4F_ERROR_compressionLevel_invalid).
+//  * LZ4F_compressBegin / Update / flush / End: the reference's buffering rules, one launch per call (end of this file).
 //  * LZ4F_decompress (lz4frame.c:1398-1860): a whole frame per call is decoded straight into the caller's buffer;
 //    a frame that arrives in pieces (or a destination too small for all of it) is collected in the context, decoded when
 //    its end mark has arrived, and handed out over the following calls - same calling convention as the reference (0 when
@@ -112,6 +113,117 @@ bool upload_geometry(DevBuf& D, aoclgpu_batch& b, const std::vector<uint64_t>& s
     return true;
 }
 
+
+// xxHash32 over data that arrives in pieces (content checksum of the streaming compressor)
+struct Xxh32Stream {
+    uint64_t total; uint32_t v[4]; uint8_t mem[16]; uint32_t memsize;
+    void reset()
+    {
+        const uint32_t P1 = 2654435761u, P2 = 2246822519u;
+        total = 0; v[0] = P1 + P2; v[1] = P2; v[2] = 0; v[3] = 0u - P1; memsize = 0;
+    }
+    static uint32_t round(uint32_t acc, uint32_t in) { return rotl(acc + in * 2246822519u, 13) * 2654435761u; }
+    void update(const void* data, size_t len)
+    {
+        const uint8_t* p = (const uint8_t*)data; const uint8_t* const end = p + len;
+        total += len;
+        if (memsize + len < 16) { memcpy(mem + memsize, p, len); memsize += (uint32_t)len; return; }
+        if (memsize) {
+            memcpy(mem + memsize, p, 16 - memsize);
+            for (int i = 0; i < 4; ++i) v[i] = round(v[i], rd32(mem + 4 * i));
+            p += 16 - memsize; memsize = 0;
+        }
+        while (p + 16 <= end) { for (int i = 0; i < 4; ++i) v[i] = round(v[i], rd32(p + 4 * i)); p += 16; }
+        if (p < end) { memcpy(mem, p, (size_t)(end - p)); memsize = (uint32_t)(end - p); }
+    }
+    uint32_t digest() const
+    {
+        const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+        uint32_t h = total >= 16 ? rotl(v[0], 1) + rotl(v[1], 7) + rotl(v[2], 12) + rotl(v[3], 18) : v[2] + P5;
+        h += (uint32_t)total;
+        const uint8_t* p = mem; const uint8_t* const end = mem + memsize;
+        while (p + 4 <= end) { h = rotl(h + rd32(p) * P3, 17) * P4; p += 4; }
+        while (p < end) { h = rotl(h + *p * P5, 11) * P1; p++; }
+        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+        return h;
+    }
+};
+
+struct BlockRef { const uint8_t* p; uint32_t len; };
+
+// LZ4F_makeBlock (lz4frame.c:740-763) for a list of blocks, all compressed in ONE launch: each block on its own, output limit
+// len - 1, stored when it does not shrink; writes {size, data, [checksum]} per block at op.  Returns the bytes written or an
+// error code (test with LZ4F_isError).
+size_t make_blocks(const std::vector<BlockRef>& blks, size_t bs, bool blockCrc, uint8_t* op)
+{
+    const size_t nb = blks.size();
+    if (!nb) return 0;
+    uint8_t* const op0 = op;
+    DevBuf D;
+    const size_t slot = (bs + 15) & ~(size_t)15;
+    size_t total = 0;
+    for (const BlockRef& b : blks) total += b.len;
+    uint8_t* d_src = (uint8_t*)D.get(total); uint8_t* d_dst = (uint8_t*)D.get(nb * slot);
+    if (!d_src || !d_dst) return err(E_allocation_failed);
+    std::vector<uint64_t> so(nb), dofs(nb); std::vector<uint32_t> sl(nb), dc(nb);
+    size_t off = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        // consecutive blocks of one buffer travel in one copy
+        size_t j = i, run = blks[i].len;
+        while (j + 1 < nb && blks[j + 1].p == blks[j].p + blks[j].len) { ++j; run += blks[j].len; }
+        if (hipMemcpy(d_src + off, blks[i].p, run, hipMemcpyHostToDevice) != hipSuccess) return err(E_allocation_failed);
+        for (size_t k = i; k <= j; ++k) { so[k] = off; sl[k] = blks[k].len; dofs[k] = k * slot; dc[k] = blks[k].len - 1; off += blks[k].len; }
+        i = j;
+    }
+    aoclgpu_batch b; memset(&b, 0, sizeof(b));
+    b.src = d_src; b.dst = d_dst;
+    if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
+    if (aoclgpu_lz4_compress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+    std::vector<int32_t> ol(nb);
+    std::vector<uint8_t> slots(nb * slot);
+    if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(slots.data(), d_dst, nb * slot, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+    for (size_t i = 0; i < nb; ++i) {
+        uint32_t c = ol[i] > 0 ? (uint32_t)ol[i] : 0;
+        if (c == 0) { c = sl[i]; wr32(op, c | kStored); memcpy(op + kBH, blks[i].p, c); }                       // stored block
+        else { wr32(op, c); memcpy(op + kBH, slots.data() + i * slot, c); }
+        if (blockCrc) wr32(op + kBH + c, xxh32(op + kBH, c, 0));
+        op += kBH + c + (blockCrc ? kBF : 0);
+    }
+    return (size_t)(op - op0);
+}
+
+// frame header (lz4frame.c:670-699); blocks are always independent here.  Returns its size.
+size_t write_header(uint8_t* dst, const LZ4F_preferences_t& prefs)
+{
+    uint8_t* op = dst;
+    wr32(op, kMagic); op += 4;
+    uint8_t* const hs = op;
+    *op++ = (uint8_t)((1 << 6) | (1 << 5) | ((prefs.frameInfo.blockChecksumFlag & 1) << 4) | ((prefs.frameInfo.contentSize > 0) << 3) |
+                      ((prefs.frameInfo.contentChecksumFlag & 1) << 2) | (prefs.frameInfo.dictID > 0));
+    *op++ = (uint8_t)(((int)prefs.frameInfo.blockSizeID & 7) << 4);
+    if (prefs.frameInfo.contentSize) { wr64(op, prefs.frameInfo.contentSize); op += 8; }
+    if (prefs.frameInfo.dictID) { wr32(op, prefs.frameInfo.dictID); op += 4; }
+    *op = (uint8_t)(xxh32(hs, (size_t)(op - hs), 0) >> 8); op++;
+    return (size_t)(op - dst);
+}
+
+// LZ4F_compressBound_internal (lz4frame.c:324-349)
+size_t bound_internal(size_t srcSize, const LZ4F_preferences_t* prefs, size_t alreadyBuffered)
+{
+    const bool worst = prefs == nullptr;
+    const int bsid = prefs ? (int)prefs->frameInfo.blockSizeID : 0;
+    const size_t bs = block_size(bsid);
+    if (!bs) return err(E_maxBlockSize_invalid);
+    const unsigned flush = (prefs ? prefs->autoFlush : 0) | (srcSize == 0);
+    const size_t maxBuffered = bs - 1, buffered = alreadyBuffered < maxBuffered ? alreadyBuffered : maxBuffered;
+    const size_t maxSrc = srcSize + buffered, full = maxSrc / bs, partial = maxSrc & (bs - 1), last = flush ? partial : 0;
+    const size_t nb = full + (last > 0);
+    const size_t blockCrc = (worst || prefs->frameInfo.blockChecksumFlag) ? kBF : 0;
+    const size_t frameEnd = kBH + ((worst || prefs->frameInfo.contentChecksumFlag) ? kBF : 0);
+    return (kBH + blockCrc) * nb + bs * full + last + frameEnd;
+}
+
 struct FrameHeader { int bsid; bool independent, blockChecksum, contentChecksum, hasSize, hasDict; uint64_t contentSize; uint32_t dictID; size_t bytes; };
 
 // LZ4F_decodeHeader (lz4frame.c:1190-1290) for a regular frame; returns 0 or an error code
@@ -182,43 +294,14 @@ size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBu
     const size_t bs = block_size((int)prefs.frameInfo.blockSizeID);
     if (srcSize > ((size_t)0xFFFFFFFFu - 64) * 1) return err(E_srcSize_tooLarge);
     uint8_t* const dst = (uint8_t*)dstBuffer; uint8_t* op = dst;
-    // ---- frame header (lz4frame.c:670-699); blocks are always independent here ----
-    wr32(op, kMagic); op += 4;
-    uint8_t* const hs = op;
-    *op++ = (uint8_t)((1 << 6) | (1 << 5) | ((prefs.frameInfo.blockChecksumFlag & 1) << 4) | ((prefs.frameInfo.contentSize > 0) << 3) |
-                      ((prefs.frameInfo.contentChecksumFlag & 1) << 2) | (prefs.frameInfo.dictID > 0));
-    *op++ = (uint8_t)(((int)prefs.frameInfo.blockSizeID & 7) << 4);
-    if (prefs.frameInfo.contentSize) { wr64(op, prefs.frameInfo.contentSize); op += 8; }
-    if (prefs.frameInfo.dictID) { wr32(op, prefs.frameInfo.dictID); op += 4; }
-    *op = (uint8_t)(xxh32(hs, (size_t)(op - hs), 0) >> 8); op++;
+    op += write_header(op, prefs);
     // ---- blocks: one launch for the whole frame ----
-    const size_t nb = (srcSize + bs - 1) / bs;
-    if (nb) {
-        DevBuf D;
-        const size_t slot = (bs + 15) & ~(size_t)15;
-        uint8_t* d_src = (uint8_t*)D.get(srcSize); uint8_t* d_dst = (uint8_t*)D.get(nb * slot);
-        if (!d_src || !d_dst) return err(E_allocation_failed);
-        std::vector<uint64_t> so(nb), dofs(nb); std::vector<uint32_t> sl(nb), dc(nb);
-        for (size_t i = 0; i < nb; ++i) {
-            so[i] = i * bs; sl[i] = (uint32_t)(srcSize - i * bs < bs ? srcSize - i * bs : bs);
-            dofs[i] = i * slot; dc[i] = sl[i] - 1;                                                             // LZ4F_makeBlock :747-749
-        }
-        aoclgpu_batch b; memset(&b, 0, sizeof(b));
-        b.src = d_src; b.dst = d_dst;
-        if (hipMemcpy(d_src, srcBuffer, srcSize, hipMemcpyHostToDevice) != hipSuccess || !upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
-        if (aoclgpu_lz4_compress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
-        std::vector<int32_t> ol(nb);
-        std::vector<uint8_t> slots(nb * slot);
-        if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(slots.data(), d_dst, nb * slot, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
-        for (size_t i = 0; i < nb; ++i) {
-            uint32_t c = ol[i] > 0 ? (uint32_t)ol[i] : 0;
-            if (c == 0) {                                                                                       // stored block
-                c = sl[i]; wr32(op, c | kStored); memcpy(op + kBH, (const uint8_t*)srcBuffer + so[i], c);
-            } else { wr32(op, c); memcpy(op + kBH, slots.data() + i * slot, c); }
-            if (prefs.frameInfo.blockChecksumFlag) wr32(op + kBH + c, xxh32(op + kBH, c, 0));
-            op += kBH + c + (prefs.frameInfo.blockChecksumFlag ? kBF : 0);
-        }
+    {
+        std::vector<BlockRef> blks;
+        for (size_t o = 0; o < srcSize; o += bs) blks.push_back(BlockRef{(const uint8_t*)srcBuffer + o, (uint32_t)(srcSize - o < bs ? srcSize - o : bs)});
+        const size_t w = make_blocks(blks, bs, prefs.frameInfo.blockChecksumFlag != 0, op);
+        if (LZ4F_isError(w)) return w;
+        op += w;
     }
     wr32(op, 0); op += 4;                                                                                     // end mark (:1002)
     if (prefs.frameInfo.contentChecksumFlag) { wr32(op, xxh32(srcBuffer, srcSize, 0)); op += 4; }
@@ -425,3 +508,104 @@ extern "C" size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstS
     if (dctx->outPos >= dctx->out.size()) { dctx->out.clear(); dctx->outPos = 0; return 0; }
     return 1;
 }
+
+// ---- streaming compressor (lz4frame.c:570-1030): same buffering rules as the reference (a block is cut when blockSize bytes
+//      are there, or at every call with autoFlush), so for LZ4F_blockIndependent the bytes equal the reference's for the same
+//      sequence of calls; every LZ4F_compressUpdate compresses the blocks it completes in one launch ----
+struct LZ4F_cctx_s {
+    unsigned version; LZ4F_preferences_t prefs; int stage; size_t bs;
+    std::vector<uint8_t> tmp; size_t tmpSize; unsigned long long total; Xxh32Stream xxh;
+};
+
+extern "C" {
+
+size_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version)
+{
+    if (!cctxPtr) return err(E_GENERIC);
+    LZ4F_cctx* c = new (std::nothrow) LZ4F_cctx();
+    if (!c) { *cctxPtr = nullptr; return err(E_allocation_failed); }
+    c->version = version; c->stage = 0; c->tmpSize = 0; c->total = 0; c->bs = 0; *cctxPtr = c;
+    return 0;
+}
+size_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx) { delete cctx; return 0; }
+
+size_t LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* prefs)
+{   // lz4frame.c:724-730
+    if (prefs && prefs->autoFlush) return bound_internal(srcSize, prefs, 0);
+    return bound_internal(srcSize, prefs, (size_t)-1);
+}
+
+size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr)
+{   // lz4frame.c:597-700
+    if (!cctx || !dstBuffer) return err(E_GENERIC);
+    if (dstCapacity < kMaxHeader) return err(E_dstMaxSize_tooSmall);
+    if (prefsPtr) cctx->prefs = *prefsPtr; else memset(&cctx->prefs, 0, sizeof(cctx->prefs));
+    if (cctx->prefs.compressionLevel < 0 || cctx->prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);
+    if (cctx->prefs.frameInfo.blockSizeID == 0) cctx->prefs.frameInfo.blockSizeID = LZ4F_max64KB;
+    cctx->bs = block_size((int)cctx->prefs.frameInfo.blockSizeID);
+    if (!cctx->bs) return err(E_maxBlockSize_invalid);
+    cctx->tmp.resize(cctx->bs); cctx->tmpSize = 0; cctx->total = 0; cctx->xxh.reset();
+    cctx->stage = 1;
+    return write_header((uint8_t*)dstBuffer, cctx->prefs);
+}
+
+size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                           const LZ4F_compressOptions_t* opts)
+{   // lz4frame.c:825-930
+    (void)opts;
+    if (!cctx || cctx->stage != 1 || !dstBuffer || (!srcBuffer && srcSize)) return err(E_GENERIC);
+    if (dstCapacity < bound_internal(srcSize, &cctx->prefs, cctx->tmpSize)) return err(E_dstMaxSize_tooSmall);
+    const size_t bs = cctx->bs;
+    const uint8_t* sp = (const uint8_t*)srcBuffer; const uint8_t* const se = sp + srcSize;
+    std::vector<BlockRef> blks;
+    if (cctx->tmpSize > 0) {                                              // complete the buffered block first
+        const size_t toCopy = bs - cctx->tmpSize;
+        if (toCopy > srcSize) { memcpy(cctx->tmp.data() + cctx->tmpSize, sp, srcSize); sp = se; cctx->tmpSize += srcSize; }
+        else {
+            memcpy(cctx->tmp.data() + cctx->tmpSize, sp, toCopy); sp += toCopy;
+            blks.push_back(BlockRef{cctx->tmp.data(), (uint32_t)bs});
+            cctx->tmpSize = 0;
+        }
+    }
+    while ((size_t)(se - sp) >= bs) { blks.push_back(BlockRef{sp, (uint32_t)bs}); sp += bs; }
+    if (cctx->prefs.autoFlush && sp < se) { blks.push_back(BlockRef{sp, (uint32_t)(se - sp)}); sp = se; }
+    const size_t w = make_blocks(blks, bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer);
+    if (LZ4F_isError(w)) return w;
+    if (sp < se) { memcpy(cctx->tmp.data(), sp, (size_t)(se - sp)); cctx->tmpSize = (size_t)(se - sp); }   // < blockSize: buffered
+    if (cctx->prefs.frameInfo.contentChecksumFlag) cctx->xxh.update(srcBuffer, srcSize);
+    cctx->total += srcSize;
+    return w;
+}
+
+size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+{   // lz4frame.c:942-985
+    (void)opts;
+    if (!cctx) return err(E_GENERIC);
+    if (cctx->tmpSize == 0) return 0;
+    if (cctx->stage != 1 || !dstBuffer) return err(E_GENERIC);
+    if (dstCapacity < cctx->tmpSize + kBH + kBF) return err(E_dstMaxSize_tooSmall);
+    std::vector<BlockRef> blks(1, BlockRef{cctx->tmp.data(), (uint32_t)cctx->tmpSize});
+    const size_t w = make_blocks(blks, cctx->bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer);
+    if (LZ4F_isError(w)) return w;
+    cctx->tmpSize = 0;
+    return w;
+}
+
+size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+{   // lz4frame.c:988-1030
+    const size_t f = LZ4F_flush(cctx, dstBuffer, dstCapacity, opts);
+    if (LZ4F_isError(f)) return f;
+    if (!cctx || cctx->stage != 1 || !dstBuffer) return err(E_GENERIC);
+    uint8_t* op = (uint8_t*)dstBuffer + f;
+    if (dstCapacity - f < 4) return err(E_dstMaxSize_tooSmall);
+    wr32(op, 0); op += 4;
+    if (cctx->prefs.frameInfo.contentChecksumFlag) {
+        if (dstCapacity - f < 8) return err(E_dstMaxSize_tooSmall);
+        wr32(op, cctx->xxh.digest()); op += 4;
+    }
+    cctx->stage = 0;
+    if (cctx->prefs.frameInfo.contentSize && cctx->prefs.frameInfo.contentSize != cctx->total) return err(E_frameSize_wrong);
+    return (size_t)(op - (uint8_t*)dstBuffer);
+}
+
+}  // extern "C"

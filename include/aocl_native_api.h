@@ -45,13 +45,24 @@ typedef struct {
 } LZ4F_frameInfo_t;
 typedef struct { LZ4F_frameInfo_t frameInfo; int compressionLevel; unsigned autoFlush; unsigned favorDecSpeed; unsigned reserved[3]; } LZ4F_preferences_t;
 typedef struct { unsigned stableDst; unsigned reserved[3]; } LZ4F_decompressOptions_t;
+typedef struct { unsigned stableSrc; unsigned reserved[3]; } LZ4F_compressOptions_t;
 typedef struct LZ4F_dctx_s LZ4F_dctx;
+typedef struct LZ4F_cctx_s LZ4F_cctx;
 unsigned    LZ4F_isError(LZ4F_errorCode_t code);
 const char* LZ4F_getErrorName(LZ4F_errorCode_t code);
 unsigned    LZ4F_getVersion(void);
 int         LZ4F_compressionLevel_max(void);
 size_t      LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
 size_t      LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
+/* streaming compression (lz4frame.c:570-1030): the reference's buffering rules, one launch per call for the blocks it completes */
+LZ4F_errorCode_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version);
+LZ4F_errorCode_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx);
+size_t      LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* preferencesPtr);
+size_t      LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* preferencesPtr);
+size_t      LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                                const LZ4F_compressOptions_t* cOptPtr);
+size_t      LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr);
+size_t      LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr);
 LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version);
 LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);
 void        LZ4F_resetDecompressionContext(LZ4F_dctx* dctx);

@@ -208,3 +208,34 @@ def test_piecewise_decompress(eng, G, R, header_first):
             assert (got, pos, r) == (data, len(frame), 0), (n, o, len(got), pos, r)
             want, wpos, wr = _stream(R, frame + b"\x00" * 9, n, rng, header_first)          # the reference under the same driver
             assert (want, wpos, wr) == (data, len(frame), 0)
+
+
+def test_compress_bound_matches_reference(G, R):
+    for n in [0, 1, 65535, 65536, 65537, 300000, 4 << 20]:
+        assert G.LZ4F_compressBound(n, None) == R.LZ4F_compressBound(n, None)
+        for o in OPTS + [dict(auto_flush=True), dict(bsid=6, auto_flush=True, block_checksum=True)]:
+            p = lf.prefs(**o)
+            assert G.LZ4F_compressBound(n, C.byref(p)) == R.LZ4F_compressBound(n, C.byref(p)), (n, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto_flush", [False, True])
+def test_streaming_compress(eng, G, R, auto_flush):
+    """LZ4F_compressBegin / Update / flush / End with the reference's buffering rules: for independent blocks the frame equals the
+    reference's for the same sequence of calls; linked-mode requests give an independent-block frame that the reference decodes"""
+    rng = np.random.default_rng(23)
+    base = a.corpus.make("jsonlog", 3 << 20).tobytes()
+    for n in [0, 1, 70000, 300000, (2 << 20) + 11]:
+        data = base[:n]
+        for o in [dict(independent=True), dict(bsid=5, independent=True, content_checksum=True, block_checksum=True), dict(bsid=6, independent=True, content_checksum=True),
+                  dict(), dict(bsid=5, content_checksum=True)]:
+            p = lf.prefs(auto_flush=auto_flush, **o)
+            pieces = []; left = n
+            while left:
+                k = min(left, int(rng.integers(1, 200000))); pieces.append(k); left -= k
+            flush_at = set(int(x) for x in rng.integers(0, max(len(pieces), 1), 2)) if pieces else set()
+            got = lf.compress_stream(G, data, p, pieces, flush_at)
+            assert isinstance(got, bytes), got
+            assert lf.decompress(R, got, n) == (data, len(got)), (n, o)
+            if o.get("independent"):
+                assert got == lf.compress_stream(R, data, p, pieces, flush_at), (n, o, auto_flush)
