@@ -127,12 +127,11 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             // table writes at k+1, k+2 and E-2 (:537, :680-681): lanes below lim join the batch commit; from the first one
             // at or beyond lim on they follow one by one (`tail`, in order) and the chain ends with this sequence
             const bool tails = E - 2 >= lim;
-            int why = E < end1 ? 0 : 1;                  // the comparison ran into the end of what is known
-            bool post = false;                                                                    // :690 immediate rep2 test
-            if (!why && rep2) {
-                if (E + 4 <= end2) why = ((q2 >> E) & 1) ? 16 : 0;
-                else post = true;                                                                 // by two loads after the walk
-            }
+            // (straight-line on purpose: every branch costs the wave far more than the few scalar operations it would skip)
+            const bool imm = rep2 != 0 && E + 4 <= end2;                                          // :690 immediate rep2 test decidable here
+            const int why = (E < end1 ? 0 : 1)           // the comparison ran into the end of what is known
+                          | ((imm & (int)((q2 >> (E & 63)) & 1)) ? 16 : 0);
+            const bool post = why == 0 && rep2 != 0 && !imm;                                      // else by two loads after the walk
             commit |= lane_range(S, k + 1);
             if (why) { o.outcome = ZC_SPECIAL; o.ev = 2; o.el = k; o.why = why; break; }
             emit((uint32_t)(q - (int)back1 - arel), 1u, back1 + 4u + (uint32_t)f, (uint32_t)((int32_t)pos0 + arel));
@@ -148,12 +147,10 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             const uint32_t back = bk4 < maxback ? bk4 : maxback;
             const int E = j + 4 + (int)fw;
             const bool tails = E - 2 >= lim;
-            int why = (fw < 24 ? 0 : 1) | (bk4 != 7 && !(bk4 == 4 && maxback > 4) ? 0 : 2) | (tails && j + 2 >= 64 ? 4 : 0);
-            bool post = false;                                                                    // rep2 becomes the old rep1
-            if (!why) {
-                if (E + 4 <= end1) why = ((q1 >> E) & 1) ? 16 : 0;
-                else post = true;
-            }
+            const bool imm = E + 4 <= end1;                                                       // rep2 becomes the old rep1
+            const int why = (fw < 24 ? 0 : 1) | (bk4 != 7 && !(bk4 == 4 && maxback > 4) ? 0 : 2) | (tails && j + 2 >= 64 ? 4 : 0)
+                          | ((imm & (int)((q1 >> (E & 63)) & 1)) ? 16 : 0);
+            const bool post = why == 0 && !imm;
             commit |= lane_range(S, j + 1);
             if (why) { o.outcome = ZC_SPECIAL; o.ev = 1; o.el = j; o.why = why; break; }
             const uint32_t off = pos0 + (uint32_t)j - c;
