@@ -134,3 +134,22 @@ def test_full_size_round_trip(eng):
     dst, dl = eng.decompress_chunks(a.SNAPPY, slots, out_len, slot, total, chunk)
     assert int((dl != chunk).sum().item()) == 0
     assert torch.equal(dst, src)
+
+
+def test_large_batch_all_kernels_agree(eng, monkeypatch, table_placement):
+    """a batch big enough for the persistent kernels (8 192 fragments): LDS-table, HBM-table and mixed kernels give the same
+    bytes, run after run (chunks are handed out dynamically, the result must not depend on who took which)"""
+    if table_placement != "auto":
+        pytest.skip("runs once")
+    base = torch.from_numpy(a.corpus.make("jsonlog", 64 << 20, seed=3)).to(eng.device)
+    src = base.repeat(8)
+    outs = {}
+    for name, flag in (("lds", "64"), ("hbm", "128"), ("mixed", "32"), ("mixed again", "32"), ("auto", "0")):
+        monkeypatch.setenv("AOCLGPU_EXPERIMENT", flag)
+        slots, out_len, slot = eng.compress_chunks(a.SNAPPY, src, 65536)
+        used = (torch.arange(slots.numel(), device=slots.device) % slot) < out_len.to(torch.int64).repeat_interleave(slot)
+        outs[name] = (out_len.clone(), torch.where(used, slots, torch.zeros_like(slots)))
+    ref_len, ref_bytes = outs["lds"]
+    for name, (ln, by) in outs.items():
+        assert torch.equal(ln, ref_len), name
+        assert torch.equal(by, ref_bytes), name
