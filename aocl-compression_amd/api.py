@@ -44,6 +44,8 @@ class Batch(C.Structure):
 
 FLAG_RAP_PARTITIONS = 0x100
 FLAG_ZSTD_LEVEL2 = 0x400      # Zstd level 2 instead of 1 (include/aocl_gpu_codec.h)
+# kernel selection (never changes an output byte; lets tests drive every kernel on small batches)
+FLAG_SNAPPY_TABLES_LDS, FLAG_SNAPPY_TABLES_HBM, FLAG_SNAPPY_TABLES_MIXED, FLAG_LZ4_TABLE_U32 = 0x1000, 0x2000, 0x4000, 0x8000
 
 
 class LlcDesc(C.Structure):
@@ -65,6 +67,8 @@ EXPORTS = [
     "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_compress_host_ex", "aoclgpu_decompress_host",
     "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes", "aoclgpu_rap_default_chunk",
     "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",
+    "aoclgpu_zstd_compress_host_frames", "aoclgpu_zstd_decompress_host_frames", "aoclgpu_set_host_device", "aoclgpu_host_device",
+    "aoclgpu_rap_assemble",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
 ]
 
@@ -98,6 +102,15 @@ def load_library() -> C.CDLL:
     lib.aoclgpu_rap_pack.argtypes = [C.c_int, C.POINTER(Batch), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     lib.aoclgpu_rap_unpack.restype = C.c_int
     lib.aoclgpu_rap_unpack.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_void_p]
+    lib.aoclgpu_rap_assemble.restype = C.c_int
+    lib.aoclgpu_rap_assemble.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    for n in ("aoclgpu_zstd_compress_host_frames",):
+        f = getattr(lib, n)
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32]
+    lib.aoclgpu_zstd_decompress_host_frames.restype = C.c_int64
+    lib.aoclgpu_zstd_decompress_host_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.aoclgpu_rap_frame_bytes.restype = C.c_uint64
     lib.aoclgpu_rap_frame_bytes.argtypes = [C.c_int, C.c_uint32]
     for n in ("aocl_llc_compress", "aocl_llc_decompress"):
@@ -134,6 +147,7 @@ class Engine:
             raise EngineError(f"aoclgpu_init({device}) failed: {self.lib.aoclgpu_last_error().decode()}")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        self.force_flags = 0      # AOCLGPU_FLAG_* kernel-selection bits OR-ed into every compress call (test hook)
 
     # ---- helpers ----
     def _stream(self):
@@ -151,8 +165,7 @@ class Engine:
         nchunks = max(1, -(-n // chunk_bytes))
         assert slots.numel() >= nchunks * slot_bytes and out_len.numel() >= nchunks
         return Batch(src=src.data_ptr(), dst=slots.data_ptr(), out_len=out_len.data_ptr(), nchunks=nchunks,
-                     total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes,
-                     reserved=int(os.environ.get("AOCLGPU_EXPERIMENT", "0")))
+                     total_bytes=n, chunk_bytes=chunk_bytes, slot_bytes=slot_bytes, reserved=self.force_flags)
 
     def uniform_decompress_batch(self, slots, comp_len, slot_bytes: int, dst, chunk_bytes: int, out_len) -> Batch:
         n = int(dst.numel())
@@ -215,6 +228,24 @@ class Engine:
                                                 C.byref(r), self._stream()), "rap_unpack")
         return dst, r.value
 
+    def rap_assemble(self, codec: int, gathered, chunk_off, chunk_len, chunk_src_len, chunk_aux=None):
+        """ONE RAP stream from gathered one-shot chunk streams (aoclgpu_rap_assemble): `gathered` is a device tensor, the
+        per-chunk arrays are host sequences in stream order.  Returns the stream as a uint8 tensor."""
+        import numpy as np
+        t = self.torch
+        k = len(chunk_len)
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        ln = np.ascontiguousarray(chunk_len, dtype=np.int32)
+        sl = np.ascontiguousarray(chunk_src_len, dtype=np.uint32)
+        ax = np.ascontiguousarray(chunk_aux, dtype=np.uint32) if chunk_aux is not None else None
+        cap = int(self.lib.aoclgpu_rap_frame_bytes(codec, k)) + int(ln.clip(min=0).sum()) + 16 * k + 64
+        out = t.empty(cap, dtype=t.uint8, device=self.device)
+        n = C.c_uint64(0)
+        self._check(self.lib.aoclgpu_rap_assemble(codec, gathered.data_ptr(), off.ctypes.data, ln.ctypes.data, sl.ctypes.data,
+                                                  ax.ctypes.data if ax is not None else None, k, out.data_ptr(), cap,
+                                                  C.byref(n), self._stream()), "rap_assemble")
+        return out[:n.value]
+
     def compact(self, slots, slot_bytes: int, out_len):
         """Gather the used prefix of each slot into one stream; returns (packed, offsets uint64-as-int64[n+1])."""
         t = self.torch
@@ -236,7 +267,7 @@ class Engine:
     def compress_host(self, codec: int, data: bytes, cap: int | None = None, flags: int = 0) -> bytes | None:
         cap = compress_bound(codec, len(data)) if cap is None else cap
         out = C.create_string_buffer(max(cap, 1))
-        r = self.lib.aoclgpu_compress_host_ex(codec, data, len(data), out, cap, flags)
+        r = self.lib.aoclgpu_compress_host_ex(codec, data, len(data), out, cap, flags | self.force_flags)
         if r < 0:
             raise EngineError(f"compress_host failed ({r}): {self.lib.aoclgpu_last_error().decode()}")
         return out.raw[:r] if r > 0 else None

@@ -24,7 +24,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 CLI_SOURCE = "bench_cli.cpp"
-SOURCES = ["capi.hip", "lz4_kernels.hip", "snappy_kernels.hip", "zstd_kernels.hip", "rap.hip", "aocl_api.cpp", "native_api.cpp", "lz4frame_api.cpp"]
+SOURCES = ["capi.hip", "lz4_kernels.hip", "snappy_kernels.hip", "zstd_kernels.hip", "rap.hip", "aocl_api.cpp", "native_api.cpp", "zstd_api.cpp", "lz4frame_api.cpp"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
           *os.environ.get("AOCLGPU_CFLAGS", "").split()]
 

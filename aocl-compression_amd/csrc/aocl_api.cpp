@@ -8,6 +8,7 @@
 // There is no CPU fallback: without a gfx950 device every call fails with ERR_COMPRESSION_FAILED.
 #include "../../include/aocl_compression.h"
 #include "../../include/aocl_gpu_codec.h"
+#include "../../include/aocl_native_api.h"
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
@@ -59,11 +60,20 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
         int64_t r = aoclgpu_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
         return r > 0 ? r : kCodecError;
     }
-    // ZSTD (api/codec.cpp:396-422): the "fast" strategy has a GPU backend, i.e. levels 1 and 2 for inputs of at most 128 KiB
-    // (level 0 is ZSTD_CLEVEL_DEFAULT = 3 in the reference, a double-fast parse: refused rather than answered with different bytes)
-    if (h->level != 1 && h->level != 2) return kCodecError;
-    int64_t r = aoclgpu_compress_host_ex(c, h->inBuf, h->inSize, h->outBuf, h->outSize, h->level == 2 ? AOCLGPU_FLAG_ZSTD_LEVEL2 : 0u);
-    return r > 0 ? r : kCodecError;
+    // ZSTD: the call sequence of the reference's wrapper (api/codec.cpp:388-422) on this library's own Zstd entry points:
+    // parameters from the level table, optVar clamps windowLog, ZSTD_compress_advanced.  Levels whose parameters are not
+    // the "fast" strategy (level 0 = default 3 and up: double-fast, greedy, ...) and windows below the input size come
+    // back as ZSTD_error_parameter_unsupported -> CODEC_ERROR, never as different bytes.
+    ZSTD_parameters zp = ZSTD_getParams((int)h->level, h->inSize, 0);
+    zp.fParams.contentSizeFlag = 1;
+    if (h->optVar && zp.cParams.windowLog > h->optVar) {
+        zp.cParams.windowLog = (unsigned)h->optVar;
+        zp.cParams.chainLog = (unsigned)h->optVar + ((zp.cParams.strategy == ZSTD_btlazy2) || (zp.cParams.strategy == ZSTD_btopt) ||
+                                                      (zp.cParams.strategy == ZSTD_btultra));
+    }
+    static ZSTD_CCtx* const kCtx = ZSTD_createCCtx();   // stateless in this library: one shared handle satisfies the signature
+    const size_t r = ZSTD_compress_advanced(kCtx, h->outBuf, h->outSize, h->inBuf, h->inSize, NULL, 0, zp);
+    return ZSTD_isError(r) ? kCodecError : (int64_t)r;
 }
 
 int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
@@ -77,7 +87,8 @@ int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
     const bool rap = (h->inSize >= 16 && memcmp(p, kRap, 8) == 0) ||
                      (t == ZSTD && h->inSize >= 24 && memcmp(p, kSkip, 4) == 0 && memcmp(p + 8, kRap, 8) == 0);
     int64_t r = rap ? aoclgpu_rap_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize)
-                    : aoclgpu_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
+              : t == ZSTD ? aoclgpu_zstd_decompress_host_frames(h->inBuf, h->inSize, h->outBuf, h->outSize)
+                          : aoclgpu_decompress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize);
     return r >= 0 ? r : kCodecError;                  // api/codec.cpp:143-151
 }
 
@@ -123,8 +134,11 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
         // (api/codec.cpp:118-122,262-266); the Zstd tables live on the device per launch.
         handle->optLevel = 0;
         handle->workBuf = NULL;
+        // the reference's setup runs the codec's dispatcher (api/codec.cpp:354-376); for Zstd that also selects the level
+        // table (optOff -> upstream parameters, zstd_compress.c:7390-7425)
+        if (codec_type == ZSTD) (void)aocl_setup_zstd_encode(handle->optOff, 0, handle->inSize, handle->level, handle->optVar);
     }
-    if (aoclgpu_init(0) != AOCLGPU_OK) return ERR_EXCLUDED_METHOD;
+    if (aoclgpu_init(aoclgpu_host_device()) != AOCLGPU_OK) return ERR_EXCLUDED_METHOD;   // AOCLGPU_DEVICE / aoclgpu_set_host_device
     return 0;
 }
 

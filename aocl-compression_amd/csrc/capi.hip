@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <new>
 #include <vector>
 
 namespace aoclgpu {
@@ -90,28 +92,42 @@ __global__ void __launch_bounds__(256) gather_slots_kernel(const uint8_t* __rest
 
 namespace {
 // Some launches need per-resident-workgroup scratch in HBM (Zstd compressor: sequence store + staged block; Zstd decoder:
-// literal buffer; Snappy compressor: hash tables).  One pool entry per (device, stream): launches on the same stream are ordered, launches on different
-// streams never share scratch.  A pool that has to grow is freed first (hipFree waits for the device).
+// literal buffer; Snappy compressor: hash tables).  One pool entry per (device, stream): launches on the same stream are
+// ordered, launches on different streams never share scratch.
+//
+// Thread safety: a launcher takes a WsGuard (one process-wide mutex) BEFORE it asks for scratch and keeps it until its
+// kernel is enqueued.  An entry is only ever freed under that mutex, and hipFree waits for everything enqueued on the
+// device, so (a) no thread can free a pointer another thread has been handed but not yet launched on, and (b) a buffer
+// that has to grow is released only after the kernels that use it have finished.
 struct WsPool { void* p = nullptr; size_t bytes = 0; int dev = -1; void* stream = nullptr; };
 WsPool g_pool[16];
 std::mutex g_pool_mu;
 
 }  // namespace
 
-void* get_workspace(size_t bytes, void* stream)
+WsGuard::WsGuard() { g_pool_mu.lock(); }
+WsGuard::~WsGuard() { g_pool_mu.unlock(); }
+
+void* get_workspace(const WsGuard&, size_t bytes, void* stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
     WsPool* e = nullptr;
     for (WsPool& q : g_pool) if (q.p && q.dev == dev && q.stream == stream) { e = &q; break; }
     if (!e) for (WsPool& q : g_pool) if (!q.p) { e = &q; break; }
-    if (!e) {                                             // more than 16 (device, stream) pairs: recycle the first entry
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    if (!e) {                                             // more than 16 (device, stream) pairs: recycle the smallest entry
         e = &g_pool[0];
+        for (WsPool& q : g_pool) if (q.bytes < e->bytes) e = &q;
     }
     if (e->p && e->dev == dev && e->stream == stream && e->bytes >= bytes) return e->p;
-    if (e->p) { (void)hipFree(e->p); e->p = nullptr; }
+    if (e->p) {
+        // the entry may belong to another device: free it there (hipFree synchronises that device first)
+        int cur = dev;
+        if (e->dev != dev) (void)hipSetDevice(e->dev);
+        (void)hipFree(e->p);
+        if (e->dev != dev) (void)hipSetDevice(cur);
+        e->p = nullptr; e->bytes = 0;
+    }
     if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return nullptr; }
     e->bytes = bytes; e->dev = dev; e->stream = stream;
     return e->p;
@@ -203,46 +219,116 @@ extern "C" double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_
 }
 
 // ---------------- host-buffer one-shot path ----------------
+// The reference's one-shot calls are re-entrant, so every call borrows a HostCtx (device buffers that only grow, one
+// non-blocking stream, one pinned result word the kernel writes straight into host memory) from a process-wide pool and
+// hands it back; concurrent callers get different contexts and overlap on the device.  Per call: one H2D of the input,
+// one kernel, one stream synchronisation, one D2H of exactly the bytes produced.
+namespace {
+struct HostCtx {
+    int dev = -1; hipStream_t stream = nullptr;
+    uint8_t* dsrc = nullptr; size_t srcCap = 0;
+    uint8_t* ddst = nullptr; size_t dstCap = 0;
+    int32_t* hres = nullptr;          // pinned, device-visible: [0] = out_len written by the kernel, [1] = src_len read by it
+    bool busy = false;
+};
+std::mutex g_host_mu;
+std::vector<HostCtx*> g_host_ctx;
+std::atomic<int> g_host_device{-1};
+
+int host_device()
+{
+    int d = g_host_device.load();
+    if (d >= 0) return d;
+    const char* e = getenv("AOCLGPU_DEVICE");             // which GPU the host-buffer API uses (default 0); documented in INTEGRATION.md
+    d = e ? atoi(e) : 0;
+    if (d < 0) d = 0;
+    g_host_device.store(d);
+    return d;
+}
+
+HostCtx* host_acquire(int dev)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (HostCtx* c : g_host_ctx) if (!c->busy && c->dev == dev) { c->busy = true; return c; }
+    }
+    HostCtx* c = new (std::nothrow) HostCtx();
+    if (!c) return nullptr;
+    c->dev = dev; c->busy = true;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->hres, 64, hipHostMallocMapped) != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c; return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_ctx.push_back(c);
+    return c;
+}
+void host_release(HostCtx* c) { std::lock_guard<std::mutex> lk(g_host_mu); c->busy = false; }
+
+bool host_grow(uint8_t** p, size_t* cap, size_t need)
+{
+    if (*cap >= need && *p) return true;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    size_t want = need < 4096 ? 4096 : need + need / 8;   // a little slack: callers usually repeat the same sizes
+    if (hipMalloc((void**)p, want) != hipSuccess) {
+        want = need ? need : 1;
+        if (hipMalloc((void**)p, want) != hipSuccess) { *p = nullptr; return false; }
+    }
+    *cap = want;
+    return true;
+}
+}  // namespace
+
+extern "C" int aoclgpu_set_host_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { set_error_msg("set_host_device: no such device"); return AOCLGPU_ERR_ARG; }
+    g_host_device.store(device);
+    return AOCLGPU_OK;
+}
+extern "C" int aoclgpu_host_device(void) { return host_device(); }
+
 static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_t n, void* hdst, size_t cap, uint32_t flags = 0)
 {
     batch_fn fn = pick(codec, op);
     if (!fn) { set_error_msg("bad codec"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     if ((!hsrc && n) || !hdst || n > 0xFFFFFFFFull) { set_error_msg("host one-shot: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     if (cap > 0xFFFFFFFFull) cap = 0xFFFFFFFFull;
-    uint8_t *dsrc = nullptr, *ddst = nullptr; int32_t* dlen = nullptr; uint32_t* dsl = nullptr;
+    const int dev = host_device();
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) { set_error("hipSetDevice", e); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    HostCtx* c = host_acquire(dev);
+    if (!c) { set_error_msg("host one-shot: no context (stream / pinned memory allocation failed)"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
     int64_t result = AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
-    hipError_t e;
 #define CK(call) do { e = (call); if (e != hipSuccess) { set_error(#call, e); goto done; } } while (0)
-    CK(hipMalloc((void**)&dsrc, n ? n : 1));
-    CK(hipMalloc((void**)&ddst, cap ? cap : 1));
-    CK(hipMalloc((void**)&dlen, sizeof(int32_t)));
-    CK(hipMalloc((void**)&dsl, sizeof(uint32_t)));
-    if (n) CK(hipMemcpy(dsrc, hsrc, n, hipMemcpyHostToDevice));
+    if (!host_grow(&c->dsrc, &c->srcCap, n ? n : 1) || !host_grow(&c->ddst, &c->dstCap, cap ? cap : 1)) {
+        set_error_msg("host one-shot: hipMalloc failed"); goto done;
+    }
+    if (n) CK(hipMemcpyAsync(c->dsrc, hsrc, n, hipMemcpyHostToDevice, c->stream));
     {
         aoclgpu_batch b; std::memset(&b, 0, sizeof(b));
-        b.src = dsrc; b.dst = ddst; b.out_len = dlen; b.nchunks = 1;
-        if (const char* ex = getenv("AOCLGPU_EXPERIMENT")) b.reserved = (uint32_t)atoi(ex) & 0xFFu;   // experiment switches of the test tools
-        b.reserved |= flags & ~0xFFu;
+        b.src = c->dsrc; b.dst = c->ddst; b.out_len = c->hres; b.nchunks = 1;
+        b.reserved = flags;
+        c->hres[0] = 0;
         if (op == 0) { b.total_bytes = n; b.chunk_bytes = n ? n : 1; b.slot_bytes = cap; }
         else {
-            uint32_t sl = (uint32_t)n;
-            CK(hipMemcpy(dsl, &sl, sizeof(sl), hipMemcpyHostToDevice));
-            b.src_len = dsl; b.total_bytes = cap; b.chunk_bytes = cap ? cap : 1; b.slot_bytes = n;
+            c->hres[1] = (int32_t)(uint32_t)n;
+            b.src_len = (const uint32_t*)(c->hres + 1); b.total_bytes = cap; b.chunk_bytes = cap ? cap : 1; b.slot_bytes = n;
         }
-        int rc = fn(&b, nullptr);
+        const int rc = fn(&b, c->stream);
         if (rc != 0) { result = AOCLGPU_HOST_FAIL + rc; goto done; }
-        CK(hipDeviceSynchronize());
-        int32_t r = 0;
-        CK(hipMemcpy(&r, dlen, sizeof(r), hipMemcpyDeviceToHost));
-        if (r > 0) CK(hipMemcpy(hdst, ddst, (size_t)r, hipMemcpyDeviceToHost));
+        CK(hipStreamSynchronize(c->stream));
+        const int32_t r = ((volatile int32_t*)c->hres)[0];
+        if (r > 0) {
+            CK(hipMemcpyAsync(hdst, c->ddst, (size_t)r, hipMemcpyDeviceToHost, c->stream));
+            CK(hipStreamSynchronize(c->stream));
+        }
         result = r;
     }
 #undef CK
 done:
-    if (dsrc) hipFree(dsrc);
-    if (ddst) hipFree(ddst);
-    if (dlen) hipFree(dlen);
-    if (dsl) hipFree(dsl);
+    host_release(c);
     return result;
 }
 

@@ -8,6 +8,8 @@ void set_error(const char* what, hipError_t e);
 void set_error_msg(const char* msg);
 int check_batch(const aoclgpu_batch* b, bool decompress);
 int check_launch(const char* kernel);
-// scratch in HBM for the launch about to be enqueued on `stream` (one pool entry per device and stream); nullptr on failure
-void* get_workspace(size_t bytes, void* stream);
+// Scratch in HBM for the launch about to be enqueued on `stream` (one pool entry per device and stream); nullptr on failure.
+// The caller holds a WsGuard from before this call until its kernel is enqueued (see capi.hip).
+struct WsGuard { WsGuard(); ~WsGuard(); WsGuard(const WsGuard&) = delete; WsGuard& operator=(const WsGuard&) = delete; };
+void* get_workspace(const WsGuard& held, size_t bytes, void* stream);
 }  // namespace aoclgpu

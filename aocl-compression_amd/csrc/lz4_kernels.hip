@@ -60,7 +60,9 @@ __device__ __forceinline__ uint32_t put_len_bytes(gbyte* d, uint32_t rem, int la
     return nff + 1;
 }
 
-__device__ unsigned long long g_lz4_prof[16];
+#ifdef AOCLGPU_EXPERIMENTS
+__device__ unsigned long long g_lz4_prof[16];     // per-stage cycle sums of the PROF instantiation (tools/lz4_stage_prof.py)
+#endif
 
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
 struct Win { uint64_t lo, hi; };
@@ -134,7 +136,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     wave_fence();
 
     const bool limited = cap < lz4_bound(n);              // lz4.c:2522
-    const bool do_st = !(expf & 1);                       // experiment: suppress per-sequence stores (timing only)
+#ifdef AOCLGPU_EXPERIMENTS
+    const bool do_st = !(expf & 1);                       // experiment build only: suppress per-sequence stores (timing)
+#else
+    constexpr bool do_st = true; (void)expf;
+#endif
     const uint32_t mfl1 = n - kMfLimit + 1;               // mflimitPlusOne
     const uint32_t matchlimit = n - kLastLiterals;
     uint32_t ip = 1, anchor = 0, op = 0;
@@ -463,7 +469,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         wave_copy(dst + op, src + anchor, lastRun, lane);
         op += lastRun;
     }
+#ifdef AOCLGPU_EXPERIMENTS
     if (PROF && lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
+#endif
 #undef STAGE
     return (int)op;
 }
@@ -829,13 +837,15 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 // ------------------------------------------------------------------------------------------------
 #include "host_util.h"
 
+#ifdef AOCLGPU_EXPERIMENTS
 extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host16)
-{   /* experiment support: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */
+{   /* experiment build: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_lz4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_prof), z, sizeof(z));
     return 0;
 }
+#endif
 
 extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
 {
@@ -844,8 +854,13 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
     // Table mode per launch: 0 = byU16 (16 KB LDS), 1 = packed byU32 (9 KB, chunks 65547 B .. 256 KiB), 2 = u32 with
     // check bits (16 KB).  Uniform batches launch the body and the ragged tail chunk separately; explicit batches
     // (sizes only known on the device) use the per-chunk dispatching kernel.
-    const uint32_t ex = b->reserved;
-    auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !(ex & (8 | 32))) ? 1 : 2); };
+#ifdef AOCLGPU_EXPERIMENTS
+    const bool prof = (b->reserved & 8u) != 0;
+#else
+    const bool prof = false;
+#endif
+    const bool forceU32 = prof || (b->reserved & AOCLGPU_FLAG_LZ4_TABLE_U32) != 0;
+    auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !forceU32) ? 1 : 2); };
     struct Launch { uint32_t first, count; int mode; } L[2]; int nl = 0;
     if (b->src_off) L[nl++] = { 0, b->nchunks, 3 };
     else {
@@ -863,8 +878,10 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
         case 0: hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<0, false>), g, t, 0, s, *b, L[i].first); break;
         case 1: hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<1, false>), g, t, 0, s, *b, L[i].first); break;
         case 2:
-            if (ex & 8) hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<2, true>), g, t, 0, s, *b, L[i].first);
-            else hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<2, false>), g, t, 0, s, *b, L[i].first);
+#ifdef AOCLGPU_EXPERIMENTS
+            if (prof) { hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<2, true>), g, t, 0, s, *b, L[i].first); break; }
+#endif
+            hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<2, false>), g, t, 0, s, *b, L[i].first);
             break;
         default: hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<3, false>), g, t, 0, s, *b, L[i].first); break;
         }

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <exception>
 #include <vector>
 
 namespace {
@@ -280,7 +281,7 @@ size_t LZ4F_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs)
     return kMaxHeader + (kBH + blockCrc) * nb + bs * full + last + frameEnd;
 }
 
-size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* prefsPtr)
+static size_t LZ4F_compressFrame_impl(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* prefsPtr)
 {
     LZ4F_preferences_t prefs;
     if (prefsPtr) prefs = *prefsPtr; else memset(&prefs, 0, sizeof(prefs));
@@ -329,7 +330,7 @@ size_t LZ4F_headerSize(const void* src, size_t srcSize)
     return 7 + ((p[4] >> 3) & 1 ? 8 : 0) + (p[4] & 1 ? 4 : 0);
 }
 
-size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* src, size_t* srcSizePtr)
+static size_t LZ4F_getFrameInfo_impl(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* src, size_t* srcSizePtr)
 {   // lz4frame.c:1310-1360: decodes the header, consumes it, hints at the next block header
     if (!dctx || !info || !src || !srcSizePtr) return err(E_GENERIC);
     FrameHeader h;
@@ -345,6 +346,16 @@ size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* sr
     dctx->out.clear(); dctx->outPos = 0;
     *srcSizePtr = h.bytes;
     return kBH;
+}
+
+// Upper bound of what a block of `len` compressed bytes can decode to: the block size of the frame, but never more than
+// LZ4's worst-case expansion (a sequence byte adds at most 255 output bytes) - a frame made of thousands of tiny blocks
+// must not make the decoder reserve blockSize for each of them.
+static inline size_t block_cap(size_t bs, uint32_t len, bool stored)
+{
+    if (stored) return len;
+    const size_t e = (size_t)len * 255u;
+    return e < bs ? e : bs;
 }
 
 // one whole frame (or skippable frame) at srcBuffer -> dstBuffer; 0 and the consumed / produced sizes, or an error code
@@ -391,9 +402,14 @@ static size_t decode_whole(void* dstBuffer, size_t* dstSizePtr, const void* srcB
         b.src = d_src;
         if (h.independent) {
             // every block into its own slot, then the slots are joined in order (blocks need not be full)
-            uint8_t* d_slots = (uint8_t*)D.get(nb * bs);
+            size_t slotBytes = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                so[i] = blks[i].off - h.bytes; sl[i] = blks[i].stored ? 1 : blks[i].len;
+                dofs[i] = slotBytes; dc[i] = (uint32_t)(blks[i].stored ? 16 : block_cap(bs, blks[i].len, false));
+                slotBytes += ((size_t)dc[i] + 15) & ~(size_t)15;
+            }
+            uint8_t* d_slots = (uint8_t*)D.get(slotBytes);
             if (!d_slots) return err(E_allocation_failed);
-            for (size_t i = 0; i < nb; ++i) { so[i] = blks[i].off - h.bytes; sl[i] = blks[i].stored ? 1 : blks[i].len; dofs[i] = i * bs; dc[i] = (uint32_t)bs; }
             // stored blocks: a one-byte dummy block for the launch (decodes to nothing useful), overwritten below
             b.dst = d_slots;
             if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
@@ -404,21 +420,25 @@ static size_t decode_whole(void* dstBuffer, size_t* dstSizePtr, const void* srcB
                 else if (ol[i] < 0) return err(E_decompressionFailed);
                 if (produced + (size_t)ol[i] > cap) return err(E_dstMaxSize_tooSmall);
                 if (blks[i].stored) memcpy((uint8_t*)dstBuffer + produced, src + blks[i].off, blks[i].len);
-                else if (hipMemcpy((uint8_t*)dstBuffer + produced, d_slots + i * bs, (size_t)ol[i], hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+                else if (hipMemcpy((uint8_t*)dstBuffer + produced, d_slots + dofs[i], (size_t)ol[i], hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
                 produced += (size_t)ol[i];
             }
         } else {
             // linked blocks: one wavefront, in order, into one contiguous device buffer
-            const size_t total = nb * bs < cap ? nb * bs : cap;
+            size_t sumCap = 0;
+            for (size_t i = 0; i < nb; ++i) {
+                so[i] = blks[i].off - h.bytes; sl[i] = blks[i].len | (blks[i].stored ? kStored : 0u); dofs[i] = 0;
+                dc[i] = (uint32_t)block_cap(bs, blks[i].len, blks[i].stored); sumCap += dc[i];
+            }
+            const size_t total = sumCap < cap ? sumCap : cap;
             if (total > 0x7FFFFFFFu) return err(E_srcSize_tooLarge);
-            uint8_t* d_out = (uint8_t*)D.get(total);
+            uint8_t* d_out = (uint8_t*)D.get(total ? total : 1);
             if (!d_out) return err(E_allocation_failed);
-            for (size_t i = 0; i < nb; ++i) { so[i] = blks[i].off - h.bytes; sl[i] = blks[i].len | (blks[i].stored ? kStored : 0u); dofs[i] = 0; dc[i] = (uint32_t)bs; }
             b.dst = d_out; b.reserved = AOCLGPU_FLAG_LZ4_LINKED; b.total_bytes = total;
             if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
             if (aoclgpu_lz4_decompress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
             if (hipMemcpy(ol.data(), b.out_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
-            for (size_t i = 0; i < nb; ++i) { if (ol[i] < 0) return err(nb * bs > cap ? E_dstMaxSize_tooSmall : E_decompressionFailed); produced += (size_t)ol[i]; }
+            for (size_t i = 0; i < nb; ++i) { if (ol[i] < 0) return err(sumCap > cap ? E_dstMaxSize_tooSmall : E_decompressionFailed); produced += (size_t)ol[i]; }
             if (produced > cap) return err(E_dstMaxSize_tooSmall);
             if (hipMemcpy(dstBuffer, d_out, produced, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
         }
@@ -458,14 +478,14 @@ static size_t frame_extent(const uint8_t* p, size_t n, size_t* need, size_t* upp
         const size_t len = (v & 0x7FFFFFFFu) + (h.blockChecksum ? kBF : 0);
         if ((v & 0x7FFFFFFFu) > bs) return err(E_maxBlockSize_invalid);
         if (n - ip < len) { *need = len - (n - ip); return 0; }
-        ip += len; *upper += bs;
+        ip += len; *upper += block_cap(bs, v & 0x7FFFFFFFu, (v & kStored) != 0);
     }
     if (h.contentChecksum) { if (n - ip < kBF) { *need = kBF - (n - ip); return 0; } ip += kBF; }
     return ip;
 }
 
-extern "C" size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
-                                  const LZ4F_decompressOptions_t* opts)
+static size_t LZ4F_decompress_impl(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                                   const LZ4F_decompressOptions_t* opts)
 {   // lz4frame.c:1398-1860.  Returns 0 when a frame is completely decoded and delivered, otherwise a hint (> 0) of how many
     // source bytes the next call should bring (output still pending: 1), or an error code.
     (void)opts;
@@ -535,7 +555,7 @@ size_t LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* prefs)
     return bound_internal(srcSize, prefs, (size_t)-1);
 }
 
-size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr)
+static size_t LZ4F_compressBegin_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr)
 {   // lz4frame.c:597-700
     if (!cctx || !dstBuffer) return err(E_GENERIC);
     if (dstCapacity < kMaxHeader) return err(E_dstMaxSize_tooSmall);
@@ -549,8 +569,8 @@ size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, 
     return write_header((uint8_t*)dstBuffer, cctx->prefs);
 }
 
-size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
-                           const LZ4F_compressOptions_t* opts)
+static size_t LZ4F_compressUpdate_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                                        const LZ4F_compressOptions_t* opts)
 {   // lz4frame.c:825-930
     (void)opts;
     if (!cctx || cctx->stage != 1 || !dstBuffer || (!srcBuffer && srcSize)) return err(E_GENERIC);
@@ -577,7 +597,7 @@ size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity,
     return w;
 }
 
-size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+static size_t LZ4F_flush_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
 {   // lz4frame.c:942-985
     (void)opts;
     if (!cctx) return err(E_GENERIC);
@@ -591,9 +611,9 @@ size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ
     return w;
 }
 
-size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+static size_t LZ4F_compressEnd_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
 {   // lz4frame.c:988-1030
-    const size_t f = LZ4F_flush(cctx, dstBuffer, dstCapacity, opts);
+    const size_t f = LZ4F_flush_impl(cctx, dstBuffer, dstCapacity, opts);
     if (LZ4F_isError(f)) return f;
     if (!cctx || cctx->stage != 1 || !dstBuffer) return err(E_GENERIC);
     uint8_t* op = (uint8_t*)dstBuffer + f;
@@ -608,4 +628,35 @@ size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, co
     return (size_t)(op - (uint8_t*)dstBuffer);
 }
 
+}  // extern "C"
+
+
+// ---- the exported names: no C++ exception crosses the C boundary (std::bad_alloc / std::length_error from the host-side
+//      staging vectors become ERROR_allocation_failed) ----
+#define LZ4F_GUARD(call) try { return call; } catch (const std::exception&) { return err(E_allocation_failed); }
+extern "C" {
+size_t LZ4F_compressFrame(void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize, const LZ4F_preferences_t* prefsPtr)
+{ LZ4F_GUARD(LZ4F_compressFrame_impl(dstBuffer, dstCapacity, srcBuffer, srcSize, prefsPtr)) }
+size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* info, const void* src, size_t* srcSizePtr)
+{ LZ4F_GUARD(LZ4F_getFrameInfo_impl(dctx, info, src, srcSizePtr)) }
+size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                       const LZ4F_decompressOptions_t* opts)
+{
+    try { return LZ4F_decompress_impl(dctx, dstBuffer, dstSizePtr, srcBuffer, srcSizePtr, opts); }
+    catch (const std::exception&) {
+        if (dctx) { dctx->in.clear(); dctx->out.clear(); dctx->outPos = 0; }
+        if (srcSizePtr) *srcSizePtr = 0;
+        if (dstSizePtr) *dstSizePtr = 0;
+        return err(E_allocation_failed);
+    }
+}
+size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr)
+{ LZ4F_GUARD(LZ4F_compressBegin_impl(cctx, dstBuffer, dstCapacity, prefsPtr)) }
+size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
+                           const LZ4F_compressOptions_t* opts)
+{ LZ4F_GUARD(LZ4F_compressUpdate_impl(cctx, dstBuffer, dstCapacity, srcBuffer, srcSize, opts)) }
+size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+{ LZ4F_GUARD(LZ4F_flush_impl(cctx, dstBuffer, dstCapacity, opts)) }
+size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* opts)
+{ LZ4F_GUARD(LZ4F_compressEnd_impl(cctx, dstBuffer, dstCapacity, opts)) }
 }  // extern "C"

@@ -22,7 +22,6 @@ bool sn_parse_len(const char* p, size_t n, uint32_t* out)
     return false;
 }
 
-size_t zerr(int code) { return (size_t)0 - (size_t)code; }
 }  // namespace
 
 extern "C" {
@@ -51,8 +50,10 @@ int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstC
     if (r >= 0) return (int)r;
     return r > -0x7FFFFFFF ? (int)r : -1;
 }
-char* aocl_setup_lz4(int, int, size_t, size_t, size_t) { return nullptr; }
+char* aocl_setup_lz4(int, int, size_t, size_t, size_t) { return nullptr; }   // lz4.h:464-470: no host ISA variant to pick
 void aocl_destroy_lz4(void) {}
+char* aocl_setup_snappy(int, int, size_t, size_t, size_t) { return nullptr; }   // snappy.h:476-482, snappy.cc:3153-3184
+void aocl_destroy_snappy(void) {}
 
 // ---------------------------------------------------------------- Snappy (C) ---------------------------------
 size_t snappy_max_compressed_length(size_t n) { return 32 + n + n / 6; }                 // snappy.cc:160-182
@@ -93,64 +94,6 @@ snappy_status snappy_validate_compressed_buffer(const char* compressed, size_t c
     free(tmp);
     return r >= 0 && (size_t)r == real ? SNAPPY_OK : SNAPPY_INVALID_INPUT;
 }
-
-// ---------------------------------------------------------------- Zstd ---------------------------------------
-unsigned ZSTD_versionNumber(void) { return 10505; }
-const char* ZSTD_versionString(void) { return "1.5.5"; }
-size_t ZSTD_compressBound(size_t n)
-{   // zstd.h:228-230 ZSTD_COMPRESSBOUND
-    if (n >= (sizeof(size_t) == 8 ? 0xFF00FF00FF00FF00ull : 0xFF00FF00u)) return zerr(72);
-    return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
-}
-unsigned ZSTD_isError(size_t code) { return code > zerr(120); }                           // zstd_errors.h:100
-const char* ZSTD_getErrorName(size_t code)
-{
-    if (!ZSTD_isError(code)) return "No error detected";
-    switch ((int)((size_t)0 - code)) {
-    case 10: return "Unknown frame descriptor";
-    case 20: return "Data corruption detected";
-    case 40: return "Unsupported parameter";
-    case 70: return "Destination buffer is too small";
-    case 72: return "Src size is incorrect";
-    default: return "Error (generic)";
-    }
-}
-size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
-{   // zstd_compress.c:5534; the "fast" strategy (levels 1 and 2 at these sizes), one block per frame, has a GPU backend
-    if (!dst || (!src && srcSize)) return zerr(1);
-    if (level != 1 && level != 2) return zerr(40);
-    if (srcSize > (128u << 10)) return zerr(72);
-    const int64_t r = aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, srcSize, dst, dstCapacity, level == 2 ? AOCLGPU_FLAG_ZSTD_LEVEL2 : 0u);
-    if (r > 0) return (size_t)r;
-    return zerr(dstCapacity < ZSTD_compressBound(srcSize) ? 70 : 1);
-}
-size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize)
-{   // zstd_decompress.c:1252
-    if ((!dst && dstCapacity) || !src) return zerr(1);
-    const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, src, compressedSize, dst ? dst : (void*)"", dstCapacity);
-    if (r >= 0) return (size_t)r;
-    return zerr(20);
-}
-unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
-{   // zstd_decompress.c:601-624 via ZSTD_getFrameHeader (zstd_decompress.c:440-560); zstd frames only
-    const unsigned long long kUnknown = 0ULL - 1, kError = 0ULL - 2;
-    const uint8_t* p = (const uint8_t*)src;
-    if (!p || srcSize < 5) return kError;
-    if ((p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)) != 0xFD2FB528u) return kError;
-    const uint32_t fhd = p[4], dictID = fhd & 3, single = (fhd >> 5) & 1, fcsID = fhd >> 6;
-    static const size_t did[4] = {0, 1, 2, 4}, fcs[4] = {0, 2, 4, 8};
-    size_t pos = 5 + (single ? 0 : 1) + did[dictID];
-    const size_t fl = (fcsID == 0) ? (single ? 1 : 0) : fcs[fcsID];
-    if (fhd & 0x08) return kError;                                    // reserved bit
-    if (srcSize < pos + fl) return kError;
-    if (fl == 0) return kUnknown;
-    unsigned long long v = 0;
-    for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
-    if (fl == 2) v += 256;
-    return v;
-}
-char* aocl_setup_zstd_encode(int, int, size_t, size_t, size_t) { return nullptr; }
-char* aocl_setup_zstd_decode(int, int, size_t, size_t, size_t) { return nullptr; }
 
 // ---------------------------------------------------------------- RAP frame ----------------------------------
 int32_t aocl_get_rap_frame_bound_mt(void)

@@ -27,35 +27,30 @@ constexpr uint32_t kRapEntry = 12;                          // offset, length, d
 constexpr uint32_t kZstdSkipMagic = 0x184D2A50u;            // ZSTD_MAGIC_SKIPPABLE_START, variant 0 (zstd_compress.c:5353)
 constexpr uint32_t kHead = 16;                              // bytes of every slot fetched for the first-token parse
 
-struct Piece {                                              // one partition of the output stream
+struct CopyOp {                                             // one contiguous piece of the output stream
     uint64_t dst;                                           // offset in the stream
-    uint64_t lit_src;                                       // offset in the uncompressed source
-    uint64_t body_src;                                      // offset in the slot buffer
-    uint32_t hdr_off, hdr_len;                              // rewritten first-sequence header, in the header blob
-    uint32_t lit_len, body_len;
+    uint64_t src;                                           // offset in the header blob (from == 0) or in the slot buffer (from == 1)
+    uint32_t len, from;
 };
 
-__global__ void __launch_bounds__(64) rap_gather_kernel(const Piece* __restrict__ pieces, uint32_t n,
-                                                        const uint8_t* __restrict__ blob, const uint8_t* __restrict__ src,
-                                                        const uint8_t* __restrict__ slots, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(64) rap_gather_kernel(const CopyOp* __restrict__ ops, uint32_t n,
+                                                        const uint8_t* __restrict__ blob, const uint8_t* __restrict__ slots,
+                                                        uint8_t* __restrict__ out)
 {
     const uint32_t k = blockIdx.x;
     if (k >= n) return;
-    const int lane = lane_id();
-    const Piece p = pieces[k];
-    gbyte* d = (gbyte*)out + p.dst;
-    wave_copy(d, (const gbyte*)blob + p.hdr_off, p.hdr_len, lane);
-    wave_copy(d + p.hdr_len, (const gbyte*)src + p.lit_src, p.lit_len, lane);
-    wave_copy(d + p.hdr_len + p.lit_len, (const gbyte*)slots + p.body_src, p.body_len, lane);
+    const CopyOp p = ops[k];
+    wave_copy((gbyte*)out + p.dst, (const gbyte*)(p.from ? slots : blob) + p.src, p.len, lane_id());
 }
 
-__global__ void rap_heads_kernel(const uint8_t* __restrict__ slots, const uint64_t* __restrict__ slot_off, uint64_t slot_bytes,
+__global__ void rap_heads_kernel(const uint8_t* __restrict__ slots, const uint64_t* __restrict__ slot_off, const int32_t* __restrict__ len,
                                  uint32_t n, uint8_t* __restrict__ heads)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const uint8_t* s = slots + (slot_off ? slot_off[k] : (uint64_t)k * slot_bytes);
-    for (uint32_t i = 0; i < kHead; ++i) heads[(uint64_t)k * kHead + i] = s[i];   // slots are >= 16 bytes (compress bounds)
+    const uint8_t* s = slots + slot_off[k];
+    const uint32_t l = len[k] > 0 ? (uint32_t)len[k] : 0;
+    for (uint32_t i = 0; i < kHead; ++i) heads[(uint64_t)k * kHead + i] = i < l ? s[i] : 0;
 }
 
 struct DevBuf {
@@ -80,6 +75,150 @@ extern "C" uint64_t aoclgpu_rap_frame_bytes(aoclgpu_codec codec, uint32_t nchunk
     if (nchunks <= 1) return 0;
     return (uint64_t)kRapHead + (uint64_t)kRapEntry * nchunks + (codec == AOCLGPU_ZSTD ? 8 : 0);
 }
+
+namespace {
+// The join of the reference's MT compressors for K partitions whose one-shot streams lie in `slots` (device) at
+// slotoff[k], olen[k] bytes each; n[k] = uncompressed size, aux[k] = length of the partition's final literal run (LZ4).
+// Everything the join needs is IN the compressed partitions: the literals LZ4 carries from partition k into the first
+// sequence of partition k+1 are the last aux[k] bytes of partition k's stream (its final sequence is token, length
+// bytes, literals), so the partitions may have been compressed on another GPU and only their streams gathered here.
+int rap_join(aoclgpu_codec codec, uint32_t K, const int32_t* olen, const uint32_t* n, const uint32_t* aux, const uint64_t* slotoff,
+             const uint8_t* slots, uint8_t* out, uint64_t cap, uint64_t* stream_bytes, hipStream_t s)
+{
+    uint64_t total_src = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        if (olen[k] <= 0) { set_error_msg("rap: a chunk failed to compress"); return AOCLGPU_ERR_ARG; }
+        total_src += n[k];
+    }
+    if (total_src > 0x7FFFFFFFull) { set_error_msg("rap: RAP offsets are 32-bit, at most 2 GiB per stream"); return AOCLGPU_ERR_ARG; }
+
+    std::vector<CopyOp> ops;
+    ops.reserve((size_t)K * 3);
+    std::vector<uint8_t> blob;                                   // frame + rewritten headers
+    const uint32_t frame = (uint32_t)aoclgpu_rap_frame_bytes(codec, K);
+    blob.resize(frame, 0);
+    uint64_t pos = frame;                                        // running output offset
+    const uint32_t base = (codec == AOCLGPU_ZSTD && K > 1) ? 8u : 0u;   // RAP offsets count from the magic word
+    auto entry = [&](uint32_t k, uint64_t off, uint32_t len, uint32_t dlen) {
+        uint8_t* e = blob.data() + base + kRapHead + (size_t)kRapEntry * k;
+        put32(e, (uint32_t)(off - base)); put32(e + 4, len); put32(e + 8, dlen);
+    };
+    auto emit = [&](uint64_t src, uint32_t len, uint32_t from) { if (len) { ops.push_back(CopyOp{pos, src, len, from}); pos += len; } };
+    if (K == 1) {                                                // one partition: the plain one-shot stream
+        pos = 0;
+        emit(slotoff[0], (uint32_t)olen[0], 1);
+    } else if (codec == AOCLGPU_ZSTD) {
+        for (uint32_t k = 0; k < K; ++k) {
+            entry(k, pos, (uint32_t)olen[k], n[k]);
+            emit(slotoff[k], (uint32_t)olen[k], 1);
+        }
+    } else if (codec == AOCLGPU_SNAPPY) {
+        const uint32_t hoff = (uint32_t)blob.size();
+        put_varint(blob, (uint32_t)total_src);                   // one length prefix for the whole stream
+        emit(hoff, (uint32_t)blob.size() - hoff, 0);
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t w = varint_len(n[k]);
+            if ((uint32_t)olen[k] < w) { set_error_msg("rap: snappy chunk shorter than its prefix"); return AOCLGPU_ERR_ARG; }
+            const uint32_t body = (uint32_t)olen[k] - w;
+            entry(k, pos, body, n[k]);
+            emit(slotoff[k] + w, body, 1);
+        }
+    } else {                                                     // LZ4 (lz4.c:2736-2906)
+        std::vector<uint8_t> heads((size_t)K * kHead);
+        {
+            DevBuf dh, doff, dlen;
+            if (!dh.alloc((size_t)K * kHead) || !doff.alloc((size_t)K * 8) || !dlen.alloc((size_t)K * 4)) { set_error_msg("rap: hipMalloc"); return AOCLGPU_ERR_HIP; }
+            HIPCK(hipMemcpyAsync(doff.p, slotoff, (size_t)K * 8, hipMemcpyHostToDevice, s));
+            HIPCK(hipMemcpyAsync(dlen.p, olen, (size_t)K * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(rap_heads_kernel, dim3((K + 255) / 256), dim3(256), 0, s, slots, (const uint64_t*)doff.p, (const int32_t*)dlen.p, K, (uint8_t*)dh.p);
+            if (int rc = check_launch("rap_heads_kernel")) return rc;
+            HIPCK(hipStreamSynchronize(s));
+            HIPCK(hipMemcpy(heads.data(), dh.p, heads.size(), hipMemcpyDeviceToHost));
+        }
+        struct Seg { uint64_t src; uint32_t len; };
+        std::vector<Seg> carry;                                  // literal runs waiting for the next partition's first sequence
+        uint64_t pend = 0;                                       // their total length
+        uint32_t prev_len = 0; uint64_t prev_off = frame;
+        for (uint32_t k = 0; k < K; ++k) {
+            const bool last = k + 1 == K;
+            const uint32_t L = last ? 0 : aux[k];
+            const uint32_t lastseq = last ? 0 : 1 + (L < 15 ? 0 : 1 + (L - 15) / 255) + L;
+            if ((uint32_t)olen[k] < lastseq || L > n[k]) { set_error_msg("rap: inconsistent aux[] (last literal run)"); return AOCLGPU_ERR_ARG; }
+            const uint32_t body_end = (uint32_t)olen[k] - lastseq;      // dst_trap_size of the reference's MT compressor
+            const Seg tail = {slotoff[k] + (uint32_t)olen[k] - L, L};   // the final literal run's bytes
+            const uint64_t off = prev_off + prev_len;
+            if (k == 0) {
+                entry(0, pos, body_end, n[0] - L);
+                prev_off = pos; prev_len = body_end;
+                emit(slotoff[0], body_end, 1);
+                carry.assign(1, tail); pend = L;
+                continue;
+            }
+            if (!last && body_end == 0) {                        // all literals: they travel on to the next partition (:2808-2823)
+                entry(k, off, 0, 0);
+                prev_off = off; prev_len = 0;
+                carry.push_back(tail); pend += L;
+                continue;
+            }
+            // rewrite the first token: its literal run grows by the carried literals (:2826-2868)
+            const uint8_t* h = heads.data() + (size_t)k * kHead;
+            std::vector<uint8_t> big;
+            const uint32_t tok = h[0];
+            uint64_t cur_lit = tok >> 4; uint32_t hdr_in = 1;
+            if (cur_lit == 15) {
+                const uint8_t* q = h; uint32_t avail = kHead;
+                for (;;) {
+                    if (hdr_in >= avail) {                       // a very long first literal run: fetch more of the slot
+                        if (!big.empty() || (uint32_t)olen[k] <= kHead) { set_error_msg("rap: truncated first token"); return AOCLGPU_ERR_ARG; }
+                        big.resize((uint32_t)olen[k] < 4096u ? (uint32_t)olen[k] : 4096u);
+                        HIPCK(hipMemcpy(big.data(), slots + slotoff[k], big.size(), hipMemcpyDeviceToHost));
+                        q = big.data(); avail = (uint32_t)big.size();
+                    }
+                    const uint32_t e = q[hdr_in++]; cur_lit += e;
+                    if (e != 255) break;
+                }
+            }
+            const uint64_t new_lit = cur_lit + pend;
+            const uint32_t hoff = (uint32_t)blob.size();
+            blob.push_back((uint8_t)(((new_lit < 15 ? new_lit : 15) << 4) | (tok & 15)));
+            if (new_lit >= 15) { uint64_t a = new_lit - 15; for (; a >= 255; a -= 255) blob.push_back(255); blob.push_back((uint8_t)a); }
+            const uint32_t hlen = (uint32_t)blob.size() - hoff;
+            if (body_end < hdr_in) { set_error_msg("rap: first token longer than the partition"); return AOCLGPU_ERR_ARG; }
+            const uint32_t body = body_end - hdr_in;
+            const uint32_t plen = hlen + (uint32_t)pend + body;
+            entry(k, off, plen, (uint32_t)((n[k] - L) + pend));
+            emit(hoff, hlen, 0);
+            for (const Seg& g : carry) emit(g.src, g.len, 1);
+            emit(slotoff[k] + hdr_in, body, 1);
+            prev_off = off; prev_len = plen;
+            carry.assign(1, tail); pend = L;
+        }
+    }
+    if (K > 1) {                                                 // frame header (threads/threads.c:104-111)
+        uint8_t* f = blob.data();
+        if (codec == AOCLGPU_ZSTD) { put32(f, kZstdSkipMagic); put32(f + 4, frame - 8); f += 8; }
+        memcpy(f, &kRapMagic, 8);
+        put32(f + 8, frame - base);
+        put32(f + 12, K);                                        // u16 partitions, u16 child threads = 0
+    }
+    if (pos > cap) { set_error_msg("rap: stream_cap too small"); return AOCLGPU_ERR_ARG; }
+    if (pos > 0xFFFFFFFFull) { set_error_msg("rap: stream exceeds 32-bit RAP offsets"); return AOCLGPU_ERR_ARG; }
+    // ---- execute: the frame, then one wavefront per piece ----
+    DevBuf dp, db;
+    if (!dp.alloc(ops.size() * sizeof(CopyOp)) || !db.alloc(blob.size())) { set_error_msg("rap: hipMalloc"); return AOCLGPU_ERR_HIP; }
+    if (!ops.empty()) HIPCK(hipMemcpyAsync(dp.p, ops.data(), ops.size() * sizeof(CopyOp), hipMemcpyHostToDevice, s));
+    if (!blob.empty()) HIPCK(hipMemcpyAsync(db.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+    if (frame) HIPCK(hipMemcpyAsync(out, db.p, frame, hipMemcpyDeviceToDevice, s));
+    if (!ops.empty()) {
+        hipLaunchKernelGGL(rap_gather_kernel, dim3((uint32_t)ops.size()), dim3(64), 0, s, (const CopyOp*)dp.p, (uint32_t)ops.size(),
+                           (const uint8_t*)db.p, slots, out);
+        if (int rc = check_launch("rap_gather_kernel")) return rc;
+    }
+    HIPCK(hipStreamSynchronize(s));                              // the plan buffers die with this call
+    *stream_bytes = pos;
+    return AOCLGPU_OK;
+}
+}  // namespace
 
 extern "C" int aoclgpu_rap_pack(aoclgpu_codec codec, const aoclgpu_batch* b, uint8_t* out, uint64_t cap,
                                 uint64_t* stream_bytes, void* stream)
@@ -110,128 +249,21 @@ extern "C" int aoclgpu_rap_pack(aoclgpu_codec codec, const aoclgpu_batch* b, uin
             n[k] = (uint32_t)(rem < b->chunk_bytes ? rem : b->chunk_bytes);
         }
     }
-    uint64_t total_src = 0;
-    for (uint32_t k = 0; k < K; ++k) {
-        if (olen[k] <= 0) { set_error_msg("rap_pack: a chunk failed to compress"); return AOCLGPU_ERR_ARG; }
-        total_src += n[k];
-    }
-    if (total_src > 0x7FFFFFFFull) { set_error_msg("rap_pack: RAP offsets are 32-bit, pack at most 2 GiB per stream"); return AOCLGPU_ERR_ARG; }
+    return rap_join(codec, K, olen.data(), n.data(), aux.data(), slotoff.data(), b->dst, out, cap, stream_bytes, s);
+}
 
-    std::vector<Piece> pieces(K);
-    std::vector<uint8_t> blob;                                   // frame + rewritten headers
-    const uint32_t frame = (uint32_t)aoclgpu_rap_frame_bytes(codec, K);
-    blob.resize(frame, 0);
-    uint64_t pos = frame;                                        // running output offset
-    const uint32_t base = (codec == AOCLGPU_ZSTD && K > 1) ? 8u : 0u;   // RAP offsets count from the magic word
-    auto entry = [&](uint32_t k, uint64_t off, uint32_t len, uint32_t dlen) {
-        uint8_t* e = blob.data() + base + kRapHead + (size_t)kRapEntry * k;
-        put32(e, (uint32_t)(off - base)); put32(e + 4, len); put32(e + 8, dlen);
-    };
-    if (K == 1) {                                                // one partition: the plain one-shot stream
-        pieces[0] = Piece{0, 0, slotoff[0], 0, 0, 0, (uint32_t)olen[0]};
-        pos = (uint64_t)olen[0];
-    } else if (codec == AOCLGPU_ZSTD) {
-        for (uint32_t k = 0; k < K; ++k) {
-            pieces[k] = Piece{pos, 0, slotoff[k], 0, 0, 0, (uint32_t)olen[k]};
-            entry(k, pos, (uint32_t)olen[k], n[k]);
-            pos += (uint32_t)olen[k];
-        }
-    } else if (codec == AOCLGPU_SNAPPY) {
-        const uint32_t hoff = (uint32_t)blob.size();
-        put_varint(blob, (uint32_t)total_src);                   // one length prefix for the whole stream
-        const uint32_t hlen = (uint32_t)blob.size() - hoff;
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint32_t w = varint_len(n[k]);
-            if ((uint32_t)olen[k] < w) { set_error_msg("rap_pack: snappy chunk shorter than its prefix"); return AOCLGPU_ERR_ARG; }
-            const uint32_t body = (uint32_t)olen[k] - w, hl = k == 0 ? hlen : 0;
-            pieces[k] = Piece{pos, 0, slotoff[k] + w, k == 0 ? hoff : 0, hl, 0, body};
-            entry(k, pos + hl, body, n[k]);
-            pos += hl + body;
-        }
-    } else {                                                     // LZ4 (lz4.c:2736-2906)
-        std::vector<uint8_t> heads((size_t)K * kHead);
-        {
-            DevBuf dh, doff;
-            if (!dh.alloc((size_t)K * kHead)) { set_error_msg("rap_pack: hipMalloc"); return AOCLGPU_ERR_HIP; }
-            const uint64_t* dso = nullptr;
-            if (b->src_off) dso = b->dst_off;
-            hipLaunchKernelGGL(rap_heads_kernel, dim3((K + 255) / 256), dim3(256), 0, s, b->dst, dso, b->slot_bytes, K, (uint8_t*)dh.p);
-            if (int rc = check_launch("rap_heads_kernel")) return rc;
-            HIPCK(hipStreamSynchronize(s));
-            HIPCK(hipMemcpy(heads.data(), dh.p, heads.size(), hipMemcpyDeviceToHost));
-        }
-        uint64_t pend = 0;                                       // literals waiting for the next partition's first sequence
-        uint32_t prev_len = 0; uint64_t prev_off = frame;
-        for (uint32_t k = 0; k < K; ++k) {
-            const bool last = k + 1 == K;
-            const uint32_t L = last ? 0 : aux[k];
-            const uint32_t lastseq = last ? 0 : 1 + (L < 15 ? 0 : 1 + (L - 15) / 255) + L;
-            if ((uint32_t)olen[k] < lastseq || L > n[k]) { set_error_msg("rap_pack: inconsistent aux[] (last literal run)"); return AOCLGPU_ERR_ARG; }
-            const uint32_t body_end = (uint32_t)olen[k] - lastseq;      // dst_trap_size of the reference's MT compressor
-            const uint64_t off = prev_off + prev_len;
-            if (k == 0) {
-                pieces[0] = Piece{pos, 0, slotoff[0], 0, 0, 0, body_end};
-                entry(0, pos, body_end, n[0] - L);
-                prev_off = pos; prev_len = body_end; pos += body_end; pend = L;
-                continue;
-            }
-            if (!last && body_end == 0) {                        // all literals: they travel on to the next partition (:2808-2823)
-                pieces[k] = Piece{pos, 0, 0, 0, 0, 0, 0};
-                entry(k, off, 0, 0);
-                prev_off = off; prev_len = 0; pend += n[k];
-                continue;
-            }
-            // rewrite the first token: its literal run grows by the carried literals (:2826-2868)
-            const uint8_t* h = heads.data() + (size_t)k * kHead;
-            std::vector<uint8_t> big;
-            const uint32_t tok = h[0];
-            uint64_t cur_lit = tok >> 4; uint32_t hdr_in = 1;
-            if (cur_lit == 15) {
-                const uint8_t* q = h; uint32_t avail = kHead;
-                for (;;) {
-                    if (hdr_in >= avail) {                       // a very long first literal run: fetch more of the slot
-                        if (!big.empty() || (uint32_t)olen[k] <= kHead) { set_error_msg("rap_pack: truncated first token"); return AOCLGPU_ERR_ARG; }
-                        big.resize((uint32_t)olen[k] < 4096u ? (uint32_t)olen[k] : 4096u);
-                        HIPCK(hipMemcpy(big.data(), b->dst + slotoff[k], big.size(), hipMemcpyDeviceToHost));
-                        q = big.data(); avail = (uint32_t)big.size();
-                    }
-                    const uint32_t e = q[hdr_in++]; cur_lit += e;
-                    if (e != 255) break;
-                }
-            }
-            const uint64_t new_lit = cur_lit + pend;
-            const uint32_t hoff = (uint32_t)blob.size();
-            blob.push_back((uint8_t)(((new_lit < 15 ? new_lit : 15) << 4) | (tok & 15)));
-            if (new_lit >= 15) { uint64_t a = new_lit - 15; for (; a >= 255; a -= 255) blob.push_back(255); blob.push_back((uint8_t)a); }
-            const uint32_t hlen = (uint32_t)blob.size() - hoff;
-            if (body_end < hdr_in) { set_error_msg("rap_pack: first token longer than the partition"); return AOCLGPU_ERR_ARG; }
-            const uint32_t body = body_end - hdr_in;
-            pieces[k] = Piece{pos, srcoff[k] - pend, slotoff[k] + hdr_in, hoff, hlen, (uint32_t)pend, body};
-            const uint32_t plen = hlen + (uint32_t)pend + body;
-            entry(k, off, plen, (uint32_t)((n[k] - L) + pend));
-            prev_off = off; prev_len = plen; pos += plen; pend = L;
-        }
-    }
-    if (K > 1) {                                                 // frame header (threads/threads.c:104-111)
-        uint8_t* f = blob.data();
-        if (codec == AOCLGPU_ZSTD) { put32(f, kZstdSkipMagic); put32(f + 4, frame - 8); f += 8; }
-        memcpy(f, &kRapMagic, 8);
-        put32(f + 8, frame - base);
-        put32(f + 12, K);                                        // u16 partitions, u16 child threads = 0
-    }
-    if (pos > cap) { set_error_msg("rap_pack: stream_cap too small"); return AOCLGPU_ERR_ARG; }
-    if (pos > 0xFFFFFFFFull) { set_error_msg("rap_pack: stream exceeds 32-bit RAP offsets"); return AOCLGPU_ERR_ARG; }
-    // ---- execute: frame + three copies per partition ----
-    DevBuf dp, db;
-    if (!dp.alloc(pieces.size() * sizeof(Piece)) || !db.alloc(blob.size())) { set_error_msg("rap_pack: hipMalloc"); return AOCLGPU_ERR_HIP; }
-    HIPCK(hipMemcpyAsync(dp.p, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice, s));
-    if (!blob.empty()) HIPCK(hipMemcpyAsync(db.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
-    if (frame) HIPCK(hipMemcpyAsync(out, db.p, frame, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(rap_gather_kernel, dim3(K), dim3(64), 0, s, (const Piece*)dp.p, K, (const uint8_t*)db.p, b->src, b->dst, out);
-    if (int rc = check_launch("rap_gather_kernel")) return rc;
-    HIPCK(hipStreamSynchronize(s));                              // the plan buffers die with this call
-    *stream_bytes = pos;
-    return AOCLGPU_OK;
+extern "C" int aoclgpu_rap_assemble(aoclgpu_codec codec, const uint8_t* gathered, const uint64_t* chunk_off, const int32_t* chunk_len,
+                                    const uint32_t* chunk_src_len, const uint32_t* chunk_aux, uint32_t nchunks,
+                                    uint8_t* out, uint64_t cap, uint64_t* stream_bytes, void* stream)
+{
+    if (!gathered || !chunk_off || !chunk_len || !chunk_src_len || !out || !stream_bytes || nchunks == 0) { set_error_msg("rap_assemble: NULL argument / no chunks"); return AOCLGPU_ERR_ARG; }
+    if (nchunks > 65535) { set_error_msg("rap_assemble: more than 65535 partitions (16-bit count, threads/threads.h:82)"); return AOCLGPU_ERR_ARG; }
+    if (codec == AOCLGPU_LZ4 && nchunks > 1 && !chunk_aux) { set_error_msg("rap_assemble: LZ4 needs the gathered aux[] (final literal run lengths)"); return AOCLGPU_ERR_ARG; }
+    std::vector<uint32_t> zero;
+    if (!chunk_aux) { zero.assign(nchunks, 0); chunk_aux = zero.data(); }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(hipStreamSynchronize(s));
+    return rap_join(codec, nchunks, chunk_len, chunk_src_len, chunk_aux, chunk_off, gathered, out, cap, stream_bytes, s);
 }
 
 extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream);
@@ -359,4 +391,124 @@ extern "C" int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* 
     if (r > 0) HCK(hipMemcpy(hdst, ddst.p, (size_t)r, hipMemcpyDeviceToHost));
 #undef HCK
     return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Zstd streams of several frames on host buffers (include/aocl_gpu_codec.h).  The one-shot Zstd kernel makes one
+// single-block frame per chunk (<= 128 KiB); a larger input becomes a sequence of such frames - what the reference's
+// decoder, and this one, read as one stream (zstd_decompress.c:1113-1200 loops over frames).
+// ------------------------------------------------------------------------------------------------
+extern "C" int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, const int32_t* out_len, uint32_t nchunks,
+                                     uint8_t* packed, uint64_t* out_off, void* stream);
+
+extern "C" int64_t aoclgpu_zstd_compress_host_frames(const void* hsrc, size_t n, void* hdst, size_t cap, uint32_t flags)
+{
+    const uint64_t chunk = 128u << 10;
+    if ((!hsrc && n) || !hdst) { set_error_msg("zstd frames: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    if (n <= chunk) return aoclgpu_compress_host_ex(AOCLGPU_ZSTD, hsrc, n, hdst, cap, flags);
+    const uint64_t K = (n + chunk - 1) / chunk;
+    if (K > 0xFFFFFFFFull) { set_error_msg("zstd frames: input too large"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    const uint64_t slot = (aoclgpu_compress_bound(AOCLGPU_ZSTD, chunk) + 15) & ~(uint64_t)15;
+    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    DevBuf dsrc, dslots, dlen, doff, dout;
+    if (!dsrc.alloc(n) || !dslots.alloc(K * slot) || !dlen.alloc(K * 4) || !doff.alloc((K + 1) * 8) || !dout.alloc(K * slot)) {
+        set_error_msg("zstd frames: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
+    }
+#define HCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(#call, e_); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; } } while (0)
+    HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    aoclgpu_batch b; memset(&b, 0, sizeof(b));
+    b.src = (const uint8_t*)dsrc.p; b.dst = (uint8_t*)dslots.p; b.out_len = (int32_t*)dlen.p;
+    b.nchunks = (uint32_t)K; b.total_bytes = n; b.chunk_bytes = chunk; b.slot_bytes = slot; b.reserved = flags;
+    int rc = aoclgpu_zstd_compress_chunks(&b, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    rc = aoclgpu_compact_slots((const uint8_t*)dslots.p, slot, (const int32_t*)dlen.p, (uint32_t)K, (uint8_t*)dout.p, (uint64_t*)doff.p, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    uint64_t total = 0;
+    HCK(hipMemcpy(&total, (const uint64_t*)doff.p + K, 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> lens(K);
+    HCK(hipMemcpy(lens.data(), dlen.p, K * 4, hipMemcpyDeviceToHost));
+    for (uint64_t k = 0; k < K; ++k) if (lens[k] <= 0) { set_error_msg("zstd frames: a chunk failed to compress"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    if (total > cap) return 0;
+    HCK(hipMemcpy(hdst, dout.p, total, hipMemcpyDeviceToHost));
+    return (int64_t)total;
+}
+
+namespace {
+// Frame boundaries from the frame and block headers alone (ZSTD_findFrameCompressedSize, zstd_decompress.c:700-790).
+// false = not decidable here (malformed, or a frame without content size): the caller lets one wavefront walk the stream.
+struct FrameSpan { uint64_t off; uint32_t len; uint64_t content; };
+bool split_frames(const uint8_t* p, size_t n, std::vector<FrameSpan>& out)
+{
+    size_t pos = 0;
+    while (pos < n) {
+        if (n - pos < 8) return false;
+        uint32_t magic; memcpy(&magic, p + pos, 4);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            uint32_t sz; memcpy(&sz, p + pos + 4, 4);
+            if ((uint64_t)sz + 8 > n - pos) return false;
+            pos += 8 + (size_t)sz; continue;
+        }
+        if (magic != 0xFD2FB528u) return false;
+        const size_t start = pos;
+        const uint32_t fhd = p[pos + 4], fcsId = fhd >> 6, single = (fhd >> 5) & 1, hasCk = (fhd >> 2) & 1, did = fhd & 3;
+        pos += 5;
+        if (!single) pos += 1;
+        pos += did == 3 ? 4 : did;
+        const size_t fl = fcsId == 0 ? (single ? 1 : 0) : (fcsId == 1 ? 2 : (fcsId == 2 ? 4 : 8));
+        if (fl == 0 || pos + fl > n) return false;
+        uint64_t fcs = 0;
+        for (size_t i = 0; i < fl; ++i) fcs |= (uint64_t)p[pos + i] << (8 * i);
+        if (fl == 2) fcs += 256;
+        pos += fl;
+        for (;;) {
+            if (n - pos < 3) return false;
+            const uint32_t bh = p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16);
+            const uint32_t last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+            pos += 3;
+            if (type == 3) return false;
+            const size_t body = type == 1 ? 1 : bsz;
+            if (body > n - pos) return false;
+            pos += body;
+            if (last) break;
+        }
+        if (hasCk) { if (n - pos < 4) return false; pos += 4; }
+        if (pos - start > 0xFFFFFFFFull || fcs > 0x7FFFFFFFull) return false;
+        out.push_back(FrameSpan{start, (uint32_t)(pos - start), fcs});
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t n, void* hdst, size_t cap)
+{
+    if (!hsrc || !hdst) { set_error_msg("zstd frames: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    std::vector<FrameSpan> fr;
+    if (n > 0xFFFFFFFFull || !split_frames((const uint8_t*)hsrc, n, fr) || fr.size() < 2)
+        return aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
+    const size_t K = fr.size();
+    uint64_t total = 0;
+    std::vector<uint64_t> soff(K), doff(K); std::vector<uint32_t> slen(K), dcap(K);
+    for (size_t k = 0; k < K; ++k) { soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = total; dcap[k] = (uint32_t)fr[k].content; total += fr[k].content; }
+    if (total > cap) return -2;
+    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    DevBuf dsrc, ddst, a, bq, c, d, o;
+    if (!dsrc.alloc(n) || !ddst.alloc(total) || !a.alloc(K * 8) || !bq.alloc(K * 4) || !c.alloc(K * 8) || !d.alloc(K * 4) || !o.alloc(K * 4)) {
+        set_error_msg("zstd frames: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
+    }
+    HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(a.p, soff.data(), K * 8, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(bq.p, slen.data(), K * 4, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(c.p, doff.data(), K * 8, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(d.p, dcap.data(), K * 4, hipMemcpyHostToDevice));
+    aoclgpu_batch bt; memset(&bt, 0, sizeof(bt));
+    bt.src = (const uint8_t*)dsrc.p; bt.dst = (uint8_t*)ddst.p; bt.src_off = (const uint64_t*)a.p; bt.src_len = (const uint32_t*)bq.p;
+    bt.dst_off = (const uint64_t*)c.p; bt.dst_cap = (const uint32_t*)d.p; bt.out_len = (int32_t*)o.p; bt.nchunks = (uint32_t)K;
+    const int rc = aoclgpu_zstd_decompress_chunks(&bt, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    std::vector<int32_t> res(K);
+    HCK(hipMemcpy(res.data(), o.p, K * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < K; ++k) if (res[k] < 0 || (uint32_t)res[k] != dcap[k]) return -1;
+    if (total) HCK(hipMemcpy(hdst, ddst.p, total, hipMemcpyDeviceToHost));
+#undef HCK
+    return (int64_t)total;
 }

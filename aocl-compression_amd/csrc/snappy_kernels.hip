@@ -578,34 +578,40 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     // Batches that LDS can hold at once (5 tables per CU) use the LDS-table kernel; larger ones the persistent
     // global-table kernel with 14 workgroups per CU (the measured optimum with check bits in the slots: 10 -> 21.7,
     // 12 -> 22.9, 14 -> 24.3, 16 -> 23.6, 20 -> 19.7 GiB/s; without check bits 12 -> 21.8; LDS kernel 14.0).
-    // Experiment 64 forces the LDS kernel, experiment 128 the global-table kernel (tests); the largest batches take the
-    // mixed kernel below.
+    // AOCLGPU_FLAG_SNAPPY_TABLES_LDS / _HBM / _MIXED pin the choice (tests); the largest batches take the mixed kernel below.
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("snappy: device query failed"); return AOCLGPU_ERR_HIP; }
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
-    if ((!(b->reserved & (64u | 128u)) && b->nchunks > 16u * cus) || (b->reserved & 32u)) {     // experiment 32 forces it (tests)
+    aoclgpu::WsGuard guard;                               // held until the kernel that uses the scratch is enqueued
+    const bool forceLds = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_LDS) != 0, forceHbm = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_HBM) != 0;
+    const bool forceMix = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_MIXED) != 0;
+    if ((!forceLds && !forceHbm && b->nchunks > 16u * cus) || forceMix) {
         // large batches: the mixed kernel, 4 workgroups of 4 waves per CU (see snappy_compress_mix_kernel)
         uint32_t grid = 4u * cus;
         if (grid > (b->nchunks + 3) / 4) grid = (b->nchunks + 3) / 4;
+#ifdef AOCLGPU_EXPERIMENTS
         if (const char* g = getenv("AOCLGPU_SNAPPY_MIX_PER_CU")) grid = (uint32_t)(atoi(g) > 0 ? atoi(g) : 4) * cus;   // tuning hook
+#endif
         const size_t tbytes = (size_t)grid * 3 * aoclgpu::kMaxTable * sizeof(uint32_t);
-        uint8_t* ws = (uint8_t*)aoclgpu::get_workspace(tbytes + 256, stream);
+        uint8_t* ws = (uint8_t*)aoclgpu::get_workspace(guard, tbytes + 256, stream);
         if (!ws) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         uint32_t* counter = (uint32_t*)(ws + tbytes);
         if (hipMemsetAsync(counter, 0, 4, (hipStream_t)stream) != hipSuccess) { aoclgpu::set_error_msg("snappy: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
         hipLaunchKernelGGL(aoclgpu::snappy_compress_mix_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *b, (uint32_t*)ws, counter);
         return aoclgpu::check_launch("snappy_compress_mix_kernel");
     }
-    if (!(b->reserved & 64u) && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || (b->reserved & 128u))) {
+    if (!forceLds && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || forceHbm)) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::snappy_compress_gt_kernel, 64, 0) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("snappy: occupancy query failed"); return AOCLGPU_ERR_HIP;
         }
         if (perCU > 14) perCU = 14;
+#ifdef AOCLGPU_EXPERIMENTS
         if (const char* g = getenv("AOCLGPU_SNAPPY_GT_PER_CU")) perCU = atoi(g) > 0 ? atoi(g) : perCU;      // tuning hook
+#endif
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > b->nchunks) grid = b->nchunks;
-        void* tables = aoclgpu::get_workspace((size_t)grid * aoclgpu::kMaxTable * sizeof(uint32_t), stream);
+        void* tables = aoclgpu::get_workspace(guard, (size_t)grid * aoclgpu::kMaxTable * sizeof(uint32_t), stream);
         if (!tables) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         hipLaunchKernelGGL(aoclgpu::snappy_compress_gt_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint16_t*)tables);
         return aoclgpu::check_launch("snappy_compress_gt_kernel");

@@ -179,7 +179,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
 #endif
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
-        const bool chain = !(expf & 32);                                // experiment 32: one match per batch everywhere
+#ifdef AOCLGPU_EXPERIMENTS
+        const bool chain = !(expf & 32);                                // experiment build: one match per batch everywhere
+#else
+        constexpr bool chain = true; (void)expf;
+#endif
         // Source ring of the chain batches.  Block b of the chunk (240 bytes) sits at ring offset (b & 1) * 240, the first
         // 32 bytes of the even block are mirrored behind the odd one so that a 32-byte read never wraps; the block after
         // the newest one is always in flight in a register (requested a block of parsing ahead of its use), so the 64
@@ -787,8 +791,11 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         else if (hi) nbSeq = fast_block<5, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
         else nbSeq = fast_block<5, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
         wave_fence();
-        if (expf & 16) cSize = 0;      // EXPERIMENT (timing only): match finder alone, block emitted raw
-        else cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
+#ifdef AOCLGPU_EXPERIMENTS
+        if (expf & 16) cSize = 0;      // experiment build (timing only): match finder alone, block emitted raw
+        else
+#endif
+        cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
         if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                      // ZSTD_minGain, zstd_compress.c:3055-3057
     }
     if (cSize == 0) {                                                    // ZSTD_noCompressBlock
@@ -1520,7 +1527,8 @@ __global__ void __launch_bounds__(64) zstd_block_sequences_kernel(const uint8_t*
 extern "C" int aoclgpu_zstd_block_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t maxSeq, uint32_t expf)
 {
     if (n < 7 || n > (128u << 10)) return AOCLGPU_ERR_ARG;
-    void* ws = get_workspace(aoclgpu::zstd_workspace_bytes(), nullptr);
+    aoclgpu::WsGuard guard;                               // the scratch is used until the synchronous copy below returns
+    void* ws = get_workspace(guard, aoclgpu::zstd_workspace_bytes(), nullptr);
     uint32_t* out = nullptr;
     const size_t bytes = (2 + 3 * (size_t)maxSeq) * sizeof(uint32_t);
     if (!ws || hipMalloc((void**)&out, bytes) != hipSuccess) return AOCLGPU_ERR_HIP;
@@ -1619,6 +1627,7 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
             L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes, level) };
         } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail, level) };
     }
+    aoclgpu::WsGuard guard;                               // held until the kernels that use the scratch are enqueued
     for (int i = 0; i < nl; ++i) {
         // persistent blocks: exactly as many as are resident at once for this LDS size (gfx950 allocates LDS in 1280-byte
         // granules, the occupancy query counts bytes: the smaller of the two, see aoclgpu_zstd_decompress_chunks)
@@ -1633,7 +1642,7 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         }
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
-        void* ws = get_workspace((size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
+        void* ws = get_workspace(guard, (size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         if (L[i].lds > 65536u) {
             hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
@@ -1649,6 +1658,7 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
 {
     if (int rc = aoclgpu::check_batch(b, true)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
+    aoclgpu::WsGuard guard;                               // also serialises the one-time occupancy query below
     // persistent blocks: exactly as many as are resident at once (LDS / VGPR limited), asked from the runtime
     static int perCU = 0, nCU = 0;
     if (!perCU) {
@@ -1664,12 +1674,14 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
         // 58.1 GiB/s.
         const int byLds = (int)((160u << 10) / (((aoclgpu::zstd_decoder_lds_bytes() + 1279u) / 1280u) * 1280u));
         if (byLds >= 1 && byLds < perCU) perCU = byLds;
+#ifdef AOCLGPU_EXPERIMENTS
         if (const char* g = getenv("AOCLGPU_ZSTD_DEC_PER_CU")) perCU = atoi(g) > 0 ? atoi(g) : perCU;      // tuning hook
+#endif
     }
     uint32_t grid = (uint32_t)(perCU * nCU);
     if (grid > b->nchunks) grid = b->nchunks;
     // the decoder's literal buffers share the stream's workspace with the compressor's (same stream order)
-    void* ws = get_workspace((size_t)grid * aoclgpu::kDecWs, stream);
+    void* ws = get_workspace(guard, (size_t)grid * aoclgpu::kDecWs, stream);
     if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
     hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws);
     return aoclgpu::check_launch("zstd_decompress_kernel");

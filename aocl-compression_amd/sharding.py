@@ -27,3 +27,44 @@ def gather_compressed(dist, packed, lens, seg_cap: int):
     segs = [torch.zeros_like(seg) for _ in range(world)]
     dist.all_gather(segs, seg)
     return ([s[:int(m[1])] for s, m in zip(segs, meta)], [l[:int(m[0])] for l, m in zip(all_lens, meta)])
+
+
+def segment_layout(seg_sizes, align: int = 16):
+    """Where rank r's compacted segment lives in the gathered buffer: the exclusive prefix sum of the segment sizes with
+    `align`-byte aligned starts.  Returns (offsets, total bytes)."""
+    offs, o = [], 0
+    for s in seg_sizes:
+        offs.append(o)
+        o += (int(s) + align - 1) // align * align
+    return offs, o
+
+
+def exchange_segments(dist, rank: int, world: int, gather_buf, seg_sizes, seg_off, host_staged: bool = False):
+    """Exact-size exchange of the compressed segments between all ranks (RCCL has no all-gatherv): this rank's segment
+    already lies at gather_buf[seg_off[rank] : +seg_sizes[rank]]; one send and one receive per peer are posted as ONE group
+    (ncclGroupStart/End under torch.distributed.batch_isend_irecv), so every pair talks over its own xGMI link at the same
+    time instead of a ring moving padded segments.  Returns the list of outstanding works (empty when `host_staged`:
+    gloo, the 1-GPU / CPU validation backend, moves host tensors and is waited for here)."""
+    mine = gather_buf[seg_off[rank]:seg_off[rank] + seg_sizes[rank]]
+    if world == 1:
+        return []
+    if host_staged:
+        import torch
+        src = mine.cpu()
+        recv, ops = {}, []
+        for d in range(1, world):
+            to, frm = (rank + d) % world, (rank - d) % world
+            recv[frm] = torch.zeros(seg_sizes[frm], dtype=torch.uint8)
+            ops.append(dist.P2POp(dist.isend, src, to))
+            ops.append(dist.P2POp(dist.irecv, recv[frm], frm))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for frm, t in recv.items():
+            gather_buf[seg_off[frm]:seg_off[frm] + seg_sizes[frm]].copy_(t)
+        return []
+    ops = []
+    for d in range(1, world):
+        to, frm = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, mine, to))
+        ops.append(dist.P2POp(dist.irecv, gather_buf[seg_off[frm]:seg_off[frm] + seg_sizes[frm]], frm))
+    return dist.batch_isend_irecv(ops)

@@ -2,19 +2,23 @@
 """bench.py -- headline benchmark of the MI355X block-codec engine.
 
 Metric (BASELINE.json): GiB/s compress + decompress on a Silesia-shaped mix, 1/2/4/8 GPUs.
-Workload at N=1 = BASELINE config[1]: LZ4 level 1, 256 KiB independent chunks, the (synthetic) Silesia
-corpus concatenated to 8 GiB, inputs resident in HBM before the timed region starts.
+Headline workload = BASELINE config[1]: LZ4 level 1, 256 KiB independent chunks, the (synthetic) Silesia corpus
+concatenated to 8 GiB per GPU, inputs resident in HBM before the timed region starts.  The same line also carries
+BASELINE configs 3 and 4 under `codecs` (Snappy 64 KiB blocks on JSON/log records; Zstd level 1, 128 KiB blocks on the
+Silesia mix), each driver-timed the same way with its own `roofline` and `cpu_baseline` (`--codec lz4|snappy|zstd` runs
+one of them alone).  N > 1 = BASELINE config 5: LZ4 + Zstd, chunks sharded over the ranks, exact-size exchange of the
+compacted compressed segments over RCCL.
 
-One STEP = one pass of the hot path over the rank's shard:
-    compress every chunk -> [N>1: compact + RCCL all-gather of the compressed segments] -> decompress.
-`value` = uncompressed GiB that went through that compress+decompress round trip per second, summed
-over ranks (weak scaling: every rank owns `--gib` GiB), using the max-over-ranks time of K steps.
-The per-direction rates are reported next to it (compress_GiBps / decompress_GiBps).
+One STEP of a codec = one pass of the hot path over the rank's shard:
+    compress every chunk -> [N>1: compact + exchange of the compressed segments between all ranks] -> decompress.
+`value` = uncompressed GiB that went through that round trip per second, summed over ranks (weak scaling: every rank
+owns `--gib` GiB), from the max-over-ranks wall time of K steps bracketed by barrier + synchronize.
 
-Extra objects on the JSON line: `roofline` (dominant kernel vs the 8 TB/s HBM peak; live HIP-event
-timing of that kernel on its own stream) and `cpu_baseline` (the real reference's one-shot functions --
-oracle/_ref -- or, if that prebuilt library is absent, this repo's C port, timed on the host cores over a
-bounded sample of the same chunks; rank 0, N=1 only).  `--codec snappy|zstd` runs BASELINE configs 3 / 4.
+`roofline`: dominant kernel vs the 8 TB/s HBM peak; algorithmic bytes N + C per launch divided
+by the live HIP-event time of that kernel on its own stream (aoclgpu_time_batch).  `cpu_baseline`: the real reference's
+one-shot functions (oracle/_ref, kind "reference"; this repo's C port if that prebuilt library is absent) over the
+same chunks on the host cores -- buffers first-touched by their threads, one warm-up pass, best / median of 5 passes,
+one thread and all threads (oracle/chunk_driver.c orc_bench_chunks); rank 0, N=1 only.
 """
 from __future__ import annotations
 
@@ -22,7 +26,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +39,8 @@ GIB = float(1 << 30)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SILESIA_BYTES = 211_938_580     # size of the real Silesia corpus; the synthetic base matches it
 CODECS = {"lz4": (0, 262144), "snappy": (1, 65536), "zstd": (2, 131072)}
+REF_FUNCS = {"lz4": ("LZ4_compress_default", "LZ4_decompress_safe"), "snappy": ("snappy_compress", "snappy_uncompress"),
+             "zstd": ("ZSTD_compress", "ZSTD_decompress")}
 
 
 def parse():
@@ -40,64 +48,446 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--codec", default="lz4", choices=list(CODECS))
-    p.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
+    p.add_argument("--codec", default="all", choices=["all", *CODECS],
+                   help="all = lz4 (headline) + snappy + zstd at N=1, lz4 + zstd at N>1")
+    p.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU and codec")
     p.add_argument("--chunk", type=int, default=0, help="chunk bytes (default: the codec's BASELINE chunk)")
     p.add_argument("--base-mib", type=float, default=SILESIA_BYTES / (1 << 20), help="size of the synthetic base corpus")
-    p.add_argument("--cpu-sample-gib", type=float, default=2.0)
+    p.add_argument("--cpu-sample-gib", type=float, default=2.0, help="cpu_baseline sample for the all-thread passes")
+    p.add_argument("--cpu-reps", type=int, default=5)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    p.add_argument("--exchange", default="sendrecv", choices=["sendrecv", "allgather"],
+                   help="N>1: exact-size grouped send/recv (default) or all-gather of segments padded to the largest")
     return p.parse_args()
 
 
-REF_FUNCS = {"lz4": ("LZ4_compress_default", "LZ4_decompress_safe"), "snappy": ("snappy_compress", "snappy_uncompress"),
-             "zstd": ("ZSTD_compress", "ZSTD_decompress")}
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib):
-    """Time the reference CPU path over the first `sample_gib` GiB of the same chunk stream."""
+def cpu_budget():
+    """(usable hardware threads, cgroup CPU quota or None): a container may see every hardware thread of the host and still
+    be throttled to a few CPUs' worth of time per period (cgroup v2 cpu.max / v1 cfs_quota_us); OpenMP threads beyond that
+    budget only add contention, so the all-thread baseline uses min(visible threads, quota) threads and reports both."""
+    try:
+        vis = len(os.sched_getaffinity(0))
+    except AttributeError:
+        vis = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    return vis, quota
+
+
+def _median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def cpu_worker(spec):
+    """Child process of cpu_baseline (started with OMP_PROC_BIND / OMP_PLACES in its environment, no GPU use):
+    times the reference CPU path over the head of the chunk stream and prints one JSON object."""
     import numpy as np
     import oracle_lib as ol
-    codec = CODECS[codec_name][0]
+    name, chunk, slot, reps = spec["codec"], spec["chunk"], spec["slot"], spec["reps"]
+    base_np = np.load(spec["base"], mmap_mode="r")
+    codec = CODECS[name][0]
     orc = ol.Oracle()
     kind, fc, fd = "port", None, None
-    cname, dname = REF_FUNCS[codec_name]
+    cname, dname = REF_FUNCS[name]
     if os.path.exists(ol.REF_SO):
         ref = C.CDLL(ol.REF_SO)
         fc = C.cast(getattr(ref, cname), C.c_void_p)
         fd = C.cast(getattr(ref, dname), C.c_void_p)
         kind = "reference"
-    n = int(min(total, sample_gib * GIB)) // chunk * chunk
-    reps = -(-n // len(base_np))
-    sample = np.ascontiguousarray(np.tile(base_np, reps)[:n])
-    nchunks = n // chunk
-    dst = np.empty(nchunks * slot, np.uint8)
-    out_len = np.zeros(nchunks, np.int32)
-    back = np.empty(n, np.uint8)
-    cores = os.cpu_count() or 1
     L = orc.L
-    L.orc_compress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
-                                         C.c_void_p, C.c_int]
-    L.orc_decompress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
-                                           C.c_size_t, C.c_size_t, C.c_int]
-    t0 = time.perf_counter()
-    fails = L.orc_compress_chunks_fn(codec, fc, sample.ctypes.data, n, chunk, dst.ctypes.data, slot, out_len.ctypes.data, cores)
-    t1 = time.perf_counter()
-    fails += L.orc_decompress_chunks_fn(codec, fd, dst.ctypes.data, slot, out_len.ctypes.data, nchunks, back.ctypes.data,
-                                        chunk, n, cores)
-    t2 = time.perf_counter()
-    assert fails == 0 and np.array_equal(back, sample)
-    tc, td = t1 - t0, t2 - t1
-    return {
-        "value": round(n / GIB / (tc + td), 3), "unit": "GiB/s", "cores": cores, "kind": kind,
-        "compress_GiBps": round(n / GIB / tc, 3), "decompress_GiBps": round(n / GIB / td, 3),
-        "sample": f"first {n / GIB:.2f} GiB of the same {chunk // 1024} KiB chunk stream, "
-                  f"{cname} + {dname}, OpenMP over chunks on {cores} host threads",
-    }, out_len
+    L.orc_bench_chunks.restype = C.c_int
+    L.orc_bench_chunks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cores = spec["cores"]
+
+    def run(nbytes, threads):
+        nbytes = min(nbytes, (64 << 20) * threads)
+        n = int(min(spec["total"], nbytes)) // chunk * chunk
+        r = -(-n // len(base_np))
+        sample = np.ascontiguousarray(np.tile(base_np, r)[:n]) if r > 1 else np.ascontiguousarray(base_np[:n])
+        out_len = np.zeros(n // chunk, np.int32)
+        tc = np.zeros(reps, np.float64)
+        td = np.zeros(reps, np.float64)
+        fails = L.orc_bench_chunks(codec, fc, fd, sample.ctypes.data, n, chunk, slot, out_len.ctypes.data, threads, reps,
+                                   tc.ctypes.data, td.ctypes.data)
+        assert fails == 0, f"cpu_baseline: {fails} failures"
+        g = n / GIB
+        return {
+            "threads": threads, "sample_GiB": round(g, 4),
+            "compress_GiBps": round(g / tc.min(), 4), "decompress_GiBps": round(g / td.min(), 4),
+            "compress_GiBps_median": round(g / _median(tc.tolist()), 4),
+            "decompress_GiBps_median": round(g / _median(td.tolist()), 4),
+            "value": round(g / (tc.min() + td.min()), 4),
+        }, out_len
+
+    one, _ = run(64 << 20, 1)
+    allt, out_len = run(spec["sample_gib"] * GIB, cores)
+    np.save(spec["lens_out"], out_len)
+    print(json.dumps({
+        "value": allt["value"], "unit": "GiB/s", "cores": cores, "kind": kind,
+        "compress_GiBps": allt["compress_GiBps"], "decompress_GiBps": allt["decompress_GiBps"],
+        "all_threads": allt, "one_thread": one,
+        "one_thread_MBps": {"compress": round(one["compress_GiBps"] * GIB / 1e6, 1), "decompress": round(one["decompress_GiBps"] * GIB / 1e6, 1)},
+        "host_cpu": host_cpu_model(), "host_threads_visible": spec["visible"], "cgroup_cpu_quota": spec["quota"],
+        "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+        "method": f"child process; buffers first-touched by their threads, 1 warm-up pass, best of {reps} passes (median "
+                  "alongside), schedule(static,1) over chunks (oracle/chunk_driver.c orc_bench_chunks)",
+        "sample": f"first {allt['sample_GiB']:.2f} GiB (all threads) / {one['sample_GiB'] * 1024:.0f} MiB (1 thread) of the same "
+                  f"{chunk // 1024} KiB chunk stream, {cname} + {dname}",
+    }), flush=True)
+
+
+_BASE_FILES = {}
+
+
+def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib, reps):
+    """The reference CPU path over the head of the same chunk stream, 1 thread and all threads, timed in a child process
+    so that the OpenMP binding (OMP_PROC_BIND=close, one place per hardware thread) cannot pin this process's HIP runtime
+    threads.  Returns (record, per-chunk compressed sizes of the all-thread sample)."""
+    import numpy as np
+    visible, quota = cpu_budget()
+    cores = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    tmp = tempfile.gettempdir()
+    key = id(base_np)
+    if key not in _BASE_FILES:
+        path = os.path.join(tmp, f"aoclgpu_bench_base_{os.getpid()}_{len(_BASE_FILES)}.npy")
+        np.save(path, base_np)
+        _BASE_FILES[key] = path
+    lens_out = os.path.join(tmp, f"aoclgpu_bench_lens_{os.getpid()}.npy")
+    spec = {"codec": codec_name, "chunk": chunk, "slot": slot, "reps": reps, "total": total, "sample_gib": sample_gib,
+            "cores": cores, "visible": visible, "quota": quota, "base": _BASE_FILES[key], "lens_out": lens_out}
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "threads")
+    env["HIP_VISIBLE_DEVICES"] = ""          # the child never touches the GPU
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps(spec)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    if p.returncode != 0:
+        raise RuntimeError("cpu_baseline worker failed: " + p.stderr[-400:])
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    out_len = np.load(lens_out)
+    os.unlink(lens_out)
+    return rec, out_len
+
+
+def config1_latency(eng, reps=20):
+    """BASELINE config 1: one 64 KiB text block through aocl_llc_compress / aocl_llc_decompress on HOST buffers
+    (PCIe both ways included), next to the reference's own aocl_llc_* on one host core.  Microseconds, best of `reps`."""
+    import aocl_compression_amd as a
+    import oracle_lib as ol
+    data = a.corpus.make("text", 65536, seed=0xA0C1 + 1).tobytes()
+    cap = a.compress_bound(a.LZ4, len(data))
+    out = {}
+
+    def best(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e6
+
+    comp = {}
+    def gc():
+        comp["r"] = eng.llc_compress(a.LZ4, data, cap)
+    out["gpu_compress_us"] = round(best(gc), 1)
+    r, blob, _ = comp["r"]
+    assert r > 0
+    def gd():
+        rr, back, _ = eng.llc_decompress(a.LZ4, blob, len(data))
+        assert rr == len(data)
+    out["gpu_decompress_us"] = round(best(gd), 1)
+    if os.path.exists(ol.REF_SO):
+        ref = C.CDLL(ol.REF_SO)
+        ref.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        ref.LZ4_decompress_safe.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        ob = C.create_string_buffer(cap)
+        bb = C.create_string_buffer(len(data))
+        n = {}
+        def rc():
+            n["c"] = ref.LZ4_compress_default(data, ob, len(data), cap)
+        out["reference_1core_compress_us"] = round(best(rc), 1)
+        assert ob.raw[:n["c"]] == blob, "config 1: GPU bytes differ from the reference's"
+        def rd():
+            ref.LZ4_decompress_safe(ob, bb, n["c"], len(data))
+        out["reference_1core_decompress_us"] = round(best(rd), 1)
+        out["bytes_identical_to_reference"] = True
+    out["note"] = "host buffers in and out (H2D + one wavefront + D2H per call); never the reported value"
+    return out
+
+
+class Run:
+    """Everything one codec needs on this rank: the HBM-resident shard, slots, batches and the exchange buffers."""
+
+    def __init__(self, eng, dist, args, name, base_np, corpus_name, rank, world):
+        import torch
+        import aocl_compression_amd as a
+        self.torch, self.eng, self.dist, self.args, self.name = torch, eng, dist, args, name
+        self.rank, self.world = rank, world
+        self.codec, def_chunk = CODECS[name]
+        self.chunk = chunk = args.chunk or def_chunk
+        self.total = total = int(args.gib * GIB) // chunk * chunk
+        self.nchunks = nchunks = total // chunk
+        self.slot = slot = (a.compress_bound(self.codec, chunk) + 15) & ~15
+        self.corpus_name = corpus_name
+        dev = eng.device
+        self.base = torch.from_numpy(base_np).to(dev)
+        self.src = self.shard_of(rank)
+        self.slots = torch.empty(nchunks * slot, dtype=torch.uint8, device=dev)
+        self.clen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+        self.dst = torch.empty(total, dtype=torch.uint8, device=dev)
+        self.dlen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+        self.aux = torch.zeros(nchunks, dtype=torch.int32, device=dev)     # LZ4: final literal run per chunk (RAP join)
+        self.cb = eng.uniform_compress_batch(self.src, chunk, self.slots, self.clen, slot)
+        self.cb.aux = self.aux.data_ptr()
+        self.db = eng.uniform_decompress_batch(self.slots, self.clen, slot, self.dst, chunk, self.dlen)
+        self.kt = {"c": [], "d": []}
+        if world > 1:
+            self.setup_exchange()
+
+    def shard_of(self, r):
+        """Rank r's shard of the stream: the base corpus rotated by a rank-specific offset, tiled to `total` bytes."""
+        torch = self.torch
+        shift = (r * 7919 * 4096) % self.base.numel()
+        b = torch.roll(self.base, -shift) if shift else self.base
+        reps = -(-self.total // b.numel())
+        return b.repeat(reps)[:self.total].contiguous()
+
+    # ---- N > 1: exchange of the compacted compressed segments ----
+    def all_gather_vec(self, out, mine):
+        """all-gather of one device vector per rank (gloo, the 1-GPU validation backend, only moves host tensors)"""
+        if not self.gloo:
+            return self.dist.all_gather_into_tensor(out, mine)
+        parts = [self.torch.zeros(mine.numel(), dtype=mine.dtype) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine.cpu())
+        out.copy_(self.torch.cat(parts))
+
+    def setup_exchange(self):
+        torch, dist, eng = self.torch, self.dist, self.eng
+        dev = eng.device
+        self.gloo = dist.get_backend() == "gloo"
+        # segment sizes are deterministic: one untimed compress pass fixes them for every rank
+        eng.time_batch(self.codec, 0, self.cb, 1)
+        mine = self.clen.sum().to(torch.int64).reshape(1)
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        self.all_gather_vec(sizes, mine)
+        self.seg = [int(x) for x in sizes.cpu().tolist()]
+        self.off = torch.zeros(self.nchunks + 1, dtype=torch.int64, device=dev)
+        self.len_all = torch.zeros(self.world * self.nchunks, dtype=torch.int32, device=dev)
+        self.aux_all = torch.zeros(self.world * self.nchunks, dtype=torch.int32, device=dev)
+        self.all_gather_vec(self.aux_all, self.aux)
+        if self.args.exchange == "allgather":
+            # RCCL has no all-gatherv: every segment is padded to the largest one (the ring moves the padding too)
+            self.seg_cap = (max(self.seg) + (1 << 20)) & ~0xFFFFF
+            self.seg_off = [r * self.seg_cap for r in range(self.world)]
+            self.packed = torch.empty(self.seg_cap, dtype=torch.uint8, device=dev)
+            self.gather_buf = torch.empty(self.world * self.seg_cap, dtype=torch.uint8, device=dev)
+        else:
+            # exact sizes (aocl_compression_amd.sharding): rank r's segment lives at the exclusive prefix sum of the segment
+            # sizes (16-byte aligned starts); this rank compacts straight into its own place
+            from aocl_compression_amd import sharding
+            self.seg_off, total = sharding.segment_layout(self.seg)
+            self.gather_buf = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+            self.packed = self.gather_buf[self.seg_off[self.rank]:self.seg_off[self.rank] + self.seg[self.rank]]
+
+    def exchange(self):
+        dist, torch = self.dist, self.torch
+        if self.args.exchange == "allgather":
+            if self.gloo:                             # validation on one GPU: same data movement, staged through the host
+                parts = [torch.zeros(self.seg_cap, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, self.packed.cpu())
+                self.gather_buf.copy_(torch.cat(parts))
+                return []
+            return [dist.all_gather_into_tensor(self.gather_buf, self.packed, async_op=True)]
+        from aocl_compression_amd import sharding
+        return sharding.exchange_segments(dist, self.rank, self.world, self.gather_buf, self.seg, self.seg_off, host_staged=self.gloo)
+
+    def step(self, record):
+        eng = self.eng
+        tc = eng.time_batch(self.codec, 0, self.cb, 1)          # HIP events around the compress kernel, same stream
+        works = []
+        if self.world > 1:
+            rc = eng.lib.aoclgpu_compact_slots(self.slots.data_ptr(), self.slot, self.clen.data_ptr(), self.nchunks,
+                                               self.packed.data_ptr(), self.off.data_ptr(), eng._stream())
+            assert rc == 0
+            self.all_gather_vec(self.len_all, self.clen)
+            # the exchange runs on RCCL's stream while this rank decodes its own chunks
+            works = self.exchange()
+        td = eng.time_batch(self.codec, 1, self.db, 1)
+        for w in works:
+            w.wait()
+        if record:
+            self.kt["c"].append(tc)
+            self.kt["d"].append(td)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self):
+        args, torch, dist = self.args, self.torch, self.dist
+        for _ in range(args.warmup):
+            self.step(False)
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            self.step(True)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.eng.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    # ---- checks outside the timed region ----
+    def verify_local(self):
+        torch = self.torch
+        assert int((self.clen <= 0).sum().item()) == 0, "a chunk failed to compress"
+        assert int((self.dlen != self.chunk).sum().item()) == 0, "a chunk failed to decompress"
+        assert torch.equal(self.dst, self.src), "round trip mismatch"
+
+    def verify_remote(self):
+        """Decode the segment this rank RECEIVED from the next rank (sizes from the gathered length table) and compare
+        it with that rank's shard, regenerated here: a wrong exchange cannot print a number."""
+        import aocl_compression_amd as a
+        torch, eng = self.torch, self.eng
+        peer = (self.rank + 1) % self.world
+        lens = self.len_all[peer * self.nchunks:(peer + 1) * self.nchunks]
+        assert int(lens.sum().item()) == self.seg[peer], "gathered chunk sizes do not add up to the peer's segment size"
+        csum = torch.cumsum(lens.to(torch.int64), 0)
+        src_off = (csum - lens + self.seg_off[peer]).contiguous()
+        dst_off = (torch.arange(self.nchunks, dtype=torch.int64, device=eng.device) * self.chunk).contiguous()
+        dst_cap = torch.full((self.nchunks,), self.chunk, dtype=torch.int32, device=eng.device)
+        out = torch.empty(self.total, dtype=torch.uint8, device=eng.device)
+        olen = torch.zeros(self.nchunks, dtype=torch.int32, device=eng.device)
+        b = a.Batch(src=self.gather_buf.data_ptr(), dst=out.data_ptr(), src_off=src_off.data_ptr(),
+                    src_len=lens.contiguous().data_ptr(), dst_off=dst_off.data_ptr(), dst_cap=dst_cap.data_ptr(),
+                    out_len=olen.data_ptr(), nchunks=self.nchunks)
+        eng._check(eng._fn(self.codec, "decompress")(C.byref(b), eng._stream()), "decode of the gathered segment")
+        torch.cuda.synchronize()
+        assert int((olen != self.chunk).sum().item()) == 0, f"rank {self.rank}: a chunk of rank {peer}'s gathered segment failed to decode"
+        want = self.shard_of(peer)
+        assert torch.equal(out, want), f"rank {self.rank}: rank {peer}'s gathered segment does not decode to its shard"
+        return peer
+
+    def verify_assemble(self, slab_bytes=1 << 30):
+        """Config 5 as a product: ONE RAP stream (threads/threads.h:77-106) from the gathered segments of TWO ranks - the last
+        `slab_bytes`/2 of this rank's shard and the first `slab_bytes`/2 of the next rank's - assembled by
+        aoclgpu_rap_assemble from the gathered buffer and size tables alone, then decoded by aoclgpu_rap_unpack and compared
+        with the source bytes of both ranks."""
+        import numpy as np
+        torch, eng = self.torch, self.eng
+        peer = (self.rank + 1) % self.world
+        half = max(1, min(self.nchunks, slab_bytes // 2 // self.chunk, 32767))
+        lens = self.len_all.cpu().numpy().reshape(self.world, self.nchunks)
+        auxs = self.aux_all.cpu().numpy().reshape(self.world, self.nchunks)
+        offs = []
+        for r in range(self.world):
+            c = np.cumsum(lens[r].astype(np.int64))
+            offs.append(c - lens[r] + self.seg_off[r])
+        pick = [(self.rank, self.nchunks - half, self.nchunks), (peer, 0, half)]
+        off = np.concatenate([offs[r][a:b] for r, a, b in pick]).astype(np.uint64)
+        ln = np.concatenate([lens[r][a:b] for r, a, b in pick])
+        ax = np.concatenate([auxs[r][a:b] for r, a, b in pick]).astype(np.uint32)
+        sl = np.full(len(ln), self.chunk, np.uint32)
+        stream = eng.rap_assemble(self.codec, self.gather_buf, off, ln, sl, ax if self.name == "lz4" else None)
+        want = torch.cat([self.src[(self.nchunks - half) * self.chunk:], self.shard_of(peer)[:half * self.chunk]])
+        got, r = eng.rap_decompress(self.codec, stream, int(want.numel()))
+        assert r == want.numel(), f"rank {self.rank}: assembled RAP stream decodes to {r} bytes, expected {want.numel()}"
+        assert torch.equal(got[:r], want), f"rank {self.rank}: assembled RAP stream does not decode to the two ranks' bytes"
+        return int(stream.numel()), 2 * half
+
+    def result(self, elapsed):
+        """Per-codec record (rank 0 prints it); collective when world > 1."""
+        torch, dist, args = self.torch, self.dist, self.args
+        comp_bytes = int(self.clen.sum().item())
+        ms_c = sum(self.kt["c"]) / len(self.kt["c"])
+        ms_d = sum(self.kt["d"]) / len(self.kt["d"])
+        comp_total = float(comp_bytes)
+        if self.world > 1:
+            agg = torch.tensor([ms_c, ms_d, float(comp_bytes)], dtype=torch.float64, device=self.eng.device)
+            mx = agg.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            ms_c, ms_d = float(mx[0]), float(mx[1])
+            comp_total = float(agg[2])
+        world, total, chunk = self.world, self.total, self.chunk
+        unc_total = float(total) * world
+        ms_step = elapsed / args.steps * 1e3
+        # dominant kernel = the slower of the two launches; algorithmic bytes per launch = N + C (DESIGN.md)
+        dom = "compress" if ms_c >= ms_d else "decompress"
+        alg_bytes = float(total) + float(comp_bytes)
+        dom_ms = ms_c if dom == "compress" else ms_d
+        ach = alg_bytes / (dom_ms * 1e-3) / 1e9
+        kernel = ("snappy_compress_mix_kernel" if (self.name, dom) == ("snappy", "compress") and self.nchunks > 16 * 256
+                  else f"{self.name}_{dom}_kernel")
+        out = {
+            "value": round(unc_total / GIB / (elapsed / args.steps), 3), "unit": "GiB/s", "ms_per_step": round(ms_step, 3),
+            "config": {
+                "workload": f"{self.name} level-1, {chunk // 1024} KiB independent chunks, {self.corpus_name} "
+                            f"({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
+                "codec": self.name, "chunk_bytes": chunk, "chunks_per_gpu": self.nchunks, "gib_per_gpu": args.gib,
+                "step": "compress" + (f" -> compact -> exchange of compressed segments between all ranks ({args.exchange}, "
+                                      "overlapped with) " if world > 1 else " -> ") + "decompress",
+                "parallelism": f"chunks sharded over {world} GPU(s), one wavefront per chunk",
+            },
+            "compress_GiBps": round(unc_total / GIB / (ms_c * 1e-3), 3),
+            "decompress_GiBps": round(unc_total / GIB / (ms_d * 1e-3), 3),
+            "ratio": round(unc_total / comp_total, 4),
+            "roofline": {
+                "bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(dom_ms, 4), "other_kernel": f"{self.name}_{'decompress' if dom == 'compress' else 'compress'}_kernel",
+                "other_kernel_ms": round(ms_d if dom == "compress" else ms_c, 4),
+                "other_kernel_frac": round(alg_bytes / ((ms_d if dom == "compress" else ms_c) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+            },
+        }
+        # HBM-side traffic of the dominant kernel: not measurable from inside this process; taken from the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/traffic.json), raw counter
+        # bytes per launch, only when this run has the profiled shape.
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                t = json.load(f).get(self.name)
+            if t and t["kernel"] == kernel and t["gib_per_gpu"] == args.gib and t["chunk_bytes"] == chunk:
+                out["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1000.0
+                out["roofline"]["traffic_source"] = t["source"]
+        except (OSError, ValueError, KeyError):
+            pass
+        return out
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(json.loads(args.cpu_worker))
     import numpy as np
     import torch
     import aocl_compression_amd as a
@@ -110,7 +500,7 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # AOCLGPU_BENCH_BACKEND=gloo + AOCLGPU_BENCH_ONE_GPU=1 exercise the N>1 code path on a 1-GPU box (validation only)
+        # AOCLGPU_BENCH_BACKEND=gloo + AOCLGPU_BENCH_ONE_GPU=1 run the N>1 code path on a 1-GPU box (tests/test_dist_gpu.py)
         backend = os.environ.get("AOCLGPU_BENCH_BACKEND", "nccl")
         if os.environ.get("AOCLGPU_BENCH_ONE_GPU") == "1":
             local = 0
@@ -122,158 +512,72 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     eng = a.Engine(local)
-    dev = eng.device
-    codec, def_chunk = CODECS[args.codec]
-    chunk = args.chunk or def_chunk
-    total = int(args.gib * GIB) // chunk * chunk
-    nchunks = total // chunk
-    slot = (a.compress_bound(codec, chunk) + 15) & ~15
+    names = [args.codec] if args.codec != "all" else (["lz4", "snappy", "zstd"] if world == 1 else ["lz4", "zstd"])
+    nbase = int(args.base_mib * (1 << 20))
+    corpora = {}
 
-    # ---- synthetic "Silesia concatenated to N GiB", resident in HBM; every rank gets a different rotation ----
-    if args.codec == "snappy":     # BASELINE config 3: JSON/log-style data
-        base_np = a.corpus.make("jsonlog", int(args.base_mib * (1 << 20)), seed=0xA0C3)
-        corpus_name = "synthetic JSON/log records"
-    else:                           # configs 2 / 4: Silesia-shaped mix
-        base_np = a.corpus.silesia_mix(int(args.base_mib * (1 << 20)), seed=0xA0C1)
-        corpus_name = "synthetic Silesia-shaped corpus"
-    base = torch.from_numpy(base_np).to(dev)
-    shift = (rank * 7919 * 4096) % base.numel()
-    if shift:
-        base = torch.roll(base, -shift)
-    reps = -(-total // base.numel())
-    src = base.repeat(reps)[:total].contiguous()
-    del base
-    slots = torch.empty(nchunks * slot, dtype=torch.uint8, device=dev)
-    clen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
-    dst = torch.empty(total, dtype=torch.uint8, device=dev)
-    dlen = torch.zeros(nchunks, dtype=torch.int32, device=dev)
-    cb = eng.uniform_compress_batch(src, chunk, slots, clen, slot)
-    db = eng.uniform_decompress_batch(slots, clen, slot, dst, chunk, dlen)
+    def corpus_for(name):
+        key = "jsonlog" if name == "snappy" else "mix"
+        if key not in corpora:
+            corpora[key] = (a.corpus.make("jsonlog", nbase, seed=0xA0C3), "synthetic JSON/log records") if key == "jsonlog" \
+                else (a.corpus.silesia_mix(nbase, seed=0xA0C1), "synthetic Silesia-shaped corpus")
+        return corpora[key]
 
-    gather_buf = None
-    if world > 1:
-        # compressed segment per rank, padded to a common size for ncclAllGather (RCCL has no allgatherv).
-        # Sizes are deterministic, so one untimed compress pass fixes the padded segment size.
-        eng.time_batch(codec, 0, cb, 1)
-        mx = clen.sum().to(torch.int64).reshape(1)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        seg_cap = (int(mx.item()) + (1 << 20)) & ~0xFFFFF
-        packed = torch.empty(seg_cap, dtype=torch.uint8, device=dev)
-        off = torch.zeros(nchunks + 1, dtype=torch.int64, device=dev)
-        gather_buf = torch.empty(world * seg_cap, dtype=torch.uint8, device=dev)
-        len_all = torch.zeros(world * nchunks, dtype=torch.int32, device=dev)
-
-    kt = {"c": [], "d": []}
-
-    def step(record):
-        tc = eng.time_batch(codec, 0, cb, 1)          # HIP events around the compress kernel, same stream
-        if world > 1:
-            rc = eng.lib.aoclgpu_compact_slots(slots.data_ptr(), slot, clen.data_ptr(), nchunks, packed.data_ptr(),
-                                               off.data_ptr(), eng._stream())
-            assert rc == 0
-            dist.all_gather_into_tensor(len_all, clen)
-            # the exchange of the compressed segments runs on RCCL's stream while this rank decodes its own chunks
-            work = dist.all_gather_into_tensor(gather_buf, packed, async_op=True)
-        td = eng.time_batch(codec, 1, db, 1)
-        if world > 1:
-            work.wait()
-        if record:
-            kt["c"].append(tc)
-            kt["d"].append(td)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- checks outside the timed region ----
-    comp_bytes = int(clen.sum().item())
-    if not args.no_verify:
-        assert int((clen <= 0).sum().item()) == 0, "a chunk failed to compress"
-        assert int((dlen != chunk).sum().item()) == 0, "a chunk failed to decompress"
-        assert torch.equal(dst, src), "round trip mismatch"
-
-    ms_c = sum(kt["c"]) / len(kt["c"])
-    ms_d = sum(kt["d"]) / len(kt["d"])
-    if world > 1:
-        agg = torch.tensor([ms_c, ms_d, float(comp_bytes)], dtype=torch.float64, device=dev)
-        mx = agg.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        ms_c, ms_d = float(mx[0]), float(mx[1])
-        comp_total = float(agg[2])
-    else:
-        comp_total = float(comp_bytes)
+    results = {}
+    for name in names:
+        base_np, corpus_name = corpus_for(name)
+        run = Run(eng, dist, args, name, base_np, corpus_name, rank, world)
+        elapsed = run.timed()
+        checks = {}
+        if not args.no_verify:
+            run.verify_local()
+            checks["round_trip"] = "every chunk decoded back to its source bytes"
+            if world > 1:
+                peer = run.verify_remote()
+                checks["exchange"] = (f"each rank decoded the segment it received from rank+1 and compared it with that "
+                                      f"rank's shard (rank 0 checked rank {peer})")
+                nbytes, parts = run.verify_assemble()
+                checks["rap_assemble"] = (f"one RAP stream of {parts} partitions across the rank boundary ({nbytes} bytes) assembled "
+                                          "from the gathered segments, decoded by aoclgpu_rap_unpack, equal to both ranks' bytes")
+        res = run.result(elapsed)
+        res["checks"] = checks
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu, cpu_len = cpu_baseline(name, base_np, run.total, run.chunk, run.slot, args.cpu_sample_gib, args.cpu_reps)
+                # ratio parity on the sample: GPU sizes == reference sizes, chunk by chunk
+                gl = run.clen[:len(cpu_len)].cpu().numpy()
+                cpu["sizes_identical_to_gpu"] = bool(np.array_equal(gl, cpu_len))
+                res["cpu_baseline"] = cpu
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                res["cpu_baseline"] = {"error": repr(e)}
+        results[name] = res
+        del run
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        unc_total = float(total) * world
-        ms_step = elapsed / args.steps * 1e3
-        value = unc_total / GIB / (elapsed / args.steps)
-        # dominant kernel = the slower of the two launches; algorithmic bytes per launch = N + C
-        dom = "compress" if ms_c >= ms_d else "decompress"
-        alg_bytes = float(total) + float(comp_bytes)
-        ach = alg_bytes / ((ms_c if dom == "compress" else ms_d) * 1e-3) / 1e9
+        head = results[names[0]]
         out = {
             "metric": "GiB/s compress + decompress (Silesia mix), ratio parity",
-            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {
-                "workload": f"{args.codec} level-1, {chunk // 1024} KiB independent chunks, {corpus_name} "
-                            f"({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
-                "codec": args.codec, "chunk_bytes": chunk, "chunks_per_gpu": nchunks, "gib_per_gpu": args.gib,
-                "step": "compress" + (" -> compact -> RCCL all-gather of compressed segments (overlapped with) " if world > 1 else " -> ")
-                        + "decompress",
-                "parallelism": f"chunks sharded over {world} GPU(s), one wavefront per chunk",
-            },
-            "compress_GiBps": round(unc_total / GIB / (ms_c * 1e-3), 3),
-            "decompress_GiBps": round(unc_total / GIB / (ms_d * 1e-3), 3),
-            "ratio": round(unc_total / comp_total, 4),
-            "roofline": {
-                "bound": "hbm", "kernel": "snappy_compress_mix_kernel" if (args.codec, dom) == ("snappy", "compress") and nchunks > 16 * 256
-                                          else f"{args.codec}_{dom}_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_c if dom == "compress" else ms_d, 4),
-                "other_kernel_ms": round(ms_d if dom == "compress" else ms_c, 4),
-            },
+            "value": head["value"], "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic", "config": head["config"],
+            "compress_GiBps": head["compress_GiBps"], "decompress_GiBps": head["decompress_GiBps"], "ratio": head["ratio"],
+            "roofline": head["roofline"],
         }
-        # HBM-side traffic of the dominant kernel: not measurable from inside this process; taken from the committed
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/traffic.json), raw counter
-        # bytes per launch, only when this run has the profiled shape.
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
-                t = json.load(f).get(args.codec)
-            if t and t["kernel"] == out["roofline"]["kernel"] and t["gib_per_gpu"] == args.gib and t["chunk_bytes"] == chunk:
-                out["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1000.0
-                out["roofline"]["traffic_source"] = t["source"]
-        except (OSError, ValueError, KeyError):
-            pass
-        if world == 1 and not args.no_cpu_baseline:
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        out["codecs"] = results
+        if world == 1 and not args.no_cpu_baseline and args.codec in ("all", "lz4"):
             try:
-                res = cpu_baseline(args.codec, base_np, total, chunk, slot, args.cpu_sample_gib)
-                if res:
-                    cpu, cpu_len = res
-                    # ratio parity on the sample: GPU sizes == reference sizes, chunk by chunk
-                    import numpy as np
-                    gl = clen[:len(cpu_len)].cpu().numpy()
-                    cpu["sizes_identical_to_gpu"] = bool(np.array_equal(gl, cpu_len))
-                    out["cpu_baseline"] = cpu
-            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
-                out["cpu_baseline"] = {"error": repr(e)}
+                out["config1_latency_us"] = config1_latency(eng)
+            except Exception as e:
+                out["config1_latency_us"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
+    for f in _BASE_FILES.values():
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -55,7 +55,8 @@ typedef struct {
     const uint32_t* dst_cap;
     int32_t*        out_len;
     uint32_t        nchunks;
-    uint32_t        reserved;     /* AOCLGPU_FLAG_* (bits below 0x100 are experiment switches of the test tools) */
+    uint32_t        reserved;     /* AOCLGPU_FLAG_* below.  Bits under 0x100 are ignored by the release library (a build
+                                     with -DAOCLGPU_EXPERIMENTS reads them as switches of the profiling tools in tools/) */
     uint64_t        total_bytes;  /* uniform mode */
     uint64_t        chunk_bytes;  /* uniform mode */
     uint64_t        slot_bytes;   /* uniform mode */
@@ -75,6 +76,16 @@ typedef struct {
 /* Zstd compress: level 2 instead of level 1 (clevels.h:82,108: still the "fast" strategy for chunks <= 128 KiB, with a 2^15-slot
  * table - 68 KB of LDS, 2 chunks per CU - and minMatch 5 / 4); frames byte-identical to ZSTD_compress(.., 2). */
 #define AOCLGPU_FLAG_ZSTD_LEVEL2 0x400u
+
+/* Kernel selection.  None of these changes one output byte; they pin a choice the launcher otherwise makes from the
+ * batch shape, so that tests can drive every kernel on small batches (tests/test_snappy_gpu.py, tests/test_lz4_gpu.py).
+ *   Snappy compress: hash tables of all waves in LDS (snappy_compress_kernel), all in an HBM workspace
+ *   (snappy_compress_gt_kernel), or the mixed-residency kernel (snappy_compress_mix_kernel).
+ *   LZ4 compress: the u32 table with check bits (any chunk size) instead of the packed 18-bit table for chunks <= 256 KiB. */
+#define AOCLGPU_FLAG_SNAPPY_TABLES_LDS   0x1000u
+#define AOCLGPU_FLAG_SNAPPY_TABLES_HBM   0x2000u
+#define AOCLGPU_FLAG_SNAPPY_TABLES_MIXED 0x4000u
+#define AOCLGPU_FLAG_LZ4_TABLE_U32       0x8000u
 
 /* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
  * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at
@@ -120,6 +131,17 @@ int aoclgpu_rap_pack(aoclgpu_codec codec, const aoclgpu_batch* compressed, uint8
                      uint64_t* stream_bytes, void* stream);
 int aoclgpu_rap_unpack(aoclgpu_codec codec, const uint8_t* rap_stream, uint64_t stream_bytes, uint8_t* dst,
                        uint64_t dst_cap, int64_t* decoded_bytes, void* stream);
+/* aoclgpu_rap_assemble: ONE RAP stream from chunks that were compressed elsewhere - on other GPUs - and gathered
+ * (BASELINE config 5: the stream is sharded over the ranks by contiguous chunk ranges, every rank compacts its one-shot
+ * chunk streams, the segments are exchanged).  `gathered` (device) holds chunk i's one-shot stream at chunk_off[i],
+ * chunk_len[i] bytes; chunk_src_len[i] = its uncompressed size; chunk_aux[i] = the aux[] side output of its compress launch
+ * (LZ4 only, may be NULL otherwise).  The four arrays are HOST arrays in stream order (rank 0's chunks, rank 1's, ...).
+ * Nothing but the compressed chunks is needed: what LZ4 carries across a partition boundary (lz4.c:2823-2901) are the last
+ * chunk_aux[i] bytes of chunk i's stream.  Same output as aoclgpu_rap_pack over one device's batch of the same chunks; at
+ * most 65535 chunks and 2 GiB of source per stream (16-bit / 32-bit RAP fields): longer streams are assembled slab by slab. */
+int aoclgpu_rap_assemble(aoclgpu_codec codec, const uint8_t* gathered, const uint64_t* chunk_off, const int32_t* chunk_len,
+                         const uint32_t* chunk_src_len, const uint32_t* chunk_aux, uint32_t nchunks,
+                         uint8_t* stream_out, uint64_t stream_cap, uint64_t* stream_bytes, void* stream);
 /* bytes of RAP framing aoclgpu_rap_pack adds for nchunks partitions (0 for one chunk) */
 uint64_t aoclgpu_rap_frame_bytes(aoclgpu_codec codec, uint32_t nchunks);
 /* Host-buffer forms (H2D, chunked compress + pack / unpack + chunked decompress, D2H): what the reference's
@@ -145,6 +167,20 @@ double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, i
  * out_host[0] = number of sequences, out_host[1] = total literal bytes, then {litLength, offBase, matchLength} per sequence
  * (offBase as in zstd: 1 = repcode, offset + 3 otherwise).  Synchronous; flags: 0. */
 int aoclgpu_zstd_block_sequences(const void* src_dev, uint32_t n, uint32_t* out_host, uint32_t max_sequences, uint32_t flags);
+
+/* Zstd, inputs of any size on host buffers: the input is cut into 128 KiB pieces, each becomes an independent frame
+ * (one launch for all of them), the frames are concatenated.  flags: AOCLGPU_FLAG_ZSTD_LEVEL2.  Returns the stream size,
+ * 0 when it does not fit `cap`, or <= AOCLGPU_HOST_FAIL/2 on a GPU failure.
+ * aoclgpu_zstd_decompress_host_frames: any Zstandard stream; a stream of several frames that all carry their content
+ * size is split on the host (frame and block headers only) and its frames are decoded in parallel, one wavefront each,
+ * otherwise one wavefront walks the stream.  Returns the decoded size, -1 malformed, -2 dst too small. */
+int64_t aoclgpu_zstd_compress_host_frames(const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
+int64_t aoclgpu_zstd_decompress_host_frames(const void* host_src, size_t n, void* host_dst, size_t cap);
+
+/* Which GPU the host-buffer entry points (this header's *_host* functions, aocl_llc_*, the native names) use: default 0,
+ * or the environment variable AOCLGPU_DEVICE read at first use. */
+int aoclgpu_set_host_device(int device);
+int aoclgpu_host_device(void);
 
 int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);

@@ -6,8 +6,9 @@
  * download).  Bulk work should use the device-resident batch API of aocl_gpu_codec.h.  There is no CPU fallback:
  * without a gfx950 device compression returns the codec's failure value.
  *
- * Scope is the north-star path only: LZ4 acceleration 1, Zstd level 1 with srcSize <= 128 KiB (one block);
- * anything else fails loudly with the codec's error convention instead of silently doing something different.
+ * Scope is the north-star path only: LZ4 (any acceleration), Snappy, Zstd levels 1-2 ("fast" strategy); anything else
+ * fails loudly with the codec's error convention instead of silently doing something different (INTEGRATION.md lists
+ * every deviation from the reference).
  */
 #ifndef AOCL_NATIVE_API_H
 #define AOCL_NATIVE_API_H
@@ -76,20 +77,52 @@ typedef enum { SNAPPY_OK = 0, SNAPPY_INVALID_INPUT = 1, SNAPPY_BUFFER_TOO_SMALL 
 snappy_status snappy_compress(const char* input, size_t input_length, char* compressed, size_t* compressed_length);
 snappy_status snappy_uncompress(const char* compressed, size_t compressed_length, char* uncompressed, size_t* uncompressed_length);
 size_t        snappy_max_compressed_length(size_t source_length);
+char*         aocl_setup_snappy(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog);   /* NULL (snappy.h:476) */
+void          aocl_destroy_snappy(void);
 snappy_status snappy_uncompressed_length(const char* compressed, size_t compressed_length, size_t* result);
 snappy_status snappy_validate_compressed_buffer(const char* compressed, size_t compressed_length);
 
-/* ---- Zstd 1.5.5 (algos/zstd/lib/zstd.h:184,201,261,291,353,423,441,455) ---- */
+/* ---- Zstd 1.5.5 (algos/zstd/lib/zstd.h:184,201,261,291,353,423-452,487-489,542,581,606-615,657-764,2416-2435,3115-3166).
+ *      GPU backend: the "fast" strategy with the parameters of levels 1 and 2, frames with content size and no checksum.
+ *      srcSize <= 128 KiB -> one block per frame, the reference's bytes; larger inputs -> concatenated independent
+ *      128 KiB frames (valid Zstandard, not the reference's bytes).  Every other request returns
+ *      ZSTD_error_parameter_unsupported (see INTEGRATION.md for the full deviation list). ---- */
+typedef enum { ZSTD_fast = 1, ZSTD_dfast = 2, ZSTD_greedy = 3, ZSTD_lazy = 4, ZSTD_lazy2 = 5, ZSTD_btlazy2 = 6, ZSTD_btopt = 7,
+               ZSTD_btultra = 8, ZSTD_btultra2 = 9 } ZSTD_strategy;
+typedef struct { unsigned windowLog, chainLog, hashLog, searchLog, minMatch, targetLength; ZSTD_strategy strategy; } ZSTD_compressionParameters;
+typedef struct { int contentSizeFlag, checksumFlag, noDictIDFlag; } ZSTD_frameParameters;
+typedef struct { ZSTD_compressionParameters cParams; ZSTD_frameParameters fParams; } ZSTD_parameters;
+typedef enum { ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103, ZSTD_c_searchLog = 104,
+               ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107, ZSTD_c_contentSizeFlag = 200,
+               ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202 } ZSTD_cParameter;
+typedef struct ZSTD_CCtx_s ZSTD_CCtx;
+typedef struct ZSTD_DCtx_s ZSTD_DCtx;
 unsigned    ZSTD_versionNumber(void);                      /* 10505 */
 const char* ZSTD_versionString(void);                      /* "1.5.5" */
+int         ZSTD_minCLevel(void);
+int         ZSTD_maxCLevel(void);
+int         ZSTD_defaultCLevel(void);
 size_t      ZSTD_compressBound(size_t srcSize);
 unsigned    ZSTD_isError(size_t code);
 const char* ZSTD_getErrorName(size_t code);
 size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
 size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
 unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
-char*       aocl_setup_zstd_encode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
+ZSTD_CCtx*  ZSTD_createCCtx(void);
+size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);
+size_t      ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+ZSTD_DCtx*  ZSTD_createDCtx(void);
+size_t      ZSTD_freeDCtx(ZSTD_DCtx* dctx);
+size_t      ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+size_t      ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, ZSTD_cParameter param, int value);   /* level and frame flags; others unsupported */
+ZSTD_compressionParameters ZSTD_getCParams(int compressionLevel, unsigned long long estimatedSrcSize, size_t dictSize);
+ZSTD_parameters ZSTD_getParams(int compressionLevel, unsigned long long estimatedSrcSize, size_t dictSize);  /* all 22 levels, both tables */
+size_t      ZSTD_compress_advanced(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                   const void* dict, size_t dictSize, ZSTD_parameters params);
+char*       aocl_setup_zstd_encode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL; optOff picks the upstream level table */
 char*       aocl_setup_zstd_decode(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
+void        aocl_destroy_zstd_encode(void);
+void        aocl_destroy_zstd_decode(void);
 
 /* ---- Block-level external sequence producer for libzstd (algos/zstd/lib/zstd.h:4065-4098): has the ZSTD_sequenceProducer_F
  *      signature (outSeqs is a ZSTD_Sequence*); a user of upstream / reference libzstd registers it with

@@ -10,6 +10,8 @@
  */
 #include "oracle.h"
 #include <omp.h>
+#include <stdlib.h>
+#include <string.h>
 
 typedef int (*lz4_fn)(const char*, char*, int, int);
 typedef int (*snappy_fn)(const char*, size_t, char*, size_t*);
@@ -74,3 +76,56 @@ int orc_compress_chunks(int codec, const uint8_t* src, size_t n, size_t chunk, u
 int orc_decompress_chunks(int codec, const uint8_t* src, size_t slot, const uint32_t* in_len, size_t nchunks,
                           uint8_t* dst, size_t chunk, size_t n, int threads)
 { return orc_decompress_chunks_fn(codec, NULL, src, slot, (const int32_t*)in_len, nchunks, dst, chunk, n, threads); }
+
+/* cpu_baseline timing (bench.py): the timing convention of the reference's own bench (test/codec_bench.c:833-921:
+ * `iterations` passes, best and average of the per-pass time; api/api.cpp:58-75: wall clock around the codec call),
+ * applied to the chunk decomposition above.
+ *   - a private copy of the sample and both output buffers are FIRST-TOUCHED by the thread that will work on them
+ *     (schedule(static,1) everywhere, so chunk i always belongs to thread i % threads): no page faults and no
+ *     remote-NUMA traffic inside the timed passes;
+ *   - one untimed warm-up pass (code, tables, branch predictors, thread pool), then `reps` timed passes of the whole
+ *     compress loop and of the whole decompress loop; tc[r] / td[r] = seconds of pass r.
+ * Returns failures (compress <= 0, decode size mismatch, or round-trip bytes differ); out_len[] = sizes of the chunks. */
+int orc_bench_chunks(int codec, void* fc, void* fd, const uint8_t* sample, size_t n, size_t chunk, size_t slot,
+                     int32_t* out_len, int threads, int reps, double* tc, double* td)
+{
+    const long nchunks = n ? (long)((n + chunk - 1) / chunk) : 1;
+    if (threads < 1) threads = 1;
+    uint8_t* src = (uint8_t*)malloc(n ? n : 1);
+    uint8_t* dst = (uint8_t*)malloc((size_t)nchunks * slot);
+    uint8_t* back = (uint8_t*)malloc(n ? n : 1);
+    if (!src || !dst || !back) { free(src); free(dst); free(back); return -1; }
+    int fails = 0;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (long i = 0; i < nchunks; i++) {                  /* first touch */
+        const size_t o = (size_t)i * chunk, len = (n - o < chunk) ? n - o : chunk;
+        memcpy(src + o, sample + o, len);
+        memset(dst + (size_t)i * slot, 0, slot);
+        memset(back + o, 0, len);
+    }
+    for (int r = -1; r < reps; r++) {                     /* r == -1: warm-up */
+        int f = 0;
+        double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(+:f)
+        for (long i = 0; i < nchunks; i++) {
+            const size_t o = (size_t)i * chunk, len = (n - o < chunk) ? n - o : chunk;
+            const int64_t c = comp_one(codec, fc, src + o, len, dst + (size_t)i * slot, slot);
+            out_len[i] = (int32_t)c;
+            if (c <= 0) f++;
+        }
+        double t1 = omp_get_wtime();
+#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(+:f)
+        for (long i = 0; i < nchunks; i++) {
+            const size_t o = (size_t)i * chunk, len = (n - o < chunk) ? n - o : chunk;
+            if (out_len[i] <= 0) continue;
+            const int64_t d = decomp_one(codec, fd, dst + (size_t)i * slot, (size_t)out_len[i], back + o, len);
+            if (d != (int64_t)len) f++;
+        }
+        double t2 = omp_get_wtime();
+        if (r >= 0) { tc[r] = t1 - t0; td[r] = t2 - t1; }
+        fails += f;
+    }
+    if (memcmp(back, src, n) != 0) fails++;
+    free(src); free(dst); free(back);
+    return fails;
+}

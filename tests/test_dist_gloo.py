@@ -1,6 +1,8 @@
-"""world_size-2 gloo test of the N>1 path: chunk ranges tile the stream in rank order, and the ordered gather
-of per-rank compacted segments + sizes reproduces the single-process stream (here with the CPU oracle standing
-in for the kernels -- the collective logic is what is under test)."""
+"""world_size-2 gloo tests of the N>1 path on CPU: chunk ranges tile the stream in rank order; the exact-size exchange of
+per-rank compacted segments (aocl_compression_amd.sharding.exchange_segments - the function bench.py runs over RCCL) puts
+every rank's segment at its place in every rank's gathered buffer; and the padded all-gather variant reproduces the
+single-process stream.  The CPU oracle stands in for the kernels here - the collective logic is what is under test;
+tests/test_dist_gpu.py drives the same path with the real kernels on the GPU box."""
 import os
 import socket
 
@@ -22,6 +24,12 @@ def test_chunk_ranges_tile():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
 
 
+def test_segment_layout():
+    offs, total = sharding.segment_layout([5, 16, 0, 33])
+    assert offs == [0, 16, 32, 32] and total == 80
+    assert sharding.segment_layout([]) == ([], 0)
+
+
 def _worker(rank, world, port, q):
     import oracle_lib as ol
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -34,15 +42,30 @@ def _worker(rank, world, port, q):
     parts = [orc.compress(ol.LZ4, data[i * chunk:(i + 1) * chunk]) for i in range(lo, hi)]
     packed = torch.from_numpy(np.frombuffer(b"".join(parts), np.uint8).copy())
     lens = torch.tensor([len(p) for p in parts], dtype=torch.int32)
+    # (1) padded all-gather
     segs, all_lens = sharding.gather_compressed(dist, packed, lens, seg_cap=nchunks * (chunk + 1024))
     stream = b"".join(bytes(s.numpy()) for s in segs)
     sizes = [int(x) for l in all_lens for x in l]
+    # (2) exact-size exchange into the prefix-sum layout
+    mine = torch.tensor([packed.numel()], dtype=torch.int64)
+    allsz = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allsz, mine)
+    seg = [int(x) for x in allsz]
+    seg_off, total = sharding.segment_layout(seg)
+    gbuf = torch.full((total,), 0xEE, dtype=torch.uint8)
+    gbuf[seg_off[rank]:seg_off[rank] + seg[rank]] = packed
+    for w in sharding.exchange_segments(dist, rank, world, gbuf, seg, seg_off):
+        w.wait()
+    stream2 = b"".join(bytes(gbuf[o:o + s].numpy()) for o, s in zip(seg_off, seg))
+    gbuf3 = torch.full((total,), 0xEE, dtype=torch.uint8)
+    gbuf3[seg_off[rank]:seg_off[rank] + seg[rank]] = packed
+    sharding.exchange_segments(dist, rank, world, gbuf3, seg, seg_off, host_staged=True)
     # decode the gathered stream in order and compare with the original
     out, pos = [], 0
     for i, sz in enumerate(sizes):
         out.append(orc.decompress(ol.LZ4, stream[pos:pos + sz], min(chunk, len(data) - i * chunk)))
         pos += sz
-    q.put((rank, b"".join(out) == data and len(sizes) == nchunks))
+    q.put((rank, b"".join(out) == data and len(sizes) == nchunks and stream2 == stream and torch.equal(gbuf3, gbuf)))
     dist.barrier()
     dist.destroy_process_group()
 

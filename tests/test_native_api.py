@@ -71,7 +71,7 @@ def test_versions_bounds_and_error_conventions(lib):
     assert lib.ZSTD_isError((1 << 64) - 1) and lib.ZSTD_isError((1 << 64) - 70) and not lib.ZSTD_isError((1 << 64) - 121)
     assert lib.ZSTD_getErrorName((1 << 64) - 70) == b"Destination buffer is too small"
     out = C.create_string_buffer(64)
-    assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, b"abc", 3, 3))       # only level 1 has a GPU backend
+    assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, b"abc", 3, 3))       # level 3 = double-fast: no GPU backend
     assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, None, 3, 1))
     assert lib.LZ4_compress_default(None, out, 5, 64) == 0                   # lz4.c AOCL NULL checks
     assert lib.LZ4_compress_fast(b"abc", out, 3, 64, 7) == 0                 # only acceleration 1
@@ -156,4 +156,7 @@ def test_native_round_trips_match_the_oracle(lib, oracle, eng):
             assert lib.ZSTD_isError(lib.ZSTD_decompress(back, size - 1, out, r))
     big = bytes(200000)
     out = C.create_string_buffer(300000)
-    assert lib.ZSTD_isError(lib.ZSTD_compress(out, 300000, big, len(big), 1))     # > 128 KiB: no multi-block compressor yet
+    r = lib.ZSTD_compress(out, 300000, big, len(big), 1)                          # > 128 KiB: concatenated 128 KiB frames
+    assert not lib.ZSTD_isError(r)
+    back = C.create_string_buffer(len(big))
+    assert lib.ZSTD_decompress(back, len(big), out, r) == len(big) and back.raw == big

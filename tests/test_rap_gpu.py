@@ -127,3 +127,75 @@ def test_gpu_pack_equals_the_join_model(eng, oracle, ref, ref_mt, codec, kind, c
     assert ref.decompress(oc, stream[ref_mt.skip(stream):], total) == data
     dst, r = eng.rap_decompress(gc, stream_t, total)
     assert r == total and torch.equal(dst[:total], src)
+
+
+def _rank_segments(eng, gc, src, chunk, ranks):
+    """what BASELINE config 5 leaves on every rank after the exchange: each 'rank' compresses its contiguous chunk range
+    into its own slots, compacts them, and the compacted segments are laid out one after the other (16-byte aligned
+    starts) in one buffer; returns (gathered tensor, chunk_off, chunk_len, chunk_src_len, chunk_aux)"""
+    from aocl_compression_amd import sharding
+    n = int(src.numel())
+    nchunks = max(1, -(-n // chunk))
+    segs, offs, lens, slens, auxs, base = [], [], [], [], [], 0
+    for r in range(ranks):
+        lo, hi = sharding.chunk_range(nchunks, r, ranks)
+        if lo == hi:
+            continue
+        part = src[lo * chunk:min(n, hi * chunk)]
+        slot = (a.compress_bound(gc, chunk) + 15) & ~15
+        k = hi - lo
+        slots = torch.empty(k * slot, dtype=torch.uint8, device=eng.device)
+        out_len = torch.zeros(k, dtype=torch.int32, device=eng.device)
+        aux = torch.zeros(k, dtype=torch.int32, device=eng.device)
+        b = eng.uniform_compress_batch(part, chunk, slots, out_len, slot)
+        b.aux = aux.data_ptr()
+        eng._check(eng._fn(gc, "compress")(C.byref(b), eng._stream()), "compress")
+        packed, off = eng.compact(slots, slot, out_len)
+        segs.append(packed)
+        o = off.cpu().numpy()[:k].astype(np.uint64) + base
+        offs.append(o)
+        lens.append(out_len.cpu().numpy())
+        slens.append(np.array([min(chunk, part.numel() - i * chunk) for i in range(k)], np.uint32))
+        auxs.append(aux.cpu().numpy().astype(np.uint32))
+        base += (int(packed.numel()) + 15) & ~15
+        if packed.numel() % 16:
+            segs.append(torch.zeros(16 - packed.numel() % 16, dtype=torch.uint8, device=eng.device))
+    return torch.cat(segs), np.concatenate(offs), np.concatenate(lens), np.concatenate(slens), np.concatenate(auxs)
+
+
+@pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
+@pytest.mark.parametrize("kind,chunk,total,ranks", [("text", 65536, 1000003, 2), ("jsonlog", 131072, 131072 * 9, 3),
+                                                     ("random", 4096, 70000, 4), ("binary", 262144, 262144 * 5 + 77, 2)])
+def test_assembled_stream_equals_the_packed_one(eng, ref, ref_mt, codec, kind, chunk, total, ranks):
+    """aoclgpu_rap_assemble over chunks compressed 'elsewhere' (separate launches, separate slot buffers, only the compacted
+    streams + sizes + aux travel) gives the bytes aoclgpu_rap_pack gives on one device, the reference decodes them (single-
+    threaded after the frame skip, and with its MT decoder), and so does the GPU"""
+    gc, oc = CODECS[codec]
+    if codec == "zstd" and chunk > 131072:
+        pytest.skip("zstd chunks are <= 128 KiB")
+    data = a.corpus.make(kind, total, seed=17).tobytes()
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+    want = bytes(eng.rap_compress(gc, src, chunk).cpu().numpy())
+    gathered, off, ln, sl, ax = _rank_segments(eng, gc, src, chunk, ranks)
+    got = bytes(eng.rap_assemble(gc, gathered, off, ln, sl, ax if codec == "lz4" else None).cpu().numpy())
+    assert got == want
+    skip = ref_mt.skip(got)
+    if codec != "zstd":
+        assert ref.decompress(oc, got[skip:], len(data)) == data
+    assert ref_mt.decompress(oc, got, len(data)) == data
+    dst, r = eng.rap_decompress(gc, torch.frombuffer(bytearray(got), dtype=torch.uint8).to(eng.device), len(data))
+    assert r == len(data) and bytes(dst[:r].cpu().numpy()) == data
+
+
+def test_assemble_all_literal_partitions_carry_across_ranks(eng, ref, ref_mt):
+    """LZ4: partitions that are all literals travel on to the next partition's first token (lz4.c:2808-2823); with the chunks
+    of several 'ranks' the carried run is stitched from the tails of several compressed chunks"""
+    rng = np.random.default_rng(5)
+    chunk = 13                                  # below LZ4_minLength: every chunk is one literal run
+    data = bytes(rng.integers(0, 256, chunk * 7, dtype=np.uint8)) + (b"abcdabcdabcdabcdabcdabcd" * 40)
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+    want = bytes(eng.rap_compress(a.LZ4, src, chunk).cpu().numpy())
+    gathered, off, ln, sl, ax = _rank_segments(eng, a.LZ4, src, chunk, 3)
+    got = bytes(eng.rap_assemble(a.LZ4, gathered, off, ln, sl, ax).cpu().numpy())
+    assert got == want
+    assert ref.decompress(ol.LZ4, got[ref_mt.skip(got):], len(data)) == data

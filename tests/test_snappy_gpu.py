@@ -17,14 +17,14 @@ def _chunks(raw, chunk):
 
 
 @pytest.fixture(params=["auto", "hbm-tables", "mixed"], autouse=True)
-def table_placement(request, monkeypatch):
+def table_placement(request, eng):
     """every test runs three times: with the launcher's own choice (LDS tables for these small batches), with the global-table
-    kernel forced (experiment switch 128) and with the mixed kernel forced (32), which otherwise only large batches reach"""
-    if request.param == "hbm-tables":
-        monkeypatch.setenv("AOCLGPU_EXPERIMENT", "128")
-    if request.param == "mixed":                     # four-wave workgroups: one LDS-table wave + three HBM-table waves
-        monkeypatch.setenv("AOCLGPU_EXPERIMENT", "32")
-    return request.param
+    kernel pinned (AOCLGPU_FLAG_SNAPPY_TABLES_HBM) and with the mixed kernel pinned (.._MIXED), which otherwise only large
+    batches reach"""
+    eng.force_flags = {"auto": 0, "hbm-tables": a.api.FLAG_SNAPPY_TABLES_HBM,
+                       "mixed": a.api.FLAG_SNAPPY_TABLES_MIXED}[request.param]   # mixed: one LDS-table wave + three HBM-table waves
+    yield request.param
+    eng.force_flags = 0
 
 
 def test_known_answers(eng):
@@ -136,7 +136,7 @@ def test_full_size_round_trip(eng):
     assert torch.equal(dst, src)
 
 
-def test_large_batch_all_kernels_agree(eng, monkeypatch, table_placement):
+def test_large_batch_all_kernels_agree(eng, table_placement):
     """a batch big enough for the persistent kernels (8 192 fragments): LDS-table, HBM-table and mixed kernels give the same
     bytes, run after run (chunks are handed out dynamically, the result must not depend on who took which)"""
     if table_placement != "auto":
@@ -144,9 +144,10 @@ def test_large_batch_all_kernels_agree(eng, monkeypatch, table_placement):
     base = torch.from_numpy(a.corpus.make("jsonlog", 64 << 20, seed=3)).to(eng.device)
     src = base.repeat(8)
     outs = {}
-    for name, flag in (("lds", "64"), ("hbm", "128"), ("mixed", "32"), ("mixed again", "32"), ("auto", "0")):
-        monkeypatch.setenv("AOCLGPU_EXPERIMENT", flag)
-        slots, out_len, slot = eng.compress_chunks(a.SNAPPY, src, 65536)
+    F = a.api
+    for name, flag in (("lds", F.FLAG_SNAPPY_TABLES_LDS), ("hbm", F.FLAG_SNAPPY_TABLES_HBM), ("mixed", F.FLAG_SNAPPY_TABLES_MIXED),
+                       ("mixed again", F.FLAG_SNAPPY_TABLES_MIXED), ("auto", 0)):
+        slots, out_len, slot = eng.compress_chunks(a.SNAPPY, src, 65536, flags=flag)
         used = (torch.arange(slots.numel(), device=slots.device) % slot) < out_len.to(torch.int64).repeat_interleave(slot)
         outs[name] = (out_len.clone(), torch.where(used, slots, torch.zeros_like(slots)))
     ref_len, ref_bytes = outs["lds"]

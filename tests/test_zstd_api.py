@@ -1,0 +1,205 @@
+"""The Zstd context family of the reference (zstd.h:261-291,542,581) on the GPU library.
+CPU part: ZSTD_getParams / ZSTD_getCParams equal the reference's for every level, size class and both level tables
+(pure host arithmetic, checked against oracle/_ref).  GPU part: the call sequence of the reference's own wrapper
+(api/codec.cpp:354-436: createCCtx, getParams, CCtx_setParameter, compress_advanced, decompressDCtx) run against this
+library gives the reference's bytes for the "fast" levels, multi-frame streams for inputs above 128 KiB that the
+reference decodes, and ZSTD_error_parameter_unsupported for everything without a GPU backend."""
+import ctypes as C
+
+import pytest
+
+import aocl_compression_amd as a
+from aocl_compression_amd import api
+import oracle_lib as ol
+
+
+class CParams(C.Structure):
+    _fields_ = [(n, C.c_uint) for n in ("windowLog", "chainLog", "hashLog", "searchLog", "minMatch", "targetLength")] + [("strategy", C.c_int)]
+
+    def tup(self):
+        return tuple(getattr(self, f[0]) for f in self._fields_)
+
+
+class FParams(C.Structure):
+    _fields_ = [("contentSizeFlag", C.c_int), ("checksumFlag", C.c_int), ("noDictIDFlag", C.c_int)]
+
+
+class Params(C.Structure):
+    _fields_ = [("cParams", CParams), ("fParams", FParams)]
+
+
+def _bind(L):
+    L.ZSTD_getParams.restype = Params
+    L.ZSTD_getParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    L.ZSTD_getCParams.restype = CParams
+    L.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    L.ZSTD_createCCtx.restype = C.c_void_p
+    L.ZSTD_createDCtx.restype = C.c_void_p
+    L.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+    L.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for n in ("ZSTD_compress_advanced", "ZSTD_compressCCtx", "ZSTD_decompressDCtx", "ZSTD_compress", "ZSTD_decompress", "ZSTD_compressBound"):
+        getattr(L, n).restype = C.c_size_t
+    L.ZSTD_compress_advanced.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, Params]
+    L.ZSTD_compressCCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    L.ZSTD_decompressDCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ZSTD_compressBound.argtypes = [C.c_size_t]
+    L.ZSTD_isError.argtypes = [C.c_size_t]
+    L.ZSTD_getErrorName.restype = C.c_char_p
+    L.ZSTD_getErrorName.argtypes = [C.c_size_t]
+    L.aocl_setup_zstd_encode.restype = C.c_void_p
+    L.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.aocl_destroy_zstd_encode.restype = None
+    return L
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _bind(api.load_library())
+
+
+@pytest.fixture(scope="module")
+def reflib():
+    if not ol.have_ref():
+        pytest.skip("reference build (oracle/_ref) not available")
+    return _bind(C.CDLL(ol.REF_SO))
+
+
+SIZES = [0, 1, 63, 64, 100, 513, 4096, 16384, 16385, 65536, 131072, 131073, 262144, 262145, 1 << 20, 100 << 20, (1 << 30) + 1, 1 << 33]
+
+
+@pytest.mark.parametrize("opt_off", [1, 0])
+def test_get_params_equal_the_reference(lib, reflib, opt_off):
+    """all levels -7..23 x the size classes, upstream table (optOff = 1) and the AOCL table (optOff = 0, what the reference's
+    dispatcher selects once it has run, zstd_compress.c:7390-7425)"""
+    for L in (lib, reflib):
+        L.aocl_destroy_zstd_encode()
+        L.aocl_setup_zstd_encode(opt_off, 3, 0, 1, 0)
+    try:
+        for level in list(range(-7, 24)) + [-131072, -200000, 100]:
+            for n in SIZES:
+                got, want = lib.ZSTD_getParams(level, n, 0), reflib.ZSTD_getParams(level, n, 0)
+                assert got.cParams.tup() == want.cParams.tup(), (level, n, got.cParams.tup(), want.cParams.tup())
+                assert (got.fParams.contentSizeFlag, got.fParams.checksumFlag, got.fParams.noDictIDFlag) == (1, 0, 0)
+                assert lib.ZSTD_getCParams(level, n, 0).tup() == reflib.ZSTD_getCParams(level, n, 0).tup()
+            for n, d in ((0, 1000), (5000, 100000), (1 << 20, 1 << 16)):
+                assert lib.ZSTD_getCParams(level, n, d).tup() == reflib.ZSTD_getCParams(level, n, d).tup(), (level, n, d)
+    finally:
+        for L in (lib, reflib):
+            L.aocl_destroy_zstd_encode()
+    assert lib.ZSTD_minCLevel() == reflib.ZSTD_minCLevel() and lib.ZSTD_maxCLevel() == reflib.ZSTD_maxCLevel()
+    assert lib.ZSTD_defaultCLevel() == reflib.ZSTD_defaultCLevel()
+
+
+def test_context_calls_check_their_arguments(lib):
+    c = lib.ZSTD_createCCtx(); d = lib.ZSTD_createDCtx()
+    assert c and d
+    out = C.create_string_buffer(64)
+    p = lib.ZSTD_getParams(1, 5, 0)
+    assert lib.ZSTD_isError(lib.ZSTD_compress_advanced(None, out, 64, b"hello", 5, None, 0, p))       # cctx == NULL (zstd_compress.c:5396)
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, None, 64, b"hello", 5, None, 0, p)) == b"Operation on NULL destination buffer"
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, b"dict", 4, p)) == b"Unsupported parameter"
+    p9 = lib.ZSTD_getParams(9, 5, 0)                                     # lazy2: no GPU backend
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, p9)) == b"Unsupported parameter"
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compressCCtx(c, out, 64, b"hello", 5, 3)) == b"Unsupported parameter"   # double-fast
+    bad = lib.ZSTD_getParams(1, 5, 0); bad.cParams.windowLog = 40
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, bad)) == b"Parameter is out of bound"
+    ck = lib.ZSTD_getParams(1, 5, 0); ck.fParams.checksumFlag = 1
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, ck)) == b"Unsupported parameter"
+    assert lib.ZSTD_CCtx_setParameter(c, 100, 1) == 0 and lib.ZSTD_CCtx_setParameter(c, 201, 0) == 0
+    assert lib.ZSTD_isError(lib.ZSTD_CCtx_setParameter(c, 160, 1))      # ZSTD_c_enableLongDistanceMatching
+    assert lib.ZSTD_isError(lib.ZSTD_decompressDCtx(None, out, 64, b"x", 1))
+    assert lib.ZSTD_freeCCtx(c) == 0 and lib.ZSTD_freeDCtx(d) == 0 and lib.ZSTD_freeCCtx(None) == 0
+
+
+def _wrapper_compress(L, data: bytes, level: int, window_log: int = 0):
+    """aocl_zstd_compress of the reference (api/codec.cpp:388-422), statement for statement, on library L"""
+    cctx = L.ZSTD_createCCtx()
+    try:
+        zp = L.ZSTD_getParams(level, len(data), 0)
+        L.ZSTD_CCtx_setParameter(cctx, 100, level)
+        zp.fParams.contentSizeFlag = 1
+        if window_log and zp.cParams.windowLog > window_log:
+            zp.cParams.windowLog = window_log
+            zp.cParams.chainLog = window_log + (1 if zp.cParams.strategy in (6, 7, 8) else 0)
+        cap = L.ZSTD_compressBound(len(data))
+        out = C.create_string_buffer(max(cap, 1))
+        r = L.ZSTD_compress_advanced(cctx, out, cap, data, len(data), None, 0, zp)
+        return None if L.ZSTD_isError(r) else out.raw[:r]
+    finally:
+        L.ZSTD_freeCCtx(cctx)
+
+
+def _wrapper_decompress(L, blob: bytes, cap: int):
+    dctx = L.ZSTD_createDCtx()
+    try:
+        out = C.create_string_buffer(max(cap, 1))
+        r = L.ZSTD_decompressDCtx(dctx, out, cap, blob, len(blob))
+        return None if L.ZSTD_isError(r) else out.raw[:r]
+    finally:
+        L.ZSTD_freeDCtx(dctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text", "binary", "jsonlog"])
+def test_reference_wrapper_sequence_on_the_gpu_library(eng, lib, reflib, kind):
+    for n in (0, 1, 100, 5000, 16384, 16385, 65536, 100000, 131072):
+        data = a.corpus.make(kind, n, seed=21).tobytes() if n else b""
+        for level in (1, 2):
+            got, want = _wrapper_compress(lib, data, level), _wrapper_compress(reflib, data, level)
+            assert got is not None and got == want, (kind, n, level)
+            assert _wrapper_decompress(lib, want, n) == data
+        assert _wrapper_compress(lib, data, 3) is None and _wrapper_compress(lib, data, 0) is None      # double-fast: no backend yet
+    # a window clamp below the input size cannot be honoured by single-segment frames: refused, not ignored
+    data = a.corpus.make(kind, 65536, seed=22).tobytes()
+    assert _wrapper_compress(lib, data, 1, window_log=12) is None
+    assert _wrapper_compress(lib, data, 1, window_log=16) == _wrapper_compress(reflib, data, 1, window_log=16)
+
+
+@pytest.mark.gpu
+def test_inputs_above_128k_become_concatenated_frames(eng, lib, reflib):
+    """a valid stream the reference decodes (zstd_decompress.c:1113 reads frame after frame); not the reference's bytes -
+    INTEGRATION.md lists this deviation"""
+    for n in (131073, 300000, (1 << 20) + 17, 3 << 20):
+        data = a.corpus.make("text", n, seed=23).tobytes()
+        for level in (1, 2):
+            blob = _wrapper_compress(lib, data, level)
+            if level == 2 and n <= 262144:                                   # level 2 is double-fast for 128 KiB < n <= 256 KiB (clevels.h:55)
+                assert blob is None
+                continue
+            assert blob is not None and blob[:4] == b"\x28\xb5\x2f\xfd"
+            assert _wrapper_decompress(reflib, blob, n) == data            # the reference reads it
+            assert _wrapper_decompress(lib, blob, n) == data               # frames decoded in parallel on the GPU
+            # every 128 KiB piece is the reference's own frame for that piece
+            first = _wrapper_compress(reflib, data[:131072], level)
+            assert blob.startswith(first)
+        out = C.create_string_buffer(16)
+        r = lib.ZSTD_compress(out, 16, data, n, 1)
+        assert lib.ZSTD_getErrorName(r) == b"Destination buffer is too small"
+    # multi-block frames of the reference (one frame, window across blocks) decode on the GPU as before
+    data = a.corpus.make("text", 1 << 20, seed=24).tobytes()
+    ref_blob = _wrapper_compress(reflib, data, 1)
+    assert _wrapper_decompress(lib, ref_blob, len(data)) == data
+    small = C.create_string_buffer(1000)
+    assert lib.ZSTD_isError(lib.ZSTD_decompress(small, 1000, ref_blob, len(ref_blob)))
+
+
+@pytest.mark.gpu
+def test_unified_api_zstd_follows_the_wrapper(eng, lib, reflib):
+    """aocl_llc_compress(ZSTD): level and optVar (window clamp) go through the same sequence (csrc/aocl_api.cpp)"""
+    data = a.corpus.make("text", 100000, seed=25).tobytes()
+    for level, ok in ((1, True), (2, True), (0, False), (3, False), (9, False)):
+        r, blob, _ = eng.llc_compress(a.ZSTD, data, 200000, level=level)
+        if ok:
+            assert r > 0 and blob == _wrapper_compress(reflib, data, level)
+        else:
+            assert r == -2                                                   # ERR_COMPRESSION_FAILED
+    big = a.corpus.make("text", 500000, seed=26).tobytes()
+    r, blob, _ = eng.llc_compress(a.ZSTD, big, 600000, level=1)
+    assert r > 0
+    r2, back, _ = eng.llc_decompress(a.ZSTD, blob, len(big))
+    assert r2 == len(big) and back == big
+    assert _wrapper_decompress(reflib, blob, len(big)) == big
