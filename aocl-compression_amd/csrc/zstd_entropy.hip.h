@@ -1,9 +1,19 @@
-// csrc/zstd_entropy.hip.h -- Zstandard entropy-stage building blocks for the gfx950 kernels.
+// csrc/zstd_entropy.hip.h -- Zstandard entropy-stage building blocks for the gfx950 kernels: table construction
+// and bit packing on a 64-lane wavefront.
 //
-// Serial table construction (a few hundred symbols; runs on lane 0 with its scratch in LDS) and the
-// wave-parallel bit packers.  Each function restates the reference routine named next to it
-// (/root/reference algos/zstd/lib/compress/{huf_compress.c,fse_compress.c,zstd_compress_sequences.c}); the
-// table contents, header bytes and bitstreams are byte-identical to the reference's.
+// The tables the reference builds with serial loops over symbols (/root/reference algos/zstd/lib/compress/
+// fse_compress.c, huf_compress.c) are built here in the shape the wave offers: ONE SYMBOL PER LANE for the FSE
+// alphabets (<= 53 symbols) and four per lane for the byte alphabet, so that
+//   * sums / maxima over the alphabet are wave reductions, "first symbol with ..." is ballot + ctz;
+//   * everything the reference accumulates while it walks the alphabet (remaining probability, cumulative state
+//     counts, bit positions of a header) is a prefix sum over lanes;
+//   * "the k-th state of symbol s" / "the k-th symbol with this code length" are ranks taken from lane masks;
+//   * the sort of the byte alphabet is a rank sort (every symbol counts the keys in front of it).
+// What stays serial is what is serial by definition: the two-queue Huffman merge (scalar, operands in lane registers),
+// the length-limit repair loop, and the quicksort of a count bucket whose order for EQUAL counts is defined by the
+// reference's partition scheme (one bucket per lane, all buckets at once).  Results - normalised counts, table
+// descriptions, state tables, code lengths and code values - are bit-identical to the reference's; the cited lines
+// say which rule each piece implements.
 #pragma once
 #include "common.hip.h"
 
@@ -48,29 +58,79 @@ __device__ __forceinline__ u32 ml_code(u32 v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// serial little bit writer (lane 0 only): headers, FSE-compressed Huffman weights
+// wave primitives
 // ------------------------------------------------------------------------------------------------
-struct BitW {
-    u8* p; u64 acc; int nb; u32 pos;
-    __device__ void init(u8* dst) { p = dst; acc = 0; nb = 0; pos = 0; }
-    __device__ void add(u64 v, int n)
-    {
-        if (n == 0) return;
-        v &= (1ull << n) - 1;
-        acc |= v << nb; nb += n;
-        while (nb >= 8) { p[pos++] = (u8)acc; acc >>= 8; nb -= 8; }
+__device__ __forceinline__ u32 wsum(u32 v) { for (int d = 32; d; d >>= 1) v += (u32)__shfl_xor((int)v, d); return v; }
+__device__ __forceinline__ u32 wmaxu(u32 v) { for (int d = 32; d; d >>= 1) { const u32 t = (u32)__shfl_xor((int)v, d); v = v > t ? v : t; } return v; }
+__device__ __forceinline__ u32 wscan(u32 v, int lane)      // inclusive prefix sum over lanes
+{
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)v, d); if (lane >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ u64 wscan64(u64 v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 lo = (u32)__shfl_up((int)(u32)v, d), hi = (u32)__shfl_up((int)(u32)(v >> 32), d);
+        if (lane >= d) v += ((u64)hi << 32) | lo;
     }
-    __device__ u32 close() { add(1, 1); if (nb > 0) { p[pos++] = (u8)acc; acc = 0; nb = 0; } return pos; }
-};
+    return v;
+}
+__device__ __forceinline__ u32 wmaxscan(u32 v, int lane)   // inclusive prefix maximum over lanes
+{
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)v, d); if (lane >= d && t > v) v = t; }
+    return v;
+}
+// number of set bits of `m` in lanes below this one
+__device__ __forceinline__ u32 below(u64 m) { return (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ int top_lane(u64 m) { return 63 - (int)__builtin_clzll(m | 1); }
+// lanes that hold the same 6-bit value as this lane (among lanes with `on`)
+__device__ __forceinline__ u64 same_value6(u32 v, bool on)
+{
+    u64 m = ballot(on);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) { const u64 k = ballot((v >> b) & 1); m &= ((v >> b) & 1) ? k : ~k; }
+    return m;
+}
+
+// Bits of one lane each, concatenated in lane order into `out` (global memory), little-endian bit order; returns the
+// number of bytes (the last one zero-padded).  tile: LDS scratch of at least (total bits / 32 + 3) words.
+__device__ u32 wave_emit_bits(u8* out, u64 v, u32 nb, u32* tile, u32 tileWords, int lane)
+{
+    const u32 incl = wscan(nb, lane), total = lane_get(incl, 63);
+    const u32 words = (total + 31) / 32 + 2;
+    for (u32 i = (u32)lane; i < words && i < tileWords; i += kWave) tile[i] = 0;
+    wave_fence();
+    if (nb) {
+        if (nb < 64) v &= (1ull << nb) - 1;
+        const u32 bit = incl - nb, w = bit >> 5, sh = bit & 31;
+        const u64 a = v << sh;
+        const u32 a2 = sh ? (u32)(v >> (64 - sh)) : 0;
+        if ((u32)a) atomicOr(&tile[w], (u32)a);
+        if ((u32)(a >> 32)) atomicOr(&tile[w + 1], (u32)(a >> 32));
+        if (a2) atomicOr(&tile[w + 2], a2);
+    }
+    wave_fence();
+    const u32 nbytes = (total + 7) >> 3;
+    const u8* tb = reinterpret_cast<const u8*>(tile);
+    for (u32 i = (u32)lane; i < nbytes; i += kWave) out[i] = tb[i];
+    wave_fence();
+    return nbytes;
+}
 
 // ------------------------------------------------------------------------------------------------
-// FSE (fse_compress.c)
+// FSE tables, one symbol per lane (fse_compress.c)
 // ------------------------------------------------------------------------------------------------
 struct FseCT {            // FSE_CTable as plain arrays (tableLog <= 9 on this path)
     int tableLog;
     u16 stateTable[512];
     int deltaNbBits[56];
     int deltaFindState[56];
+};
+struct FseScratch {       // LDS scratch of the table builders
+    u8 cell[512];         // state -> symbol
+    u8 occ[512];          // spread: k-th occurrence -> symbol
+    u16 next[64];         // next free state-table slot per symbol
+    u32 bits[40];         // header bits
 };
 
 __device__ __forceinline__ u32 fse_min_log(u32 srcSize, u32 maxSym)
@@ -89,153 +149,197 @@ __device__ __forceinline__ u32 fse_optimal_log(u32 maxLog, u32 srcSize, u32 maxS
     return t;
 }
 
-// FSE_normalizeM2 (fse_compress.c:376-461): 0 ok, -1 error
-__device__ int fse_normalize_m2(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSym, s16 lowProb)
+// Secondary normalisation, used when the correction of the primary one would eat more than half of the largest
+// probability (FSE_normalizeM2, fse_compress.c:376-461).  0 ok, -1 error.
+__device__ int fse_renormalize_wave(int& norm, const u32 c, u32 total, const u32 maxSym, const u32 tableLog, const int lowProb, int lane)
 {
-    const s16 NYA = -2;
-    u32 s, distributed = 0, toDist;
+    const bool valid = (u32)lane <= maxSym, live = valid && c != 0;
     const u32 lowThreshold = total >> tableLog;
     u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
-    for (s = 0; s <= maxSym; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProb; distributed++; total -= count[s]; continue; }
-        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
-        norm[s] = NYA;
+    bool open = false;                                       // probability still to be assigned
+    {
+        const bool isLow = live && c <= lowThreshold, isOne = live && !isLow && c <= lowOne;
+        norm = !live ? 0 : (isLow ? lowProb : (isOne ? 1 : 0));
+        open = live && !isLow && !isOne;
     }
-    toDist = (1u << tableLog) - distributed;
+    u32 distributed = wsum((live && !open) ? 1u : 0u);
+    total -= wsum((live && !open) ? c : 0u);
+    u32 toDist = (1u << tableLog) - distributed;
     if (toDist == 0) return 0;
-    if ((total / toDist) > lowOne) {
+    if (total / toDist > lowOne) {                           // a second round with a higher bar for "1"
         lowOne = (u32)(((u64)total * 3) / (toDist * 2));
-        for (s = 0; s <= maxSym; s++)
-            if (norm[s] == NYA && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        const bool now = open && c <= lowOne;
+        if (now) { norm = 1; open = false; }
+        distributed += wsum(now ? 1u : 0u);
+        total -= wsum(now ? c : 0u);
         toDist = (1u << tableLog) - distributed;
     }
-    if (distributed == maxSym + 1) {
-        u32 maxV = 0, maxC = 0;
-        for (s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
-        norm[maxV] += (s16)toDist;
+    if (distributed == maxSym + 1) {                         // everything is small: the most frequent symbol takes the rest
+        const u32 cmax = wmaxu(valid ? c : 0u);
+        const int who = first_lane(ballot(valid && c == cmax && cmax > 0));
+        if (lane == (who < 64 ? who : 0)) norm += (int)toDist;
         return 0;
     }
-    if (total == 0) {
-        for (s = 0; toDist > 0; s = (s + 1) % (maxSym + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+    if (total == 0) {                                        // only 1s and lows are left to grow: round robin over the positive ones
+        const u64 pos = ballot(norm > 0);
+        const u32 p = (u32)__builtin_popcountll(pos);
+        if (p == 0) return -1;
+        if ((pos >> lane) & 1) norm += (int)(toDist / p + (below(pos) < toDist % p ? 1u : 0u));
         return 0;
     }
-    {   const u64 vStepLog = 62 - tableLog, mid = (1ull << (vStepLog - 1)) - 1;
-        const u64 rStep = ((((u64)1 << vStepLog) * toDist) + mid) / total;
-        u64 tmpTotal = mid;
-        for (s = 0; s <= maxSym; s++) if (norm[s] == NYA) {
-            const u64 end = tmpTotal + ((u64)count[s] * rStep);
-            const u32 w = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
-            if (w < 1) return -1;
-            norm[s] = (s16)w; tmpTotal = end;
-        }
+    {   // the open symbols share toDist in proportion to their counts: positions on a 2^vStepLog grid, prefix sum over lanes
+        const u32 vStepLog = 62 - tableLog;
+        const u64 mid = (1ull << (vStepLog - 1)) - 1;
+        const u64 rStep = (((1ull << vStepLog) * toDist) + mid) / total;
+        const u64 mine = open ? (u64)c * rStep : 0;
+        const u64 end = mid + wscan64(mine, lane), start = end - mine;
+        const u32 w = (u32)(end >> vStepLog) - (u32)(start >> vStepLog);
+        if (ballot(open && w < 1)) return -1;
+        if (open) norm = (int)w;
     }
     return 0;
 }
 
-// FSE_normalizeCount (fse_compress.c:464-526): tableLog on success, 0 = rle special case, -1 error
-__device__ int fse_normalize(s16* norm, u32 tableLog, const u32* count, u32 total, u32 maxSym, int useLowProb)
+// Normalised counts for a table of 2^tableLog states (FSE_normalizeCount, fse_compress.c:464-526).  c = this lane's
+// count (0 beyond maxSym).  Returns tableLog, 0 for a single-symbol distribution, -1 on error; norm = this lane's result.
+__device__ int fse_normalize_wave(int& norm, const u32 c, const u32 total, const u32 maxSym, const u32 tableLog, const bool useLowProb, int lane)
 {
-    const u32 rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
-    if (tableLog < 5 || tableLog > 12) return -1;
-    if (tableLog < fse_min_log(total, maxSym)) return -1;
-    const s16 lowProb = useLowProb ? -1 : 1;
-    const u64 scale = 62 - tableLog, step = ((u64)1 << 62) / total, vStep = 1ull << (scale - 20);
-    int still = 1 << tableLog;
-    u32 s, largest = 0; s16 largestP = 0;
+    norm = 0;
+    if (tableLog < 5 || tableLog > 12 || tableLog < fse_min_log(total, maxSym)) return -1;
+    const bool valid = (u32)lane <= maxSym;
+    if (ballot(valid && c == total)) return 0;
+    const int lowProb = useLowProb ? -1 : 1;
+    const u32 scale = 62 - tableLog;
+    const u64 step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
     const u32 lowThreshold = total >> tableLog;
-    for (s = 0; s <= maxSym; s++) {
-        if (count[s] == total) return 0;
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProb; still--; }
-        else {
-            s16 proba = (s16)(((u64)count[s] * step) >> scale);
-            if (proba < 8) {
-                const u64 rest = vStep * rtb[proba];
-                proba += ((u64)count[s] * step) - ((u64)proba << scale) > rest;
-            }
-            if (proba > largestP) { largestP = proba; largest = s; }
-            norm[s] = proba; still -= proba;
+    const bool live = valid && c != 0, isLow = live && c <= lowThreshold, big = live && !isLow;
+    u32 proba = 0;
+    if (big) {
+        const u64 x = (u64)c * step;
+        proba = (u32)(x >> scale);
+        if (proba < 8) {                                     // rounding thresholds of the small probabilities (rtbTable :467)
+            const u32 rtb = proba == 0 ? 0u : (proba == 1 ? 473195u : (proba == 2 ? 504333u : (proba == 3 ? 520860u :
+                            (proba == 4 ? 550000u : (proba == 5 ? 700000u : (proba == 6 ? 750000u : 830000u))))));
+            proba += (x - ((u64)proba << scale)) > vStep * rtb ? 1u : 0u;
         }
     }
-    if (-still >= (norm[largest] >> 1)) {
-        if (fse_normalize_m2(norm, tableLog, count, total, maxSym, lowProb)) return -1;
-    } else norm[largest] += (s16)still;
+    norm = isLow ? lowProb : (int)proba;
+    const int still = (1 << tableLog) - (int)wsum(isLow ? 1u : proba);
+    const u32 pmax = wmaxu(proba);
+    const int fl = first_lane(ballot(big && proba == pmax));   // the first symbol with the largest probability
+    const int largest = fl < 64 ? fl : 0;
+    const int nl = (int)lane_get((u32)norm, largest);
+    if (-still >= (nl >> 1)) return fse_renormalize_wave(norm, c, total, maxSym, tableLog, lowProb, lane) ? -1 : (int)tableLog;
+    if (lane == largest) norm += still;
     return (int)tableLog;
 }
 
-// FSE_writeNCount (fse_compress.c:236-329): bytes written, 0 on error
-__device__ u32 fse_write_ncount(u8* out, const s16* norm, u32 maxSym, u32 tableLog)
+// Table description (FSE_writeNCount, fse_compress.c:236-329): 4 bits of tableLog, then per symbol a value whose width
+// follows the probability still unassigned, zero runs as repeat codes.  What the reference tracks while walking the
+// alphabet - `remaining`, the width - is a prefix sum over lanes here, every lane forms its own bits (<= 53), and the bit
+// positions are another prefix sum.  Returns bytes written to out (global), 0 on error.
+__device__ u32 fse_write_ncount_wave(u8* out, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
 {
-    u8* const ostart = out;
     const int tableSize = 1 << tableLog;
-    int nbBits = (int)tableLog + 1, remaining = tableSize + 1, threshold = tableSize, bitCount = 0, previousIs0 = 0;
-    u32 bitStream = 0, symbol = 0;
-    const u32 alphabetSize = maxSym + 1;
-    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
-    while (symbol < alphabetSize && remaining > 1) {
-        if (previousIs0) {
-            u32 start = symbol;
-            while (symbol < alphabetSize && !norm[symbol]) symbol++;
-            if (symbol == alphabetSize) break;
-            while (symbol >= start + 24) {
-                start += 24; bitStream += 0xFFFFu << bitCount;
-                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16;
-            }
-            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
-            bitStream += (symbol - start) << bitCount; bitCount += 2;
-            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    const bool valid = (u32)lane <= maxSym;
+    const u32 a = valid ? (u32)(norm < 0 ? -norm : norm) : 0u;
+    const u32 incl = wscan(a, lane);
+    const int remBefore = tableSize + 1 - (int)(incl - a), remAfter = remBefore - (int)a;
+    const u64 nz = ballot(valid && norm != 0);
+    const bool prevZero = lane > 0 && !((nz >> (lane - 1)) & 1);
+    // a symbol gets its own value unless it continues a run of zeros (the run's first zero does); nothing follows once
+    // the whole probability is assigned
+    const bool emit = valid && remBefore > 1 && (norm != 0 || !prevZero);
+    if (ballot(emit && remAfter < 1)) return 0;
+    const u64 em = ballot(emit);
+    if (!em || (int)lane_get((u32)remAfter, top_lane(em)) != 1) return 0;
+    const int thr = remBefore >= tableSize ? tableSize : (1 << hb((u32)remBefore));
+    const u32 width = (u32)hb((u32)thr) + 1;
+    const int mx = (2 * thr - 1) - remBefore;
+    int cnt = norm + 1;
+    if (cnt >= thr) cnt += mx;
+    u64 v = 0; u32 nb = 0;
+    if (emit) {
+        if (lane == 0) { v = tableLog - 5; nb = 4; }
+        if (norm != 0 && prevZero) {                         // zeros since the run's first one: 24 at a time, 3 at a time, rest
+            const u64 before = nz & ((1ull << lane) - 1);
+            const int prevNz = before ? top_lane(before) : -1;
+            const u32 r = (u32)(lane - 1 - prevNz) - 1u;
+            const u32 rem = r % 24, ones = 16 * (r / 24) + 2 * (rem / 3);
+            v |= (((1ull << ones) - 1) | ((u64)(rem % 3) << ones)) << nb;
+            nb += ones + 2;
         }
-        {   int count = norm[symbol++];
-            const int max = (2 * threshold - 1) - remaining;
-            remaining -= count < 0 ? -count : count;
-            count++;
-            if (count >= threshold) count += max;
-            bitStream += (u32)count << bitCount;
-            bitCount += nbBits; bitCount -= (count < max);
-            previousIs0 = (count == 1);
-            if (remaining < 1) return 0;
-            while (remaining < threshold) { nbBits--; threshold >>= 1; }
-        }
-        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        v |= (u64)(u32)cnt << nb;
+        nb += width - (cnt < mx ? 1u : 0u);
     }
-    if (remaining != 1) return 0;
-    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
-    out += (bitCount + 7) / 8;
-    return (u32)(out - ostart);
+    return wave_emit_bits(out, v, nb, sc->bits, 40, lane);
 }
 
-// FSE_buildCTable_wksp (fse_compress.c:68-214).  `scratch` holds tableSize bytes + (maxSym+2) u16.
-__device__ void fse_build_ctable(FseCT* ct, const s16* norm, u32 maxSym, u32 tableLog, u8* tableSymbol, u16* cumul)
+// Encoding table (FSE_buildCTable_wksp, fse_compress.c:68-214).  The reference spreads the symbols over the states by
+// stepping through the table; occurrence k of the spread lands on the k-th visited state that is not reserved for a
+// low-probability symbol, so the lanes take the visit numbers 64 at a time: reserved states are skipped by a ballot
+// count, the symbol of occurrence k comes from a prefix maximum over "first occurrence" marks.  A symbol's states are
+// then numbered in increasing state order: rank among the lanes holding the same symbol + the symbol's running base.
+__device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
 {
     const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    u32 high = tableSize - 1, u, s, pos = 0;
-    ct->tableLog = (int)tableLog;
-    cumul[0] = 0;
-    for (u = 1; u <= maxSym + 1; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[high--] = (u8)(u - 1); }
-        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
-    }
-    cumul[maxSym + 1] = (u16)(tableSize + 1);
-    for (s = 0; s <= maxSym; s++) {
-        for (int i = 0; i < norm[s]; i++) {
-            tableSymbol[pos] = (u8)s;
-            pos = (pos + step) & mask;
-            while (pos > high) pos = (pos + step) & mask;
+    const bool valid = (u32)lane <= maxSym;
+    const u32 w = !valid ? 0u : (norm == -1 ? 1u : (norm > 0 ? (u32)norm : 0u));       // states the symbol owns
+    const u32 cum = wscan(w, lane) - w;                                               // first of them in the state table
+    const u64 lowm = ballot(valid && norm == -1);
+    const u32 high = tableSize - 1 - (u32)__builtin_popcountll(lowm);
+    if (lane == 0) ct->tableLog = (int)tableLog;
+    if (valid) {
+        sc->next[lane] = (u16)cum;
+        if (norm == 0) { ct->deltaNbBits[lane] = (int)(((tableLog + 1) << 16) - tableSize); ct->deltaFindState[lane] = 0; }
+        else if (w == 1) { ct->deltaNbBits[lane] = (int)((tableLog << 16) - tableSize); ct->deltaFindState[lane] = (int)cum - 1; }
+        else {
+            const u32 maxBitsOut = tableLog - (u32)hb(w - 1), minStatePlus = w << maxBitsOut;
+            ct->deltaNbBits[lane] = (int)((maxBitsOut << 16) - minStatePlus);
+            ct->deltaFindState[lane] = (int)cum - (int)w;
         }
     }
-    for (u = 0; u < tableSize; u++) { const u8 sym = tableSymbol[u]; ct->stateTable[cumul[sym]++] = (u16)(tableSize + u); }
-    u32 total = 0;
-    for (s = 0; s <= maxSym; s++) {
-        if (norm[s] == 0) { ct->deltaNbBits[s] = (int)(((tableLog + 1) << 16) - (1u << tableLog)); ct->deltaFindState[s] = 0; }
-        else if (norm[s] == -1 || norm[s] == 1) {
-            ct->deltaNbBits[s] = (int)((tableLog << 16) - (1u << tableLog));
-            ct->deltaFindState[s] = (int)(total - 1); total++;
-        } else {
-            const u32 maxBitsOut = tableLog - (u32)hb((u32)norm[s] - 1), minStatePlus = (u32)norm[s] << maxBitsOut;
-            ct->deltaNbBits[s] = (int)((maxBitsOut << 16) - minStatePlus);
-            ct->deltaFindState[s] = (int)(total - (u32)norm[s]); total += (u32)norm[s];
+    // low-probability symbols own the top states, in symbol order from the top down
+    if ((lowm >> lane) & 1) sc->cell[tableSize - 1 - below(lowm)] = (u8)lane;
+    // occurrence -> symbol: mark every spread symbol's first occurrence, prefix maximum (symbols ascend with k)
+    const u32 sp = (valid && norm > 0) ? (u32)norm : 0u;
+    const u32 scum = wscan(sp, lane) - sp;
+    for (u32 i = (u32)lane; i < tableSize; i += kWave) sc->occ[i] = 0;
+    wave_fence();
+    if (sp) sc->occ[scum] = (u8)(lane + 1);
+    wave_fence();
+    u32 carry = 0;
+    for (u32 k0 = 0; k0 < tableSize; k0 += kWave) {
+        const u32 k = k0 + (u32)lane;
+        u32 m = k < tableSize ? (u32)sc->occ[k] : 0u;
+        m = wmaxscan(m, lane);
+        m = m > carry ? m : carry;
+        if (k < tableSize) sc->occ[k] = (u8)m;
+        carry = lane_get(m, 63);
+    }
+    wave_fence();
+    // visit j of the walk is state (j * step) & mask; visits of reserved states do not consume an occurrence
+    u32 skipped = 0;
+    for (u32 j0 = 0; j0 < tableSize; j0 += kWave) {
+        const u32 j = j0 + (u32)lane, p = (j * step) & mask;
+        const bool in = j < tableSize, skip = in && p > high;
+        const u64 sk = ballot(skip);
+        if (in && !skip) sc->cell[p] = (u8)(sc->occ[j - skipped - below(sk)] - 1);
+        skipped += (u32)__builtin_popcountll(sk);
+    }
+    wave_fence();
+    // state table: the states of a symbol in increasing order (tableU16[cumul[s]++] = tableSize + u, :118-121)
+    for (u32 u0 = 0; u0 < tableSize; u0 += kWave) {
+        const u32 u = u0 + (u32)lane;
+        const bool in = u < tableSize;
+        const u32 sym = in ? (u32)sc->cell[u] : 0u;
+        const u64 same = same_value6(sym, in);
+        if (in) {
+            const u32 base = sc->next[sym];
+            ct->stateTable[base + below(same)] = (u16)(tableSize + u);
+            if (lane == top_lane(same)) sc->next[sym] = (u16)(base + (u32)__builtin_popcountll(same));
         }
+        wave_fence();
     }
 }
 __device__ __forceinline__ void fse_build_rle(FseCT* ct, u32 sym)
@@ -251,211 +355,344 @@ __device__ __forceinline__ u32 fse_init_state(const FseCT* ct, u32 sym)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Huffman (huf_compress.c)
+// Huffman code of the literals (huf_compress.c), byte alphabet: symbol 64*t + lane lives in lane `lane`, slot t
 // ------------------------------------------------------------------------------------------------
-struct HNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 struct HufCT { u8 nbBits[256]; u16 val[256]; u32 tableLog; };
+struct HufScratch {
+    u32 key[256];         // sort keys, then the sorted leaves: count << 8 | symbol
+    u32 tmp[256];
+    u8  len[256];         // code length per sorted leaf
+    u8  weight[256];
+    u32 cnt13[16];
+    FseCT wct;            // FSE table of the weights
+    FseScratch fs;
+    u32 wbits[2][128];    // weight chain output: value << 8 | bits
+    short todo[11][64];   // per-bucket work lists of the tie-order sort
+};
 
-constexpr u32 kHufCutoff = 165;      // RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158)
-__device__ __forceinline__ u32 huf_rank_index(u32 c) { return c < kHufCutoff ? c : (u32)hb(c) + 158; }
+constexpr u32 kHufCutoff = 165;      // RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) (huf_compress.c:552)
+// bucket of the reference's sort (huf_compress.c:560-570): one per count below the cutoff, one per power of two above
+__device__ __forceinline__ u32 huf_bucket(u32 c) { return c < kHufCutoff ? c : (u32)hb(c) + 158; }
 
-__device__ void huf_insertion_sort(HNode* a, int low, int high)
+// The reference orders equal counts inside a power-of-two bucket by what its quicksort happens to do (partition around
+// the last element; a range handed on as a whole is insertion-sorted when it has at most 8 elements, the rest of a
+// partitioned range keeps being partitioned - huf_compress.c:572-622).  That order is part of the visible result (equal
+// counts can get different code lengths), so such a bucket is sorted by the same scheme: a[lo..hi] are keys
+// (count << 8 | symbol) in symbol order, compared by count only.  Runs on one lane per bucket, all buckets at once;
+// `todo` is that lane's list of ranges still to do (ranges are disjoint, so their order is free).
+__device__ void huf_bucket_sort(u32* a, int lo0, int hi0, short* todo /* 64 */)
 {
-    const int size = high - low + 1; a += low;
-    for (int i = 1; i < size; i++) {
-        const HNode key = a[i]; int j = i - 1;
-        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
-        a[j + 1] = key;
-    }
-}
-__device__ int huf_partition(HNode* a, int low, int high)
-{
-    const u32 pivot = a[high].count; int i = low - 1;
-    for (int j = low; j < high; j++) if (a[j].count > pivot) { i++; const HNode t = a[i]; a[i] = a[j]; a[j] = t; }
-    { const HNode t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
-    return i + 1;
-}
-// HUF_simpleQuickSort (huf_compress.c:603-622) with an explicit stack: every recursive call of the reference is
-// one stack frame here; frames cover disjoint ranges, so the processing order does not change the result.
-__device__ void huf_quicksort(HNode* a, int low0, int high0, short* stack /* >= 128 shorts */)
-{
+    auto insertion = [&](int lo, int hi) {                   // stable, descending by count
+        for (int i = lo + 1; i <= hi; i++) {
+            const u32 key = a[i]; int j = i - 1;
+            while (j >= lo && (a[j] >> 8) < (key >> 8)) { a[j + 1] = a[j]; j--; }
+            a[j + 1] = key;
+        }
+    };
     int sp = 0;
-    stack[sp++] = (short)low0; stack[sp++] = (short)high0;
+    todo[sp++] = (short)lo0; todo[sp++] = (short)hi0;
     while (sp > 0) {
-        int high = stack[--sp], low = stack[--sp];
-        if (high - low < 8) { huf_insertion_sort(a, low, high); continue; }
-        while (low < high) {
-            const int idx = huf_partition(a, low, high);
-            int cl, ch;                                  // the side the reference recurses into
-            if (idx - low < high - idx) { cl = low; ch = idx - 1; low = idx + 1; }
-            else { cl = idx + 1; ch = high; high = idx - 1; }
-            if (ch - cl < 8) { if (ch > cl) huf_insertion_sort(a, cl, ch); }     // small call: sort it now, no frame
-            else { stack[sp++] = (short)cl; stack[sp++] = (short)ch; }           // <= n/8 pending frames
+        int hi = todo[--sp], lo = todo[--sp];
+        if (hi - lo < 8) { insertion(lo, hi); continue; }
+        while (lo < hi) {
+            const u32 pivot = a[hi] >> 8; int i = lo - 1;    // counts above the pivot's to the front
+            for (int j = lo; j < hi; j++) if ((a[j] >> 8) > pivot) { i++; const u32 t = a[i]; a[i] = a[j]; a[j] = t; }
+            { const u32 t = a[i + 1]; a[i + 1] = a[hi]; a[hi] = t; }
+            const int mid = i + 1;
+            int cl, ch;                                      // the smaller side is handed on, the other one stays in this loop
+            if (mid - lo < hi - mid) { cl = lo; ch = mid - 1; lo = mid + 1; }
+            else { cl = mid + 1; ch = hi; hi = mid - 1; }
+            if (ch - cl < 8) { if (ch > cl) insertion(cl, ch); }
+            else if (sp < 62) { todo[sp++] = (short)cl; todo[sp++] = (short)ch; }
         }
     }
 }
-struct RankPos { u16 base, curr; };
-// HUF_sort (huf_compress.c:624-668)
-__device__ void huf_sort(HNode* node, const u32* count, u32 maxSym, RankPos* rp /* 192 */, short* stack)
+
+// Code lengths and code values of the literals (HUF_buildCTable_wksp, huf_compress.c:758-794, with HUF_sort :624-668,
+// HUF_buildTree :685-725, HUF_setMaxHeight :378-495).  hist = counts of symbols 0..maxSym (LDS).  Returns the table log.
+__device__ u32 huf_build_wave(HufCT* ct, const u32* hist, const u32 maxSym, const u32 maxNbBits, HufScratch* sc, int lane)
 {
-    u32 n; const u32 n1 = maxSym + 1;
-    for (n = 0; n < 192; n++) { rp[n].base = 0; rp[n].curr = 0; }
-    for (n = 0; n < n1; n++) rp[huf_rank_index(count[n])].base++;
-    for (n = 191; n > 0; n--) { rp[n - 1].base += rp[n].base; rp[n - 1].curr = rp[n - 1].base; }
-    for (n = 0; n < n1; n++) {
-        const u32 c = count[n], r = huf_rank_index(c) + 1, pos = rp[r].curr++;
-        node[pos].count = c; node[pos].byte = (u8)n;
+    // ---- 1. sort: count descending; equal counts in symbol order (the reference's bucket fill order), except inside a
+    //         power-of-two bucket of more than 8 symbols, where the quicksort's own order for ties applies ----
+    u32 c[4], key[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const u32 s = 64u * t + (u32)lane;
+        c[t] = s <= maxSym ? hist[s] : 0u;
+        key[t] = (c[t] << 8) | (255u - s);                   // larger key = earlier in the order
+        sc->key[s] = key[t];
     }
-    for (n = kHufCutoff; n < 191; n++) {
-        const int size = rp[n].curr - rp[n].base;
-        if (size > 1) huf_quicksort(node + rp[n].base, 0, size - 1, stack);
+    wave_fence();
+    u32 rank[4] = {0, 0, 0, 0};
+    const u32 n1 = maxSym + 1;
+    for (u32 j = 0; j < n1; ++j) {                           // rank sort: every symbol counts the keys in front of it
+        const u32 kj = sc->key[j];                           // (one LDS broadcast per key)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rank[t] += kj > key[t] ? 1u : 0u;
     }
-}
-// HUF_buildTree (huf_compress.c:685-725); node[-1] must be addressable
-__device__ int huf_build_tree(HNode* node, u32 maxSym)
-{
-    const int START = 256;
-    int nonNull = (int)maxSym, lowS, lowN, nodeNb = START, n, root;
-    while (node[nonNull].count == 0) nonNull--;
-    lowS = nonNull; root = nodeNb + lowS - 1; lowN = nodeNb;
-    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
-    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
-    nodeNb++; lowS -= 2;
-    for (n = nodeNb; n <= root; n++) node[n].count = 1u << 30;
-    node[-1].count = 1u << 31;
-    while (nodeNb <= root) {
-        const int n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        const int n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        node[nodeNb].count = node[n1].count + node[n2].count;
-        node[n1].parent = node[n2].parent = (u16)nodeNb;
-        nodeNb++;
-    }
-    node[root].nbBits = 0;
-    for (n = root - 1; n >= START; n--) node[n].nbBits = (u8)(node[node[n].parent].nbBits + 1);
-    for (n = 0; n <= nonNull; n++) node[n].nbBits = (u8)(node[node[n].parent].nbBits + 1);
-    return nonNull;
-}
-// HUF_setMaxHeight (huf_compress.c:378-495)
-__device__ u32 huf_set_max_height(HNode* node, u32 lastNonNull, u32 target)
-{
-    const u32 largest = node[lastNonNull].nbBits;
-    if (largest <= target) return largest;
-    int totalCost = 0, n = (int)lastNonNull;
-    const u32 baseCost = 1u << (largest - target);
-    while (node[n].nbBits > target) {
-        totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits)));
-        node[n].nbBits = (u8)target; n--;
-    }
-    while (node[n].nbBits == target) --n;
-    totalCost >>= (largest - target);
-    const u32 noSym = 0xF0F0F0F0u;
-    u32 rankLast[14]; u32 cur = target;
-    for (int p = 0; p < 14; p++) rankLast[p] = noSym;
-    for (int pos = n; pos >= 0; pos--) {
-        if (node[pos].nbBits >= cur) continue;
-        cur = node[pos].nbBits; rankLast[target - cur] = (u32)pos;
-    }
-    while (totalCost > 0) {
-        u32 dec = (u32)hb((u32)totalCost) + 1;
-        for (; dec > 1; dec--) {
-            const u32 highPos = rankLast[dec], lowPos = rankLast[dec - 1];
-            if (highPos == noSym) continue;
-            if (lowPos == noSym) break;
-            if (node[highPos].count <= 2 * node[lowPos].count) break;
+    wave_fence();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const u32 s = 64u * t + (u32)lane; if (s <= maxSym) sc->tmp[rank[t]] = (c[t] << 8) | s; }
+    wave_fence();
+    const u32 nonNull = wsum((c[0] ? 1u : 0u) + (c[1] ? 1u : 0u) + (c[2] ? 1u : 0u) + (c[3] ? 1u : 0u));   // leaves 0..nonNull-1
+    {   // power-of-two buckets: lane b owns bucket hb = 7 + b (counts 165.. fall into hb >= 7); sorted[] is count-descending,
+        // so a bucket is one contiguous range
+        const u32 hbv = 7u + (u32)lane;
+        int lo = -1, hi = -2;
+        if (lane < 11) {
+            const u32 cmin = hbv == 7 ? kHufCutoff : (1u << hbv), cmax = (2u << hbv) - 1;
+            // entries with count in [cmin, cmax]: binary search on the descending array
+            int a = 0, b = (int)nonNull;                     // first index with count <= cmax
+            while (a < b) { const int m = (a + b) >> 1; if ((sc->tmp[m] >> 8) > cmax) a = m + 1; else b = m; }
+            lo = a; b = (int)nonNull;                        // first index with count < cmin
+            while (a < b) { const int m = (a + b) >> 1; if ((sc->tmp[m] >> 8) >= cmin) a = m + 1; else b = m; }
+            hi = a - 1;
+            bool ties = false;
+            if (hi - lo >= 8) for (int i = lo; i < hi; ++i) ties |= (sc->tmp[i] >> 8) == (sc->tmp[i + 1] >> 8);
+            if (ties) {
+                // back to the bucket's fill order (symbol ascending), then the reference's scheme
+                for (int i = lo + 1; i <= hi; i++) {
+                    const u32 k = sc->tmp[i]; int j = i - 1;
+                    while (j >= lo && (sc->tmp[j] & 0xFF) > (k & 0xFF)) { sc->tmp[j + 1] = sc->tmp[j]; j--; }
+                    sc->tmp[j + 1] = k;
+                }
+                huf_bucket_sort(sc->tmp, lo, hi, sc->todo[lane]);
+            }
         }
-        while (dec <= 12 && rankLast[dec] == noSym) dec++;
-        totalCost -= 1 << (dec - 1);
-        node[rankLast[dec]].nbBits++;
-        if (rankLast[dec - 1] == noSym) rankLast[dec - 1] = rankLast[dec];
-        if (rankLast[dec] == 0) rankLast[dec] = noSym;
-        else { rankLast[dec]--; if (node[rankLast[dec]].nbBits != target - dec) rankLast[dec] = noSym; }
     }
-    while (totalCost < 0) {
-        if (rankLast[1] == noSym) {
-            while (node[n].nbBits == target) n--;
-            node[n + 1].nbBits--; rankLast[1] = (u32)(n + 1); totalCost++;
-            continue;
+    wave_fence();
+    // sorted leaves, four per lane: leaf i = 64*t + lane
+    u32 leafCnt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; leafCnt[t] = i < nonNull ? sc->tmp[i] >> 8 : 0u; }
+
+    // ---- 2. tree: two-queue merge.  Serial by definition; runs as scalar code with the queues in lane registers
+    //         (leaf i in lane i & 63 of leafCnt[i >> 6], internal node k likewise in intCnt) ----
+    u32 intCnt[4] = {0, 0, 0, 0}, leafPar[4] = {0, 0, 0, 0}, intPar[4] = {0, 0, 0, 0};
+    auto rd = [&](const u32 (&r)[4], int i) -> u32 {
+        const int t = i >> 6, l = i & 63;
+        return t == 0 ? lane_get(r[0], l) : (t == 1 ? lane_get(r[1], l) : (t == 2 ? lane_get(r[2], l) : lane_get(r[3], l)));
+    };
+    auto wr = [&](u32 (&r)[4], int i, u32 v) {
+        const int t = i >> 6; const bool me = lane == (i & 63);
+        if (t == 0) r[0] = me ? v : r[0]; else if (t == 1) r[1] = me ? v : r[1]; else if (t == 2) r[2] = me ? v : r[2]; else r[3] = me ? v : r[3];
+    };
+    const int nInt = (int)nonNull - 1;                       // internal nodes, created in non-decreasing count order
+    {
+        int li = (int)nonNull - 1, ii = 0;                   // smallest unused leaf, oldest unused internal node
+        u32 lc = rd(leafCnt, li), ic = 0;
+        for (int k = 0; k < nInt; ++k) {
+            u32 sum = 0;
+#pragma unroll
+            for (int pick = 0; pick < 2; ++pick) {           // the smaller of the two queue heads; a leaf only if strictly smaller
+                const bool leaf = li >= 0 && (ii >= k || lc < ic);     // (huf_compress.c:707-708)
+                if (leaf) { sum += lc; wr(leafPar, li, (u32)k); li--; lc = li >= 0 ? rd(leafCnt, li) : 0u; }
+                else { sum += ic; wr(intPar, ii, (u32)k); ii++; ic = ii < k ? rd(intCnt, ii) : 0u; }
+            }
+            wr(intCnt, k, sum);
+            if (ii == k) ic = sum;                           // the node just made is the queue's head when the queue was empty
         }
-        node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
     }
-    return target;
-}
-// HUF_buildCTable_wksp (huf_compress.c:758-794); tbl = 513 nodes (tbl[0] is the barrier entry)
-__device__ u32 huf_build(HufCT* ct, const u32* count, u32 maxSym, u32 maxNbBits, HNode* tbl, RankPos* rp, short* stack)
-{
-    HNode* const node = tbl + 1;
-    u16 nbPerRank[13], valPerRank[13];
-    for (int i = 0; i < 513; i++) { tbl[i].count = 0; tbl[i].parent = 0; tbl[i].byte = 0; tbl[i].nbBits = 0; }
-    for (int i = 0; i < 13; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
-    huf_sort(node, count, maxSym, rp, stack);
-    const int nonNull = huf_build_tree(node, maxSym);
-    const u32 bits = huf_set_max_height(node, (u32)nonNull, maxNbBits);
-    for (int n = 0; n <= nonNull; n++) nbPerRank[node[n].nbBits]++;
-    {   u16 min = 0;
-        for (int n = (int)bits; n > 0; n--) { valPerRank[n] = min; min = (u16)(min + nbPerRank[n]); min >>= 1; }
+    // depth of every internal node below the root (node nInt-1): pointer jumping over the parent links
+    u32 dep[4], par[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int k = 64 * t + lane; const bool root = k >= nInt - 1; dep[t] = root ? 0u : 1u; par[t] = root ? (u32)(nInt > 0 ? nInt - 1 : 0) : intPar[t]; }
+    auto gather = [&](const u32 (&r)[4], u32 idx) -> u32 {
+        const u32 l = idx & 63, t = idx >> 6;
+        const u32 a0 = (u32)__shfl((int)r[0], (int)l), a1 = (u32)__shfl((int)r[1], (int)l), a2 = (u32)__shfl((int)r[2], (int)l), a3 = (u32)__shfl((int)r[3], (int)l);
+        return t == 0 ? a0 : (t == 1 ? a1 : (t == 2 ? a2 : a3));
+    };
+    for (int round = 0; round < 8; ++round) {
+        u32 nd[4], np[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { nd[t] = dep[t] + gather(dep, par[t]); np[t] = gather(par, par[t]); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { dep[t] = nd[t]; par[t] = np[t]; }
     }
-    for (int n = 0; n < 256; n++) { ct->nbBits[n] = 0; ct->val[n] = 0; }
-    for (int n = 0; n <= (int)maxSym; n++) ct->nbBits[node[n].byte] = node[n].nbBits;
-    for (int n = 0; n <= (int)maxSym; n++) ct->val[n] = ct->nbBits[n] ? valPerRank[ct->nbBits[n]]++ : 0;
-    ct->tableLog = bits;
+    u32 len[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; len[t] = i < nonNull ? gather(dep, leafPar[t]) + 1u : 0u; }
+    if (nonNull == 1) len[0] = lane == 0 ? 1u : len[0];
+
+    // ---- 3. length limit (HUF_setMaxHeight).  Leaves are in count-descending = length-ascending order ----
+    u32 bits;
+    {
+        // the reference takes the length of the last (rarest) leaf as the largest one and cuts from the end while lengths
+        // exceed the target (:384-405)
+        const u32 largest = rd(len, (int)nonNull - 1);
+        bits = largest;
+        if (largest > maxNbBits) {
+            const u32 target = maxNbBits;
+            int n0 = -1;                                     // last leaf that is already short enough
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const u64 m = ballot(64u * t + (u32)lane < nonNull && len[t] <= target); if (m) n0 = 64 * t + top_lane(m); }
+            // too-long codes are cut to the target; the debt (in units of the deepest level) is paid back below
+            u32 cost = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = 64 * t + lane;
+                if (i > n0 && (u32)i < nonNull) { cost += (1u << (largest - target)) - (1u << (largest - len[t])); len[t] = target; }
+            }
+            int totalCost = (int)(wsum(cost) >> (largest - target));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; if (i < nonNull) { sc->len[i] = (u8)len[t]; } }
+            wave_fence();
+            if (lane == 0) {
+                // rankLast[r]: last leaf whose length is target - r.  Each step lengthens the cheapest such leaf that pays
+                // off the largest affordable power of two (:430-476), then hands back any overpayment (:478-492).
+                const u32 none = 0xFFFFFFFFu;
+                u32 rankLast[14];
+                for (int r = 0; r < 14; ++r) rankLast[r] = none;
+                int n = (int)nonNull - 1;
+                while (n >= 0 && sc->len[n] == target) n--;
+                {   u32 cur = target;
+                    for (int pos = n; pos >= 0; pos--) { const u32 l = sc->len[pos]; if (l >= cur) continue; cur = l; rankLast[target - cur] = (u32)pos; }
+                }
+                while (totalCost > 0) {
+                    u32 dec = (u32)hb((u32)totalCost) + 1;
+                    for (; dec > 1; dec--) {
+                        const u32 hp = rankLast[dec], lp = rankLast[dec - 1];
+                        if (hp == none) continue;
+                        if (lp == none) break;
+                        if ((sc->tmp[hp] >> 8) <= 2 * (sc->tmp[lp] >> 8)) break;
+                    }
+                    while (dec <= 12 && rankLast[dec] == none) dec++;
+                    totalCost -= 1 << (dec - 1);
+                    sc->len[rankLast[dec]]++;
+                    if (rankLast[dec - 1] == none) rankLast[dec - 1] = rankLast[dec];
+                    if (rankLast[dec] == 0) rankLast[dec] = none;
+                    else { rankLast[dec]--; if (sc->len[rankLast[dec]] != target - dec) rankLast[dec] = none; }
+                }
+                while (totalCost < 0) {
+                    if (rankLast[1] == none) {
+                        while (n >= 0 && sc->len[n] == target) n--;
+                        sc->len[n + 1]--; rankLast[1] = (u32)(n + 1); totalCost++;
+                        continue;
+                    }
+                    sc->len[rankLast[1] + 1]--; rankLast[1]++; totalCost++;
+                }
+            }
+            wave_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; len[t] = i < nonNull ? (u32)sc->len[i] : 0u; }
+            bits = target;
+        }
+    }
+    // ---- 4. canonical values: symbols of one length are numbered in symbol order, the lengths' first values come from
+    //         the per-length counts, longest first (:776-790) ----
+    for (u32 s = (u32)lane; s < 256; s += kWave) ct->nbBits[s] = 0;
+    wave_fence();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; if (i < nonNull) ct->nbBits[sc->tmp[i] & 0xFF] = (u8)len[t]; }
+    wave_fence();
+    u32 sl[4];                                               // code length by symbol (slot t = symbols 64t..64t+63)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sl[t] = ct->nbBits[64u * t + (u32)lane];
+    u32 val[4] = {0, 0, 0, 0};
+    {
+        u32 first = 0;                                       // first value of the current length
+        for (u32 b = bits; b > 0; --b) {
+            u32 before = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u64 m = ballot(sl[t] == b);
+                if (sl[t] == b) val[t] = first + before + below(m);
+                before += (u32)__builtin_popcountll(m);
+            }
+            first = (first + before) >> 1;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ct->val[64u * t + (u32)lane] = (u16)val[t];
+    if (lane == 0) ct->tableLog = bits;
+    wave_fence();
     return bits;
 }
 
-// FSE_compress_usingCTable on the Huffman weights (fse_compress.c:558-615): two interleaved states
-__device__ u32 fse_compress_weights(u8* dst, const u8* w, u32 n, const FseCT* ct)
+// The code lengths as the frame stores them (HUF_writeCTable_wksp, huf_compress.c:256-295): weights, FSE-compressed when
+// that pays (HUF_compressWeights :173-213), else packed two per byte.  Returns bytes written to op (global), 0 on failure.
+__device__ u32 huf_write_table_wave(u8* op, const HufCT* ct, const u32 maxSym, const u32 huffLog, HufScratch* sc, int lane)
 {
-    BitW b; u32 st[2] = {0, 0}; int init[2] = {0, 0};
-    if (n <= 2) return 0;
-    b.init(dst);
-    for (u32 i = n; i-- > 0;) {
-        const int k = (int)(i & 1);
-        const u32 sym = w[i];
-        if (!init[k]) { st[k] = fse_init_state(ct, sym); init[k] = 1; }
-        else {
-            const u32 nb = (st[k] + (u32)ct->deltaNbBits[sym]) >> 16;
-            b.add(st[k], (int)nb);
-            st[k] = ct->stateTable[(int)(st[k] >> nb) + ct->deltaFindState[sym]];
+    // weight of symbol s < maxSym (the last symbol's is implied)
+    u32 wsym[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const u32 s = 64u * t + (u32)lane;
+        const u32 l = s < maxSym ? (u32)ct->nbBits[s] : 0u;
+        wsym[t] = l ? huffLog + 1 - l : 0u;
+        if (s < maxSym) sc->weight[s] = (u8)wsym[t];
+    }
+    if (lane == 0) sc->weight[maxSym] = 0;
+    wave_fence();
+    u32 h = 0;
+    const u32 n = maxSym;
+    if (n > 1) {                                             // FSE over the 13 possible weights
+        u32 cw = 0;                                          // count of weight `lane`
+        for (u32 v = 0; v <= 12; ++v) {
+            const u32 k = (u32)__builtin_popcountll(ballot(wsym[0] == v && (u32)lane < n)) + (u32)__builtin_popcountll(ballot(wsym[1] == v && 64u + (u32)lane < n)) +
+                          (u32)__builtin_popcountll(ballot(wsym[2] == v && 128u + (u32)lane < n)) + (u32)__builtin_popcountll(ballot(wsym[3] == v && 192u + (u32)lane < n));
+            if ((u32)lane == v) cw = k;
+        }
+        const u64 present = ballot(cw != 0);
+        const u32 maxW = (u32)top_lane(present), maxCount = wmaxu(cw);
+        if (maxCount == n) h = 1;                            // one weight only: not compressible this way
+        else if (maxCount != 1) {
+            const u32 tableLog = fse_optimal_log(6, n, maxW, 2);
+            int norm = 0;
+            if (fse_normalize_wave(norm, cw, n, maxW, tableLog, false, lane) >= 0) {
+                const u32 hd = fse_write_ncount_wave(op + 1, norm, maxW, tableLog, &sc->fs, lane);
+                if (hd) {
+                    fse_build_ctable_wave(&sc->wct, norm, maxW, tableLog, &sc->fs, lane);
+                    wave_fence();
+                    // FSE_compress_usingCTable (fse_compress.c:558-615) on n > 2 weights, last to first, two interleaved
+                    // states: lane k runs the chain of the weights with index parity k, then all lanes place the bits
+                    if (n > 2) {
+                        const FseCT* t = &sc->wct;
+                        if (lane < 2) {
+                            u32 st = 0; bool started = false;
+                            for (int i = (int)n - 1; i >= 0; --i) if ((i & 1) == lane) {
+                                const u32 sym = sc->weight[i];
+                                if (!started) { st = fse_init_state(t, sym); started = true; sc->wbits[lane][i >> 1] = 0; }
+                                else {
+                                    const u32 nb = (st + (u32)t->deltaNbBits[sym]) >> 16;
+                                    sc->wbits[lane][i >> 1] = ((st & ((1u << nb) - 1)) << 8) | nb;
+                                    st = t->stateTable[(int)(st >> nb) + t->deltaFindState[sym]];
+                                }
+                            }
+                            sc->cnt13[lane] = st;
+                        }
+                        wave_fence();
+                        // emission order: weight n-1 first; then the two final states (state 1, state 0), then the end mark
+                        u8* dst = op + 1 + hd;
+                        u32 done = 0, carryV = 0, carryN = 0;          // bits (< 8) waiting for the next round
+                        for (u32 e0 = 0; e0 < n + 1; e0 += kWave) {
+                            const u32 e = e0 + (u32)lane;
+                            u64 v = 0; u32 nb = 0;
+                            if (e < n) { const u32 i = n - 1 - e; const u32 x = sc->wbits[i & 1][i >> 1]; v = x >> 8; nb = x & 0xFF; }
+                            else if (e == n) {
+                                const u32 tl = (u32)t->tableLog;
+                                v = (u64)(sc->cnt13[1] & ((1u << tl) - 1)) | ((u64)(sc->cnt13[0] & ((1u << tl) - 1)) << tl) | (1ull << (2 * tl));
+                                nb = 2 * tl + 1;
+                            }
+                            if (lane == 0) { v = (v << carryN) | carryV; nb += carryN; }
+                            const u32 tot = lane_get(wscan(nb, lane), 63);
+                            const u32 by = wave_emit_bits(dst + done, v, nb, sc->fs.bits, 40, lane);
+                            const bool lastRound = e0 + kWave >= n + 1;
+                            if (lastRound) done += by;
+                            else { done += tot >> 3; carryN = tot & 7; carryV = carryN ? ((u32)reinterpret_cast<const u8*>(sc->fs.bits)[tot >> 3]) : 0u; }
+                        }
+                        const u32 cs = done;
+                        if (cs) h = hd + cs;
+                    }
+                }
+            }
         }
     }
-    b.add(st[1], ct->tableLog);
-    b.add(st[0], ct->tableLog);
-    return b.close();
-}
-
-// scratch needed by the literal-table writer
-struct HufWriteScratch { u8 weight[256]; u32 count[13]; s16 norm[13]; FseCT ct; u8 tableSymbol[64]; u16 cumul[16]; };
-
-// HUF_compressWeights (huf_compress.c:173-213)
-__device__ u32 huf_compress_weights(u8* dst, const u8* w, u32 n, HufWriteScratch* sc)
-{
-    u32 maxSym = 0, maxCount = 0, i;
-    if (n <= 1) return 0;
-    for (i = 0; i < 13; i++) sc->count[i] = 0;
-    for (i = 0; i < n; i++) sc->count[w[i]]++;
-    for (i = 0; i <= 12; i++) { if (sc->count[i]) maxSym = i; if (sc->count[i] > maxCount) maxCount = sc->count[i]; }
-    if (maxCount == n) return 1;
-    if (maxCount == 1) return 0;
-    const u32 tableLog = fse_optimal_log(6, n, maxSym, 2);
-    if (fse_normalize(sc->norm, tableLog, sc->count, n, maxSym, 0) < 0) return 0;
-    const u32 h = fse_write_ncount(dst, sc->norm, maxSym, tableLog);
-    if (!h) return 0;
-    fse_build_ctable(&sc->ct, sc->norm, maxSym, tableLog, sc->tableSymbol, sc->cumul);
-    const u32 c = fse_compress_weights(dst + h, w, n, &sc->ct);
-    if (!c) return 0;
-    return h + c;
-}
-// HUF_writeCTable_wksp (huf_compress.c:256-295); 0 on failure
-__device__ u32 huf_write_ctable(u8* op, const HufCT* ct, u32 maxSym, u32 huffLog, HufWriteScratch* sc)
-{
-    u32 n;
-    for (n = 0; n < maxSym; n++) sc->weight[n] = ct->nbBits[n] ? (u8)(huffLog + 1 - ct->nbBits[n]) : 0;
-    {   const u32 h = huf_compress_weights(op + 1, sc->weight, maxSym, sc);
-        if (h > 1 && h < maxSym / 2) { op[0] = (u8)h; return h + 1; }
-    }
+    if (h > 1 && h < maxSym / 2) { if (lane == 0) op[0] = (u8)h; wave_fence(); return h + 1; }
     if (maxSym > 128) return 0;
-    op[0] = (u8)(128 + (maxSym - 1));
-    sc->weight[maxSym] = 0;
-    for (n = 0; n < maxSym; n += 2) op[(n / 2) + 1] = (u8)((sc->weight[n] << 4) + sc->weight[n + 1]);
+    if (lane == 0) op[0] = (u8)(128 + (maxSym - 1));
+    for (u32 k = (u32)lane; 2 * k < maxSym; k += kWave) op[k + 1] = (u8)((sc->weight[2 * k] << 4) + sc->weight[2 * k + 1]);
+    wave_fence();
     return ((maxSym + 1) / 2) + 1;
 }
 

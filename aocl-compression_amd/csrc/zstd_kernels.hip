@@ -73,15 +73,9 @@ struct Workspace {
 struct EntropyLds {
     u32 hist[256];
     u32 count[64];
-    s16 norm[64];
-    HNode nodes[513];
-    RankPos rank[192];
-    short qstack[192];
     HufCT huf;
-    HufWriteScratch hw;
+    HufScratch hs;           // (its FseScratch also serves the three sequence tables)
     FseCT ctLL, ctOF, ctML;
-    u8 tableSymbol[512];
-    u16 cumul[64];
     u32 tile[WavePacker::kTileWords];
     u32 fseBits[3][64];      // per tile: (value << 8) | nbBits from the three state chains
     u32 misc[16];
@@ -575,13 +569,9 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
     if (largest == n) { if (lane == 0) dst[0] = src[0]; return 1; }
     if (largest <= (n >> 7) + 4) return 0;
     u32 huffLog = fse_optimal_log(11, n, maxSym, 1);                     // HUF_optimalTableLog :1268-1283
-    u32 h = 0;
-    if (lane == 0) {
-        huffLog = huf_build(&L->huf, L->hist, maxSym, huffLog, L->nodes, L->rank, L->qstack);
-        h = huf_write_ctable(dst, &L->huf, maxSym, huffLog, &L->hw);
-    }
+    huffLog = huf_build_wave(&L->huf, L->hist, maxSym, huffLog, &L->hs, lane);
+    const u32 h = huf_write_table_wave(dst, &L->huf, maxSym, huffLog, &L->hs, lane);
     wave_fence();
-    h = uni(h);
     if (!h) return 0;
     if (h + 12 >= n) return 0;
     const u32 c = single ? huf_encode_1x(dst + h, src, n, &L->huf, L->tile, lane)
@@ -631,31 +621,33 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
     wave_fence();
     for (u32 i = (u32)lane; i < nbSeq; i += kWave) atomicAdd(&L->count[codes[i]], 1u);
     wave_fence();
+    // one symbol per lane from here on (the alphabets have at most 53 symbols)
     int type = 0; u32 adv = 0, lc = 0;
-    if (lane == 0) {
-        u32 max = 0, most = 0;
-        for (u32 i = 0; i <= maxCode; i++) { if (L->count[i]) max = i; if (L->count[i] > most) most = L->count[i]; }
-        const bool defaultAllowed = (defMax == 28) ? (max <= 28) : true;              // zstd_compress.c:2847-2848
-        type = select_type(most, nbSeq, defLog, defaultAllowed);
-        if (type == 1) { fse_build_rle(ct, max); base[*op] = codes[0]; adv = 1; }
-        else if (type == 0) {
-            for (u32 i = 0; i <= defMax; i++) L->norm[i] = defNorm[i];
-            fse_build_ctable(ct, L->norm, defMax, defLog, L->tableSymbol, L->cumul);
-        } else {
-            u32 nbSeq1 = nbSeq;
-            const u32 tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
-            const u32 last = codes[nbSeq - 1];
-            if (L->count[last] > 1) { L->count[last]--; nbSeq1--; }
-            if (fse_normalize(L->norm, tableLog, L->count, nbSeq1, max, nbSeq1 >= 2048) < 0) type = -1;
-            else {
-                const u32 h = fse_write_ncount(base + *op, L->norm, max, tableLog);
-                if (!h) type = -1;
-                else { fse_build_ctable(ct, L->norm, max, tableLog, L->tableSymbol, L->cumul); adv = h; lc = h; }
-            }
+    u32 c = (u32)lane <= maxCode ? L->count[lane] : 0u;
+    const u32 max = (u32)top_lane(ballot(c != 0)), most = uni(wmaxu(c));
+    const bool defaultAllowed = (defMax == 28) ? (max <= 28) : true;                  // zstd_compress.c:2847-2848
+    type = select_type(most, nbSeq, defLog, defaultAllowed);
+    FseScratch* fs = &L->hs.fs;
+    if (type == 1) {
+        if (lane == 0) { fse_build_rle(ct, max); base[*op] = codes[0]; }
+        adv = 1;
+    } else if (type == 0) {
+        const int norm = (u32)lane <= defMax ? (int)defNorm[lane] : 0;
+        fse_build_ctable_wave(ct, norm, defMax, defLog, fs, lane);
+    } else {
+        u32 nbSeq1 = nbSeq;
+        const u32 tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
+        const u32 last = uni(codes[nbSeq - 1]);
+        if (lane_get(c, (int)last) > 1) { if ((u32)lane == last) c--; nbSeq1--; }     // zstd_compress_sequences.c:264-268
+        int norm = 0;
+        if (fse_normalize_wave(norm, c, nbSeq1, max, tableLog, nbSeq1 >= 2048, lane) < 0) type = -1;
+        else {
+            const u32 h = fse_write_ncount_wave(base + *op, norm, max, tableLog, fs, lane);
+            if (!h) type = -1;
+            else { fse_build_ctable_wave(ct, norm, max, tableLog, fs, lane); adv = h; lc = h; }
         }
     }
     wave_fence();
-    type = (int)uni((u32)type); adv = uni(adv); lc = uni(lc);
     *op += adv;
     if (lc) *lastCount = lc;
     return type;
