@@ -45,7 +45,13 @@ class Batch(C.Structure):
 FLAG_RAP_PARTITIONS = 0x100
 FLAG_ZSTD_LEVEL2 = 0x400      # Zstd level 2 instead of 1 (include/aocl_gpu_codec.h)
 # kernel selection (never changes an output byte; lets tests drive every kernel on small batches)
-FLAG_SNAPPY_TABLES_LDS, FLAG_SNAPPY_TABLES_HBM, FLAG_SNAPPY_TABLES_MIXED, FLAG_LZ4_TABLE_U32 = 0x1000, 0x2000, 0x4000, 0x8000
+FLAG_SNAPPY_TABLES_LDS, FLAG_SNAPPY_TABLES_HBM, FLAG_SNAPPY_TABLES_MIXED, FLAG_LZ4_TABLE_U32 = 0x1000, 0x2000, 0x4000, 0x0800
+
+
+def lz4_acceleration(a: int) -> int:
+    """AOCLGPU_LZ4_ACCELERATION(a): LZ4_compress_fast's acceleration (1..65537) as batch flags"""
+    return (min(max(int(a), 1), 65537) - 1) << 15
+
 
 
 class LlcDesc(C.Structure):

@@ -36,12 +36,19 @@ constexpr uint32_t kSrcRing = 544;        // compressor's source ring: 2 x 256 B
 
 __device__ __forceinline__ uint32_t lz4_bound(uint32_t n) { return n + n / 255 + 16; }   // lz4.h:261
 
-// Sum of the first i steps of the search schedule (lz4.c:1486-1510): step_0 = 1, step_j = (63+j)>>6.
-__device__ __forceinline__ uint32_t sched(uint32_t i)
+// Sum of the first i steps of the search schedule (lz4.c:1486-1510): step_0 = 1, step_j = (64*a - 1 + j) >> 6 for
+// acceleration a (LZ4_compress_fast; a = 1 for LZ4_compress_default).  With S(x) = sum of (m >> 6) over m < x this is
+// 1 + S(64a + i - 1) - S(64a); saturates at 2^32 - 1 (positions that large are beyond any chunk).
+__device__ __forceinline__ uint32_t sched(uint32_t i, uint32_t a)
 {
     if (i == 0) return 0;
-    const uint32_t n = 62 + i, q = n >> 6, r = n & 63;
-    return 1 + 32 * q * (q - 1) + q * (r + 1);
+    if (a == 1) {
+        const uint32_t n = 62 + i, q = n >> 6, r = n & 63;
+        return 1 + 32 * q * (q - 1) + q * (r + 1);
+    }
+    const uint64_t x = 64ull * a + i - 1, q = x >> 6, r = x & 63;
+    const uint64_t v = 1 + 32 * q * (q - 1) + q * r - 32ull * a * (a - 1);
+    return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
 }
 
 template <bool U16>
@@ -93,6 +100,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     gbyte* __restrict__ dst = uni_ptr(dst_);
     lbyte* lds = uni_ptr(lds_);
     const uint32_t n = uni(n_), cap = uni(cap_), expf = uni(expf_);
+    const uint32_t accel = (expf >> 15) + 1;              // AOCLGPU_LZ4_ACCELERATION(a) in batch.reserved
     constexpr bool U16 = (MODE == 0);
     using T = typename std::conditional<MODE == 2, uint32_t, uint16_t>::type;
     typedef __attribute__((address_space(3))) T LT;
@@ -172,15 +180,17 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             asm volatile("; batch begin" ::: "memory");
             // ---------------- one batch of 64 speculative probes (lz4.c:1483-1608, 1746-1804) ----------------
             uint32_t pos, posmax; bool valid;
-            if (i0 == 0) {                                // first 64 probes of a search: consecutive positions
+            if (i0 == 0 && accel == 1) {                  // first 64 probes of a search: consecutive positions
                 pos = ip + (uint32_t)lane; posmax = ip + 63;
                 valid = pos + 1 <= mfl1;                                        // lz4.c:1513
-            } else {
+            } else {                                      // probe j of the schedule (j = -1: the post-match probe at ip)
                 const uint32_t base = extra ? ip + 1 : ip;
                 const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-                pos = base + sched((uint32_t)j);
-                posmax = base + sched(i0 + 63u - (extra ? 1u : 0u));
-                valid = base + sched((uint32_t)(j + 1)) <= mfl1;
+                const uint64_t p64 = j < 0 ? (uint64_t)base - 1 : (uint64_t)base + sched((uint32_t)j, accel);
+                const uint64_t pm64 = (uint64_t)base + sched(i0 + 63u - (extra ? 1u : 0u), accel);
+                pos = p64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)p64;
+                posmax = pm64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)pm64;
+                valid = (uint64_t)base + sched((uint32_t)(j + 1), accel) <= mfl1;
             }
             // 16-byte windows [p-4, p+12) around the probe and around its candidate: the 4 bytes of the match
             // test, 4 bytes of catch-up and 8 bytes of forward extension arrive in one round trip
@@ -249,7 +259,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             const int e = first_lane(ballot(!valid));
             const int lim = f < e ? f : e;                // lanes < lim saw exactly the sequential candidates
             const uint64_t okmask = ballot(lane < lim && plausible && (uint32_t)(cw.lo >> 32) == (uint32_t)(pw.lo >> 32));
-            const bool linear = (i0 == 0);                // lane L probes pos0 + L (sched is the identity below 66)
+            const bool linear = (i0 == 0) && accel == 1;  // lane L probes pos0 + L (the default schedule is the identity below 66)
             // in-lane forward extension (<= 24 bytes), LZ4_count lz4.c:656-679: the probe-side bytes beyond +12 sit in
             // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
             uint32_t fw; bool mf;

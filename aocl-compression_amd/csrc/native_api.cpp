@@ -32,11 +32,10 @@ const char* LZ4_versionString(void) { return "1.9.3"; }
 int LZ4_compressBound(int isize) { return (unsigned)isize > 0x7E000000u ? 0 : isize + isize / 255 + 16; }   // lz4.h:261
 
 int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration)
-{   // lz4.c:2937-2975 (AOCL adds the NULL checks): only the default acceleration has a GPU backend
+{   // lz4.c:2937-2975 (AOCL adds the NULL checks); acceleration < 1 -> 1, > 65537 -> 65537 (lz4.c:2521-2522)
     if ((!src && srcSize != 0) || !dst || srcSize < 0 || dstCapacity < 0) return 0;
-    if (acceleration > 1) return 0;
     if ((unsigned)srcSize > 0x7E000000u) return 0;
-    const int64_t r = aoclgpu_compress_host(AOCLGPU_LZ4, src, (size_t)srcSize, dst, (size_t)dstCapacity);
+    const int64_t r = aoclgpu_compress_host_ex(AOCLGPU_LZ4, src, (size_t)srcSize, dst, (size_t)dstCapacity, AOCLGPU_LZ4_ACCELERATION(acceleration));
     return r > 0 && r <= 0x7FFFFFFF ? (int)r : 0;
 }
 int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)

@@ -275,19 +275,58 @@ __device__ u32 fse_write_ncount_wave(u8* out, const int norm, const u32 maxSym, 
     return wave_emit_bits(out, v, nb, sc->bits, 40, lane);
 }
 
-// Encoding table (FSE_buildCTable_wksp, fse_compress.c:68-214).  The reference spreads the symbols over the states by
-// stepping through the table; occurrence k of the spread lands on the k-th visited state that is not reserved for a
-// low-probability symbol, so the lanes take the visit numbers 64 at a time: reserved states are skipped by a ballot
-// count, the symbol of occurrence k comes from a prefix maximum over "first occurrence" marks.  A symbol's states are
-// then numbered in increasing state order: rank among the lanes holding the same symbol + the symbol's running base.
-__device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
+// State -> symbol map shared by the encoding and the decoding tables (FSE_buildCTable_wksp fse_compress.c:68-110 and
+// ZSTD_buildFSETable zstd_decompress_block.c:497-560 spread identically).  The reference steps through the table;
+// occurrence k of the spread lands on the k-th visited state that is not reserved for a low-probability symbol, so the
+// lanes take the visit numbers 64 at a time: reserved states are skipped by a ballot count, the symbol of occurrence k
+// comes from a prefix maximum over "first occurrence" marks.  put(state, symbol) stores the result; occ = 2^tableLog
+// bytes of LDS scratch.
+template <class Put>
+__device__ __forceinline__ void fse_spread_wave(u8* occ, const int norm, const u32 maxSym, const u32 tableLog, int lane, Put put)
 {
     const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
     const bool valid = (u32)lane <= maxSym;
-    const u32 w = !valid ? 0u : (norm == -1 ? 1u : (norm > 0 ? (u32)norm : 0u));       // states the symbol owns
-    const u32 cum = wscan(w, lane) - w;                                               // first of them in the state table
     const u64 lowm = ballot(valid && norm == -1);
     const u32 high = tableSize - 1 - (u32)__builtin_popcountll(lowm);
+    // low-probability symbols own the top states, in symbol order from the top down
+    if ((lowm >> lane) & 1) put(tableSize - 1 - below(lowm), (u32)lane);
+    // occurrence -> symbol: mark every spread symbol's first occurrence, prefix maximum (symbols ascend with k)
+    const u32 sp = (valid && norm > 0) ? (u32)norm : 0u;
+    const u32 scum = wscan(sp, lane) - sp;
+    for (u32 i = (u32)lane; i < tableSize; i += kWave) occ[i] = 0;
+    wave_fence();
+    if (sp) occ[scum] = (u8)(lane + 1);
+    wave_fence();
+    u32 carry = 0;
+    for (u32 k0 = 0; k0 < tableSize; k0 += kWave) {
+        const u32 k = k0 + (u32)lane;
+        u32 m = k < tableSize ? (u32)occ[k] : 0u;
+        m = wmaxscan(m, lane);
+        m = m > carry ? m : carry;
+        if (k < tableSize) occ[k] = (u8)m;
+        carry = lane_get(m, 63);
+    }
+    wave_fence();
+    // visit j of the walk is state (j * step) & mask; visits of reserved states do not consume an occurrence
+    u32 skipped = 0;
+    for (u32 j0 = 0; j0 < tableSize; j0 += kWave) {
+        const u32 j = j0 + (u32)lane, p = (j * step) & mask;
+        const bool in = j < tableSize, skip = in && p > high;
+        const u64 sk = ballot(skip);
+        if (in && !skip) put(p, (u32)occ[j - skipped - below(sk)] - 1u);
+        skipped += (u32)__builtin_popcountll(sk);
+    }
+    wave_fence();
+}
+
+// Encoding table (FSE_buildCTable_wksp, fse_compress.c:68-214): spread, then a symbol's states are numbered in
+// increasing state order: rank among the lanes holding the same symbol + the symbol's running base.
+__device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
+{
+    const u32 tableSize = 1u << tableLog;
+    const bool valid = (u32)lane <= maxSym;
+    const u32 w = !valid ? 0u : (norm == -1 ? 1u : (norm > 0 ? (u32)norm : 0u));       // states the symbol owns
+    const u32 cum = wscan(w, lane) - w;                                               // first of them in the state table
     if (lane == 0) ct->tableLog = (int)tableLog;
     if (valid) {
         sc->next[lane] = (u16)cum;
@@ -299,35 +338,7 @@ __device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSy
             ct->deltaFindState[lane] = (int)cum - (int)w;
         }
     }
-    // low-probability symbols own the top states, in symbol order from the top down
-    if ((lowm >> lane) & 1) sc->cell[tableSize - 1 - below(lowm)] = (u8)lane;
-    // occurrence -> symbol: mark every spread symbol's first occurrence, prefix maximum (symbols ascend with k)
-    const u32 sp = (valid && norm > 0) ? (u32)norm : 0u;
-    const u32 scum = wscan(sp, lane) - sp;
-    for (u32 i = (u32)lane; i < tableSize; i += kWave) sc->occ[i] = 0;
-    wave_fence();
-    if (sp) sc->occ[scum] = (u8)(lane + 1);
-    wave_fence();
-    u32 carry = 0;
-    for (u32 k0 = 0; k0 < tableSize; k0 += kWave) {
-        const u32 k = k0 + (u32)lane;
-        u32 m = k < tableSize ? (u32)sc->occ[k] : 0u;
-        m = wmaxscan(m, lane);
-        m = m > carry ? m : carry;
-        if (k < tableSize) sc->occ[k] = (u8)m;
-        carry = lane_get(m, 63);
-    }
-    wave_fence();
-    // visit j of the walk is state (j * step) & mask; visits of reserved states do not consume an occurrence
-    u32 skipped = 0;
-    for (u32 j0 = 0; j0 < tableSize; j0 += kWave) {
-        const u32 j = j0 + (u32)lane, p = (j * step) & mask;
-        const bool in = j < tableSize, skip = in && p > high;
-        const u64 sk = ballot(skip);
-        if (in && !skip) sc->cell[p] = (u8)(sc->occ[j - skipped - below(sk)] - 1);
-        skipped += (u32)__builtin_popcountll(sk);
-    }
-    wave_fence();
+    fse_spread_wave(sc->occ, norm, maxSym, tableLog, lane, [&](u32 state, u32 sym) { sc->cell[state] = (u8)sym; });
     // state table: the states of a symbol in increasing order (tableU16[cumul[s]++] = tableSize + u, :118-121)
     for (u32 u0 = 0; u0 < tableSize; u0 += kWave) {
         const u32 u = u0 + (u32)lane;

@@ -955,7 +955,35 @@ __device__ u32 fse_read_ncount(s16* norm, u32* maxSym, u32* tableLog, const u8* 
     if (used > n) return 0xFFFFFFFFu;
     return used;
 }
-// FSE decoding table (zstd_decompress_block.c:497-615); lane-serial
+// FSE decoding table (ZSTD_buildFSETable, zstd_decompress_block.c:497-615), one symbol per lane: the spread is the encoder's
+// (fse_spread_wave); the j-th state of a symbol (in increasing state order) continues from value norm + j, which gives its
+// bit count and base.  norm = this lane's normalised count.  false when the counts do not fill the table.
+// occ: 2^tableLog bytes, next: 64 u16 of LDS scratch (the decoder lends its bitstream window, not yet in use)
+__device__ bool fse_build_dtable_wave(FseD* dt, const int norm, u32 maxSym, u32 tableLog, u8* occ, u16* next, int lane)
+{
+    const u32 size = 1u << tableLog;
+    const bool valid = (u32)lane <= maxSym;
+    const u32 w = !valid ? 0u : (norm == -1 ? 1u : (norm > 0 ? (u32)norm : 0u));
+    if (wsum(w) != size) return false;                     // (the reference notices the same through pos != 0 after its walk)
+    fse_spread_wave(occ, norm, maxSym, tableLog, lane, [&](u32 state, u32 sym) { dt[state].symbol = (u8)sym; });
+    if (valid) next[lane] = (u16)w;
+    wave_fence();
+    for (u32 u0 = 0; u0 < size; u0 += kWave) {
+        const u32 u = u0 + (u32)lane;
+        const bool in = u < size;
+        const u32 sym = in ? (u32)dt[u].symbol : 0u;
+        const u64 same = same_value6(sym, in);
+        if (in) {
+            const u32 base = next[sym], ns = base + below(same);
+            const u32 nb = tableLog - (u32)hb(ns);
+            dt[u].nbBits = (u8)nb; dt[u].newState = (u16)((ns << nb) - size);
+            if (lane == top_lane(same)) next[sym] = (u16)(base + (u32)__builtin_popcountll(same));
+        }
+        wave_fence();
+    }
+    return true;
+}
+// (the table of the Huffman weights, <= 64 states of <= 13 symbols, is built by the lane that also decodes them)
 __device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tableLog, u16* next)
 {
     const u32 size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
@@ -1097,26 +1125,38 @@ __device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout,
     return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane);
 }
 
-// ZSTD_buildSeqTable (zstd_decompress_block.c:659-705); lane-serial
+// ZSTD_buildSeqTable (zstd_decompress_block.c:659-705).  All lanes call it: lane 0 reads a transmitted description (the bit
+// positions of its values depend on the values before them), the table itself is built by the wave, one symbol per lane.
 __device__ __attribute__((noinline)) bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
-                          const s16* defNorm, u32 defMax, u32 defLog, DecLds* L)
+                          const s16* defNorm, u32 defMax, u32 defLog, DecLds* L, int lane)
 {
+    u8* occ = L->bswin; u16* next = (u16*)(L->bswin + 512);
     if (mode == 0) {
-        for (u32 i = 0; i <= defMax; ++i) L->norm[i] = defNorm[i];
-        fse_build_dtable(dt, L->norm, defMax, defLog, L->next); *log = defLog; *have = 1; return true;
+        const int norm = (u32)lane <= defMax ? (int)defNorm[lane] : 0;
+        fse_build_dtable_wave(dt, norm, defMax, defLog, occ, next, lane);
+        if (lane == 0) { *log = defLog; *have = 1; }
+        wave_fence();
+        return true;
     }
     if (mode == 1) {
         if (*ip >= iend || src[*ip] > maxSym) return false;
-        dt[0].symbol = src[*ip]; dt[0].nbBits = 0; dt[0].newState = 0; *log = 0; *have = 1; (*ip)++; return true;
+        if (lane == 0) { dt[0].symbol = src[*ip]; dt[0].nbBits = 0; dt[0].newState = 0; *log = 0; *have = 1; }
+        wave_fence();
+        (*ip)++; return true;
     }
     if (mode == 2) {
-        u32 ms = maxSym, tl;
-        const u32 h = fse_read_ncount(L->norm, &ms, &tl, src + *ip, iend - *ip, maxLog);
+        u32 ms = maxSym, tl = 0, h = 0;
+        if (lane == 0) h = fse_read_ncount(L->norm, &ms, &tl, src + *ip, iend - *ip, maxLog);
+        wave_fence();
+        h = uni(h); ms = uni(ms); tl = uni(tl);
         if (h == 0xFFFFFFFFu) return false;
-        if (!fse_build_dtable(dt, L->norm, ms, tl, L->next)) return false;
-        *log = tl; *have = 1; *ip += h; return true;
+        const int norm = (u32)lane <= ms ? (int)L->norm[lane] : 0;
+        if (!fse_build_dtable_wave(dt, norm, ms, tl, occ, next, lane)) return false;
+        if (lane == 0) { *log = tl; *have = 1; }
+        wave_fence();
+        *ip += h; return true;
     }
-    return *have != 0;
+    return uni(*have) != 0;
 }
 
 // copy of `len` bytes inside dst from distance `offset` back (overlap allowed), whole wave
@@ -1221,15 +1261,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (ip >= n) return 0xFFFFFFFFu;
         const u32 modes = src[ip++];
         if (modes & 3) return 0xFFFFFFFFu;
-        u32 okT = 1, ipT = ip;
-        if (lane == 0) {
-            okT = seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ipT, n, 35, 9, kLLnorm, 35, 6, L)
-               && seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ipT, n, 31, 8, kOFnorm, 28, 5, L)
-               && seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ipT, n, 52, 9, kMLnorm, 52, 6, L);
-        }
+        if (!seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return 0xFFFFFFFFu;
+        if (!seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return 0xFFFFFFFFu;
+        if (!seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return 0xFFFFFFFFu;
         wave_fence();
-        okT = uni(okT); ip = uni(ipT);
-        if (!okT) return 0xFFFFFFFFu;
         for (u32 i = (u32)lane; i < 36 + 53; i += kWave) {                       // length-code tables (they share LDS with the Huffman windows)
             if (i < 36) L->llTab[i] = kLLbase[i] | ((u32)kLLbits[i] << 24);
             else L->mlTab[i - 36] = kMLbase[i - 36] | ((u32)kMLbits[i - 36] << 24);

@@ -85,7 +85,10 @@ typedef struct {
 #define AOCLGPU_FLAG_SNAPPY_TABLES_LDS   0x1000u
 #define AOCLGPU_FLAG_SNAPPY_TABLES_HBM   0x2000u
 #define AOCLGPU_FLAG_SNAPPY_TABLES_MIXED 0x4000u
-#define AOCLGPU_FLAG_LZ4_TABLE_U32       0x8000u
+#define AOCLGPU_FLAG_LZ4_TABLE_U32       0x0800u
+/* LZ4 compress: the `acceleration` of LZ4_compress_fast (lz4.c:2937-2965; the probe step starts at `a` instead of 1 and
+ * grows from there), 1 .. 65537, in bits 15..31 of the flags.  0 in those bits = acceleration 1 = LZ4_compress_default. */
+#define AOCLGPU_LZ4_ACCELERATION(a)      ((uint32_t)(((a) < 1 ? 1 : ((a) > 65537 ? 65537 : (a))) - 1) << 15)
 
 /* In uniform-mode DEcompression, src holds the slots (slot_bytes apart, src_len[i] = compressed size of
  * slot i, a device array that IS required), dst is the contiguous output: chunk i is written at

@@ -24,7 +24,7 @@ int         LZ4_versionNumber(void);                       /* 10903 */
 const char* LZ4_versionString(void);                       /* "1.9.3" */
 int         LZ4_compressBound(int inputSize);              /* 0 if inputSize > 0x7E000000 */
 int         LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);   /* 0 = failure */
-int         LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration); /* acceleration <= 1 only */
+int         LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration); /* any acceleration (clamped to 1..65537) */
 int         LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);    /* < 0 = malformed */
 char*       aocl_setup_lz4(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
 void        aocl_destroy_lz4(void);

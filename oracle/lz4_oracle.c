@@ -49,6 +49,14 @@ static uint32_t lz4_count(const uint8_t* s, uint32_t a, uint32_t b, uint32_t lim
 
 int orc_lz4_compress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap)
 {
+    return orc_lz4_compress_fast(src, srcSize, dst, dstCap, 1);
+}
+
+/* == LZ4_compress_fast (lz4.c:2937-2965): acceleration < 1 -> 1, > 65537 -> 65537 (lz4.c:2521-2522) */
+int orc_lz4_compress_fast(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap, int acceleration)
+{
+    if (acceleration < 1) acceleration = 1;
+    if (acceleration > 65537) acceleration = 65537;
     if (dst == NULL || (src == NULL && srcSize != 0)) return 0;              /* lz4.c:2516 */
     if ((uint32_t)srcSize > (uint32_t)LZ4_MAX_INPUT) return 0;               /* lz4.c:2417 */
     const int limited = dstCap < orc_lz4_compress_bound(srcSize);            /* lz4.c:2522 */
@@ -76,7 +84,7 @@ int orc_lz4_compress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap)
         uint32_t match, token_pos;
         /* ---- find a match (lz4.c:1483-1608) ---- */
         {
-            uint32_t fwd = ip, step = 1, nb = 1u << LZ4_SKIPTRIGGER;
+            uint32_t fwd = ip, step = 1, nb = (uint32_t)acceleration << LZ4_SKIPTRIGGER;     /* lz4.c:1486-1490 */
             uint32_t fwdH = lz4_hash(src + fwd, u16mode);
             for (;;) {
                 const uint32_t h = fwdH, cur = fwd;

@@ -22,6 +22,8 @@ extern "C" {
 int orc_lz4_compress_bound(int srcSize);                               /* lz4.h:261 LZ4_COMPRESSBOUND */
 /* == LZ4_compress_default (lz4.c:2967-2975): returns compressed size, 0 on failure. */
 int orc_lz4_compress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap);
+/* == LZ4_compress_fast (lz4.c:2937-2965) */
+int orc_lz4_compress_fast(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap, int acceleration);
 /* == LZ4_decompress_safe (lz4.c:4898-4923): returns decoded size, <0 on malformed input. */
 int orc_lz4_decompress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap);
 

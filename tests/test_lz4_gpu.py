@@ -198,3 +198,31 @@ def test_lz4hc_streams_decode(eng, ref):
         assert lib.aocl_llc_decompress(C.byref(d), 1) == size and back.raw == raw
         d.inBuf = C.cast(back, C.c_void_p); d.inSize = size; d.outBuf = C.cast(out, C.c_void_p); d.outSize = len(out)
         assert lib.aocl_llc_compress(C.byref(d), 1) == -2                 # ERR_COMPRESSION_FAILED
+
+
+@pytest.mark.parametrize("acc", [2, 3, 7, 64, 65, 1000, 65537])
+def test_acceleration_bit_exact(eng, oracle, acc):
+    """LZ4_compress_fast's acceleration on the GPU (AOCLGPU_LZ4_ACCELERATION in the batch flags, LZ4_compress_fast of the
+    native API): bytes identical to the oracle for both table types and ragged chunks, streams decode back"""
+    import ctypes as C
+    oracle.L.orc_lz4_compress_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    for kind, chunk in (("text", 65536), ("binary", 262144), ("jsonlog", 5000), ("random", 70000), ("database", 1 << 20)):
+        data = a.corpus.make(kind, (1 << 20) + 4321, seed=acc)
+        src = torch.from_numpy(data).to(eng.device)
+        slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk, flags=a.api.lz4_acceleration(acc))
+        lens = out_len.cpu().tolist(); host = slots.cpu().numpy(); raw = data.tobytes()
+        for i, ln in enumerate(lens):
+            part = raw[i * chunk:(i + 1) * chunk]
+            cap = ol.bound(ol.LZ4, len(part))
+            w = C.create_string_buffer(cap)
+            r = oracle.L.orc_lz4_compress_fast(part, len(part), w, cap, acc)
+            assert ln == r and host[i * slot:i * slot + ln].tobytes() == w.raw[:r], (kind, chunk, i)
+        dst, dl = eng.decompress_chunks(a.LZ4, slots, out_len, slot, len(raw), chunk)
+        assert torch.equal(dst, src)
+    lib = eng.lib
+    lib.LZ4_compress_fast.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    part = a.corpus.make("text", 100000, seed=acc + 1).tobytes()
+    cap = ol.bound(ol.LZ4, len(part))
+    g = C.create_string_buffer(cap); w = C.create_string_buffer(cap)
+    assert lib.LZ4_compress_fast(part, g, len(part), cap, acc) == oracle.L.orc_lz4_compress_fast(part, len(part), w, cap, acc)
+    assert g.raw == w.raw

@@ -104,3 +104,21 @@ def test_decode_foreign_zstd_frames(oracle, ref):
         out = C.create_string_buffer(len(raw) + len(raw) // 200 + 1024)
         r = ref.L.ZSTD_compress(out, len(out), raw, len(raw), rng.choice([1, 3, 5, 9, 19, -3]))
         assert oracle.decompress(ol.ZSTD, out.raw[:r], max(len(raw), 1)) == raw
+
+
+def test_lz4_acceleration_bit_exact(oracle, ref):
+    """LZ4_compress_fast(.., acceleration): the probe step starts at `acceleration` (lz4.c:1486-1510); out-of-range values are
+    clamped to 1..65537 (lz4.c:2521-2522).  Both table types (below / above 65547 bytes), limited output included."""
+    import ctypes as C
+    ref.L.LZ4_compress_fast.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    oracle.L.orc_lz4_compress_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    for kind in ("text", "binary", "random", "jsonlog"):
+        for n in (0, 13, 100, 5000, 65546, 65547, 300000):
+            data = a.corpus.make(kind, n, seed=31).tobytes() if n else b""
+            cap = ol.bound(ol.LZ4, n)
+            for acc in (-3, 0, 1, 2, 3, 7, 64, 65, 1000, 65537, 70000):
+                for c in (cap, max(1, cap // 3)):
+                    w = C.create_string_buffer(cap + 8); g = C.create_string_buffer(cap + 8)
+                    rw = ref.L.LZ4_compress_fast(data, w, n, c, acc)
+                    rg = oracle.L.orc_lz4_compress_fast(data, n, g, c, acc)
+                    assert rw == rg and w.raw[:max(rw, 0)] == g.raw[:max(rg, 0)], (kind, n, acc, c)
