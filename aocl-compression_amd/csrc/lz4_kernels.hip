@@ -255,10 +255,26 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             if (valid) table[h] = (T)ent;                 // undo the lane ids (the low halves; extra bits were not touched)
             wave_fence();
             STAGE(2);
-            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
             const int e = first_lane(ballot(!valid));
-            const int lim = f < e ? f : e;                // lanes < lim saw exactly the sequential candidates
-            const uint64_t okmask = ballot(lane < lim && plausible && (uint32_t)(cw.lo >> 32) == (uint32_t)(pw.lo >> 32));
+            // Lanes whose slot an earlier lane of the batch also names ("duplicates") have a candidate that depends on the
+            // parse: the earlier lane's position if that lane's table write happens, else the table entry.  Such a lane is
+            // still decided when NEITHER can match - its table candidate fails the 4-byte test and no earlier lane on its slot
+            // holds the same 4 bytes: it is a probe that finds nothing, whoever its candidate is.  The batch is cut at the
+            // first duplicate that could match.  `later` = this lane's slot is named again by these later lanes (the last
+            // one whose write happens owns the slot when the batch commits).
+            const uint32_t my4 = (uint32_t)(pw.lo >> 32);
+            const uint64_t tabok = ballot(plausible && (uint32_t)(cw.lo >> 32) == my4);
+            uint64_t later = 0;
+            int f = 64;
+            for (uint64_t d = ballot(valid && w != (uint32_t)lane); d; d &= d - 1) {
+                const int j = (int)__builtin_ctzll(d);
+                const uint64_t before = (1ull << j) - 1;
+                const uint64_t same = ballot(valid && h == lane_get(h, j)) & before;
+                if (((tabok >> j) & 1) || (ballot(my4 == lane_get(my4, j)) & same) != 0) { f = j; break; }
+                if ((same >> lane) & 1) later |= 1ull << j;
+            }
+            const int lim = f < e ? f : e;                // lanes < lim are decided exactly as the sequential parse decides them
+            const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
             const bool linear = (i0 == 0) && accel == 1;  // lane L probes pos0 + L (the default schedule is the identity below 66)
             // in-lane forward extension (<= 24 bytes), LZ4_count lz4.c:656-679: the probe-side bytes beyond +12 sit in
             // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
@@ -328,7 +344,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
                 const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
                 const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
-                if ((commit >> lane) & 1) tput(h, pos | mychk, ent);
+                if (((commit >> lane) & 1) && (later & commit) == 0) tput(h, pos | mychk, ent);
             }
             wave_fence();
             STAGE(3);

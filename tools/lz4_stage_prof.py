@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment: per-stage cycle breakdown of lz4_compress_kernel (batch.reserved & 8 build path)."""
+"""Experiment: per-stage cycle breakdown of lz4_compress_kernel.  Needs a library built with
+AOCLGPU_CFLAGS="-DAOCLGPU_EXPERIMENTS" (the release library ignores the switch and exports no aoclgpu_debug_* symbol)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,8 +9,7 @@ eng = a.engine(0)
 data = a.corpus.silesia_mix(64 << 20)
 src = torch.from_numpy(data).to(eng.device).repeat(16)
 chunk = 262144
-os.environ["AOCLGPU_EXPERIMENT"] = "8"
-slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk)
+slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk, flags=8)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_lz4_prof(buf)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment: per-stage cycle breakdown of the Zstd match finder (library built with AOCLGPU_CFLAGS=-DZSTD_PROF)."""
+"""Experiment: per-stage cycle breakdown of the Zstd match finder and decoder.  Needs a library built with
+AOCLGPU_CFLAGS="-DAOCLGPU_EXPERIMENTS -DZSTD_PROF"; ZEXP=16 skips the entropy stage (raw blocks), ZEXP=32 disables chain batches."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,8 +8,8 @@ import aocl_compression_amd as a
 eng = a.engine(0)
 data = a.corpus.silesia_mix(64 << 20)
 src = torch.from_numpy(data).to(eng.device).repeat(8)
-os.environ["AOCLGPU_EXPERIMENT"] = os.environ.get("ZEXP", "0")
-slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072)
+ZEXP = int(os.environ.get("ZEXP", "0"))
+slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072, flags=ZEXP)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_zstd_prof(buf)
@@ -22,6 +23,6 @@ torch.cuda.synchronize()
 eng.lib.aoclgpu_debug_zstd_dprof(buf)
 dn = ["literals section (Huffman table + 4 streams)", "sequence tables + bitstream init", "FSE sequence decode (lane 0)", "prefix sums + literal copies", "match copies (in order)"]
 tot = sum(buf[:5])
-print("---- decoder (entropy stage skipped on the compress side -> raw blocks!)" if os.environ.get("AOCLGPU_EXPERIMENT") == "16" else "---- decoder")
+print("---- decoder (entropy stage skipped on the compress side -> raw blocks!)" if ZEXP == 16 else "---- decoder")
 for n, v in zip(dn, buf[:5]):
     print(f"{n:48s} {v/tot*100:6.2f}%")
