@@ -193,10 +193,29 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 if (valid) table[h] = (uint16_t)cand;                     // undo the lane ids
             }
             wave_fence();
-            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
             const int e = first_lane(ballot(!valid));
+            // Lanes that share their slot with an earlier lane of the batch have a candidate that depends on the parse (the
+            // earlier lane's position if its table write happens, else the table entry).  Such a lane is still decided when
+            // neither can match: its table candidate fails the 4-byte test and no earlier lane on its slot holds its 4 bytes.
+            // The batch is cut at the first one that could match.  (With the 10-bit scratch of the HBM-table waves `w` also
+            // flags lanes whose full hashes differ: those are ordinary lanes.)  `later` = this lane's slot is named again by
+            // these later lanes; within one table commit the last of them owns the slot.
+            const uint64_t tabok = ballot(valid && (uint32_t)(cw.lo >> 32) == seq);
+            uint64_t later = 0;
+            int f = 64;
+            for (uint64_t d = ballot(valid && w != (uint32_t)lane); d; d &= d - 1) {
+                const int j = (int)__builtin_ctzll(d);
+                const uint64_t same = ballot(valid && h == lane_get(h, j)) & ((1ull << j) - 1);
+                if (!same) continue;
+                if (((tabok >> j) & 1) || (ballot(seq == lane_get(seq, j)) & same) != 0) { f = j; break; }
+                if ((same >> lane) & 1) later |= 1ull << j;
+            }
             const int lim = f < e ? f : e;
-            const uint64_t okmask = ballot(lane < lim && (uint32_t)(cw.lo >> 32) == seq);
+            const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
+            auto owns = [&](int a, int b) -> bool {       // lane in [a, b) and no later lane of [a, b) names its slot
+                const uint64_t r = (b >= 64 ? ~0ull : ((1ull << b) - 1)) & ~((1ull << a) - 1);
+                return ((r >> lane) & 1) && (later & r) == 0;
+            };
             const uint32_t pos0 = lane_get(pos, 0);
             // lanes [0, linlim) probe consecutive positions pos0 + lane (the schedule's first 33 steps are 1 byte)
             // in-lane forward extension (<= 24 bytes beyond the 4 tested), FindMatchLength snappy-internal.h:228-352
@@ -223,7 +242,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
                 const int m = first_lane(rem);
                 if (m >= 64) {                                            // lanes [start, hi) were probed without a match
-                    if (lane >= start && lane < hi) tput(h, pos, seq);
+                    if (owns(start, hi)) tput(h, pos, seq);
                     wave_fence();
                     // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
                     // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
@@ -234,7 +253,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     else i0 = (uint32_t)(hi - start);
                     break;
                 }
-                if (lane >= start && lane <= m) tput(h, pos, seq);                   // probes the reference executed
+                if (owns(start, m + 1)) tput(h, pos, seq);                           // probes the reference executed
                 wave_fence();
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
                 uint32_t matched = 4 + lane_get(fw, m);
