@@ -48,6 +48,14 @@ FLAG_ZSTD_LEVEL2 = 0x400      # Zstd level 2 instead of 1 (include/aocl_gpu_code
 FLAG_SNAPPY_TABLES_LDS, FLAG_SNAPPY_TABLES_HBM, FLAG_SNAPPY_TABLES_MIXED, FLAG_LZ4_TABLE_U32 = 0x1000, 0x2000, 0x4000, 0x0800
 
 
+FLAG_ZSTD_UPSTREAM_TABLE = 0x80000
+
+
+def zstd_level(level: int, upstream_table: bool = False) -> int:
+    """AOCLGPU_ZSTD_LEVEL(level) [| AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE]: Zstd level 1..4 as batch flags"""
+    return ((int(level) & 7) << 16) | (FLAG_ZSTD_UPSTREAM_TABLE if upstream_table else 0)
+
+
 def lz4_acceleration(a: int) -> int:
     """AOCLGPU_LZ4_ACCELERATION(a): LZ4_compress_fast's acceleration (1..65537) as batch flags"""
     return (min(max(int(a), 1), 65537) - 1) << 15

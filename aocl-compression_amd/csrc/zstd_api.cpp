@@ -3,8 +3,8 @@
 // ZSTD_getParams / ZSTD_CCtx_setParameter / ZSTD_compress_advanced / ZSTD_decompressDCtx) and the parameter tables.
 // Host buffers, no CPU fallback.
 //
-// What has a GPU backend: the "fast" strategy with the parameters of levels 1 and 2 (clevels.h:24-130), single-segment
-// frames with a content size and no checksum.  Inputs of at most 128 KiB give the reference's bytes (one block per
+// What has a GPU backend: the "fast" and "double-fast" strategies with the parameters of levels 1-4 (clevels.h:24-130,
+// 155-262; level 0 is the default, 3), single-segment frames with a content size and no checksum.  Inputs of at most 128 KiB give the reference's bytes (one block per
 // frame).  Larger inputs are cut into 128 KiB pieces that become independent frames, concatenated: a valid Zstandard
 // stream that every decoder reads (ZSTD_decompress handles multi-frame input, zstd_decompress.c:1113), but NOT the
 // reference's bytes, which come from one multi-block frame with a window across blocks (deviations).
@@ -124,16 +124,19 @@ bool params_in_bounds(const ZSTD_compressionParameters& c)
            (int)c.strategy >= 1 && (int)c.strategy <= 9;
 }
 
-// which GPU parse (1 or 2) these parameters describe for an n-byte input; 0 = none
+// which level's GPU parse (1..4) these parameters describe for an n-byte input; 0 = none.  Levels 1-2 are the "fast"
+// strategy, 3-4 "double-fast" (for the sizes where the level table says so).
 int gpu_level_for(const ZSTD_compressionParameters& c, size_t n)
 {
-    if (c.strategy != ZSTD_fast || c.targetLength > 1) return 0;         // stepSize 2 only (zstd_fast.c:440)
+    if ((c.strategy != ZSTD_fast && c.strategy != ZSTD_dfast) || c.targetLength > 1) return 0;   // fast: stepSize 2 only (zstd_fast.c:440)
     if (n == 0) return 1;                                                // an empty frame: no parameter shows in the output
-    // the parameters must be those of level 1 or 2 for THIS input size (inputs above 128 KiB are then cut into 128 KiB
-    // pieces, each compressed with that level's parameters for a piece: the documented multi-frame deviation)
-    for (int level = 1; level <= 2; ++level) {
+    // the parameters must be those of a level for THIS input size (inputs above 128 KiB are then cut into 128 KiB pieces,
+    // each compressed with that level's parameters for a piece: the documented multi-frame deviation)
+    for (int level = 1; level <= 4; ++level) {
         const ZSTD_compressionParameters w = cparams_for(level, n, 0);
-        if (w.strategy == ZSTD_fast && w.hashLog == c.hashLog && w.minMatch == c.minMatch) return level;
+        if (w.strategy != c.strategy || w.hashLog != c.hashLog || w.minMatch != c.minMatch) continue;
+        if (c.strategy == ZSTD_dfast && w.chainLog != c.chainLog) continue;
+        return level;
     }
     return 0;
 }
@@ -145,11 +148,11 @@ size_t compress_with(const ZSTD_compressionParameters& c, const ZSTD_frameParame
     if (!level) return zerr(kErrParamUnsupported);
     if (!f.contentSizeFlag || f.checksumFlag) return zerr(kErrParamUnsupported);
     if (((size_t)1 << c.windowLog) < (n > (128u << 10) ? (128u << 10) : n)) return zerr(kErrParamUnsupported);   // frames are single-segment
-    const uint32_t flags = level == 2 ? AOCLGPU_FLAG_ZSTD_LEVEL2 : 0u;
+    const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
     const int64_t r = n > (128u << 10) ? aoclgpu_zstd_compress_host_frames(src, n, dst, cap, flags)
                                        : aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, n, dst, cap, flags);
     if (r > 0) return (size_t)r;
-    if (r == 0) return zerr(kErrDstTooSmall);
+    if (r == 0) return zerr(cap < ZSTD_compressBound(n) ? kErrDstTooSmall : kErrParamUnsupported);   // 0 with room: no GPU parse for a piece
     return zerr(kErrGeneric);
 }
 }  // namespace

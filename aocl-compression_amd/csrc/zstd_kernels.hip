@@ -39,6 +39,7 @@ constexpr u32 kSchedLen = 960;
 constexpr u32 kRingBlk = 240;                   // source ring of the chain batches: two 240-byte blocks + a 32-byte mirror
 }
 constexpr uint32_t kSrcRingBytes = 512;
+constexpr uint32_t kDfScratchBytes = 4096;
 namespace {
 
 // ---- pair schedule of the fast match finder (zstd_fast.c:491-631): offset of pair m from the search
@@ -106,6 +107,31 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
         if (l == 64) { n += 256; continue; }
         return n + 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
     }
+}
+
+// Literal buffer of a block: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the search
+// loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal lengths, short runs one per
+// lane, long runs by the whole wave.  Returns the size of the last literal run (the others were counted by the parse).
+__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws, const u32 nbSeq, const u32 anchor, int lane)
+{
+    u32 lpos = 0;
+    for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
+        const u32 q = q0 + (u32)lane;
+        u32 ll = 0, sp = 0;
+        if (q < nbSeq) { ll = ws->seqLL[q]; sp = ws->seqSrc[q]; }
+        u32 inc = ll;
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        const u32 dp = lpos + inc - ll;
+        if (ll <= 24) for (u32 i = 0; i < ll; ++i) ws->lits[dp + i] = src[sp + i];
+        for (u64 lm = ballot(ll > 24); lm; lm &= lm - 1) {
+            const int k = (int)__builtin_ctzll(lm);
+            wave_copy(ws->lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
+        }
+        lpos += lane_get(inc, 63);
+    }
+    wave_copy(ws->lits + lpos, src + anchor, n - anchor, lane);
+    wave_fence();
+    return n - anchor;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,29 +482,186 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq); }
 #endif
     flush_seq(nbSeq & ~63u, nbSeq & 63u);
-    // ---- literal buffer: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the
-    //      search loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal
-    //      lengths, short runs one per lane, long runs by the whole wave.
     wave_fence();
-    u32 lpos = 0;
-    for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
-        const u32 q = q0 + (u32)lane;
-        u32 ll = 0, sp = 0;
-        if (q < nbSeq) { ll = ws->seqLL[q]; sp = ws->seqSrc[q]; }
-        u32 inc = ll;
-        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-        const u32 dp = lpos + inc - ll;
-        if (ll <= 24) for (u32 i = 0; i < ll; ++i) ws->lits[dp + i] = src[sp + i];
-        for (u64 lm = ballot(ll > 24); lm; lm &= lm - 1) {
-            const int k = (int)__builtin_ctzll(lm);
-            wave_copy(ws->lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
+    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    return nbSeq;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Double-fast match finder (levels 3-4): AOCL_ZSTD_compressBlock_doubleFast_noDict_generic, zstd_double_fast.c:332-573
+// (ilimit = iend - 8 - 19, :351).  Two tables: L hashes 8 bytes, S hashes minMatch bytes; 2^16-2^17 + 2^13-2^17 u32 entries -
+// far beyond LDS - so both live in this workgroup's slice of the HBM workspace (relaxed agent-scope accesses: served by L2,
+// never by a stale L1 line; a wave's vector memory operations reach L2 in order).
+//
+// Same exact speculation as the other parsers.  Between two sequences the reference probes a data-independent schedule of
+// positions (1-byte steps for 256 bytes, then the step grows by one every 256 bytes, :403-473); lane k evaluates probe k:
+// both hashes, both table entries, both candidates, the repcode test at position + 1.  The batch is cut at the first lane
+// whose long or short slot an earlier lane of the batch names (LDS scratch rounds on 10 hash bits, then the full hashes);
+// the first event in probe order wins (per probe: repcode, long match, short match - :425, :438, :456), and exactly the
+// probes up to it write both tables.  What follows an event is wave-uniform: the "long match one position further" test
+// reads the table after the commit, so it sees what the reference sees.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kDfSchedLen = 1800;               // probes of one search within a 128 KiB block (offset 131072 is passed at probe 1758)
+struct DfSched {
+    u32 a[kDfSchedLen + 1];
+    constexpr DfSched() : a() {
+        u32 ip = 0, step = 1, nextStep = 256, ip1 = 1;
+        for (u32 m = 0; m <= kDfSchedLen; ++m) {
+            a[m] = ip;
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 += step;
         }
-        lpos += lane_get(inc, 63);
     }
-    wave_copy(ws->lits + lpos, src + anchor, n - anchor, lane);
-    litSize += n - anchor;
+};
+__device__ const DfSched g_dfs{};
+constexpr u32 kDfScratch = 1024;                // u16 slots per hash for the slot-reuse rounds
+
+__device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }   // ZSTD_hash8
+
+template <int MLS>
+__device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlogL, const u32 hlogS, u32* tabs, lbyte* lds,
+                           Workspace* ws, u32* litSizeOut, int lane)
+{
+    typedef __attribute__((address_space(1))) u32 gu32;
+    typedef __attribute__((address_space(3))) uint16_t lu16;
+    gu32* L = (gu32*)tabs;
+    gu32* S = L + (1u << hlogL);
+    {   // fresh tables (ZSTD_reset_matchState clears them for a new frame)
+        typedef u32 u4 __attribute__((ext_vector_type(4)));
+        const u32 quads = ((1u << hlogL) + (1u << hlogS)) / 4;
+        for (u32 i = (u32)lane; i < quads; i += kWave) ((__attribute__((address_space(1))) u4*)L)[i] = u4{0, 0, 0, 0};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+    auto tget = [&](gu32* t, u32 h) -> u32 { return __hip_atomic_load((u32*)(t + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tput = [&](gu32* t, u32 h, u32 v) { __hip_atomic_store((u32*)(t + h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    lu16* scrL = (lu16*)lds; lu16* scrS = scrL + kDfScratch;
+    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;           // sequence records parked one per lane, written 64 at a time
+    auto flush_seq = [&](u32 first, u32 count) {
+        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
+    };
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
+        const bool me = (u32)lane == (idx & 63u);
+        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
+        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
+    };
+    // backward extension of a match at (ip, m): bytes equal before both, at most maxback (catch-up loops :446, :502, :510)
+    auto back_count = [&](u32 ip, u32 m, u32 maxback) -> u32 {
+        u32 back = 0;
+        while (back < maxback) {
+            const u32 k = back + (u32)lane;
+            bool eq = false;
+            if (k < maxback) eq = src[ip - 1 - k] == src[m - 1 - k];
+            const int c = first_lane(ballot(!eq));
+            back += (u32)c;
+            if (c < 64) break;
+        }
+        return back < maxback ? back : maxback;
+    };
+    u32 nbSeq = 0, litSize = 0, anchor = 0, s = 1, rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399)
+    const int64_t ilimit = (int64_t)n - 8 - 19;
+    u32 i0 = 0;                                              // probes of the current search already examined
+    for (;;) {
+        // ---------------- one batch of 64 speculative probes ----------------
+        const u32 m = i0 + (u32)lane;
+        u32 am, am1;
+        if (m < 256) { am = m; am1 = m + 1; }                // (the schedule is the identity for the first 256 bytes)
+        else if (m < kDfSchedLen) { am = g_dfs.a[m]; am1 = g_dfs.a[m + 1]; }
+        else { am = 0x40000000u; am1 = 0x40000000u; }
+        const bool valid = (int64_t)s + (int64_t)am1 <= ilimit;             // the loop reaches probe m (:405, :473)
+        const u32 pos = s + am;
+        u64 v8 = 0;
+        if (valid) v8 = ld64(src + pos);
+        const u32 hl = z_hash8(v8, hlogL), hs = z_hash<MLS>(v8, hlogS);
+        u32 idxl = 0, idxs = 0;
+        if (valid) { idxl = tget(L, hl); idxs = tget(S, hs); }
+        u64 cl = ~v8; u32 cs = ~(u32)v8, r4 = ~(u32)(v8 >> 8);
+        if (valid && idxl > 2) cl = ld64(src + idxl - 2);
+        if (valid && idxs > 2) cs = ld32(src + idxs - 2);
+        if (valid && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
+        const bool repHit = r4 == (u32)(v8 >> 8), longHit = cl == v8, shortHit = cs == (u32)v8;
+        wave_fence();
+        const u32 wl = lds_first_lane_per_slot((u32)(uintptr_t)(scrL + (hl & (kDfScratch - 1))), (u32)lane, valid);
+        wave_fence();
+        const u32 wsm = lds_first_lane_per_slot((u32)(uintptr_t)(scrS + (hs & (kDfScratch - 1))), (u32)lane, valid);
+        wave_fence();
+        int f = 64;                                          // first lane whose long or short slot an earlier lane names
+        for (u64 d = ballot(valid && (wl != (u32)lane || wsm != (u32)lane)); d; d &= d - 1) {
+            const int j = (int)__builtin_ctzll(d);
+            const u64 before = (1ull << j) - 1;
+            if (((ballot(valid && hl == lane_get(hl, j)) | ballot(valid && hs == lane_get(hs, j))) & before) != 0) { f = j; break; }
+        }
+        const int e = first_lane(ballot(!valid));
+        const int lim = f < e ? f : e;
+        const int el = first_lane(ballot(lane < lim && (repHit || longHit || shortHit)));
+        const int ncommit = el < 64 ? el + 1 : lim;
+        if (lane < ncommit) { tput(L, hl, pos + 2); tput(S, hs, pos + 2); }   // hashLong[hl0] = hashSmall[hs0] = curr (:423)
+        wave_fence();
+        if (el >= 64) {
+            if (e < 64 && e <= f) break;                     // the next probe's successor would pass ilimit: _cleanup
+            i0 += (u32)lim;
+            continue;
+        }
+        // ---------------- the event, wave-uniform from here ----------------
+        const u32 curr = lane_get(pos, el), ip1 = s + lane_get(am1, el), stepE = lane_get(am1, el) - lane_get(am, el);
+        const int kind = lane_get((u32)repHit, el) ? 2 : (lane_get((u32)longHit, el) ? 1 : 3);
+        u32 ip = curr, mLength;
+        if (kind == 2) {                                     // repcode at ip+1 (:425-431)
+            ip = curr + 1;
+            mLength = wave_count(src, ip + 4, ip + 4 - rep1, n, lane) + 4;
+            put_seq(nbSeq, ip - anchor, 1u, mLength, anchor);
+            litSize += ip - anchor; nbSeq++;
+        } else {
+            const u64 v1 = ld64(src + ip1);
+            const u32 hl1 = uni(z_hash8(v1, hlogL));
+            u32 mpos;
+            bool isLong = kind == 1;
+            if (kind == 1) mpos = lane_get(idxl, el) - 2;    // long match at ip (:436-449)
+            else {                                           // short match: a long match at ip1 wins (:495-504)
+                const u32 idxl1 = uni(tget(L, hl1));
+                u64 c1 = ~v1;
+                if (idxl1 > 2) c1 = ld64(src + idxl1 - 2);
+                if (uni(c1 == v1 ? 1u : 0u)) { ip = ip1; mpos = idxl1 - 2; isLong = true; }
+                else mpos = lane_get(idxs, el) - 2;
+            }
+            const u32 base = isLong ? 8u : 4u;
+            mLength = wave_count(src, ip + base, mpos + base, n, lane) + base;
+            const u32 offset = ip - mpos;
+            {   const u32 a = ip - anchor, maxback = a < mpos ? a : mpos;
+                const u32 back = back_count(ip, mpos, maxback);
+                ip -= back; mLength += back;
+            }
+            rep2 = rep1; rep1 = offset;
+            if (stepE < 4) { if (lane == 0) tput(L, hl1, ip1 + 2); }         // :516-526
+            put_seq(nbSeq, ip - anchor, offset + 3u, mLength, anchor);
+            litSize += ip - anchor; nbSeq++;
+        }
+        ip += mLength; anchor = ip;                          // _match_stored
+        if ((int64_t)ip <= ilimit) {
+            const u32 ins = curr + 2;                        // complementary insertions (:550-554), in the reference's order
+            const u64 va = ld64(src + ins), vb = ld64(src + ip - 2), vc = ld64(src + ip - 1);
+            if (lane == 0) {
+                tput(L, z_hash8(va, hlogL), ins + 2);
+                tput(L, z_hash8(vb, hlogL), ip - 2 + 2);
+                tput(S, z_hash<MLS>(va, hlogS), ins + 2);
+                tput(S, z_hash<MLS>(vc, hlogS), ip - 1 + 2);
+            }
+            wave_fence();
+            while ((int64_t)ip <= ilimit && rep2 > 0 && uni(ld32(src + ip) == ld32(src + ip - rep2) ? 1u : 0u)) {   // :558-572
+                const u32 rLength = wave_count(src, ip + 4, ip + 4 - rep2, n, lane) + 4;
+                const u32 t = rep2; rep2 = rep1; rep1 = t;
+                const u64 vi = ld64(src + ip);
+                if (lane == 0) { tput(S, z_hash<MLS>(vi, hlogS), ip + 2); tput(L, z_hash8(vi, hlogL), ip + 2); }
+                put_seq(nbSeq, 0, 1u, rLength, ip);
+                wave_fence();
+                nbSeq++;
+                ip += rLength; anchor = ip;
+            }
+        }
+        s = ip; i0 = 0;
+    }
+    flush_seq(nbSeq & ~63u, nbSeq & 63u);
     wave_fence();
-    *litSizeOut = litSize;
+    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
     return nbSeq;
 }
 
@@ -602,11 +785,11 @@ __device__ u32 compress_literals(u8* dst, const u8* src, u32 n, bool suspect, En
 // sequences
 // ------------------------------------------------------------------------------------------------
 // ZSTD_selectEncodingType, strategy fast, first block (zstd_compress_sequences.c:156-204): 0 basic, 1 rle, 2 compressed
-__device__ int select_type(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool defaultAllowed)
+__device__ int select_type(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool defaultAllowed, u32 strategy)
 {
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
-        const u32 dynMin = ((1u << defaultNormLog) * 9) >> 3;
+        const u32 dynMin = ((1u << defaultNormLog) * (10 - strategy)) >> 3;               // mult = 10 - strategy (:184-186)
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defaultNormLog - 1))) return 0;
     }
     return 2;
@@ -615,7 +798,7 @@ __device__ int select_type(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool
 // histogram + mode + table description + CTable of one symbol stream (ZSTD_buildCTable :242-288).
 // All lanes call it; returns type (or -1), advances *op, updates *lastCount.
 __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 nbSeq, u32 maxCode, u32 fseLog,
-                            const s16* defNorm, u32 defLog, u32 defMax, u32* lastCount, EntropyLds* L, int lane)
+                            const s16* defNorm, u32 defLog, u32 defMax, u32* lastCount, EntropyLds* L, int lane, u32 strategy)
 {
     for (u32 i = (u32)lane; i < 64; i += kWave) L->count[i] = 0;
     wave_fence();
@@ -626,7 +809,7 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
     u32 c = (u32)lane <= maxCode ? L->count[lane] : 0u;
     const u32 max = (u32)top_lane(ballot(c != 0)), most = uni(wmaxu(c));
     const bool defaultAllowed = (defMax == 28) ? (max <= 28) : true;                  // zstd_compress.c:2847-2848
-    type = select_type(most, nbSeq, defLog, defaultAllowed);
+    type = select_type(most, nbSeq, defLog, defaultAllowed, strategy);
     FseScratch* fs = &L->hs.fs;
     if (type == 1) {
         if (lane == 0) { fse_build_rle(ct, max); base[*op] = codes[0]; }
@@ -654,7 +837,7 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
 }
 
 // ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027): block content size, 0 = emit raw
-__device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, EntropyLds* L, int lane)
+__device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, EntropyLds* L, int lane, u32 strategy)
 {
     u32 op = 0;
     const bool suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
@@ -675,11 +858,11 @@ __device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, 
     wave_fence();
     const u32 seqHead = op++;
     u32 lastCount = 0;
-    const int tLL = build_stream(dst, &op, &L->ctLL, ws->llc, nbSeq, 35, 9, kLLnorm, 6, 35, &lastCount, L, lane);
+    const int tLL = build_stream(dst, &op, &L->ctLL, ws->llc, nbSeq, 35, 9, kLLnorm, 6, 35, &lastCount, L, lane, strategy);
     if (tLL < 0) return 0;
-    const int tOF = build_stream(dst, &op, &L->ctOF, ws->ofc, nbSeq, 31, 8, kOFnorm, 5, 28, &lastCount, L, lane);
+    const int tOF = build_stream(dst, &op, &L->ctOF, ws->ofc, nbSeq, 31, 8, kOFnorm, 5, 28, &lastCount, L, lane, strategy);
     if (tOF < 0) return 0;
-    const int tML = build_stream(dst, &op, &L->ctML, ws->mlc, nbSeq, 52, 9, kMLnorm, 6, 52, &lastCount, L, lane);
+    const int tML = build_stream(dst, &op, &L->ctML, ws->mlc, nbSeq, 52, 9, kMLnorm, 6, 52, &lastCount, L, lane, strategy);
     if (tML < 0) return 0;
     if (lane == 0) dst[seqHead] = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
 
@@ -743,22 +926,53 @@ __device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, 
     return op;
 }
 
-// cParams for levels 1 and 2 and a known size (clevels.h:80-82,107-108 + ZSTD_adjustCParams_internal zstd_compress.c:1575-1595):
-// both are the "fast" strategy with step 2 for chunks of at most 128 KiB; level 2 has a 2^15-slot table and minMatch 5
-// (4 for chunks of at most 16 KiB)
-__device__ __forceinline__ void level_params(u32 level, u32 n, u32* hlog, u32* mls)
+// cParams of levels 1..4 for a known size of at most 128 KiB: the rows of clevels.h:80-88,106-114 (upstream table) and
+// :211-219,237-245 (the AOCL table the reference uses once its dispatcher has run: it differs in the double-fast rows) after
+// ZSTD_adjustCParams_internal (zstd_compress.c:1575-1595: windowLog <= srcLog, hashLog <= windowLog + 1, chainLog <= windowLog).
+// strategy 1 = fast (levels 1-2: one table of 2^hlog slots, step 2), 2 = double-fast (levels 3-4: long table 2^hlog, short
+// table 2^clog), 0 = no GPU parse (level 4 is "greedy" for inputs of at most 16 KiB).
+struct ZParams { u32 strategy, hlog, clog, mls; };
+__device__ __forceinline__ ZParams level_cparams(u32 level, bool upstream, u32 n)
 {
     const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
-    if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; *hlog = (15 < w + 1) ? 15 : w + 1; *mls = level == 2 ? 4 : 5; }
-    else { const u32 w = srcLog < 17 ? srcLog : 17, hl = level == 2 ? 15 : 13; *hlog = (hl < w + 1) ? hl : w + 1; *mls = level == 2 ? 5 : 6; }
+    u32 W, C, H, M, strat;
+    if (n <= 16384) {
+        W = 14;
+        if (level <= 1) { C = 14; H = 15; M = 5; strat = 1; }
+        else if (level == 2) { C = 14; H = 15; M = 4; strat = 1; }
+        else if (level == 3) { C = upstream ? 14 : 13; H = 15; M = 4; strat = 2; }
+        else { C = 14; H = 14; M = 4; strat = 0; }
+    } else {
+        W = 17;
+        if (level <= 1) { C = 12; H = 13; M = 6; strat = 1; }
+        else if (level == 2) { C = 13; H = 15; M = 5; strat = 1; }
+        else if (level == 3) { C = upstream ? 15 : 14; H = 16; M = 5; strat = 2; }
+        else { C = upstream ? 17 : 15; H = 17; M = 4; strat = 2; }
+    }
+    const u32 w = srcLog < W ? srcLog : W;
+    ZParams p;
+    p.strategy = strat; p.hlog = H < w + 1 ? H : w + 1; p.clog = C < w ? C : w; p.mls = M;
+    return p;
+}
+__device__ __forceinline__ void level_params(u32 level, u32 n, u32* hlog, u32* mls)
+{
+    const ZParams p = level_cparams(level, false, n);
+    *hlog = p.hlog; *mls = p.mls;
 }
 __device__ __forceinline__ void level1_params(u32 n, u32* hlog, u32* mls) { level_params(1, n, hlog, mls); }
+__device__ __forceinline__ u32 flags_level(u32 flags)
+{   // AOCLGPU_ZSTD_LEVEL(l) in bits 16-18 (0 = not given); AOCLGPU_FLAG_ZSTD_LEVEL2 is the older spelling of level 2
+    const u32 l = (flags >> 16) & 7u;
+    return l ? l : ((flags & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2u : 1u);
+}
 
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
-                                  void* lds, u32 ldsBytes, Workspace* ws, int lane, u32 expf)
+                                  void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf)
 {
     const u32 bound = n + (n >> 8) + (n < kBlockMax ? ((kBlockMax - n) >> 11) : 0);
     if (n > kBlockMax || cap < bound || cap < 9) return 0;
+    const ZParams zp = level_cparams(flags_level(expf), (expf & AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE) != 0, n);
+    if (zp.strategy == 0 || (zp.strategy == 2 && !tabs)) return 0;      // no GPU parse for these parameters / launcher gave no tables
     u32 op = 0;
     const u32 fcs = (n >= 256) + (n >= 65536 + 256);
     if (lane == 0) {                                                     // ZSTD_writeFrameHeader :4586-4632
@@ -772,22 +986,27 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n == 0) { if (lane == 0) { dst[op] = 1; dst[op + 1] = 0; dst[op + 2] = 0; } return (int)(op + 3); }   // ZSTD_writeEpilogue
     u32 cSize = 0;
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
-        u32 hlog, mls, litSize = 0, nbSeq;
-        const u32 level = (expf & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2u : 1u;
-        level_params(level, n, &hlog, &mls);
-        const bool hi = n > 16384;
-        const u32 need = (2u << hlog) + (hi ? (1u << hlog) / 8 : 0u) + kSrcRingBytes;
-        if (need > ldsBytes) return 0;                                   // launcher sizes LDS per chunk class
-        if (mls == 4) nbSeq = fast_block<4, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
-        else if (mls == 6) nbSeq = fast_block<6, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
-        else if (hi) nbSeq = fast_block<5, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
-        else nbSeq = fast_block<5, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        u32 litSize = 0, nbSeq;
+        const u32 hlog = zp.hlog, mls = zp.mls;
+        if (zp.strategy == 2) {
+            if (2u * 2u * kDfScratch > ldsBytes) return 0;
+            if (mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+            else nbSeq = dfast_block<5>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+        } else {
+            const bool hi = n > 16384;
+            const u32 need = (2u << hlog) + (hi ? (1u << hlog) / 8 : 0u) + kSrcRingBytes;
+            if (need > ldsBytes) return 0;                               // launcher sizes LDS per chunk class
+            if (mls == 4) nbSeq = fast_block<4, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+            else if (mls == 6) nbSeq = fast_block<6, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+            else if (hi) nbSeq = fast_block<5, u16, true>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+            else nbSeq = fast_block<5, u16, false>((const gbyte*)src, n, hlog, (lbyte*)lds, ws, &litSize, lane, expf);
+        }
         wave_fence();
 #ifdef AOCLGPU_EXPERIMENTS
         if (expf & 16) cSize = 0;      // experiment build (timing only): match finder alone, block emitted raw
         else
 #endif
-        cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane);
+        cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane, zp.strategy);
         if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                      // ZSTD_minGain, zstd_compress.c:3055-3057
     }
     if (cSize == 0) {                                                    // ZSTD_noCompressBlock
@@ -1479,14 +1698,15 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
 }  // namespace
 
 __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
-                                                           uint32_t first, uint32_t count)
+                                                           uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
+    u32* tabs = tabBase ? reinterpret_cast<u32*>(tabBase + (size_t)blockIdx.x * tabBytes) : nullptr;   // double-fast: this workgroup's two tables
     const int lane = lane_id();
     for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = zstd_compress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, lane, b.reserved);
+        const int r = zstd_compress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, tabs, lane, b.reserved);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -1519,7 +1739,8 @@ using aoclgpu::get_workspace;
 uint32_t lds_for_chunk(uint64_t n, int level = 1)
 {   // hash table bytes of the level's parameters for an n-byte chunk, never less than the entropy-stage LDS
     uint32_t need;
-    if (n <= 16384) {
+    if (level >= 3) need = aoclgpu::kDfScratchBytes;     // double-fast: tables in HBM, LDS only holds the slot-reuse scratch
+    else if (n <= 16384) {
         uint32_t srcLog = 6; if (n >= 64) { srcLog = 0; uint64_t t = n - 1; while (t) { srcLog++; t >>= 1; } }
         const uint32_t w = srcLog < 14 ? srcLog : 14, hl = (15 < w + 1) ? 15 : w + 1;
         need = (2u << hl) + aoclgpu::kSrcRingBytes;
@@ -1643,8 +1864,11 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
     // launch classes: uniform mode -> body chunks share one LDS size, the ragged tail chunk gets its own launch;
     // explicit mode -> sizes live on the device, so every block gets the largest table (64 KiB)
     struct Launch { uint32_t first, count, lds; } L[2]; int nl = 0;
-    const int level = (b->reserved & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2 : 1;
-    if (b->src_off) { L[nl++] = { 0, b->nchunks, level == 2 ? lds_for_chunk(128u << 10, 2) : 65536u }; }
+    const int level = (int)(((b->reserved >> 16) & 7u) ? ((b->reserved >> 16) & 7u) : ((b->reserved & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2u : 1u));
+    if (level > 4) { aoclgpu::set_error_msg("zstd: levels 1-4 have a GPU match finder"); return AOCLGPU_ERR_ARG; }
+    // double-fast (levels 3-4): the two hash tables of a resident workgroup live in the workspace, behind the sequence stores
+    const size_t tabBytes = level >= 4 ? ((size_t)2 << 17) * 4 : (level == 3 ? (((size_t)1 << 16) + ((size_t)1 << 15)) * 4 : 0);
+    if (b->src_off) { L[nl++] = { 0, b->nchunks, level >= 2 ? lds_for_chunk(128u << 10, level) : 65536u }; }
     else {
         const uint64_t tail = b->total_bytes - (uint64_t)(b->nchunks - 1) * b->chunk_bytes;
         if (b->chunk_bytes > (128u << 10) && b->nchunks > 1) { aoclgpu::set_error_msg("zstd: chunk_bytes > 128 KiB"); return AOCLGPU_ERR_ARG; }
@@ -1669,13 +1893,16 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         }
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
-        void* ws = get_workspace(guard, (size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
+        const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
+        void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+        uint8_t* tabBase = tabBytes ? (uint8_t*)ws + seqBytes : nullptr;
         if (L[i].lds > 65536u) {
             hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
             if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
         }
-        hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count);
+        hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
+                           tabBase, (uint32_t)tabBytes);
         if (int rc = aoclgpu::check_launch("zstd_compress_kernel")) return rc;
     }
     return AOCLGPU_OK;

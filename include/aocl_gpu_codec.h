@@ -76,6 +76,14 @@ typedef struct {
 /* Zstd compress: level 2 instead of level 1 (clevels.h:82,108: still the "fast" strategy for chunks <= 128 KiB, with a 2^15-slot
  * table - 68 KB of LDS, 2 chunks per CU - and minMatch 5 / 4); frames byte-identical to ZSTD_compress(.., 2). */
 #define AOCLGPU_FLAG_ZSTD_LEVEL2 0x400u
+/* Zstd compress: compression level 1..4 in bits 16-18 (0 there = level 1, or 2 with AOCLGPU_FLAG_ZSTD_LEVEL2).  Every chunk
+ * gets the parameters the reference derives for (level, chunk size): levels 1-2 the "fast" strategy, levels 3-4 "double-fast"
+ * (zstd_double_fast.c; two hash tables per resident workgroup in an HBM workspace; level 4 has no GPU parse for chunks of at
+ * most 16 KiB, where the reference switches to "greedy": such chunks report 0).  AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE selects the
+ * upstream level table (clevels.h:24-130) instead of the AOCL one (:155-262) the reference's dispatcher installs - they
+ * differ in the double-fast rows only. */
+#define AOCLGPU_ZSTD_LEVEL(l)            (((uint32_t)(l) & 7u) << 16)
+#define AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE 0x80000u
 
 /* Kernel selection.  None of these changes one output byte; they pin a choice the launcher otherwise makes from the
  * batch shape, so that tests can drive every kernel on small batches (tests/test_snappy_gpu.py, tests/test_lz4_gpu.py).

@@ -559,11 +559,12 @@ static u32 ml_code(u32 v)
 }
 
 /* ZSTD_selectEncodingType for strategy ZSTD_fast, first block (zstd_compress_sequences.c:156-204): 0 basic,1 rle,2 compressed */
+static u32 g_strategy = 1;      /* ZSTD_strategy of the frame being written: 1 fast, 2 double-fast (set by orc_zstd_compress_cparams) */
 static int select_type(u32 mostFrequent, size_t nbSeq, u32 defaultNormLog, int defaultAllowed)
 {
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
-        const size_t dynMin = (((size_t)1 << defaultNormLog) * 9) >> 3;
+        const size_t dynMin = (((size_t)1 << defaultNormLog) * (10 - g_strategy)) >> 3;   /* mult = 10 - strategy (:184-186) */
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defaultNormLog - 1))) return 0;
     }
     return 2;
@@ -731,6 +732,97 @@ cleanup:
     return nbSeq;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * match finder of levels 3-4: AOCL_ZSTD_compressBlock_doubleFast_noDict_generic (zstd_double_fast.c:332-573, the variant
+ * the default build dispatches to; AOCL_ZSTD_SEARCH_SKIP_OPT_DFAST_FAST is off, so it is the upstream parse :99-305 with
+ * ilimit = iend - 8 - 19, :351).  Two tables: `L` hashes 8 bytes (hashLog bits), `S` hashes minMatch bytes (chainLog
+ * bits); fresh context: indices are position + 2, a candidate is usable when its index is > 2 (:438, :456).
+ * ------------------------------------------------------------------------------------------ */
+static u32 z_hash8(const u8* p, u32 hlog) { return (u32)((z_rd64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); }   /* ZSTD_hash8 */
+
+static size_t dfast_block(const u8* src, u32 n, u32 hlogL, u32 hlogS, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+{
+    u32* L = (u32*)calloc((size_t)1 << hlogL, sizeof(u32));
+    u32* S = (u32*)calloc((size_t)1 << hlogS, sizeof(u32));
+    size_t nbSeq = 0, litSize = 0;
+    u32 anchor = 0, ip = 1, off1 = 1, off2 = 0;                      /* rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399) */
+    const int64_t ilimit = (int64_t)n - 8 - 19;
+#define DF_STORE(ll_, ob_, ml_) do { seqs[nbSeq].litLength = (ll_); seqs[nbSeq].offBase = (ob_); seqs[nbSeq].matchLength = (ml_); nbSeq++; \
+        memcpy(lits + litSize, src + anchor, (ll_)); litSize += (ll_); } while (0)
+    for (;;) {                                                        /* one iteration per sequence (:402) */
+        u32 step = 1, nextStep = ip + 256, ip1 = ip + 1;
+        u32 hl0, hl1 = 0, idxl0, idxl1 = 0, idxs0 = 0, curr = 0, mLength, offset, m;
+        if ((int64_t)ip1 > ilimit) goto cleanup;
+        hl0 = z_hash8(src + ip, hlogL); idxl0 = L[hl0];
+        do {                                                          /* one iteration per position (:419) */
+            const u32 hs0 = z_hash(src + ip, hlogS, mls);
+            idxs0 = S[hs0];
+            curr = ip;                                                /* (position; the tables hold curr + 2) */
+            L[hl0] = S[hs0] = curr + 2;
+            if (off1 > 0 && z_rd32(src + ip + 1 - off1) == z_rd32(src + ip + 1)) {      /* repcode at ip+1 (:425-431) */
+                mLength = z_count(src, ip + 1 + 4, ip + 1 + 4 - off1, n) + 4;
+                ip++;
+                DF_STORE(ip - anchor, 1, mLength);
+                goto match_stored;
+            }
+            hl1 = z_hash8(src + ip1, hlogL);
+            if (idxl0 > 2 && z_rd64(src + idxl0 - 2) == z_rd64(src + ip)) {             /* long match at ip (:436-449) */
+                m = idxl0 - 2;
+                mLength = z_count(src, ip + 8, m + 8, n) + 8;
+                offset = ip - m;
+                while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+                goto match_found;
+            }
+            idxl1 = L[hl1];
+            if (idxs0 > 2 && z_rd32(src + idxs0 - 2) == z_rd32(src + ip)) goto search_next_long;   /* short match (:454-460) */
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1;
+        } while ((int64_t)ip1 <= ilimit);
+        goto cleanup;
+search_next_long:
+        if (idxl1 > 2 && z_rd64(src + idxl1 - 2) == z_rd64(src + ip1)) {                /* a long match one position on wins (:495-504) */
+            m = idxl1 - 2;
+            ip = ip1;
+            mLength = z_count(src, ip + 8, m + 8, n) + 8;
+            offset = ip - m;
+            while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+            goto match_found;
+        }
+        m = idxs0 - 2;
+        mLength = z_count(src, ip + 4, m + 4, n) + 4;
+        offset = ip - m;
+        while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+match_found:
+        off2 = off1; off1 = offset;
+        if (step < 4) L[hl1] = ip1 + 2;                               /* :516-526 */
+        DF_STORE(ip - anchor, offset + 3, mLength);
+match_stored:
+        ip += mLength; anchor = ip;
+        if ((int64_t)ip <= ilimit) {
+            const u32 ins = curr + 2;                                 /* complementary insertions (:550-554) */
+            L[z_hash8(src + ins, hlogL)] = ins + 2;
+            L[z_hash8(src + ip - 2, hlogL)] = ip - 2 + 2;
+            S[z_hash(src + ins, hlogS, mls)] = ins + 2;
+            S[z_hash(src + ip - 1, hlogS, mls)] = ip - 1 + 2;
+            while ((int64_t)ip <= ilimit && off2 > 0 && z_rd32(src + ip) == z_rd32(src + ip - off2)) {   /* :558-572 */
+                const u32 rLength = z_count(src, ip + 4, ip + 4 - off2, n) + 4;
+                const u32 t = off2; off2 = off1; off1 = t;
+                S[z_hash(src + ip, hlogS, mls)] = ip + 2;
+                L[z_hash8(src + ip, hlogL)] = ip + 2;
+                DF_STORE(0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+cleanup:
+#undef DF_STORE
+    memcpy(lits + litSize, src + anchor, n - anchor); litSize += n - anchor;
+    *litSizeOut = litSize;
+    free(L); free(S);
+    return nbSeq;
+}
+
 /* cParams for levels 1 and 2 and a known source size <= 128 KiB (clevels.h:80-82,107-108 + ZSTD_adjustCParams_internal
  * zstd_compress.c:1575-1595): both levels use the "fast" strategy with step 2 there; level 2 has a 2^15 table and minMatch
  * 5 (4 for inputs of at most 16 KiB) */
@@ -744,11 +836,15 @@ static void level1_params(size_t n, u32* hlog, u32* mls) { level_params(1, n, hl
 
 size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, int level);
 size_t orc_zstd_compress(const u8* src, size_t n, u8* dst, size_t dstCap) { return orc_zstd_compress_level(src, n, dst, dstCap, 1); }
-/* level 1 or 2 */
-size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, int level)
+
+/* One single-block frame (n <= 128 KiB) with explicit compression parameters, as ZSTD_compress_advanced makes it:
+ * strategy 1 = fast (hashLog, minMatch; chainLog unused), 2 = double-fast (hashLog = long table, chainLog = short table,
+ * minMatch = bytes hashed into the short table).  Returns the frame size, 0 on failure. */
+size_t orc_zstd_compress_cparams(const u8* src, size_t n, u8* dst, size_t dstCap, int strategy, u32 hashLog, u32 chainLog, u32 minMatch)
 {
     u8* op = dst;
     if (n > (128u << 10) || dstCap < orc_zstd_compress_bound(n) || dstCap < 9) return 0;
+    if (strategy != 1 && strategy != 2) return 0;
     /* frame header: magic, FHD (single segment, FCS size code), FCS (zstd_compress.c:4586-4632) */
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
     {   const u32 fcs = (n >= 256) + (n >= 65536 + 256);
@@ -760,14 +856,15 @@ size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, 
     if (n == 0) { op[0] = 1; op[1] = 0; op[2] = 0; return (size_t)(op + 3 - dst); }   /* ZSTD_writeEpilogue */
     {   size_t cSize = 0;
         if (n >= 7) {                                                 /* ZSTD_buildSeqStore :3268 (MIN_CBLOCK_SIZE+3+1+1) */
-            u32 hlog, mls; size_t litSize, nbSeq;
+            size_t litSize, nbSeq;
             zseq* seqs = (zseq*)malloc(sizeof(zseq) * (n / 3 + 8));
             u8* lits = (u8*)malloc(n + 8);
             u8* tmp = (u8*)malloc(2 * n + 1024);
-            if (level != 1 && level != 2) { free(seqs); free(lits); free(tmp); return 0; }
-            level_params(level, n, &hlog, &mls);
-            nbSeq = fast_block(src, (u32)n, hlog, mls, seqs, lits, &litSize);
+            g_strategy = (u32)strategy;
+            nbSeq = strategy == 1 ? fast_block(src, (u32)n, hashLog, minMatch, seqs, lits, &litSize)
+                                  : dfast_block(src, (u32)n, hashLog, chainLog, minMatch, seqs, lits, &litSize);
             cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq);
+            g_strategy = 1;
             if (cSize >= n - ((n >> 6) + 2)) cSize = 0;               /* ZSTD_minGain, zstd_compress.c:3055-3057 */
             if (cSize) memcpy(op + 3, tmp, cSize);
             free(seqs); free(lits); free(tmp);
@@ -782,6 +879,15 @@ size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, 
         }
     }
     return (size_t)(op - dst);
+}
+
+/* level 1 or 2 (the "fast" rows of clevels.h for inputs <= 128 KiB) */
+size_t orc_zstd_compress_level(const u8* src, size_t n, u8* dst, size_t dstCap, int level)
+{
+    u32 hlog = 0, mls = 0;
+    if (level != 1 && level != 2) return 0;
+    if (n >= 7 && n <= (128u << 10)) level_params(level, n, &hlog, &mls);
+    return orc_zstd_compress_cparams(src, n, dst, dstCap, 1, hlog, 0, mls);
 }
 
 /* ==========================================================================================

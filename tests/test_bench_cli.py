@@ -76,7 +76,9 @@ def test_cli_native_mode_is_the_one_shot_stream(eng, oracle, tmp_path):
         assert rc == 0, out
         assert dump.read_bytes() == oracle.compress(codec, data)
     rc, out = _run("-ezstd:3", "-n", "-t", str(f))
-    assert rc == 1 and "Compression: failed" in out                          # only level 1 has a GPU backend
+    assert rc == 0 and "verification: passed" in out, out                    # double-fast
+    rc, out = _run("-ezstd:7", "-n", "-t", str(f))
+    assert rc == 1 and "Compression: failed" in out                          # levels 1-4 have a GPU backend
     rc, out = _run("-ezlib", "-t", str(f))
     assert rc == 1 and "no GPU backend" in out
 

@@ -122,3 +122,41 @@ def test_lz4_acceleration_bit_exact(oracle, ref):
                     rw = ref.L.LZ4_compress_fast(data, w, n, c, acc)
                     rg = oracle.L.orc_lz4_compress_fast(data, n, g, c, acc)
                     assert rw == rg and w.raw[:max(rw, 0)] == g.raw[:max(rg, 0)], (kind, n, acc, c)
+
+
+def _ref_cparams(ref, level, n):
+    import ctypes as C
+    class CP(C.Structure):
+        _fields_ = [(k, C.c_uint) for k in ("windowLog", "chainLog", "hashLog", "searchLog", "minMatch", "targetLength")] + [("strategy", C.c_int)]
+    ref.L.ZSTD_getCParams.restype = CP
+    ref.L.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    return ref.L.ZSTD_getCParams(level, n, 0)
+
+
+@pytest.mark.parametrize("kind", list(a.corpus.KINDS))
+def test_zstd_double_fast_bit_exact(oracle, ref, kind):
+    """levels 3 and 4 (double-fast, zstd_double_fast.c) on inputs of at most 128 KiB: the oracle's parse with the reference's
+    own parameters for (level, size) gives the reference's frame.  The reference's one-shot ZSTD_compress runs its dispatcher
+    first, which selects the AOCL level table (zstd_compress.c:7390-7425); aocl_setup_zstd_encode does the same up front so
+    that ZSTD_getCParams reports the rows ZSTD_compress will use."""
+    import ctypes as C
+    ref.L.aocl_setup_zstd_encode.restype = C.c_void_p
+    ref.L.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    ref.L.aocl_setup_zstd_encode(0, 3, 0, 3, 0)
+    oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
+    oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    seen = set()
+    for n in (0, 1, 6, 7, 20, 27, 28, 40, 100, 513, 1000, 4096, 16384, 16385, 30000, 65536, 100000, 131071, 131072):
+        data = a.corpus.make(kind, n, seed=41 + n).tobytes() if n else b""
+        for level in (3, 4):
+            cp = _ref_cparams(ref, level, n)
+            if cp.strategy != 2:
+                continue                                       # (level 4 is "greedy" for inputs of at most 16 KiB)
+            want = ref.compress(ol.ZSTD, data, level=level)
+            cap = ol.bound(ol.ZSTD, n)
+            out = C.create_string_buffer(max(cap, 16))
+            r = oracle.L.orc_zstd_compress_cparams(data, n, out, max(cap, 16), 2, cp.hashLog, cp.chainLog, cp.minMatch)
+            assert want is not None and out.raw[:r] == want, (kind, n, level, cp.hashLog, cp.chainLog, cp.minMatch)
+            assert oracle.decompress(ol.ZSTD, want, n) == data
+            seen.add((cp.hashLog, cp.chainLog, cp.minMatch))
+    assert len(seen) >= 4

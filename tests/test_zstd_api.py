@@ -2,7 +2,7 @@
 CPU part: ZSTD_getParams / ZSTD_getCParams equal the reference's for every level, size class and both level tables
 (pure host arithmetic, checked against oracle/_ref).  GPU part: the call sequence of the reference's own wrapper
 (api/codec.cpp:354-436: createCCtx, getParams, CCtx_setParameter, compress_advanced, decompressDCtx) run against this
-library gives the reference's bytes for the "fast" levels, multi-frame streams for inputs above 128 KiB that the
+library gives the reference's bytes for levels 1-4 ("fast" and "double-fast"), multi-frame streams for inputs above 128 KiB that the
 reference decodes, and ZSTD_error_parameter_unsupported for everything without a GPU backend."""
 import ctypes as C
 
@@ -104,7 +104,7 @@ def test_context_calls_check_their_arguments(lib):
     assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, b"dict", 4, p)) == b"Unsupported parameter"
     p9 = lib.ZSTD_getParams(9, 5, 0)                                     # lazy2: no GPU backend
     assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, p9)) == b"Unsupported parameter"
-    assert lib.ZSTD_getErrorName(lib.ZSTD_compressCCtx(c, out, 64, b"hello", 5, 3)) == b"Unsupported parameter"   # double-fast
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compressCCtx(c, out, 64, b"hello", 5, 5)) == b"Unsupported parameter"   # greedy
     bad = lib.ZSTD_getParams(1, 5, 0); bad.cParams.windowLog = 40
     assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, bad)) == b"Parameter is out of bound"
     ck = lib.ZSTD_getParams(1, 5, 0); ck.fParams.checksumFlag = 1
@@ -148,11 +148,15 @@ def _wrapper_decompress(L, blob: bytes, cap: int):
 def test_reference_wrapper_sequence_on_the_gpu_library(eng, lib, reflib, kind):
     for n in (0, 1, 100, 5000, 16384, 16385, 65536, 100000, 131072):
         data = a.corpus.make(kind, n, seed=21).tobytes() if n else b""
-        for level in (1, 2):
-            got, want = _wrapper_compress(lib, data, level), _wrapper_compress(reflib, data, level)
+        for level in (1, 2, 3, 4, 0):                                        # 0 = default = 3; 3-4 = double-fast
+            want = _wrapper_compress(reflib, data, level)
+            got = _wrapper_compress(lib, data, level)
+            if level == 4 and 0 < n <= 16384:                                # "greedy" there (clevels.h:114): no GPU parse
+                assert got is None
+                continue
             assert got is not None and got == want, (kind, n, level)
             assert _wrapper_decompress(lib, want, n) == data
-        assert _wrapper_compress(lib, data, 3) is None and _wrapper_compress(lib, data, 0) is None      # double-fast: no backend yet
+        assert _wrapper_compress(lib, data, 5) is None                        # greedy and up: no backend
     # a window clamp below the input size cannot be honoured by single-segment frames: refused, not ignored
     data = a.corpus.make(kind, 65536, seed=22).tobytes()
     assert _wrapper_compress(lib, data, 1, window_log=12) is None
@@ -165,11 +169,8 @@ def test_inputs_above_128k_become_concatenated_frames(eng, lib, reflib):
     INTEGRATION.md lists this deviation"""
     for n in (131073, 300000, (1 << 20) + 17, 3 << 20):
         data = a.corpus.make("text", n, seed=23).tobytes()
-        for level in (1, 2):
+        for level in (1, 2, 3):
             blob = _wrapper_compress(lib, data, level)
-            if level == 2 and n <= 262144:                                   # level 2 is double-fast for 128 KiB < n <= 256 KiB (clevels.h:55)
-                assert blob is None
-                continue
             assert blob is not None and blob[:4] == b"\x28\xb5\x2f\xfd"
             assert _wrapper_decompress(reflib, blob, n) == data            # the reference reads it
             assert _wrapper_decompress(lib, blob, n) == data               # frames decoded in parallel on the GPU
@@ -191,7 +192,7 @@ def test_inputs_above_128k_become_concatenated_frames(eng, lib, reflib):
 def test_unified_api_zstd_follows_the_wrapper(eng, lib, reflib):
     """aocl_llc_compress(ZSTD): level and optVar (window clamp) go through the same sequence (csrc/aocl_api.cpp)"""
     data = a.corpus.make("text", 100000, seed=25).tobytes()
-    for level, ok in ((1, True), (2, True), (0, False), (3, False), (9, False)):
+    for level, ok in ((1, True), (2, True), (0, True), (3, True), (4, True), (9, False)):
         r, blob, _ = eng.llc_compress(a.ZSTD, data, 200000, level=level)
         if ok:
             assert r > 0 and blob == _wrapper_compress(reflib, data, level)

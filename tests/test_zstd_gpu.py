@@ -174,3 +174,47 @@ def test_level2_sizes_and_native_api(eng, oracle, ref, size):
     out2 = C.create_string_buffer(cap)
     r2 = L.ZSTD_compress(out2, cap, raw, len(raw), 2)                    # the GPU library under the reference's name
     assert out2.raw[:r2] == want
+
+
+class _CP(__import__("ctypes").Structure):
+    _fields_ = [(k, __import__("ctypes").c_uint) for k in ("windowLog", "chainLog", "hashLog", "searchLog", "minMatch", "targetLength")] + [("strategy", __import__("ctypes").c_int)]
+
+
+@pytest.mark.parametrize("upstream", [False, True])
+@pytest.mark.parametrize("level", [3, 4])
+def test_double_fast_levels_bit_exact(eng, oracle, level, upstream):
+    """levels 3 and 4 (double-fast, zstd_double_fast.c): every chunk of a batch gets the parameters the reference derives
+    for (level, chunk size) from the AOCL or the upstream level table; frames byte-identical to the oracle's parse with those
+    parameters (pinned to the reference in tests/test_oracle_vs_ref.py), and they decode back"""
+    import ctypes as C
+    lib = eng.lib
+    lib.ZSTD_getCParams.restype = _CP
+    lib.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    lib.aocl_setup_zstd_encode.restype = C.c_void_p
+    lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
+    oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    lib.aocl_setup_zstd_encode(1 if upstream else 0, 0, 0, level, 0)
+    try:
+        for kind, chunk in (("text", 131072), ("binary", 65536), ("jsonlog", 20000), ("database", 100000), ("random", 40000),
+                            ("text", 16384), ("binary", 5000), ("jsonlog", 700)):
+            total = 6 * chunk + 777
+            data = a.corpus.make(kind, total, seed=level * 7 + chunk)
+            src = torch.from_numpy(data).to(eng.device)
+            slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.zstd_level(level, upstream))
+            lens = out_len.cpu().tolist(); host = slots.cpu().numpy(); raw = data.tobytes()
+            for i, ln in enumerate(lens):
+                part = raw[i * chunk:(i + 1) * chunk]
+                cp = lib.ZSTD_getCParams(level, len(part), 0)
+                if cp.strategy != 2:
+                    assert ln == 0, (kind, chunk, i)                    # level 4 at <= 16 KiB is "greedy": no GPU parse, reported as 0
+                    continue
+                cap = ol.bound(ol.ZSTD, len(part))
+                w = C.create_string_buffer(max(cap, 16))
+                r = oracle.L.orc_zstd_compress_cparams(part, len(part), w, max(cap, 16), 2, cp.hashLog, cp.chainLog, cp.minMatch)
+                assert ln == r and host[i * slot:i * slot + ln].tobytes() == w.raw[:r], (kind, chunk, i, level, upstream)
+            if all(l > 0 for l in lens):
+                dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, len(raw), chunk)
+                assert torch.equal(dst, src)
+    finally:
+        lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
