@@ -75,3 +75,54 @@ def test_gpu_tiny(eng):
         raw = bytes.fromhex(t["input_hex"])
         for name, hx in t["out"].items():
             assert eng.compress_host(CODECS[name], raw).hex() == hx, (name, raw)
+
+
+# ---- round-2 vectors (tests/golden/make_golden_r02.py): Zstd levels 3-4 (double-fast) and LZ4_compress_fast accelerations ----
+with open(os.path.join(os.path.dirname(__file__), "golden", "golden_r02.json")) as f:
+    GOLD2 = json.load(f)
+
+
+def _oracle_zstd_params(oracle, raw, e):
+    import ctypes as C
+    oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
+    oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    cap = max(ol.bound(ol.ZSTD, len(raw)), 16)
+    out = C.create_string_buffer(cap)
+    r = oracle.L.orc_zstd_compress_cparams(raw, len(raw), out, cap, e["strategy"], e["hashLog"], e["chainLog"], e["minMatch"])
+    return out.raw[:r]
+
+
+@pytest.mark.parametrize("idx", range(len(GOLD2["vectors"])))
+def test_oracle_matches_golden_r02(oracle, idx):
+    import ctypes as C
+    v = GOLD2["vectors"][idx]
+    raw = _data(v)
+    assert hashlib.sha256(raw).hexdigest() == v["input_sha256"], "corpus generator drifted"
+    for level, e in v["zstd"].items():
+        if e["strategy"] != 2:
+            continue                                           # level 4 is "greedy" below 16 KiB: outside the path
+        c = _oracle_zstd_params(oracle, raw, e)
+        assert len(c) == e["size"] and hashlib.sha256(c).hexdigest() == e["sha256"], ("zstd", level)
+        assert oracle.decompress(2, c, len(raw)) == raw
+    oracle.L.orc_lz4_compress_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    for acc, e in v["lz4_fast"].items():
+        cap = ol.bound(ol.LZ4, len(raw))
+        out = C.create_string_buffer(cap)
+        r = oracle.L.orc_lz4_compress_fast(raw, len(raw), out, cap, int(acc))
+        assert r == e["size"] and hashlib.sha256(out.raw[:r]).hexdigest() == e["sha256"], ("lz4", acc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(GOLD2["vectors"])))
+def test_gpu_matches_golden_r02(eng, idx):
+    v = GOLD2["vectors"][idx]
+    raw = _data(v)
+    for level, e in v["zstd"].items():
+        if e["strategy"] != 2:
+            continue
+        c = eng.compress_host(2, raw, flags=a.api.zstd_level(int(level)))
+        assert c is not None and len(c) == e["size"] and hashlib.sha256(c).hexdigest() == e["sha256"], ("zstd", level)
+        assert eng.decompress_host(2, c, len(raw)) == raw
+    for acc, e in v["lz4_fast"].items():
+        c = eng.compress_host(0, raw, flags=a.api.lz4_acceleration(int(acc)))
+        assert len(c) == e["size"] and hashlib.sha256(c).hexdigest() == e["sha256"], ("lz4", acc)
