@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (tools/round_profile.sh) into the files kept under profiles/:
-bench_r01_<codec>_<ver>.json, r01_<codec>_<ver>_kernel_trace_and_pmc.txt, traffic.json.
-usage: tools/collect_profiles.py <tag> <ver> [codec ...]   e.g.  r01_v7 v7"""
+bench_<round>_<codec>_<ver>.json, <round>_<codec>_<ver>_kernel_trace_and_pmc.txt, traffic.json.
+usage: tools/collect_profiles.py <tag> <ver> [codec ...]   e.g.  r02_v1 v1   (round = the tag's prefix up to the first "_")"""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ver = sys.argv[1], sys.argv[2]
+RND = tag.split("_")[0]
 O = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(ROOT, "profiles")
 tpath = os.path.join(P, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
     line = [l for l in open(os.path.join(O, f"bench_{c}.json")) if l.startswith("{")][-1]
-    open(os.path.join(P, f"bench_r01_{c}_{ver}.json"), "w").write(line)
+    open(os.path.join(P, f"bench_{RND}_{c}_{ver}.json"), "w").write(line)
     bench = json.loads(line)
     dom = bench["roofline"]["kernel"]
-    name = f"r01_{c}_{ver}_kernel_trace_and_pmc.txt"
+    name = f"{RND}_{c}_{ver}_kernel_trace_and_pmc.txt"
     with open(os.path.join(P, name), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --codec {c} --no-cpu-baseline  (round 1, {ver} kernels, 1x MI355X, 8 GiB)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --codec {c} --no-cpu-baseline  ({RND}, {ver} kernels, 1x MI355X, 8 GiB)\n")
         rows = list(csv.reader(open(os.path.join(O, f"trace_{c}", f"{c}_kernel_stats.csv"))))
         f.write(",".join(f'"{x}"' for x in rows[0]) + "\n")
         for r in rows[1:]:
