@@ -435,8 +435,8 @@ extern "C" int64_t aoclgpu_zstd_compress_host_frames(const void* hsrc, size_t n,
 
 namespace {
 // Frame boundaries from the frame and block headers alone (ZSTD_findFrameCompressedSize, zstd_decompress.c:700-790).
-// false = not decidable here (malformed, or a frame without content size): the caller lets one wavefront walk the stream.
-struct FrameSpan { uint64_t off; uint32_t len; uint64_t content; };
+// content = -1 when the frame header carries no content size; ck = the stored checksum when the frame has one.
+struct FrameSpan { uint64_t off; uint32_t len; int64_t content; bool hasCk; uint32_t ck; };
 bool split_frames(const uint8_t* p, size_t n, std::vector<FrameSpan>& out)
 {
     size_t pos = 0;
@@ -455,10 +455,15 @@ bool split_frames(const uint8_t* p, size_t n, std::vector<FrameSpan>& out)
         if (!single) pos += 1;
         pos += did == 3 ? 4 : did;
         const size_t fl = fcsId == 0 ? (single ? 1 : 0) : (fcsId == 1 ? 2 : (fcsId == 2 ? 4 : 8));
-        if (fl == 0 || pos + fl > n) return false;
-        uint64_t fcs = 0;
-        for (size_t i = 0; i < fl; ++i) fcs |= (uint64_t)p[pos + i] << (8 * i);
-        if (fl == 2) fcs += 256;
+        if (pos + fl > n) return false;
+        int64_t content = -1;
+        if (fl) {
+            uint64_t fcs = 0;
+            for (size_t i = 0; i < fl; ++i) fcs |= (uint64_t)p[pos + i] << (8 * i);
+            if (fl == 2) fcs += 256;
+            if (fcs > 0x7FFFFFFFull) return false;
+            content = (int64_t)fcs;
+        }
         pos += fl;
         for (;;) {
             if (n - pos < 3) return false;
@@ -471,9 +476,52 @@ bool split_frames(const uint8_t* p, size_t n, std::vector<FrameSpan>& out)
             pos += body;
             if (last) break;
         }
-        if (hasCk) { if (n - pos < 4) return false; pos += 4; }
-        if (pos - start > 0xFFFFFFFFull || fcs > 0x7FFFFFFFull) return false;
-        out.push_back(FrameSpan{start, (uint32_t)(pos - start), fcs});
+        uint32_t ck = 0;
+        if (hasCk) { if (n - pos < 4) return false; memcpy(&ck, p + pos, 4); pos += 4; }
+        if (pos - start > 0xFFFFFFFFull) return false;
+        out.push_back(FrameSpan{start, (uint32_t)(pos - start), content, hasCk != 0, ck});
+    }
+    return true;
+}
+
+// XXH64 (the published xxHash algorithm, seed 0): Zstandard's content checksum is its low 32 bits (zstd_decompress.c:1087-1094)
+uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+uint64_t xxh64(const uint8_t* p, size_t len)
+{
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    auto rd64 = [](const uint8_t* q) { uint64_t v; memcpy(&v, q, 8); return v; };
+    auto rd32 = [](const uint8_t* q) { uint32_t v; memcpy(&v, q, 4); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { return rotl64(acc + in * P2, 31) * P1; };
+    auto merge = [&](uint64_t h, uint64_t v) { return (h ^ round(0, v)) * P1 + P4; };
+    const uint8_t* const end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+        do { v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24)); p += 32; } while (p + 32 <= end);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else h = P5;
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= round(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl64(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// content checksums of a decoded stream: true when every frame that carries one matches (frames are laid out back to
+// back in dst; a frame without a content size can only be checked when it is the stream's only frame)
+bool checksums_ok(const std::vector<FrameSpan>& fr, const uint8_t* dst, size_t total)
+{
+    size_t o = 0;
+    for (size_t k = 0; k < fr.size(); ++k) {
+        size_t len;
+        if (fr[k].content >= 0) len = (size_t)fr[k].content;
+        else if (fr.size() == 1) len = total;
+        else return true;                                      // cannot locate the frames behind this one: not checked
+        if (o + len > total) return false;
+        if (fr[k].hasCk && (uint32_t)xxh64(dst + o, len) != fr[k].ck) return false;
+        o += len;
     }
     return true;
 }
@@ -483,12 +531,18 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
 {
     if (!hsrc || !hdst) { set_error_msg("zstd frames: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     std::vector<FrameSpan> fr;
-    if (n > 0xFFFFFFFFull || !split_frames((const uint8_t*)hsrc, n, fr) || fr.size() < 2)
-        return aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
+    const bool split = n <= 0xFFFFFFFFull && split_frames((const uint8_t*)hsrc, n, fr);
+    bool sized = split && fr.size() >= 2;
+    if (sized) for (const FrameSpan& f : fr) sized = sized && f.content >= 0;
+    if (!sized) {                                             // one wavefront walks the stream
+        const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
+        if (r >= 0 && split && !checksums_ok(fr, (const uint8_t*)hdst, (size_t)r)) return -1;   // checksum_wrong (zstd_decompress.c:1094)
+        return r;
+    }
     const size_t K = fr.size();
     uint64_t total = 0;
     std::vector<uint64_t> soff(K), doff(K); std::vector<uint32_t> slen(K), dcap(K);
-    for (size_t k = 0; k < K; ++k) { soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = total; dcap[k] = (uint32_t)fr[k].content; total += fr[k].content; }
+    for (size_t k = 0; k < K; ++k) { soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = total; dcap[k] = (uint32_t)fr[k].content; total += (uint64_t)fr[k].content; }
     if (total > cap) return -2;
     if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     DevBuf dsrc, ddst, a, bq, c, d, o;
@@ -510,5 +564,6 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     for (size_t k = 0; k < K; ++k) if (res[k] < 0 || (uint32_t)res[k] != dcap[k]) return -1;
     if (total) HCK(hipMemcpy(hdst, ddst.p, total, hipMemcpyDeviceToHost));
 #undef HCK
+    if (!checksums_ok(fr, (const uint8_t*)hdst, (size_t)total)) return -1;
     return (int64_t)total;
 }

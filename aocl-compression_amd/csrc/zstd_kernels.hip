@@ -969,8 +969,9 @@ __device__ __forceinline__ u32 flags_level(u32 flags)
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
                                   void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf)
 {
-    const u32 bound = n + (n >> 8) + (n < kBlockMax ? ((kBlockMax - n) >> 11) : 0);
-    if (n > kBlockMax || cap < bound || cap < 9) return 0;
+    // (the block is staged in the workspace and only copied out when it fits: a slot smaller than ZSTD_compressBound works
+    //  whenever the frame itself fits, as with the reference's ZSTD_compress)
+    if (n > kBlockMax || cap < 5u + ((n < 256) ? 1u : (n < 65536 + 256 ? 2u : 4u)) + 3u) return 0;
     const ZParams zp = level_cparams(flags_level(expf), (expf & AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE) != 0, n);
     if (zp.strategy == 0 || (zp.strategy == 2 && !tabs)) return 0;      // no GPU parse for these parameters / launcher gave no tables
     u32 op = 0;
@@ -1009,6 +1010,7 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane, zp.strategy);
         if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                      // ZSTD_minGain, zstd_compress.c:3055-3057
     }
+    if ((u64)op + 3 + (cSize ? cSize : n) > cap) return 0;               // dstSize_tooSmall
     if (cSize == 0) {                                                    // ZSTD_noCompressBlock
         const u32 h = 1 + (0 << 1) + (n << 3);
         if (lane == 0) { dst[op] = (u8)h; dst[op + 1] = (u8)(h >> 8); dst[op + 2] = (u8)(h >> 16); }

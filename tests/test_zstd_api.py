@@ -204,3 +204,36 @@ def test_unified_api_zstd_follows_the_wrapper(eng, lib, reflib):
     r2, back, _ = eng.llc_decompress(a.ZSTD, blob, len(big))
     assert r2 == len(big) and back == big
     assert _wrapper_decompress(reflib, blob, len(big)) == big
+
+
+@pytest.mark.gpu
+def test_content_checksums_are_verified_on_the_host_paths(eng, lib, reflib):
+    """frames that carry an XXH64 content checksum (zstd_decompress.c:1087-1094): right checksum accepted, wrong one refused -
+    single frame, a frame without content size, and two concatenated frames (decoded in parallel)"""
+    def ref_frame(data, level=3, checksum=1, content_size=1):
+        cctx = reflib.ZSTD_createCCtx()
+        zp = reflib.ZSTD_getParams(level, len(data), 0)
+        zp.fParams.checksumFlag = checksum
+        zp.fParams.contentSizeFlag = content_size
+        cap = reflib.ZSTD_compressBound(len(data))
+        out = C.create_string_buffer(cap)
+        r = reflib.ZSTD_compress_advanced(cctx, out, cap, data, len(data), None, 0, zp)
+        reflib.ZSTD_freeCCtx(cctx)
+        assert not reflib.ZSTD_isError(r)
+        return out.raw[:r]
+
+    d1 = a.corpus.make("text", 200000, seed=51).tobytes()
+    d2 = a.corpus.make("binary", 70000, seed=52).tobytes()
+    f1, f2 = ref_frame(d1), ref_frame(d2)
+    f3 = ref_frame(d2, content_size=0)
+    assert _wrapper_decompress(lib, f1, len(d1)) == d1
+    assert _wrapper_decompress(lib, f3, len(d2)) == d2
+    assert _wrapper_decompress(lib, f1 + f2, len(d1) + len(d2)) == d1 + d2
+    for blob, n in ((f1, len(d1)), (f3, len(d2)), (f1 + f2, len(d1) + len(d2)), (f2 + f1, len(d1) + len(d2))):
+        bad = bytearray(blob); bad[-1] ^= 0x40                         # the last frame's stored checksum
+        assert _wrapper_decompress(lib, bytes(bad), n) is None
+        assert _wrapper_decompress(reflib, bytes(bad), n) is None       # the reference refuses it too
+    bad = bytearray(f1 + f2); bad[len(f1) - 2] ^= 1                     # the first frame's checksum
+    assert _wrapper_decompress(lib, bytes(bad), len(d1) + len(d2)) is None
+    r, back, _ = eng.llc_decompress(a.ZSTD, f1 + f2, len(d1) + len(d2))
+    assert r == len(d1) + len(d2) and back == d1 + d2

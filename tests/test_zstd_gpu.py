@@ -218,3 +218,21 @@ def test_double_fast_levels_bit_exact(eng, oracle, level, upstream):
                 assert torch.equal(dst, src)
     finally:
         lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
+
+
+def test_slots_smaller_than_the_bound(eng, oracle):
+    """a destination smaller than ZSTD_compressBound succeeds whenever the frame itself fits (as ZSTD_compress does), and fails
+    (0 / dstSize_tooSmall) one byte below that"""
+    import ctypes as C
+    lib = eng.lib
+    lib.ZSTD_compress.restype = C.c_size_t
+    lib.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    lib.ZSTD_isError.argtypes = [C.c_size_t]
+    for kind, n in (("text", 100000), ("random", 50000), ("binary", 131072), ("text", 1), ("text", 300)):
+        data = a.corpus.make(kind, n, seed=61).tobytes()
+        want = oracle.compress(ol.ZSTD, data)
+        assert eng.compress_host(a.ZSTD, data, cap=len(want)) == want
+        assert eng.compress_host(a.ZSTD, data, cap=len(want) - 1) is None
+        out = C.create_string_buffer(len(want))
+        assert lib.ZSTD_compress(out, len(want), data, n, 1) == len(want) and out.raw == want
+        assert lib.ZSTD_isError(lib.ZSTD_compress(out, len(want) - 1, data, n, 1))
