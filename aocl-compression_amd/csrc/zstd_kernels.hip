@@ -966,6 +966,10 @@ __device__ __forceinline__ u32 flags_level(u32 flags)
     return l ? l : ((flags & AOCLGPU_FLAG_ZSTD_LEVEL2) ? 2u : 1u);
 }
 
+// DF = the double-fast launches (levels 3-4).  Two kernels on purpose: the register budget of the level 1-2 kernel decides how
+// many chunks are resident per CU (136 VGPRs -> 9 by LDS; with the double-fast finder compiled into the same kernel it needed
+// 181 -> 8 per CU and level 1 lost 10 %).
+template <bool DF>
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
                                   void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf)
 {
@@ -973,7 +977,7 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     //  whenever the frame itself fits, as with the reference's ZSTD_compress)
     if (n > kBlockMax || cap < 5u + ((n < 256) ? 1u : (n < 65536 + 256 ? 2u : 4u)) + 3u) return 0;
     const ZParams zp = level_cparams(flags_level(expf), (expf & AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE) != 0, n);
-    if (zp.strategy == 0 || (zp.strategy == 2 && !tabs)) return 0;      // no GPU parse for these parameters / launcher gave no tables
+    if (zp.strategy == 0 || (zp.strategy == 2) != DF || (DF && !tabs)) return 0;   // no GPU parse for these parameters / wrong launch class
     u32 op = 0;
     const u32 fcs = (n >= 256) + (n >= 65536 + 256);
     if (lane == 0) {                                                     // ZSTD_writeFrameHeader :4586-4632
@@ -989,7 +993,7 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 litSize = 0, nbSeq;
         const u32 hlog = zp.hlog, mls = zp.mls;
-        if (zp.strategy == 2) {
+        if constexpr (DF) {
             if (2u * 2u * kDfScratch > ldsBytes) return 0;
             if (mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
             else nbSeq = dfast_block<5>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
@@ -1699,6 +1703,7 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
 
 }  // namespace
 
+template <bool DF>
 __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
                                                            uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes)
 {
@@ -1708,7 +1713,7 @@ __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint
     const int lane = lane_id();
     for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = zstd_compress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, tabs, lane, b.reserved);
+        const int r = zstd_compress_wave<DF>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, tabs, lane, b.reserved);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -1880,13 +1885,14 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
             L[nl++] = { 0, b->nchunks - 1, lds_for_chunk(b->chunk_bytes, level) };
         } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail, level) };
     }
+    const void* kfn = level >= 3 ? (const void*)aoclgpu::zstd_compress_kernel<true> : (const void*)aoclgpu::zstd_compress_kernel<false>;
     aoclgpu::WsGuard guard;                               // held until the kernels that use the scratch are enqueued
     for (int i = 0; i < nl; ++i) {
         // persistent blocks: exactly as many as are resident at once for this LDS size (gfx950 allocates LDS in 1280-byte
         // granules, the occupancy query counts bytes: the smaller of the two, see aoclgpu_zstd_decompress_chunks)
         int perCU = 0, dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void*)aoclgpu::zstd_compress_kernel, 64, L[i].lds) != hipSuccess || perCU < 1) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, 64, L[i].lds) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("zstd: occupancy query failed"); return AOCLGPU_ERR_HIP;
         }
         {
@@ -1900,11 +1906,13 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         uint8_t* tabBase = tabBytes ? (uint8_t*)ws + seqBytes : nullptr;
         if (L[i].lds > 65536u) {
-            hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_compress_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
+            hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
             if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
         }
-        hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
-                           tabBase, (uint32_t)tabBytes);
+        if (level >= 3) hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<true>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
+                                           tabBase, (uint32_t)tabBytes);
+        else hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<false>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
+                                tabBase, (uint32_t)tabBytes);
         if (int rc = aoclgpu::check_launch("zstd_compress_kernel")) return rc;
     }
     return AOCLGPU_OK;
