@@ -19,6 +19,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libaocl_compression_gpu.so")
+# the same code with only the engine's own names exported (aoclgpu_*, aocl_llc_*, RAP helpers): for programs that also link
+# upstream libzstd / liblz4 / libsnappy - e.g. users of the sequence producer - where the drop-in native names must not clash
+CORE_LIB = os.path.join(HERE, "libaocl_compression_gpu_core.so")
 CLI = os.path.join(HERE, "aocl_compression_bench")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
@@ -61,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
-    if force or jobs or not os.path.exists(LIB):
+    if force or jobs or not os.path.exists(LIB) or not os.path.exists(CORE_LIB):
         stubdir = os.path.join(OBJDIR, "stub")
         os.makedirs(stubdir, exist_ok=True)
         stub_c = os.path.join(stubdir, "empty.c")
@@ -70,6 +73,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         _run(["gcc", "-shared", "-fPIC", stub_c, "-o", os.path.join(stubdir, "libamdhip64.so")])
         _run(["g++", "-shared", "-fPIC", *objs, "-o", LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
               "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+        vmap = os.path.join(stubdir, "core.map")
+        with open(vmap, "w") as f:
+            f.write("{ global: aoclgpu_*; aocl_llc_*; aocl_get_rap_frame_bound_mt; aocl_skip_rap_frame_mt; local: *; };\n")
+        _run(["g++", "-shared", "-fPIC", *objs, "-o", CORE_LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-Wl,--version-script=" + vmap])
     # the bench CLI (counterpart of the reference's aocl_compression_bench, test/codec_bench.c)
     cli_src = os.path.join(CSRC, "bench_cli.cpp")
     if force or not os.path.exists(CLI) or _newer(cli_src, CLI, headers + [LIB]):

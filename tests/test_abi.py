@@ -69,3 +69,16 @@ def test_no_cpu_fallback():
     out = C.create_string_buffer(64)
     d.inBuf = C.cast(buf, C.c_void_p); d.inSize = 5; d.outBuf = C.cast(out, C.c_void_p); d.outSize = 64
     assert lib.aocl_llc_compress(C.byref(d), 0) == -2                  # ERR_COMPRESSION_FAILED, never a silent CPU path
+
+
+def test_core_library_exports_only_the_engine_names():
+    """libaocl_compression_gpu_core.so = the same code with the drop-in native names (LZ4_*, ZSTD_*, snappy_*, LZ4F_*) hidden: a
+    program that also links upstream libzstd / liblz4 / libsnappy (users of the sequence producer) links this one"""
+    import subprocess
+    core = os.path.join(ROOT, "aocl-compression_amd", "libaocl_compression_gpu_core.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", core], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1] for l in out.splitlines() if l.split()}
+    assert names and all(n.startswith(("aoclgpu_", "aocl_llc_", "aocl_get_rap", "aocl_skip_rap")) for n in names), sorted(names)[:10]
+    lib = C.CDLL(core)
+    for n in sorted(_declared()) + ["aoclgpu_zstd_sequence_producer"]:
+        assert hasattr(lib, n), n

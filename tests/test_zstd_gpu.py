@@ -64,9 +64,12 @@ def test_special_inputs(eng, oracle):
         assert eng.compress_host(a.ZSTD, raw) == oracle.compress(ol.ZSTD, raw), i
 
 
-def test_small_output_buffer_fails(eng):
+def test_small_output_buffer_fails(eng, oracle):
     raw = a.corpus.make("text", 5000, seed=3).tobytes()
-    assert eng.compress_host(a.ZSTD, raw, a.compress_bound(a.ZSTD, len(raw)) - 1) is None
+    want = oracle.compress(ol.ZSTD, raw)
+    assert eng.compress_host(a.ZSTD, raw, a.compress_bound(a.ZSTD, len(raw)) - 1) == want     # below the bound, but the frame fits
+    assert eng.compress_host(a.ZSTD, raw, len(want) - 1) is None
+    assert eng.compress_host(a.ZSTD, raw, 8) is None
 
 
 @pytest.mark.parametrize("kind", list(a.corpus.KINDS))
