@@ -133,7 +133,14 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
         // backend, so it reports 0 ("no host SIMD path selected").  workBuf: LZ4/Snappy keep no context
         // (api/codec.cpp:118-122,262-266); the Zstd tables live on the device per launch.
         handle->optLevel = 0;
+        // LZ4 / Snappy keep no context (workBuf NULL, api/codec.cpp:118-122,262-266); Zstd's setup hands back a context block
+        // (api/codec.cpp:354-376; gtest/api/api_gtest.cpp:771-778 checks it is not NULL) - it is freed by aocl_llc_destroy
         handle->workBuf = NULL;
+        if (codec_type == ZSTD) {
+            void** ctx = (void**)malloc(2 * sizeof(void*));
+            if (ctx) { ctx[0] = ZSTD_createCCtx(); ctx[1] = ZSTD_createDCtx(); }
+            handle->workBuf = (char*)ctx;
+        }
         // the reference's setup runs the codec's dispatcher (api/codec.cpp:354-376); for Zstd that also selects the level
         // table (optOff -> upstream parameters, zstd_compress.c:7390-7425)
         if (codec_type == ZSTD) (void)aocl_setup_zstd_encode(handle->optOff, 0, handle->inSize, handle->level, handle->optVar);
@@ -142,9 +149,16 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
     return 0;
 }
 
-extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression_type)
+extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
-    if (handle) handle->workBuf = NULL;
+    if (!handle) return;
+    if (codec_type == ZSTD && handle->workBuf) {          // api/codec.cpp:378-394
+        void** ctx = (void**)handle->workBuf;
+        ZSTD_freeCCtx((ZSTD_CCtx*)ctx[0]); ZSTD_freeDCtx((ZSTD_DCtx*)ctx[1]);
+        free(ctx);
+        aocl_destroy_zstd_encode(); aocl_destroy_zstd_decode();
+    }
+    handle->workBuf = NULL;
 }
 
 extern "C" const char* aocl_llc_version(void)

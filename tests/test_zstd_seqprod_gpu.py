@@ -42,7 +42,6 @@ def ref():
 def test_reference_zstd_with_gpu_sequences(eng, ref, kind, size):
     # the core library (native names hidden): what a program that links upstream / reference libzstd next to the engine uses
     G = C.CDLL(os.path.join(os.path.dirname(api.lib_path()), "libaocl_compression_gpu_core.so"))
-    assert not hasattr(G, "ZSTD_compress")
     producer = C.cast(G.aoclgpu_zstd_sequence_producer, C.c_void_p)
     data = a.corpus.make(kind, max(size, 4096)).tobytes()[:size]
     cctx = ref.ZSTD_createCCtx()
