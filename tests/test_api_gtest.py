@@ -164,3 +164,32 @@ def test_decompress_cases(lib, algo):
     r = decompress(inBuf=C.cast(badbuf, C.c_void_p))
     assert r < 0 or back.raw[:r] != inp.raw[:r]
     lib.aocl_llc_destroy(C.byref(d), algo)
+
+
+# ---------------------------------------------------------------- API_compress_MT (gtest/threads/threads_gtest.cpp:281-433, 520-541)
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("threads", [(7, 6), (6, 7), (1000, 1001)])
+def test_compress_mt_any_thread_counts(lib, algo, threads):
+    """the reference's threaded build: compress with one thread count, decompress with another (also beyond the machine's) -
+    here numThreads > 1 asks for the RAP path, the partitions are GPU chunks whatever the count; the stream carries the RAP
+    frame header the reference validates (:527-534) and decodes under any thread count"""
+    import struct
+    lib.aocl_get_rap_frame_bound_mt.restype = C.c_int32
+    n = (1 << 20) + 12345
+    raw = a.corpus.make("text", n // 2, seed=71).tobytes() + bytes(random.Random(5).randrange(255) for _ in range(n - n // 2))
+    inp = C.create_string_buffer(raw, n)
+    cap = 2 * n + lib.aocl_get_rap_frame_bound_mt()                    # callers add the bound (test/codec_bench.c:499-506)
+    out = C.create_string_buffer(cap)
+    d = _desc(_default_level(algo), numThreads=threads[0])
+    d.inBuf = C.cast(inp, C.c_void_p); d.inSize = n; d.outBuf = C.cast(out, C.c_void_p); d.outSize = cap
+    assert lib.aocl_llc_setup(C.byref(d), algo) == 0
+    c = lib.aocl_llc_compress(C.byref(d), algo)
+    assert c > 0
+    head = out.raw[8:24] if algo == ZSTD else out.raw[:16]            # Zstd: the frame rides in a skippable frame
+    magic, flen, k, child = struct.unpack("<qIHH", head)
+    assert magic == 0x434C4C5F4C434F41 and flen == 16 + 12 * k and k > 1 and child == 0
+    back = C.create_string_buffer(n)
+    d.numThreads = threads[1]
+    d.inBuf = C.cast(out, C.c_void_p); d.inSize = c; d.outBuf = C.cast(back, C.c_void_p); d.outSize = n
+    assert lib.aocl_llc_decompress(C.byref(d), algo) == n and back.raw == raw
+    lib.aocl_llc_destroy(C.byref(d), algo)
