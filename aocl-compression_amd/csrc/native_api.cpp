@@ -4,6 +4,7 @@
 #include "../../include/aocl_gpu_codec.h"
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 
 namespace {
 const int kErrInvalidInput = -5;                          // api/aocl_compression.h:97 ERR_INVALID_INPUT
@@ -136,5 +137,22 @@ bool RawUncompress(const char* compressed, size_t compressed_length, char* uncom
 bool IsValidCompressedBuffer(const char* compressed, size_t compressed_length)
 {
     return snappy_validate_compressed_buffer(compressed, compressed_length) == SNAPPY_OK;
+}
+size_t Compress(const char* input, size_t input_length, std::string* compressed)
+{   // snappy.cc:2656-2680: the string is resized to the bound, filled, trimmed; returns the compressed size
+    if (!compressed || (!input && input_length)) return 0;
+    try { compressed->resize(MaxCompressedLength(input_length)); } catch (const std::exception&) { return 0; }
+    size_t n = 0;
+    RawCompress(input, input_length, &(*compressed)[0], &n);
+    compressed->resize(n);
+    return n;
+}
+bool Uncompress(const char* compressed, size_t compressed_length, std::string* uncompressed)
+{   // snappy.cc:2392-2410
+    size_t ulen;
+    if (!uncompressed || !GetUncompressedLength(compressed, compressed_length, &ulen)) return false;
+    try { uncompressed->resize(ulen); } catch (const std::exception&) { return false; }
+    if (ulen == 0) { char tmp; return RawUncompress(compressed, compressed_length, &tmp); }
+    return RawUncompress(compressed, compressed_length, &(*uncompressed)[0]);
 }
 }  // namespace snappy

@@ -267,7 +267,9 @@ unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
     const unsigned long long kUnknown = 0ULL - 1, kError = 0ULL - 2;
     const uint8_t* p = (const uint8_t*)src;
     if (!p || srcSize < 5) return kError;
-    if ((p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)) != 0xFD2FB528u) return kError;
+    const uint32_t magic = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) return srcSize >= 8 ? 0 : kError;     // skippable frame (:609)
+    if (magic != 0xFD2FB528u) return kError;
     const uint32_t fhd = p[4], dictID = fhd & 3, single = (fhd >> 5) & 1, fcsID = fhd >> 6;
     static const size_t did[4] = {0, 1, 2, 4}, fcs[4] = {0, 2, 4, 8};
     size_t pos = 5 + (single ? 0 : 1) + did[dictID];
@@ -279,6 +281,85 @@ unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
     for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
     if (fl == 2) v += 256;
     return v;
+}
+
+// ---- frame inspection (host arithmetic on headers; zstd_decompress.c:601-790) ----
+static size_t first_frame_size(const uint8_t* p, size_t n, unsigned long long* content /* may be NULL */)
+{   // ZSTD_findFrameSizeInfo: compressed size of the frame (or skippable frame) at p; error code when it is not complete
+    if (content) *content = 0ULL - 1;
+    if (!p || n < 8) return zerr(kErrSrcSize);
+    uint32_t magic; memcpy(&magic, p, 4);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+        uint32_t sz; memcpy(&sz, p + 4, 4);
+        if ((uint64_t)sz + 8 > n) return zerr(kErrSrcSize);
+        if (content) *content = 0;
+        return 8 + (size_t)sz;
+    }
+    if (magic != 0xFD2FB528u) return zerr(kErrPrefix);
+    const uint32_t fhd = p[4], fcsId = fhd >> 6, single = (fhd >> 5) & 1, hasCk = (fhd >> 2) & 1, did = fhd & 3;
+    size_t pos = 5 + (single ? 0 : 1) + (did == 3 ? 4 : did);
+    const size_t fl = fcsId == 0 ? (single ? 1 : 0) : (fcsId == 1 ? 2 : (fcsId == 2 ? 4 : 8));
+    if (pos + fl > n) return zerr(kErrSrcSize);
+    if (content && fl) {
+        unsigned long long v = 0;
+        for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
+        *content = fl == 2 ? v + 256 : v;
+    }
+    pos += fl;
+    for (;;) {
+        if (n - pos < 3) return zerr(kErrSrcSize);
+        const uint32_t bh = p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16);
+        pos += 3;
+        if (((bh >> 1) & 3) == 3) return zerr(kErrCorrupt);
+        const size_t body = ((bh >> 1) & 3) == 1 ? 1 : (bh >> 3);
+        if (body > n - pos) return zerr(kErrSrcSize);
+        pos += body;
+        if (bh & 1) break;
+    }
+    if (hasCk) { if (n - pos < 4) return zerr(kErrSrcSize); pos += 4; }
+    return pos;
+}
+size_t ZSTD_findFrameCompressedSize(const void* src, size_t srcSize) { return first_frame_size((const uint8_t*)src, srcSize, nullptr); }
+unsigned long long ZSTD_getDecompressedSize(const void* src, size_t srcSize)
+{   // zstd_decompress.c:692-698: 0 when unknown or on error
+    const unsigned long long r = ZSTD_getFrameContentSize(src, srcSize);
+    return r >= 0ULL - 2 ? 0 : r;
+}
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize)
+{   // zstd_decompress.c:795-812: sum over the frames of the content size, or of (blocks x block size) when it is absent
+    const uint8_t* p = (const uint8_t*)src;
+    unsigned long long bound = 0;
+    while (srcSize > 0) {
+        unsigned long long content;
+        const size_t fs = first_frame_size(p, srcSize, &content);
+        if (ZSTD_isError(fs)) return 0ULL - 2;
+        if (content == 0ULL - 1) {                                     // no content size: count the blocks
+            unsigned long long blocks = 0; size_t pos = 5 + ((p[4] >> 5) & 1 ? 0 : 1) + ((p[4] & 3) == 3 ? 4 : (p[4] & 3));
+            unsigned long long blockMax = 128u << 10;
+            if (!((p[4] >> 5) & 1)) { const uint32_t wb = p[5], wl = (wb >> 3) + 10; unsigned long long w = 1ULL << wl; w += (w >> 3) * (wb & 7); if (w < blockMax) blockMax = w; }
+            for (;;) { const uint32_t bh = p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16); pos += 3 + (((bh >> 1) & 3) == 1 ? 1 : (bh >> 3)); blocks++; if (bh & 1) break; }
+            content = blocks * blockMax;
+        }
+        bound += content;
+        p += fs; srcSize -= fs;
+    }
+    return bound;
+}
+
+// ---- context-parameter API (zstd.h:1021,1057,1202): ZSTD_compress2 takes the level and frame flags stored in the context ----
+size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
+{
+    if (!c) return zerr(kErrGeneric);
+    if ((int)reset & 2) { c->level = 3; memset(&c->f, 0, sizeof(c->f)); c->f.contentSizeFlag = 1; }
+    return 0;
+}
+size_t ZSTD_DCtx_reset(ZSTD_DCtx* d, ZSTD_ResetDirective) { return d ? 0 : zerr(kErrGeneric); }
+size_t ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{   // zstd_compress.c:6333-6360
+    if (!cctx || (!src && srcSize > 0)) return zerr(kErrGeneric);
+    if (!dst) return zerr(kErrDstNull);
+    const ZSTD_parameters p = ZSTD_getParams(cctx->level, srcSize, 0);
+    return compress_with(p.cParams, cctx->f, dst, dstCapacity, src, srcSize);
 }
 
 // the reference's dispatcher hooks (zstd.h:423-452): there is no host ISA variant to pick here; optOff selects the

@@ -108,6 +108,13 @@ const char* ZSTD_getErrorName(size_t code);
 size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
 size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
 unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
+unsigned long long ZSTD_getDecompressedSize(const void* src, size_t srcSize);   /* 0 = unknown or error */
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);       /* over all frames of the stream */
+size_t      ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);
+typedef enum { ZSTD_reset_session_only = 1, ZSTD_reset_parameters = 2, ZSTD_reset_session_and_parameters = 3 } ZSTD_ResetDirective;
+size_t      ZSTD_CCtx_reset(ZSTD_CCtx* cctx, ZSTD_ResetDirective reset);
+size_t      ZSTD_DCtx_reset(ZSTD_DCtx* dctx, ZSTD_ResetDirective reset);
+size_t      ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);   /* level / frame flags from the context */
 ZSTD_CCtx*  ZSTD_createCCtx(void);
 size_t      ZSTD_freeCCtx(ZSTD_CCtx* cctx);
 size_t      ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
@@ -140,6 +147,7 @@ int32_t aocl_skip_rap_frame_mt(char* src, int32_t src_size); /* 0: no RAP frame;
 
 #ifdef __cplusplus
 }
+#include <string>
 
 /* ---- Snappy C++ binding (algos/snappy/snappy.h:255,280,369,391; snappy.cc:2271,2494) ---- */
 namespace snappy {
@@ -148,6 +156,8 @@ bool   RawUncompress(const char* compressed, size_t compressed_length, char* unc
 size_t MaxCompressedLength(size_t source_bytes);
 bool   GetUncompressedLength(const char* compressed, size_t compressed_length, size_t* result);
 bool   IsValidCompressedBuffer(const char* compressed, size_t compressed_length);
+size_t Compress(const char* input, size_t input_length, std::string* compressed);        /* snappy.h:268 */
+bool   Uncompress(const char* compressed, size_t compressed_length, std::string* uncompressed);   /* snappy.h:282 */
 }
 #endif
 #endif

@@ -16,7 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CXX = {"RawCompress": "_ZN6snappy11RawCompressEPKcmPcPm", "RawUncompress": "_ZN6snappy13RawUncompressEPKcmPc",
        "MaxCompressedLength": "_ZN6snappy19MaxCompressedLengthEm",
        "GetUncompressedLength": "_ZN6snappy21GetUncompressedLengthEPKcmPm",
-       "IsValidCompressedBuffer": "_ZN6snappy23IsValidCompressedBufferEPKcm"}
+       "IsValidCompressedBuffer": "_ZN6snappy23IsValidCompressedBufferEPKcm",
+       "Compress": "_ZN6snappy8CompressEPKcmPNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEE",
+       "Uncompress": "_ZN6snappy10UncompressEPKcmPNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEE"}
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +73,7 @@ def test_versions_bounds_and_error_conventions(lib):
     assert lib.ZSTD_isError((1 << 64) - 1) and lib.ZSTD_isError((1 << 64) - 70) and not lib.ZSTD_isError((1 << 64) - 121)
     assert lib.ZSTD_getErrorName((1 << 64) - 70) == b"Destination buffer is too small"
     out = C.create_string_buffer(64)
-    assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, b"abc", 3, 3))       # level 3 = double-fast: no GPU backend
+    assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, b"abc", 3, 7))       # level 7 = lazy: no GPU backend
     assert lib.ZSTD_isError(lib.ZSTD_compress(out, 64, None, 3, 1))
     assert lib.LZ4_compress_default(None, out, 5, 64) == 0                   # lz4.c AOCL NULL checks
     assert lib.LZ4_compress_fast(None, out, 3, 64, 7) == 0
@@ -160,3 +162,16 @@ def test_native_round_trips_match_the_oracle(lib, oracle, eng):
     assert not lib.ZSTD_isError(r)
     back = C.create_string_buffer(len(big))
     assert lib.ZSTD_decompress(back, len(big), out, r) == len(big) and back.raw == big
+
+
+@pytest.mark.gpu
+def test_cxx_caller_of_the_string_and_context_apis(eng, tmp_path):
+    """tests/native_cxx_check.cpp, a C++ program written against the reference's names (snappy::Compress / Uncompress with
+    std::string, ZSTD_compress2 + ZSTD_CCtx_setParameter / reset, frame inspection), built and linked against the library"""
+    import subprocess
+    exe = tmp_path / "native_cxx_check"
+    libdir = os.path.dirname(api.lib_path())
+    subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "native_cxx_check.cpp"), "-o", str(exe), "-L" + libdir,
+                    "-laocl_compression_gpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "native C++ check OK" in r.stdout, r.stdout + r.stderr

@@ -237,3 +237,39 @@ def test_content_checksums_are_verified_on_the_host_paths(eng, lib, reflib):
     assert _wrapper_decompress(lib, bytes(bad), len(d1) + len(d2)) is None
     r, back, _ = eng.llc_decompress(a.ZSTD, f1 + f2, len(d1) + len(d2))
     assert r == len(d1) + len(d2) and back == d1 + d2
+
+
+def test_frame_inspection_equals_the_reference(lib, reflib):
+    """ZSTD_findFrameCompressedSize / ZSTD_decompressBound / ZSTD_getDecompressedSize / ZSTD_getFrameContentSize: host
+    arithmetic on headers, compared with the reference on its own frames (single- and multi-block, with and without content
+    size, concatenated, behind a skippable frame, truncated)"""
+    import struct
+    for L in (lib, reflib):
+        L.ZSTD_findFrameCompressedSize.restype = C.c_size_t
+        L.ZSTD_findFrameCompressedSize.argtypes = [C.c_char_p, C.c_size_t]
+        for n in ("ZSTD_decompressBound", "ZSTD_getDecompressedSize", "ZSTD_getFrameContentSize"):
+            getattr(L, n).restype = C.c_ulonglong
+            getattr(L, n).argtypes = [C.c_char_p, C.c_size_t]
+
+    def ref_frame(data, level, content_size):
+        cctx = reflib.ZSTD_createCCtx()
+        zp = reflib.ZSTD_getParams(level, len(data), 0)
+        zp.fParams.contentSizeFlag = content_size
+        cap = reflib.ZSTD_compressBound(len(data))
+        out = C.create_string_buffer(cap)
+        r = reflib.ZSTD_compress_advanced(cctx, out, cap, data, len(data), None, 0, zp)
+        reflib.ZSTD_freeCCtx(cctx)
+        return out.raw[:r]
+
+    d1 = a.corpus.make("text", 400000, seed=81).tobytes()
+    d2 = a.corpus.make("binary", 5000, seed=82).tobytes()
+    frames = [ref_frame(d1, 1, 1), ref_frame(d1, 3, 0), ref_frame(d2, 5, 1), ref_frame(b"", 1, 1), ref_frame(d2, 1, 0)]
+    skippable = struct.pack("<II", 0x184D2A53, 7) + b"1234567"
+    streams = frames + [frames[0] + frames[2], skippable + frames[1] + frames[4], frames[2][:-3], frames[0][:50], b"\x00" * 20, b""]
+    for blob in streams:
+        for name in ("ZSTD_findFrameCompressedSize", "ZSTD_decompressBound", "ZSTD_getDecompressedSize", "ZSTD_getFrameContentSize"):
+            got, want = getattr(lib, name)(blob, len(blob)), getattr(reflib, name)(blob, len(blob))
+            if name == "ZSTD_findFrameCompressedSize" and reflib.ZSTD_isError(want):
+                assert lib.ZSTD_isError(got), (name, len(blob))                    # both refuse (error codes may differ)
+            else:
+                assert got == want, (name, len(blob), got, want)
