@@ -798,6 +798,9 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 + LZ4_LDS_PAD : kTableBytes) + kSrcRing];
     const uint32_t c = first + blockIdx.x;
     if (c >= b.nchunks) return;
+#ifdef AOCLGPU_EXPERIMENTS
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
     const ChunkView v = compress_view(b, c);
     const uint32_t n = v.src_len;
     int r;
@@ -814,6 +817,12 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     }
     else if ((MODE == 0) != (n < k64KLimit) || (MODE == 1 && n > (1u << 18))) r = 0;   // launcher picked the wrong mode
     else r = lz4_compress_wave<MODE == 3 ? 2 : MODE, PROF>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
+#ifdef AOCLGPU_EXPERIMENTS
+    if ((b.reserved & 2u) && b.aux) {                      // experiment build: per-chunk duration (s_memtime ticks / 1024) instead of the run length
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        lastrun = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+    }
+#endif
     if (threadIdx.x == 0) { b.out_len[c] = r; if (b.aux) b.aux[c] = lastrun; }
 }
 
@@ -849,11 +858,20 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 16];
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
+#ifdef AOCLGPU_EXPERIMENTS
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
     const ChunkView v = decompress_view(b, c);
     int r;
     if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
     else r = lz4_decompress_wave<RAP>(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring, RAP && c + 1 < b.nchunks);
     if (threadIdx.x == 0) b.out_len[c] = r;
+#ifdef AOCLGPU_EXPERIMENTS
+    if ((b.reserved & 2u) && b.aux) {                      // experiment build: per-chunk duration (s_memtime ticks / 64)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) b.aux[c] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 6);
+    }
+#endif
 }
 
 }  // namespace aoclgpu

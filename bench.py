@@ -315,6 +315,17 @@ class Run:
             self.seg_off, total = sharding.segment_layout(self.seg)
             self.gather_buf = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
             self.packed = self.gather_buf[self.seg_off[self.rank]:self.seg_off[self.rank] + self.seg[self.rank]]
+            # one untimed exchange: if this RCCL build cannot run the grouped send/recv, every rank sees the same exception and
+            # all of them fall back to the padded all-gather together (the JSON line says which exchange ran)
+            try:
+                for w in self.exchange():
+                    w.wait()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                if self.rank == 0:
+                    print(f"bench: grouped send/recv exchange failed ({e!r}); using the padded all-gather", file=sys.stderr)
+                self.args.exchange = "allgather"
+                self.setup_exchange()
 
     def exchange(self):
         dist, torch = self.dist, self.torch
