@@ -44,7 +44,7 @@ while time.time() < t_end:
     soff = np.concatenate([[0], np.cumsum((slen.astype(np.int64) + 15) & ~15)[:-1]]).astype(np.uint64)
     dcap = np.array(caps, np.uint32)
     doff = np.concatenate([[0], np.cumsum((dcap.astype(np.int64) + 63) & ~63)[:-1]]).astype(np.uint64)
-    blob = np.zeros(int(soff[-1]) + int((slen[-1] + 15) & ~15) + 64, np.uint8)
+    blob = np.zeros(int(soff[-1]) + ((int(slen[-1]) + 15) & ~15) + 64, np.uint8)
     for s, o in zip(streams, soff):
         blob[int(o):int(o) + len(s)] = np.frombuffer(s, np.uint8)
     t = torch; dev = eng.device
