@@ -46,6 +46,10 @@ size_t orc_zstd_compress_level(const uint8_t* src, size_t n, uint8_t* dst, size_
  * (zstd_double_fast.c:332-573; hashLog = long table, chainLog = short table, minMatch = short-hash bytes) */
 size_t orc_zstd_compress_cparams(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, int strategy,
                                  uint32_t hashLog, uint32_t chainLog, uint32_t minMatch);
+/* == ZSTD_compress_advanced with "fast" parameters on an input of any size below 2 GiB: one frame of 128 KiB blocks
+ * (zstd_compress.c:4504-4583) */
+size_t orc_zstd_compress_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap,
+                               uint32_t windowLog, uint32_t hashLog, uint32_t minMatch);
 /* == ZSTD_decompress: returns decoded size, (size_t)-1 on error */
 size_t orc_zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
 

@@ -470,10 +470,26 @@ static size_t huf_encode_4x(u8* dst, const u8* src, size_t n, const huf_ct* ct)
     return (size_t)(op - dst);
 }
 
-/* HUF_compress_internal without table reuse (huf_compress.c:1326-1434): 0 = not compressible, 1 = rle */
-static size_t huf_compress(u8* dst, const u8* src, size_t n, int single, int suspect)
+/* HUF_compress_internal (huf_compress.c:1326-1434): 0 = not compressible, 1 = rle.  `old` holds the table of the last
+ * confirmed block (all-zero lengths before the first) and `*repeat` its state (0 = HUF_repeat_none, 1 = HUF_repeat_check);
+ * when a new table is written it replaces `old` and `*repeat` becomes 0, when the old one is reused `*repeat` stays 1 and
+ * the output has no table description. */
+static u32 huf_estimate(const huf_ct* ct, const u32* count, u32 maxSym)
+{   /* HUF_estimateCompressedSize :809-818 */
+    size_t nbBits = 0; u32 s2;
+    for (s2 = 0; s2 <= maxSym; s2++) nbBits += (size_t)ct->nbBits[s2] * count[s2];
+    return (u32)(nbBits >> 3);
+}
+static size_t huf_encode(u8* dst, const u8* src, size_t n, int single, const huf_ct* ct, size_t h)
+{   /* HUF_compressCTable_internal :1216-1240 with `h` header bytes already at dst */
+    const size_t c = single ? huf_encode_1x(dst + h, src, n, ct) : huf_encode_4x(dst + h, src, n, ct);
+    if (!c) return 0;
+    if (h + c >= n - 1) return 0;
+    return h + c;
+}
+static size_t huf_compress(u8* dst, const u8* src, size_t n, int single, int suspect, int preferRepeat, huf_ct* old, int* repeat)
 {
-    u32 count[256], maxSym = 255, largest = 0, i, huffLog; huf_ct ct; size_t h, c;
+    u32 count[256], maxSym = 255, largest = 0, i, huffLog; huf_ct ct; size_t h;
     if (!n) return 0;
     if (suspect && n >= 4096 * 10) {                                  /* :1361-1375 */
         u32 cnt[256], lb = 0, le = 0;
@@ -489,15 +505,23 @@ static size_t huf_compress(u8* dst, const u8* src, size_t n, int single, int sus
     for (i = 0; i < 256; i++) { if (count[i]) maxSym = i; if (count[i] > largest) largest = count[i]; }
     if (largest == n) { dst[0] = src[0]; return 1; }
     if (largest <= (n >> 7) + 4) return 0;
+    if (*repeat) {                                                    /* HUF_validateCTable :796-807, :1386-1391 */
+        int bad = 0;
+        for (i = 0; i <= maxSym; i++) bad |= (count[i] != 0) & (old->nbBits[i] == 0);
+        if (bad) *repeat = 0;
+    }
+    if (preferRepeat && *repeat) return huf_encode(dst, src, n, single, old, 0);   /* :1392-1397 */
     huffLog = fse_optimal_log(11, n, maxSym, 1);                      /* HUF_optimalTableLog :1268-1283 */
     huffLog = huf_build(&ct, count, maxSym, huffLog);
     h = huf_write_ctable(dst, &ct, maxSym, huffLog);
     if (!h) return 0;                                                 /* error -> raw literals */
+    if (*repeat) {                                                    /* :1419-1426 */
+        const u32 oldSize = huf_estimate(old, count, maxSym), newSize = huf_estimate(&ct, count, maxSym);
+        if (oldSize <= h + newSize || h + 12 >= n) return huf_encode(dst, src, n, single, old, 0);
+    }
     if (h + 12 >= n) return 0;
-    c = single ? huf_encode_1x(dst + h, src, n, &ct) : huf_encode_4x(dst + h, src, n, &ct);
-    if (!c) return 0;
-    if (h + c >= n - 1) return 0;                                     /* HUF_compressCTable_internal :1232-1236 */
-    return h + c;
+    *repeat = 0; *old = ct;                                           /* :1429-1432 */
+    return huf_encode(dst, src, n, single, &ct, h);
 }
 
 /* ZSTD_compressLiterals for a first block (zstd_compress_literals.c:129-235) */
@@ -510,18 +534,24 @@ static size_t lit_raw(u8* dst, const u8* src, size_t n, u32 type)
     if (type == 0) { memcpy(dst + fl, src, n); return fl + n; }
     dst[fl] = src[0]; return fl + 1;
 }
-static size_t compress_literals(u8* dst, const u8* src, size_t n, int suspect)
+/* Huffman state carried from block to block of one frame (ZSTD_hufCTables_t, zstd_compress_internal.h:70-73) */
+typedef struct { huf_ct ct; int repeat; } huf_state;
+static size_t compress_literals(u8* dst, const u8* src, size_t n, int suspect, const huf_state* prev, huf_state* next)
 {
     const size_t lh = 3 + (n >= 1024) + (n >= 16384);
     const int single = n < 256;
+    int repeat = prev->repeat; u32 hType;
     size_t c;
+    *next = *prev;                                                    /* :144 */
     if (n < 64) return lit_raw(dst, src, n, 0);                       /* ZSTD_minLiteralsToCompress: 8 << 3 */
-    c = huf_compress(dst + lh, src, n, single, suspect);
-    if (c == 0 || c >= n - ((n >> 6) + 2)) return lit_raw(dst, src, n, 0);   /* ZSTD_minGain */
-    if (c == 1) return lit_raw(dst, src, n, 1);                       /* n >= 64 >= 8: rle */
-    if (lh == 3) { const u32 v = 2 + ((u32)(!single) << 2) + ((u32)n << 4) + ((u32)c << 14); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
-    else if (lh == 4) { const u32 v = 2 + (2 << 2) + ((u32)n << 4) + ((u32)c << 18); memcpy(dst, &v, 4); }
-    else { const u32 v = 2 + (3 << 2) + ((u32)n << 4) + ((u32)c << 22); memcpy(dst, &v, 4); dst[4] = (u8)(c >> 10); }
+    c = huf_compress(dst + lh, src, n, single, suspect, n <= 1024, &next->ct, &repeat);   /* preferRepeat: strategy < lazy, :164 */
+    hType = repeat ? 3 : 2;                                           /* set_repeat : set_compressed, :185-189 */
+    if (c == 0 || c >= n - ((n >> 6) + 2)) { *next = *prev; return lit_raw(dst, src, n, 0); }   /* ZSTD_minGain */
+    if (c == 1) { *next = *prev; return lit_raw(dst, src, n, 1); }    /* n >= 64 >= 8: rle */
+    if (hType == 2) next->repeat = 1;                                 /* a new table: HUF_repeat_check, :213-216 */
+    if (lh == 3) { const u32 v = hType + ((u32)(!single) << 2) + ((u32)n << 4) + ((u32)c << 14); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
+    else if (lh == 4) { const u32 v = hType + (2 << 2) + ((u32)n << 4) + ((u32)c << 18); memcpy(dst, &v, 4); }
+    else { const u32 v = hType + (3 << 2) + ((u32)n << 4) + ((u32)c << 22); memcpy(dst, &v, 4); dst[4] = (u8)(c >> 10); }
     return lh + c;
 }
 
@@ -596,11 +626,11 @@ static int build_stream(u8** op, fse_ct* ct, const u8* codes, size_t nbSeq, u32 
 }
 
 /* ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027); returns block content size, 0 = emit raw */
-static size_t entropy_compress(u8* dst, const u8* lits, size_t litSize, const zseq* seqs, size_t nbSeq)
+static size_t entropy_compress(u8* dst, const u8* lits, size_t litSize, const zseq* seqs, size_t nbSeq, const huf_state* prev, huf_state* next)
 {
     u8* op = dst;
     const int suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-    op += compress_literals(op, lits, litSize, suspect);
+    op += compress_literals(op, lits, litSize, suspect, prev, next);
     if (nbSeq < 128) *op++ = (u8)nbSeq;
     else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
     else { op[0] = 0xFF; op[1] = (u8)(nbSeq - 0x7F00); op[2] = (u8)((nbSeq - 0x7F00) >> 8); op += 3; }
@@ -652,7 +682,8 @@ static u32 z_hash(const u8* p, u32 hlog, u32 mls)
     const u64 v = z_rd64(p);
     if (mls == 4) return ((u32)v * 2654435761u) >> (32 - hlog);                   /* ZSTD_hash4 (zstd_compress_internal.h:836-841) */
     if (mls == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
-    return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    if (mls == 6) return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    return (u32)(((v << 8) * 58295818150454627ull) >> (64 - hlog));               /* ZSTD_hash7 (:848-850) */
 }
 static u32 z_count(const u8* s, u32 a, u32 b, u32 end)
 {   /* ZSTD_count: common prefix of s[a..end) and s[b..] */
@@ -660,11 +691,24 @@ static u32 z_count(const u8* s, u32 a, u32 b, u32 end)
 }
 #define PUT(pos) table[z_hash(src + (pos), hlog, mls)] = (pos) + 2
 
-static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+/* window state of one frame (ZSTD_window_t, zstd_compress_internal.h:178-185): indices are position + 2 */
+typedef struct { u32 dictLimit, lowLimit, maxDist; } zwin;
+/* ZSTD_getLowestPrefixIndex (zstd_compress_internal.h:1305-1320), no dictionary */
+static u32 lowest_prefix(const zwin* w, u32 curr) { return (curr - w->dictLimit > w->maxDist) ? curr - w->maxDist : w->dictLimit; }
+
+/* One block [bs, be) of a frame whose bytes start at src[0]: `table` and `rep` carry over from the previous block.
+ * Returns the number of sequences; positions are offsets into src, table entries position + 2. */
+static size_t fast_block_at(const u8* src, u32 bs, u32 be, u32* table, u32 hlog, u32 mls, const zwin* w, u32 rep[2],
+                            zseq* seqs, u8* lits, size_t* litSizeOut)
 {
-    u32* table = (u32*)calloc((size_t)1 << hlog, sizeof(u32));
+    const u32 n = be;                                                 /* iend */
+    const u32 prefixIdx = lowest_prefix(w, be + 2), prefixPos = prefixIdx - 2;     /* :443-446 */
     size_t nbSeq = 0, litSize = 0;
-    u32 anchor = 0, ip0 = 1, rep1 = 1, rep2 = 0;                      /* rep {1,4,8}: 4 > maxRep=1 is parked (:484-489) */
+    u32 anchor = bs, ip0 = bs + (bs == prefixPos), rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    {   const u32 curr = ip0 + 2, maxRep = curr - lowest_prefix(w, curr);          /* :481-489 */
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
     if (n < 16 + 4) goto cleanup;                                     /* ilimit = n - 16 must leave room for ip3 */
     {   const u32 ilimit = n - 16;
         for (;;) {                                                    /* _start */
@@ -685,12 +729,12 @@ static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8
                     table[hash1] = ip1 + 2;
                     found = 2; break;
                 }
-                if (idx >= 2 && z_rd32(src + idx - 2) == z_rd32(src + ip0)) { table[hash1] = ip1 + 2; found = 1; break; }
+                if (idx >= prefixIdx && z_rd32(src + idx - 2) == z_rd32(src + ip0)) { table[hash1] = ip1 + 2; found = 1; break; }
                 idx = table[hash1];
                 hash0 = hash1; hash1 = z_hash(src + ip2, hlog, mls);
                 ip0 = ip1; ip1 = ip2; ip2 = ip3;
                 current0 = ip0; table[hash0] = ip0 + 2;
-                if (idx >= 2 && z_rd32(src + idx - 2) == z_rd32(src + ip0)) {
+                if (idx >= prefixIdx && z_rd32(src + idx - 2) == z_rd32(src + ip0)) {
                     if (step <= 4) table[hash1] = ip1 + 2;
                     found = 1; break;
                 }
@@ -703,7 +747,7 @@ static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8
             if (found == 1) {                                         /* _offset (:651-665) */
                 match0 = idx - 2;
                 rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3; mLength = 4;
-                while (ip0 > anchor && match0 > 0 && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+                while (ip0 > anchor && match0 > prefixPos && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
             }
             mLength += z_count(src, ip0 + mLength, match0 + mLength, n);      /* _match */
             seqs[nbSeq].litLength = ip0 - anchor; seqs[nbSeq].offBase = offcode; seqs[nbSeq].matchLength = mLength; nbSeq++;
@@ -726,8 +770,20 @@ static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8
         }
     }
 cleanup:
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;            /* :626-630 */
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
     memcpy(lits + litSize, src + anchor, n - anchor); litSize += n - anchor;     /* ZSTD_storeLastLiterals */
     *litSizeOut = litSize;
+    return nbSeq;
+}
+/* the only block of a fresh context: rep {1,4,8}, where 4 > maxRep = 1 is parked (:484-489) */
+static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+{
+    u32* table = (u32*)calloc((size_t)1 << hlog, sizeof(u32));
+    const zwin w = { 2, 2, 1u << 31 };
+    u32 rep[2] = { 1, 4 };
+    const size_t nbSeq = fast_block_at(src, 0, n, table, hlog, mls, &w, rep, seqs, lits, litSizeOut);
     free(table);
     return nbSeq;
 }
@@ -863,7 +919,8 @@ size_t orc_zstd_compress_cparams(const u8* src, size_t n, u8* dst, size_t dstCap
             g_strategy = (u32)strategy;
             nbSeq = strategy == 1 ? fast_block(src, (u32)n, hashLog, minMatch, seqs, lits, &litSize)
                                   : dfast_block(src, (u32)n, hashLog, chainLog, minMatch, seqs, lits, &litSize);
-            cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq);
+            {   huf_state hprev, hnext; memset(&hprev, 0, sizeof(hprev));
+                cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq, &hprev, &hnext); }
             g_strategy = 1;
             if (cSize >= n - ((n >> 6) + 2)) cSize = 0;               /* ZSTD_minGain, zstd_compress.c:3055-3057 */
             if (cSize) memcpy(op + 3, tmp, cSize);
@@ -877,6 +934,78 @@ size_t orc_zstd_compress_cparams(const u8* src, size_t n, u8* dst, size_t dstCap
             const u32 h = 1 + (2 << 1) + ((u32)cSize << 3);
             op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16); op += 3 + cSize;
         }
+    }
+    return (size_t)(op - dst);
+}
+
+/* A whole frame of any size with the "fast" strategy, as ZSTD_compress_advanced makes it (contentSizeFlag 1, no checksum):
+ * ZSTD_compress_frameChunk (zstd_compress.c:4504-4583) cuts the input into 128 KiB blocks that share the hash table, the
+ * repeat offsets and the Huffman table of the last block written compressed; ZSTD_compressBlock_internal (:4333-4395)
+ * turns a block that is one repeated byte into an RLE block unless it is the first; a block that ends raw or RLE leaves
+ * the repeat offsets and the entropy tables as they were (:4385-4387).  FSE tables are never repeated at strategies below
+ * "lazy" without a dictionary (ZSTD_selectEncodingType, zstd_compress_sequences.c:166-196: set_repeat needs
+ * FSE_repeat_valid, which only a dictionary sets).  Returns the frame size, 0 on failure. */
+size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch)
+{
+    u8* op = dst;
+    /* blockSize = MIN(ZSTD_BLOCKSIZE_MAX, windowSize) (ZSTD_resetCCtx_internal, zstd_compress.c:2129-2131) */
+    const size_t blockMax = windowLog < 17 ? (size_t)1 << windowLog : 128u << 10;
+    if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31) return 0;
+    /* ZSTD_writeFrameHeader (zstd_compress.c:4586-4632) */
+    op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
+    {   const u32 single = ((u64)1 << windowLog) >= n;
+        const u32 fcs = (n >= 256) + (n >= 65536 + 256);
+        *op++ = (u8)((single << 5) | (fcs << 6));
+        if (!single) *op++ = (u8)((windowLog - 10) << 3);
+        if (fcs == 0) { if (single) *op++ = (u8)n; }
+        else if (fcs == 1) { const u32 v = (u32)n - 256; *op++ = (u8)v; *op++ = (u8)(v >> 8); }
+        else { const u32 v = (u32)n; memcpy(op, &v, 4); op += 4; }
+    }
+    if (n == 0) { op[0] = 1; op[1] = 0; op[2] = 0; return (size_t)(op + 3 - dst); }   /* ZSTD_writeEpilogue */
+    {   u32* table = (u32*)calloc((size_t)1 << hashLog, sizeof(u32));
+        zseq* seqs = (zseq*)malloc(sizeof(zseq) * (blockMax / 3 + 8));
+        u8* lits = (u8*)malloc(blockMax + 8);
+        u8* tmp = (u8*)malloc(2 * blockMax + 1024);
+        zwin w = { 2, 2, 1u << windowLog };
+        u32 rep[2] = { 1, 4 };
+        huf_state hprev, hnext;
+        size_t bs;
+        memset(&hprev, 0, sizeof(hprev));
+        g_strategy = 1;
+        for (bs = 0; bs < n; bs += blockMax) {
+            const size_t bn = n - bs < blockMax ? n - bs : blockMax;
+            const u32 last = bs + bn == n;
+            size_t cSize = 0;
+            if ((u32)bs + 2 > w.maxDist) {                            /* ZSTD_window_enforceMaxDist at the block's start (:4532) */
+                const u32 low = (u32)bs + 2 - w.maxDist;
+                if (w.lowLimit < low) w.lowLimit = low;
+                if (w.dictLimit < w.lowLimit) w.dictLimit = w.lowLimit;
+            }
+            if (bn >= 7) {                                            /* ZSTD_buildSeqStore :3268 */
+                size_t litSize, nbSeq; u32 nrep[2] = { rep[0], rep[1] };
+                nbSeq = fast_block_at(src, (u32)bs, (u32)(bs + bn), table, hashLog, minMatch, &w, nrep, seqs, lits, &litSize);
+                cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq, &hprev, &hnext);
+                if (cSize >= bn - ((bn >> 6) + 2)) cSize = 0;         /* ZSTD_minGain, zstd_compress.c:3055-3057 */
+                if (bs != 0 && cSize < 25) {                          /* ZSTD_isRLE, :4372-4383 */
+                    size_t i = 1; while (i < bn && src[bs + i] == src[bs]) i++;
+                    if (i == bn) { cSize = 1; tmp[0] = src[bs]; }
+                }
+                if (cSize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; hprev = hnext; }   /* confirmRepcodesAndEntropyTables */
+            }
+            if (cSize == 0) {                                         /* ZSTD_noCompressBlock */
+                const u32 h = last + (0 << 1) + ((u32)bn << 3);
+                op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16);
+                memcpy(op + 3, src + bs, bn); op += 3 + bn;
+            } else if (cSize == 1) {
+                const u32 h = last + (1 << 1) + ((u32)bn << 3);
+                op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16); op[3] = tmp[0]; op += 4;
+            } else {
+                const u32 h = last + (2 << 1) + ((u32)cSize << 3);
+                op[0] = (u8)h; op[1] = (u8)(h >> 8); op[2] = (u8)(h >> 16);
+                memcpy(op + 3, tmp, cSize); op += 3 + cSize;
+            }
+        }
+        free(table); free(seqs); free(lits); free(tmp);
     }
     return (size_t)(op - dst);
 }

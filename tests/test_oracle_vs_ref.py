@@ -7,6 +7,7 @@ import pytest
 
 import aocl_compression_amd as a
 import oracle_lib as ol
+import zstd_frame_cases as zfc
 
 CODECS = [ol.LZ4, ol.SNAPPY, ol.ZSTD]
 SIZES = [0, 1, 6, 7, 12, 13, 14, 15, 16, 19, 20, 21, 63, 64, 65, 255, 256, 257, 1000, 1024, 4096, 16383, 16384, 16385, 40000,
@@ -160,3 +161,34 @@ def test_zstd_double_fast_bit_exact(oracle, ref, kind):
             assert oracle.decompress(ol.ZSTD, want, n) == data
             seen.add((cp.hashLog, cp.chainLog, cp.minMatch))
     assert len(seen) >= 4
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
+def test_zstd_multi_block_frames_bit_exact(oracle, ref, kind):
+    """Inputs above 128 KiB: one frame of 128 KiB blocks (min(128 KiB, window) in general) that share the hash table, the
+    repeat offsets and the last compressed block's Huffman table (ZSTD_compress_frameChunk, zstd_compress.c:4504-4583;
+    HUF_compress_internal's table reuse, huf_compress.c:1386-1432; RLE blocks after the first, :4372-4383).  The level's own
+    parameters and explicit ones: a window below the input (window descriptor, ZSTD_window_enforceMaxDist), a window below
+    the block size (smaller blocks), every minMatch of the fast strategy."""
+    import ctypes as C
+    f = oracle.L.orc_zstd_compress_frame
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+    checked = 0
+    for i, n in enumerate(zfc.EDGE_SIZES + (3000000,)):
+        data = zfc.make(kind, n, seed=100 + i)
+        cps = [zfc.ref_level_cparams(ref, 1, n)]
+        cps += [zfc.CParams(*row) for row in ((17, 13, 14, 1, 6, 0, 1), (12, 13, 13, 1, 5, 0, 1), (19, 13, 14, 1, 7, 0, 1), (23, 13, 12, 1, 4, 0, 1))]
+        l2 = zfc.ref_level_cparams(ref, 2, n)
+        if l2.strategy == 1:
+            cps.append(l2)
+        for cp in cps:
+            want = zfc.ref_frame(ref, data, cp)
+            cap = n + (n >> 8) + 64
+            out = C.create_string_buffer(cap)
+            r = f(data, n, out, cap, cp.windowLog, cp.hashLog, cp.minMatch)
+            assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.minMatch)
+            checked += 1
+        if i % 4 == 0:
+            assert oracle.decompress(ol.ZSTD, want, n) == data
+    assert checked >= 50
