@@ -62,6 +62,12 @@ def lz4_acceleration(a: int) -> int:
 
 
 
+class ZstdFrames(C.Structure):
+    """aoclgpu_zstd_frames (include/aocl_gpu_codec.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_off", C.c_void_p), ("dst_off", C.c_void_p), ("out_len", C.c_void_p),
+                ("nframes", C.c_uint32), ("windowLog", C.c_uint32), ("hashLog", C.c_uint32), ("minMatch", C.c_uint32)]
+
+
 class LlcDesc(C.Structure):
     """aocl_compression_desc (api/aocl_compression.h:125-152)."""
     _fields_ = [
@@ -82,7 +88,7 @@ EXPORTS = [
     "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes", "aoclgpu_rap_default_chunk",
     "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",
     "aoclgpu_zstd_compress_host_frames", "aoclgpu_zstd_decompress_host_frames", "aoclgpu_set_host_device", "aoclgpu_host_device",
-    "aoclgpu_rap_assemble",
+    "aoclgpu_rap_assemble", "aoclgpu_zstd_compress_frames",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
 ]
 
@@ -125,6 +131,8 @@ def load_library() -> C.CDLL:
         f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32]
     lib.aoclgpu_zstd_decompress_host_frames.restype = C.c_int64
     lib.aoclgpu_zstd_decompress_host_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.aoclgpu_zstd_compress_frames.restype = C.c_int
+    lib.aoclgpu_zstd_compress_frames.argtypes = [C.POINTER(ZstdFrames), C.c_void_p]
     lib.aoclgpu_rap_frame_bytes.restype = C.c_uint64
     lib.aoclgpu_rap_frame_bytes.argtypes = [C.c_int, C.c_uint32]
     for n in ("aocl_llc_compress", "aocl_llc_decompress"):
@@ -259,6 +267,27 @@ class Engine:
                                                   ax.ctypes.data if ax is not None else None, k, out.data_ptr(), cap,
                                                   C.byref(n), self._stream()), "rap_assemble")
         return out[:n.value]
+
+    def zstd_compress_frames(self, src, src_off, window_log: int, hash_log: int, min_match: int, caps=None):
+        """One Zstd frame per input of any size (aoclgpu_zstd_compress_frames): `src` is a device uint8 tensor, `src_off` a
+        host sequence of nframes + 1 offsets into it.  Returns (dst tensor, dst offsets as a list, frame sizes as a list)."""
+        import numpy as np
+        t = self.torch
+        so = np.ascontiguousarray(src_off, dtype=np.uint64)
+        k = len(so) - 1
+        sizes = (so[1:] - so[:-1]).astype(np.int64)
+        if caps is None:
+            caps = [compress_bound(ZSTD, int(n)) + 32 for n in sizes]
+        do = np.zeros(k + 1, dtype=np.uint64)
+        do[1:] = np.cumsum(np.asarray(caps, dtype=np.uint64))
+        dst = t.empty(max(int(do[-1]), 1), dtype=t.uint8, device=self.device)
+        d_so = t.from_numpy(so.view(np.int64)).to(self.device)
+        d_do = t.from_numpy(do.view(np.int64)).to(self.device)
+        out_len = t.zeros(max(k, 1), dtype=t.int64, device=self.device)
+        f = ZstdFrames(src.data_ptr(), dst.data_ptr(), d_so.data_ptr(), d_do.data_ptr(), out_len.data_ptr(), k,
+                       window_log, hash_log, min_match)
+        self._check(self.lib.aoclgpu_zstd_compress_frames(C.byref(f), self._stream()), "zstd_compress_frames")
+        return dst, [int(x) for x in do], [int(x) for x in out_len[:k].cpu().tolist()]
 
     def compact(self, slots, slot_bytes: int, out_len):
         """Gather the used prefix of each slot into one stream; returns (packed, offsets uint64-as-int64[n+1])."""

@@ -87,7 +87,8 @@ __device__ __forceinline__ u32 z_hash(u64 v, u32 hlog)
 {   // ZSTD_hash4Ptr / ZSTD_hash5Ptr / ZSTD_hash6Ptr (zstd_compress_internal.h:836-875)
     if (MLS == 4) return ((u32)v * 2654435761u) >> (32 - hlog);
     if (MLS == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
-    return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    if (MLS == 6) return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    return (u32)(((v << 8) * 58295818150454627ull) >> (64 - hlog));       // ZSTD_hash7Ptr (:848-850)
 }
 
 // common prefix of src[a..end) and src[b..], 256 bytes per step (ZSTD_count)
@@ -728,8 +729,25 @@ __device__ u32 huf_encode_4x(u8* dst, const u8* src, u32 n, const HufCT* ct, u32
     return op + c;
 }
 
-// HUF_compress_internal for a first block (huf_compress.c:1326-1434): 0 = not compressible, 1 = rle
-__device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool suspect, EntropyLds* L, int lane)
+// Huffman state a frame carries from block to block (ZSTD_hufCTables_t, zstd_compress_internal.h:70-73): the table of the
+// last block that was written compressed and whether it may be reused (HUF_repeat_check; HUF_repeat_valid only comes from
+// dictionaries).  `fresh` is set when the block just coded wrote a new table into EntropyLds::huf: the frame loop copies it
+// into `prev` if the block is confirmed (ZSTD_blockState_confirmRepcodesAndEntropyTables, zstd_compress.c:4385-4387).
+struct FrameHuf { HufCT* prev; u32 repeat; u32 fresh; };
+
+// HUF_estimateCompressedSize (huf_compress.c:809-818)
+__device__ u32 huf_estimate(const HufCT* ct, const u32* hist, u32 maxSym, int lane)
+{
+    u32 bits = 0;
+    for (u32 i = (u32)lane; i <= maxSym; i += kWave) bits += (u32)ct->nbBits[i] * hist[i];
+    return uni(wsum(bits)) >> 3;
+}
+
+// HUF_compress_internal (huf_compress.c:1326-1434): 0 = not compressible, 1 = rle.  FR: with the previous block's table
+// (validation :1386-1391, small inputs prefer it :1392-1397, otherwise it is kept when it costs no more than a new table
+// plus its description :1419-1426); `repeat` stays set exactly when the old table coded the literals.
+template <bool FR>
+__device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool suspect, EntropyLds* L, int lane, FrameHuf* fh, u32& repeat)
 {
     if (suspect && n >= 4096 * 10) {                                     // :1361-1375
         wave_hist(L->hist, src, 4096, lane);
@@ -751,32 +769,53 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
     }
     if (largest == n) { if (lane == 0) dst[0] = src[0]; return 1; }
     if (largest <= (n >> 7) + 4) return 0;
+    auto encode = [&](const HufCT* ct, u32 h) -> u32 {                   // HUF_compressCTable_internal :1216-1240
+        const u32 c = single ? huf_encode_1x(dst + h, src, n, ct, L->tile, lane) : huf_encode_4x(dst + h, src, n, ct, L->tile, lane);
+        if (!c) return 0;
+        if (h + c >= n - 1) return 0;
+        return h + c;
+    };
+    if constexpr (FR) {
+        if (repeat) {                                                    // HUF_validateCTable :796-807
+            bool bad = false;
+            for (u32 i = (u32)lane; i <= maxSym; i += kWave) bad |= L->hist[i] != 0 && fh->prev->nbBits[i] == 0;
+            if (ballot(bad)) repeat = 0;
+        }
+        if (repeat && n <= 1024) return encode(fh->prev, 0);             // HUF_flags_preferRepeat (zstd_compress_literals.c:164)
+    }
     u32 huffLog = fse_optimal_log(11, n, maxSym, 1);                     // HUF_optimalTableLog :1268-1283
     huffLog = huf_build_wave(&L->huf, L->hist, maxSym, huffLog, &L->hs, lane);
     const u32 h = huf_write_table_wave(dst, &L->huf, maxSym, huffLog, &L->hs, lane);
     wave_fence();
     if (!h) return 0;
+    if constexpr (FR) {
+        if (repeat) {
+            const u32 oldSize = huf_estimate(fh->prev, L->hist, maxSym, lane), newSize = huf_estimate(&L->huf, L->hist, maxSym, lane);
+            if (oldSize <= h + newSize || h + 12 >= n) return encode(fh->prev, 0);
+        }
+    }
     if (h + 12 >= n) return 0;
-    const u32 c = single ? huf_encode_1x(dst + h, src, n, &L->huf, L->tile, lane)
-                         : huf_encode_4x(dst + h, src, n, &L->huf, L->tile, lane);
-    if (!c) return 0;
-    if (h + c >= n - 1) return 0;                                        // HUF_compressCTable_internal :1232-1236
-    return h + c;
+    if constexpr (FR) { repeat = 0; fh->fresh = 1; }
+    return encode(&L->huf, h);
 }
 
-// ZSTD_compressLiterals for a first block (zstd_compress_literals.c:129-235)
-__device__ u32 compress_literals(u8* dst, const u8* src, u32 n, bool suspect, EntropyLds* L, int lane)
+// ZSTD_compressLiterals (zstd_compress_literals.c:129-235)
+template <bool FR>
+__device__ u32 compress_literals(u8* dst, const u8* src, u32 n, bool suspect, EntropyLds* L, int lane, FrameHuf* fh)
 {
     const u32 lh = 3 + (n >= 1024) + (n >= 16384);
     const bool single = n < 256;
+    u32 repeat = 0;
+    if constexpr (FR) { repeat = fh->repeat; fh->fresh = 0; }
     if (n < 64) return lit_raw(dst, src, n, 0, lane);                    // ZSTD_minLiteralsToCompress = 8 << 3
-    const u32 c = huf_compress(dst + lh, src, n, single, suspect, L, lane);
-    if (c == 0 || c >= n - ((n >> 6) + 2)) return lit_raw(dst, src, n, 0, lane);
-    if (c == 1) return lit_raw(dst, src, n, 1, lane);
+    const u32 c = huf_compress<FR>(dst + lh, src, n, single, suspect, L, lane, fh, repeat);
+    const u32 hType = repeat ? 3u : 2u;                                  // set_repeat : set_compressed (:185-189)
+    if (c == 0 || c >= n - ((n >> 6) + 2)) { if constexpr (FR) fh->fresh = 0; return lit_raw(dst, src, n, 0, lane); }
+    if (c == 1) { if constexpr (FR) fh->fresh = 0; return lit_raw(dst, src, n, 1, lane); }
     if (lane == 0) {
-        if (lh == 3) { const u32 v = 2 + ((u32)(!single) << 2) + (n << 4) + (c << 14); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
-        else if (lh == 4) { const u32 v = 2 + (2 << 2) + (n << 4) + (c << 18); st32(dst, v); }
-        else { const u32 v = 2 + (3 << 2) + (n << 4) + (c << 22); st32(dst, v); dst[4] = (u8)(c >> 10); }
+        if (lh == 3) { const u32 v = hType + ((u32)(!single) << 2) + (n << 4) + (c << 14); dst[0] = (u8)v; dst[1] = (u8)(v >> 8); dst[2] = (u8)(v >> 16); }
+        else if (lh == 4) { const u32 v = hType + (2 << 2) + (n << 4) + (c << 18); st32(dst, v); }
+        else { const u32 v = hType + (3 << 2) + (n << 4) + (c << 22); st32(dst, v); dst[4] = (u8)(c >> 10); }
     }
     return lh + c;
 }
@@ -837,11 +876,12 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
 }
 
 // ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027): block content size, 0 = emit raw
-__device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, EntropyLds* L, int lane, u32 strategy)
+template <bool FR = false>
+__device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, EntropyLds* L, int lane, u32 strategy, FrameHuf* fh = nullptr)
 {
     u32 op = 0;
     const bool suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-    op += compress_literals(dst, ws->lits, litSize, suspect, L, lane);
+    op += compress_literals<FR>(dst, ws->lits, litSize, suspect, L, lane, fh);
     if (lane == 0) {
         if (nbSeq < 128) dst[op] = (u8)nbSeq;
         else if (nbSeq < 0x7F00) { dst[op] = (u8)((nbSeq >> 8) + 0x80); dst[op + 1] = (u8)nbSeq; }
@@ -1026,6 +1066,262 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     wave_fence();
     wave_copy(dst + op + 3, ws->tmp, cSize, lane);
     return (int)(op + 3 + cSize);
+}
+
+
+
+// ================================================================================================
+// Frames of any size (inputs above 128 KiB): ZSTD_compress_frameChunk (zstd_compress.c:4504-4583) cuts the input into blocks
+// of min(128 KiB, window) bytes that share the hash table, the repeat offsets and the Huffman table of the last block
+// written compressed.  Blocks depend on each other in order, so a frame is one wave's work from the first block to the last;
+// frames of a batch run side by side.  "fast" strategy only (levels 1-2 where the level table says so, or explicit
+// parameters through ZSTD_compress_advanced).
+//
+// The match finder is the same exact speculation as above with what a later block needs: positions are offsets into the
+// frame (table entries position + 2, ZSTD_WINDOW_START_INDEX), the table has 2^hashLog u32 entries in the HBM workspace and
+// persists, candidates below the prefix start (ZSTD_getLowestPrefixIndex, zstd_compress_internal.h:1336-1347) are ignored,
+// matches stop at the block's end, and the repeat offsets come in and go out (zstd_fast.c:481-489, :614-634).
+// ================================================================================================
+constexpr u32 kFrScratch = 1024;                // u16 slots for the slot-reuse rounds
+
+struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
+__device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
+{   // ZSTD_getLowestPrefixIndex without a dictionary
+    return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit;
+}
+
+template <int MLS>
+__device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, u32* tab, lbyte* scr,
+                                const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane)
+{
+    typedef __attribute__((address_space(1))) u32 gu32;
+    typedef __attribute__((address_space(3))) uint16_t lu16;
+    gu32* T = (gu32*)tab;
+    lu16* scratch = (lu16*)scr;
+    auto tget = [&](u32 h) -> u32 { return __hip_atomic_load((u32*)(T + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tput = [&](u32 h, u32 v) { __hip_atomic_store((u32*)(T + h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;           // sequence records parked one per lane, written 64 at a time
+    auto flush_seq = [&](u32 first, u32 count) {
+        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
+    };
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
+        const bool me = (u32)lane == (idx & 63u);
+        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
+        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
+    };
+    const u32 n = be;                                                    // iend
+    const u32 prefixIdx = lowest_prefix(win, be + 2), prefixPos = prefixIdx - 2;   // :443-446
+    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u);
+    u32 rep1 = rep1io, rep2 = rep2io, saved1 = 0, saved2 = 0;
+    {   const u32 curr = s + 2, maxRep = curr - lowest_prefix(win, curr);           // :481-489
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+    if (n >= 20) {
+        const u32 ilimit = n - 16;                                       // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
+        auto rep_loop = [&](u32 ip0) -> u32 {                            // immediate rep2 matches behind a sequence (:690-702)
+            bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            while (hit) {
+                const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
+                const u32 t = rep2; rep2 = rep1; rep1 = t;
+                const u32 hc = z_hash<MLS>(ld64(src + ip0), hlog);
+                if (lane == 0) tput(hc, ip0 + 2);
+                put_seq(nbSeq, 0, 1, rLength, ip0);
+                wave_fence();
+                nbSeq++;
+                ip0 += rLength;
+                hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            }
+            return ip0;
+        };
+        for (;;) {                                                      // _start
+            u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
+            u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
+            bool e_ok1 = false, e_ok2 = false;
+            for (;;) {
+                const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
+                u32 am, sg, st;
+                if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
+                else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
+                else { am = 0x40000000u; sg = 2; st = 2; }
+                const bool valid = (u64)s + am + sg + 1 < ilimit;       // ip3 < ilimit (:503, :631)
+                const u32 pos = s + am + half;
+                u64 seq = 0;
+                if (valid) seq = ld64(src + pos);
+                const u32 h = z_hash<MLS>(seq, hlog);
+                u32 ent = 0;
+                if (valid) ent = tget(h);
+                bool rep_hit = false;
+                if (valid && half == 0 && rep1 > 0) {                   // repcode at ip2 (:519-542)
+                    const u32 r = pos + sg;
+                    rep_hit = ld32(src + r) == ld32(src + r - rep1);
+                }
+                u32 m4 = ~(u32)seq;
+                if (valid && ent >= prefixIdx) m4 = ld32(src + ent - 2);
+                wave_fence();
+                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)(scratch + (h & (kFrScratch - 1))), (u32)lane, valid);
+                wave_fence();
+                int f = 64;                                             // first lane whose slot an earlier lane of the batch names
+                for (u64 d = ballot(valid && w != (u32)lane); d; d &= d - 1) {
+                    const int j = (int)__builtin_ctzll(d);
+                    if ((ballot(valid && h == lane_get(h, j)) & ((1ull << j) - 1)) != 0) { f = j; break; }
+                }
+                const int e = first_lane(ballot(!valid));
+                const int lim = f < e ? f : e;
+                const bool mat_hit = m4 == (u32)seq;
+                const int el = first_lane(ballot(lane < lim && (rep_hit || mat_hit)));
+                const int ncommit = (el < 64) ? el + 1 : lim;
+                if (lane < ncommit) tput(h, pos + 2);
+                wave_fence();
+                if (el < 64) {
+                    ev = lane_get((u32)rep_hit, el) ? 2 : 1;
+                    e_pos = lane_get(pos, el); e_cand = lane_get(ent, el);
+                    e_sig = lane_get(sg, el); e_st = lane_get(st, el); e_half = lane_get(half, el);
+                    e_ok1 = el + 1 < 64 && lane_get((u32)valid, (el + 1) & 63) != 0;
+                    e_p1 = lane_get(pos, (el + 1) & 63); e_h1 = lane_get(h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64 && lane_get((u32)valid, (el + 2) & 63) != 0 && lane_get(pos, (el + 2) & 63) == e_pos + 2;
+                    e_h2 = lane_get(h, (el + 2) & 63);
+                    break;
+                }
+                if (e < 64 && e <= f) break;
+                i0 += (u32)lim;
+            }
+            if (!ev) break;                                             // _cleanup
+            {   // table write of ip1 that accompanies the hit (:537, :557, :586-598)
+                const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
+                if (e_half == 0 || e_st <= 4) {
+                    const u32 h1 = (e_ok1 && e_p1 == ip1) ? e_h1 : z_hash<MLS>(ld64(src + ip1), hlog);
+                    if (lane == 0) tput(h1, ip1 + 2);
+                    wave_fence();
+                }
+            }
+            const u32 current0 = e_pos;
+            u32 ip0, match0, offcode, mLength, maxback;
+            if (ev == 2) { ip0 = e_pos + e_sig; match0 = ip0 - rep1; offcode = 1; maxback = 1; }       // :519-542
+            else {                                                      // _offset (:651-665)
+                ip0 = e_pos; match0 = e_cand - 2;
+                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
+                const u32 a = ip0 - anchor, b = match0 - prefixPos; maxback = a < b ? a : b;
+            }
+            {
+                u32 back = 0;
+                while (back < maxback) {
+                    const u32 k = back + (u32)lane;
+                    bool eq = false;
+                    if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
+                    const int c = first_lane(ballot(!eq));
+                    back += (u32)c;
+                    if (c < 64) break;
+                }
+                if (back > maxback) back = maxback;
+                const u32 fwd = wave_count(src, ip0 + 4, match0 + 4, n, lane);
+                ip0 -= back; match0 -= back; mLength = 4 + back + fwd;   // _match (:669)
+            }
+            {
+                const u32 ll = ip0 - anchor;
+                put_seq(nbSeq, ll, offcode, mLength, anchor);
+                litSize += ll; nbSeq++;
+            }
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {                                        // :678-702
+                const u32 ha = e_ok2 ? e_h2 : z_hash<MLS>(ld64(src + current0 + 2), hlog), hb2 = z_hash<MLS>(ld64(src + ip0 - 2), hlog);
+                if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
+                wave_fence();
+                if (rep2 > 0) { ip0 = rep_loop(ip0); anchor = ip0; }
+            }
+            s = ip0;
+        }
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;               // :614-630
+    rep1io = rep1 ? rep1 : saved1;
+    rep2io = rep2 ? rep2 : saved2;
+    flush_seq(nbSeq & ~63u, nbSeq & 63u);
+    wave_fence();
+    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    return nbSeq;
+}
+
+struct FrameLds {
+    EntropyLds e;
+    HufCT prev;                                  // Huffman table of the last confirmed block
+    uint16_t scratch[kFrScratch];
+};
+
+// One frame: returns its size, 0 when it does not fit `cap` (dstSize_tooSmall) or the parameters have no GPU parse.
+__device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 windowLog,
+                                     const u32 hlog, const u32 mls, FrameLds* L, Workspace* ws, u32* tab, int lane)
+{
+    if (n64 >= (1ull << 31) || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
+    const u32 n = (u32)n64;
+    const u32 blockMax = windowLog < 17 ? 1u << windowLog : kBlockMax;   // MIN(ZSTD_BLOCKSIZE_MAX, windowSize), zstd_compress.c:2129-2131
+    const u32 single = ((1ull << windowLog) >= n64) ? 1u : 0u;
+    const u32 fcs = (n >= 256) + (n >= 65536 + 256);
+    u64 op = 5 + (single ? 0 : 1) + (fcs == 0 ? single : (fcs == 1 ? 2 : 4));
+    if (cap < op + 3) return 0;
+    if (lane == 0) {                                                     // ZSTD_writeFrameHeader :4586-4632
+        u32 p = 5;
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        dst[4] = (u8)((single << 5) | (fcs << 6));
+        if (!single) dst[p++] = (u8)((windowLog - 10) << 3);
+        if (fcs == 0) { if (single) dst[p] = (u8)n; }
+        else if (fcs == 1) { const u32 v = n - 256; dst[p] = (u8)v; dst[p + 1] = (u8)(v >> 8); }
+        else st32(dst + p, n);
+    }
+    if (n == 0) { if (lane == 0) { dst[op] = 1; dst[op + 1] = 0; dst[op + 2] = 0; } return (long long)(op + 3); }   // ZSTD_writeEpilogue
+    {   // fresh table (ZSTD_reset_matchState clears it for a new frame)
+        typedef u32 u4 __attribute__((ext_vector_type(4)));
+        const u32 quads = (1u << hlog) / 4;
+        for (u32 i = (u32)lane; i < quads; i += kWave) ((__attribute__((address_space(1))) u4*)tab)[i] = u4{0, 0, 0, 0};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+    FrameWindow win = { 2u, 2u, 1u << windowLog };
+    FrameHuf fh = { &L->prev, 0u, 0u };
+    u32 rep1 = 1, rep2 = 4;
+    for (u32 bs = 0; bs < n; bs += blockMax) {
+        const u32 bn = n - bs < blockMax ? n - bs : blockMax;
+        const u32 last = bs + bn == n ? 1u : 0u;
+        if (bs + 2 > win.maxDist) {                                      // ZSTD_window_enforceMaxDist at the block's start (:4532)
+            const u32 low = bs + 2 - win.maxDist;
+            if (win.lowLimit < low) win.lowLimit = low;
+            if (win.dictLimit < win.lowLimit) win.dictLimit = win.lowLimit;
+        }
+        u32 cSize = 0;
+        if (bn >= 7) {                                                   // ZSTD_buildSeqStore :3268
+            u32 litSize = 0, nbSeq, nr1 = rep1, nr2 = rep2;
+            const gbyte* g = (const gbyte*)src;
+            if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+            else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+            else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+            else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+            wave_fence();
+            cSize = entropy_compress<true>(ws->tmp, ws, litSize, nbSeq, &L->e, lane, 1u, &fh);
+            if (cSize >= bn - ((bn >> 6) + 2)) cSize = 0;                // ZSTD_minGain, zstd_compress.c:3055-3057
+            if (bs != 0 && cSize < 25) {                                 // ZSTD_isRLE, never for the first block (:4372-4383)
+                const u32 b0 = src[bs];
+                bool same = true;
+                for (u32 i = (u32)lane; i < bn && same; i += kWave) same = src[bs + i] == b0;
+                if (!ballot(!same)) { cSize = 1; if (lane == 0) ws->tmp[0] = (u8)b0; }
+            }
+            if (cSize > 1) {                                             // ZSTD_blockState_confirmRepcodesAndEntropyTables
+                rep1 = nr1; rep2 = nr2;
+                if (fh.fresh) {
+                    for (u32 i = (u32)lane; i < 256; i += kWave) { L->prev.nbBits[i] = L->e.huf.nbBits[i]; L->prev.val[i] = L->e.huf.val[i]; }
+                    if (lane == 0) L->prev.tableLog = L->e.huf.tableLog;
+                    fh.repeat = 1;
+                }
+            }
+            wave_fence();
+        }
+        const u32 body = cSize == 0 ? bn : cSize;
+        if (op + 3 + body > cap) return 0;                               // dstSize_tooSmall
+        const u32 h = last + ((cSize == 0 ? 0u : (cSize == 1 ? 1u : 2u)) << 1) + ((cSize > 1 ? cSize : bn) << 3);
+        if (lane == 0) { dst[op] = (u8)h; dst[op + 1] = (u8)(h >> 8); dst[op + 2] = (u8)(h >> 16); }
+        if (cSize == 0) wave_copy(dst + op + 3, src + bs, bn, lane);     // ZSTD_noCompressBlock
+        else wave_copy(dst + op + 3, ws->tmp, cSize, lane);
+        wave_fence();
+        op += 3 + body;
+    }
+    return (long long)op;
 }
 
 
@@ -1732,6 +2028,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 }
 
+__global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, uint8_t* tabBase, uint32_t tabBytes)
+{
+    __shared__ FrameLds L;
+    Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
+    u32* tab = reinterpret_cast<u32*>(tabBase + (size_t)blockIdx.x * tabBytes);
+    const int lane = lane_id();
+    for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
+        const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
+        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.windowLog, f.hashLog, f.minMatch, &L, ws, tab, lane);
+        if (lane == 0) f.out_len[i] = r;
+        wave_fence();
+    }
+}
+
 size_t zstd_workspace_bytes() { return sizeof(Workspace); }
 uint32_t zstd_decoder_lds_bytes() { return (uint32_t)sizeof(DecLds); }
 size_t zstd_entropy_lds_bytes() { return sizeof(EntropyLds); }
@@ -1949,4 +2259,26 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
     if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
     hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws);
     return aoclgpu::check_launch("zstd_decompress_kernel");
+}
+
+// One frame per input, any size below 2 GiB (see zstd_frame_wave).
+extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream)
+{
+    if (!f || (f->nframes && (!f->src_off || !f->dst_off || !f->out_len || !f->dst))) { aoclgpu::set_error_msg("zstd frames: bad arguments"); return AOCLGPU_ERR_ARG; }
+    if (f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 20 || f->minMatch < 4 || f->minMatch > 7) {
+        aoclgpu::set_error_msg("zstd frames: parameters outside the fast strategy's GPU parse (windowLog 10-31, hashLog 6-20, minMatch 4-7)");
+        return AOCLGPU_ERR_ARG;
+    }
+    if (f->nframes == 0) return AOCLGPU_OK;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("zstd frames: device query failed"); return AOCLGPU_ERR_HIP; }
+    uint32_t grid = (uint32_t)prop.multiProcessorCount * 4u;             // one wave per frame; four frames per CU keep its SIMDs busy
+    if (grid > f->nframes) grid = f->nframes;
+    const size_t tabBytes = (size_t)4 << f->hashLog;
+    const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
+    aoclgpu::WsGuard guard;
+    void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);
+    if (!ws) { aoclgpu::set_error_msg("zstd frames: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+    hipLaunchKernelGGL(aoclgpu::zstd_frame_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *f, (uint8_t*)ws, (uint8_t*)ws + seqBytes, (uint32_t)tabBytes);
+    return aoclgpu::check_launch("zstd_frame_kernel");
 }

@@ -117,6 +117,24 @@ int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
 
+/* Zstd, one frame per input of ANY size below 2 GiB with the "fast" strategy: what ZSTD_compress_advanced writes for these
+ * compression parameters (zstd_compress.c:5388-5470 -> ZSTD_compress_frameChunk :4504-4583): blocks of min(128 KiB, window)
+ * bytes that share the hash table, the repeat offsets and the last compressed block's Huffman table; RLE blocks after the
+ * first; a window descriptor instead of the single-segment flag when the window is smaller than the input.  Blocks of a frame
+ * depend on each other in order, so a frame is one wavefront's work; the frames of a batch run side by side.
+ * Frame i covers src[src_off[i], src_off[i+1]) and may use dst[dst_off[i], dst_off[i+1]); out_len[i] = frame size, 0 when
+ * it does not fit (ZSTD_error_dstSize_tooSmall).  All arrays are device memory, nframes + 1 offsets each. */
+typedef struct {
+    const uint8_t*  src;
+    uint8_t*        dst;
+    const uint64_t* src_off;
+    const uint64_t* dst_off;
+    int64_t*        out_len;
+    uint32_t        nframes;
+    uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters of the fast strategy (targetLength 0 or 1) */
+} aoclgpu_zstd_frames;
+int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream);
+
 /* Compaction: gather the used prefix of every slot into one contiguous stream (the serial memcpy join
  * of the reference's MT path, lz4.c:2736-2906 / snappy.cc:2567-2654 / zstd_compress.c:5499-5517).
  * out_off[i] (device, uint64, nchunks+1 entries) receives the exclusive prefix sum of out_len. */

@@ -1,0 +1,83 @@
+"""Zstd frames of any size on the GPU (aoclgpu_zstd_compress_frames) against the oracle's frame (pinned byte for byte against
+the reference's ZSTD_compress_advanced in tests/test_oracle_vs_ref.py) and, when the reference build is present, against the
+reference itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aocl_compression_amd as a
+import oracle_lib as ol
+import zstd_frame_cases as zfc
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = ((17, 14, 6), (12, 13, 5), (19, 14, 7), (23, 12, 4), (18, 14, 6), (23, 14, 7), (20, 16, 6))
+
+
+def oracle_frame(oracle, data, wl, hl, mm):
+    f = oracle.L.orc_zstd_compress_frame
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+    n = len(data)
+    cap = n + (n >> 8) + 64
+    out = C.create_string_buffer(cap)
+    r = f(data, n, out, cap, wl, hl, mm)
+    assert r > 0
+    return out.raw[:r]
+
+
+def gpu_frames(eng, inputs, wl, hl, mm, caps=None):
+    t = eng.torch
+    off = np.zeros(len(inputs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in inputs])
+    blob = b"".join(inputs)
+    src = t.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=t.uint8).to(eng.device)
+    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps)
+    host = dst.cpu().numpy().tobytes()
+    return [host[doff[i]:doff[i] + lens[i]] for i in range(len(inputs))]
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
+def test_frames_bit_exact(eng, oracle, kind):
+    """a batch of frames per parameter set: block-boundary sizes, a window below the input, a window below the block size"""
+    sizes = zfc.EDGE_SIZES + (3000000, 0, 1, 6, 7, 100, 70000, 131072)
+    inputs = [zfc.make(kind, n, seed=200 + i) if n else b"" for i, n in enumerate(sizes)]
+    for (wl, hl, mm) in PARAMS:
+        got = gpu_frames(eng, inputs, wl, hl, mm)
+        for data, g in zip(inputs, got):
+            want = oracle_frame(oracle, data, wl, hl, mm)
+            assert g == want, (kind, len(data), wl, hl, mm, len(g), len(want))
+    # the frames decode on the GPU too (multi-block frames, treeless literal blocks, RLE and raw blocks)
+    for data, g in zip(inputs[:6], got[:6]):
+        out = C.create_string_buffer(len(data))
+        r = eng.lib.aoclgpu_zstd_decompress_host_frames(g, len(g), out, len(data))
+        assert r == len(data) and out.raw == data, (kind, len(data), r)
+
+
+def test_frames_against_reference(eng, ref):
+    """the level's own parameters for the size (AOCL table), straight against the reference build"""
+    for i, n in enumerate((131073, 262145, 400000, 1 << 20, 2500000)):
+        data = zfc.make("mixed", n, seed=300 + i)
+        for level in (1, 2):
+            cp = zfc.ref_level_cparams(ref, level, n)
+            if cp.strategy != 1:
+                continue
+            want = zfc.ref_frame(ref, data, cp)
+            got = gpu_frames(eng, [data], cp.windowLog, cp.hashLog, cp.minMatch)[0]
+            assert got == want, (n, level)
+
+
+def test_small_capacity_reports_zero(eng, oracle):
+    data = zfc.make("text", 300000, seed=9)
+    want = oracle_frame(oracle, data, 19, 14, 7)
+    got = gpu_frames(eng, [data, data, data], 19, 14, 7, caps=[len(want), len(want) - 1, 10])
+    assert got[0] == want and got[1] == b"" and got[2] == b""
+
+
+def test_bad_parameters_are_refused(eng):
+    t = eng.torch
+    src = t.zeros(16, dtype=t.uint8, device=eng.device)
+    for (wl, hl, mm) in ((9, 14, 6), (32, 14, 6), (19, 21, 6), (19, 14, 3), (19, 14, 8)):
+        with pytest.raises(a.EngineError):
+            eng.zstd_compress_frames(src, [0, 16], wl, hl, mm)
