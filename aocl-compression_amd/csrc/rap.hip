@@ -567,3 +567,42 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     if (!checksums_ok(fr, (const uint8_t*)hdst, (size_t)total)) return -1;
     return (int64_t)total;
 }
+
+#define HCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(#call, e_); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; } } while (0)
+// ONE frame for an input of any size below 2 GiB with explicit "fast" parameters: host buffers in and out around
+// aoclgpu_zstd_compress_frames.  checksumFlag: the frame ends with the low 32 bits of XXH64(src) and says so in its header
+// (ZSTD_writeEpilogue, zstd_compress.c:4700-4706).  Returns the frame size, 0 when it does not fit `cap`, negative on failure.
+extern "C" int64_t aoclgpu_zstd_compress_host_frame(const void* hsrc, size_t n, void* hdst, size_t cap,
+                                                    uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength,
+                                                    uint32_t checksumFlag)
+{
+    if ((!hsrc && n) || !hdst || n >= ((size_t)1 << 31)) { set_error_msg("zstd frame: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
+    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frame: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    const size_t tail = checksumFlag ? 4 : 0;
+    if (cap < tail) return 0;
+    const size_t bound = aoclgpu_compress_bound(AOCLGPU_ZSTD, n) + 32, room = cap - tail < bound ? cap - tail : bound;
+    DevBuf dsrc, ddst, dmeta;
+    if (!dsrc.alloc(n ? n : 1) || !ddst.alloc(room ? room : 1) || !dmeta.alloc(5 * 8)) { set_error_msg("zstd frame: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    const uint64_t meta[5] = { 0, n, 0, room, 0 };                       // src_off[2], dst_off[2], out_len
+    if (n) HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(dmeta.p, meta, sizeof(meta), hipMemcpyHostToDevice));
+    aoclgpu_zstd_frames f; memset(&f, 0, sizeof(f));
+    f.src = (const uint8_t*)dsrc.p; f.dst = (uint8_t*)ddst.p;
+    f.src_off = (const uint64_t*)dmeta.p; f.dst_off = (const uint64_t*)dmeta.p + 2; f.out_len = (int64_t*)dmeta.p + 4;
+    f.nframes = 1; f.windowLog = windowLog; f.hashLog = hashLog; f.minMatch = minMatch; f.targetLength = targetLength;
+    const int rc = aoclgpu_zstd_compress_frames(&f, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    int64_t r = 0;
+    HCK(hipMemcpy(&r, (const int64_t*)dmeta.p + 4, 8, hipMemcpyDeviceToHost));
+    if (r <= 0) return 0;
+    HCK(hipMemcpy(hdst, ddst.p, (size_t)r, hipMemcpyDeviceToHost));
+    if (checksumFlag) {
+        const uint32_t ck = (uint32_t)xxh64((const uint8_t*)hsrc, n);
+        ((uint8_t*)hdst)[4] |= 4;                                        // Content_Checksum_flag of the frame header descriptor
+        memcpy((uint8_t*)hdst + r, &ck, 4);
+        r += 4;
+    }
+    return r;
+}
+
+#undef HCK

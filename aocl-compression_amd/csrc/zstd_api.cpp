@@ -128,7 +128,8 @@ bool params_in_bounds(const ZSTD_compressionParameters& c)
 // strategy, 3-4 "double-fast" (for the sizes where the level table says so).
 int gpu_level_for(const ZSTD_compressionParameters& c, size_t n)
 {
-    if ((c.strategy != ZSTD_fast && c.strategy != ZSTD_dfast) || c.targetLength > 1) return 0;   // fast: stepSize 2 only (zstd_fast.c:440)
+    if (c.strategy != ZSTD_fast && c.strategy != ZSTD_dfast) return 0;
+    if (c.strategy == ZSTD_fast && c.targetLength != 0) return 0;       // (a target length leaves literals raw and, above 1, widens the step: frame path)
     if (n == 0) return 1;                                                // an empty frame: no parameter shows in the output
     // the parameters must be those of a level for THIS input size (inputs above 128 KiB are then cut into 128 KiB pieces,
     // each compressed with that level's parameters for a piece: the documented multi-frame deviation)
@@ -141,16 +142,45 @@ int gpu_level_for(const ZSTD_compressionParameters& c, size_t n)
     return 0;
 }
 
+// Inputs above 128 KiB with "fast" parameters: 0 (default) = ONE frame of blocks, the reference's bytes, one wavefront's work
+// from the first block to the last (every block needs the hash table the previous one left); 1 = 128 KiB pieces as
+// concatenated frames compressed side by side (a valid stream every Zstd decoder reads, ~1000x the throughput on large
+// inputs, not the reference's bytes).  AOCLGPU_ZSTD_LARGE_INPUTS=pieces in the environment selects 1 at start-up.
+std::atomic<int> g_large_input_mode{-1};
+int large_input_mode()
+{
+    int m = g_large_input_mode.load();
+    if (m < 0) {
+        const char* e = getenv("AOCLGPU_ZSTD_LARGE_INPUTS");
+        m = (e && !strcmp(e, "pieces")) ? 1 : 0;
+        g_large_input_mode.store(m);
+    }
+    return m;
+}
+
 size_t compress_with(const ZSTD_compressionParameters& c, const ZSTD_frameParameters& f, void* dst, size_t cap, const void* src, size_t n)
 {
     if (!params_in_bounds(c)) return zerr(kErrParamOutOfBound);
+    if (!f.contentSizeFlag) return zerr(kErrParamUnsupported);
+    const bool covers = ((unsigned long long)1 << c.windowLog) >= n;     // single-segment frame
     const int level = gpu_level_for(c, n);
-    if (!level) return zerr(kErrParamUnsupported);
-    if (!f.contentSizeFlag || f.checksumFlag) return zerr(kErrParamUnsupported);
-    if (((size_t)1 << c.windowLog) < (n > (128u << 10) ? (128u << 10) : n)) return zerr(kErrParamUnsupported);   // frames are single-segment
-    const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
-    const int64_t r = n > (128u << 10) ? aoclgpu_zstd_compress_host_frames(src, n, dst, cap, flags)
-                                       : aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, n, dst, cap, flags);
+    int64_t r;
+    if (n <= (128u << 10) && level && covers && !f.checksumFlag) {
+        // one block with a level's own parameters: the chunk kernels (hash table in LDS)
+        const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
+        r = aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, n, dst, cap, flags);
+    } else if (c.strategy == ZSTD_fast && c.targetLength <= 1 && c.hashLog <= 24 && n < ((size_t)1 << 31) &&
+               !(n > (128u << 10) && large_input_mode() == 1 && level && c.windowLog >= 17 && !f.checksumFlag)) {
+        // any size, any "fast" parameters with stepSize 2 (zstd_fast.c:440): one frame of blocks, exactly the reference's.
+        // minMatch 3 runs the 4-byte hash (ZSTD_compressBlock_fast's switch, zstd_fast.c:764-790: "default: includes case 3")
+        r = aoclgpu_zstd_compress_host_frame(src, n, dst, cap, c.windowLog, c.hashLog, c.minMatch < 4 ? 4u : c.minMatch, c.targetLength, f.checksumFlag ? 1u : 0u);
+        if (r == 0) return zerr(kErrDstTooSmall);
+    } else if (n > (128u << 10) && level && c.windowLog >= 17 && !f.checksumFlag) {
+        // double-fast above 128 KiB (or "fast" when the caller asked for pieces): 128 KiB pieces, one frame each - the
+        // documented multi-frame deviation
+        const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
+        r = aoclgpu_zstd_compress_host_frames(src, n, dst, cap, flags);
+    } else return zerr(kErrParamUnsupported);
     if (r > 0) return (size_t)r;
     if (r == 0) return zerr(cap < ZSTD_compressBound(n) ? kErrDstTooSmall : kErrParamUnsupported);   // 0 with room: no GPU parse for a piece
     return zerr(kErrGeneric);
@@ -161,6 +191,9 @@ struct ZSTD_CCtx_s { int level; ZSTD_frameParameters f; };
 struct ZSTD_DCtx_s { int unused; };
 
 extern "C" {
+
+void aoclgpu_zstd_set_large_input_mode(int pieces) { g_large_input_mode.store(pieces ? 1 : 0); }
+int aoclgpu_zstd_large_input_mode(void) { return large_input_mode(); }
 
 unsigned ZSTD_versionNumber(void) { return 10505; }
 const char* ZSTD_versionString(void) { return "1.5.5"; }

@@ -733,7 +733,7 @@ __device__ u32 huf_encode_4x(u8* dst, const u8* src, u32 n, const HufCT* ct, u32
 // last block that was written compressed and whether it may be reused (HUF_repeat_check; HUF_repeat_valid only comes from
 // dictionaries).  `fresh` is set when the block just coded wrote a new table into EntropyLds::huf: the frame loop copies it
 // into `prev` if the block is confirmed (ZSTD_blockState_confirmRepcodesAndEntropyTables, zstd_compress.c:4385-4387).
-struct FrameHuf { HufCT* prev; u32 repeat; u32 fresh; };
+struct FrameHuf { HufCT* prev; u32 repeat; u32 fresh; u32 disabled; };   // disabled: ZSTD_literalsCompressionIsDisabled
 
 // HUF_estimateCompressedSize (huf_compress.c:809-818)
 __device__ u32 huf_estimate(const HufCT* ct, const u32* hist, u32 maxSym, int lane)
@@ -806,7 +806,10 @@ __device__ u32 compress_literals(u8* dst, const u8* src, u32 n, bool suspect, En
     const u32 lh = 3 + (n >= 1024) + (n >= 16384);
     const bool single = n < 256;
     u32 repeat = 0;
-    if constexpr (FR) { repeat = fh->repeat; fh->fresh = 0; }
+    if constexpr (FR) {
+        repeat = fh->repeat; fh->fresh = 0;
+        if (fh->disabled) return lit_raw(dst, src, n, 0, lane);          // fast with a target length (zstd_compress_internal.h:609-622)
+    }
     if (n < 64) return lit_raw(dst, src, n, 0, lane);                    // ZSTD_minLiteralsToCompress = 8 << 3
     const u32 c = huf_compress<FR>(dst + lh, src, n, single, suspect, L, lane, fh, repeat);
     const u32 hType = repeat ? 3u : 2u;                                  // set_repeat : set_compressed (:185-189)
@@ -1249,9 +1252,9 @@ struct FrameLds {
 
 // One frame: returns its size, 0 when it does not fit `cap` (dstSize_tooSmall) or the parameters have no GPU parse.
 __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 windowLog,
-                                     const u32 hlog, const u32 mls, FrameLds* L, Workspace* ws, u32* tab, int lane)
+                                     const u32 hlog, const u32 mls, const u32 targetLength, FrameLds* L, Workspace* ws, u32* tab, int lane)
 {
-    if (n64 >= (1ull << 31) || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
+    if (n64 >= (1ull << 31) || targetLength > 1 || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
     const u32 n = (u32)n64;
     const u32 blockMax = windowLog < 17 ? 1u << windowLog : kBlockMax;   // MIN(ZSTD_BLOCKSIZE_MAX, windowSize), zstd_compress.c:2129-2131
     const u32 single = ((1ull << windowLog) >= n64) ? 1u : 0u;
@@ -1275,7 +1278,7 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
     FrameWindow win = { 2u, 2u, 1u << windowLog };
-    FrameHuf fh = { &L->prev, 0u, 0u };
+    FrameHuf fh = { &L->prev, 0u, 0u, targetLength };
     u32 rep1 = 1, rep2 = 4;
     for (u32 bs = 0; bs < n; bs += blockMax) {
         const u32 bn = n - bs < blockMax ? n - bs : blockMax;
@@ -2036,7 +2039,7 @@ __global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, u
     const int lane = lane_id();
     for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
         const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
-        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.windowLog, f.hashLog, f.minMatch, &L, ws, tab, lane);
+        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.windowLog, f.hashLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
         if (lane == 0) f.out_len[i] = r;
         wave_fence();
     }
@@ -2265,16 +2268,17 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
 extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream)
 {
     if (!f || (f->nframes && (!f->src_off || !f->dst_off || !f->out_len || !f->dst))) { aoclgpu::set_error_msg("zstd frames: bad arguments"); return AOCLGPU_ERR_ARG; }
-    if (f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 20 || f->minMatch < 4 || f->minMatch > 7) {
-        aoclgpu::set_error_msg("zstd frames: parameters outside the fast strategy's GPU parse (windowLog 10-31, hashLog 6-20, minMatch 4-7)");
+    if (f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 24 || f->minMatch < 4 || f->minMatch > 7 || f->targetLength > 1) {
+        aoclgpu::set_error_msg("zstd frames: parameters outside the fast strategy's GPU parse (windowLog 10-31, hashLog 6-24, minMatch 4-7, targetLength 0-1)");
         return AOCLGPU_ERR_ARG;
     }
     if (f->nframes == 0) return AOCLGPU_OK;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("zstd frames: device query failed"); return AOCLGPU_ERR_HIP; }
-    uint32_t grid = (uint32_t)prop.multiProcessorCount * 4u;             // one wave per frame; four frames per CU keep its SIMDs busy
+    uint32_t grid = (uint32_t)prop.multiProcessorCount * 8u;             // one wave per frame; eight frames per CU (19 KB of LDS each)
     if (grid > f->nframes) grid = f->nframes;
     const size_t tabBytes = (size_t)4 << f->hashLog;
+    if ((size_t)grid * tabBytes > ((size_t)1 << 30)) grid = (uint32_t)(((size_t)1 << 30) / tabBytes);   // at most 1 GiB of tables
     const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
     aoclgpu::WsGuard guard;
     void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);

@@ -131,9 +131,24 @@ typedef struct {
     const uint64_t* dst_off;
     int64_t*        out_len;
     uint32_t        nframes;
-    uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters of the fast strategy (targetLength 0 or 1) */
+    uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters of the fast strategy */
+    uint32_t        targetLength;                   /* 0 or 1: both mean step 2 (zstd_fast.c:440); 1 (level -1, row 0 of the level
+                                                       tables) also leaves literals uncompressed (zstd_compress_internal.h:609-622) */
 } aoclgpu_zstd_frames;
 int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream);
+/* the same for ONE input in host memory; checksumFlag appends the frame checksum (low 32 bits of XXH64 of the input).
+ * Returns the frame size, 0 when it does not fit `cap`, < 0 on failure */
+int64_t aoclgpu_zstd_compress_host_frame(const void* src_host, size_t n, void* dst_host, size_t cap,
+                                         uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength,
+                                         uint32_t checksumFlag);
+
+/* What the native Zstd entry points (ZSTD_compress, ZSTD_compressCCtx, ZSTD_compress_advanced, ZSTD_compress2, aocl_llc_compress)
+ * do with an input above 128 KiB and "fast" parameters: 0 (default) = one frame of blocks, byte-identical to the reference,
+ * serial per input (one wavefront, a few MiB/s); 1 = 128 KiB pieces as concatenated frames compressed side by side (any Zstd
+ * decoder reads it as one stream, zstd_decompress.c:1113-1200; GiB/s; not the reference's bytes).  The environment variable
+ * AOCLGPU_ZSTD_LARGE_INPUTS=pieces selects 1 at start-up. */
+void aoclgpu_zstd_set_large_input_mode(int pieces);
+int aoclgpu_zstd_large_input_mode(void);
 
 /* Compaction: gather the used prefix of every slot into one contiguous stream (the serial memcpy join
  * of the reference's MT path, lz4.c:2736-2906 / snappy.cc:2567-2654 / zstd_compress.c:5499-5517).

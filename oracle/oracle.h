@@ -50,6 +50,10 @@ size_t orc_zstd_compress_cparams(const uint8_t* src, size_t n, uint8_t* dst, siz
  * (zstd_compress.c:4504-4583) */
 size_t orc_zstd_compress_frame(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap,
                                uint32_t windowLog, uint32_t hashLog, uint32_t minMatch);
+/* targetLength 0 or 1 (both mean step 2, zstd_fast.c:440); 1 also leaves the literals uncompressed (level -1, and row 0 of the
+ * level tables) */
+size_t orc_zstd_compress_frame_tl(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap,
+                                  uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength);
 /* == ZSTD_decompress: returns decoded size, (size_t)-1 on error */
 size_t orc_zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
 

@@ -535,7 +535,7 @@ static size_t lit_raw(u8* dst, const u8* src, size_t n, u32 type)
     dst[fl] = src[0]; return fl + 1;
 }
 /* Huffman state carried from block to block of one frame (ZSTD_hufCTables_t, zstd_compress_internal.h:70-73) */
-typedef struct { huf_ct ct; int repeat; } huf_state;
+typedef struct { huf_ct ct; int repeat; int disabled; } huf_state;   /* disabled: ZSTD_literalsCompressionIsDisabled */
 static size_t compress_literals(u8* dst, const u8* src, size_t n, int suspect, const huf_state* prev, huf_state* next)
 {
     const size_t lh = 3 + (n >= 1024) + (n >= 16384);
@@ -543,6 +543,7 @@ static size_t compress_literals(u8* dst, const u8* src, size_t n, int suspect, c
     int repeat = prev->repeat; u32 hType;
     size_t c;
     *next = *prev;                                                    /* :144 */
+    if (prev->disabled) return lit_raw(dst, src, n, 0);               /* :146-147 */
     if (n < 64) return lit_raw(dst, src, n, 0);                       /* ZSTD_minLiteralsToCompress: 8 << 3 */
     c = huf_compress(dst + lh, src, n, single, suspect, n <= 1024, &next->ct, &repeat);   /* preferRepeat: strategy < lazy, :164 */
     hType = repeat ? 3 : 2;                                           /* set_repeat : set_compressed, :185-189 */
@@ -945,12 +946,12 @@ size_t orc_zstd_compress_cparams(const u8* src, size_t n, u8* dst, size_t dstCap
  * the repeat offsets and the entropy tables as they were (:4385-4387).  FSE tables are never repeated at strategies below
  * "lazy" without a dictionary (ZSTD_selectEncodingType, zstd_compress_sequences.c:166-196: set_repeat needs
  * FSE_repeat_valid, which only a dictionary sets).  Returns the frame size, 0 on failure. */
-size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch)
+size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch, u32 targetLength)
 {
     u8* op = dst;
     /* blockSize = MIN(ZSTD_BLOCKSIZE_MAX, windowSize) (ZSTD_resetCCtx_internal, zstd_compress.c:2129-2131) */
     const size_t blockMax = windowLog < 17 ? (size_t)1 << windowLog : 128u << 10;
-    if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31) return 0;
+    if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31 || targetLength > 1) return 0;
     /* ZSTD_writeFrameHeader (zstd_compress.c:4586-4632) */
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
     {   const u32 single = ((u64)1 << windowLog) >= n;
@@ -971,6 +972,7 @@ size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, 
         huf_state hprev, hnext;
         size_t bs;
         memset(&hprev, 0, sizeof(hprev));
+        hprev.disabled = targetLength > 0;                            /* fast with a target length: literals stay raw (zstd_compress_internal.h:609-622) */
         g_strategy = 1;
         for (bs = 0; bs < n; bs += blockMax) {
             const size_t bn = n - bs < blockMax ? n - bs : blockMax;
@@ -1008,6 +1010,11 @@ size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, 
         free(table); free(seqs); free(lits); free(tmp);
     }
     return (size_t)(op - dst);
+}
+
+size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch)
+{
+    return orc_zstd_compress_frame_tl(src, n, dst, dstCap, windowLog, hashLog, minMatch, 0);
 }
 
 /* level 1 or 2 (the "fast" rows of clevels.h for inputs <= 128 KiB) */

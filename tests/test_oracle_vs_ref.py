@@ -171,14 +171,15 @@ def test_zstd_multi_block_frames_bit_exact(oracle, ref, kind):
     parameters and explicit ones: a window below the input (window descriptor, ZSTD_window_enforceMaxDist), a window below
     the block size (smaller blocks), every minMatch of the fast strategy."""
     import ctypes as C
-    f = oracle.L.orc_zstd_compress_frame
+    f = oracle.L.orc_zstd_compress_frame_tl
     f.restype = C.c_size_t
-    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     checked = 0
     for i, n in enumerate(zfc.EDGE_SIZES + (3000000,)):
         data = zfc.make(kind, n, seed=100 + i)
         cps = [zfc.ref_level_cparams(ref, 1, n)]
-        cps += [zfc.CParams(*row) for row in ((17, 13, 14, 1, 6, 0, 1), (12, 13, 13, 1, 5, 0, 1), (19, 13, 14, 1, 7, 0, 1), (23, 13, 12, 1, 4, 0, 1))]
+        cps += [zfc.CParams(*row) for row in ((17, 13, 14, 1, 6, 0, 1), (12, 13, 13, 1, 5, 0, 1), (19, 13, 14, 1, 7, 0, 1), (23, 13, 12, 1, 4, 0, 1),
+                                                (19, 12, 13, 1, 6, 1, 1), (11, 12, 9, 1, 3, 1, 1))]   # targetLength 1: raw literals; minMatch 3 = 4
         l2 = zfc.ref_level_cparams(ref, 2, n)
         if l2.strategy == 1:
             cps.append(l2)
@@ -186,8 +187,8 @@ def test_zstd_multi_block_frames_bit_exact(oracle, ref, kind):
             want = zfc.ref_frame(ref, data, cp)
             cap = n + (n >> 8) + 64
             out = C.create_string_buffer(cap)
-            r = f(data, n, out, cap, cp.windowLog, cp.hashLog, cp.minMatch)
-            assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.minMatch)
+            r = f(data, n, out, cap, cp.windowLog, cp.hashLog, max(cp.minMatch, 4), cp.targetLength)
+            assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.minMatch, cp.targetLength)
             checked += 1
         if i % 4 == 0:
             assert oracle.decompress(ol.ZSTD, want, n) == data

@@ -2,8 +2,9 @@
 CPU part: ZSTD_getParams / ZSTD_getCParams equal the reference's for every level, size class and both level tables
 (pure host arithmetic, checked against oracle/_ref).  GPU part: the call sequence of the reference's own wrapper
 (api/codec.cpp:354-436: createCCtx, getParams, CCtx_setParameter, compress_advanced, decompressDCtx) run against this
-library gives the reference's bytes for levels 1-4 ("fast" and "double-fast"), multi-frame streams for inputs above 128 KiB that the
-reference decodes, and ZSTD_error_parameter_unsupported for everything without a GPU backend."""
+library gives the reference's bytes for levels 1-4 ("fast" and "double-fast") up to 128 KiB and for every "fast" parameter set at
+any size (one frame of blocks), multi-frame streams the reference decodes for double-fast inputs above 128 KiB, and
+ZSTD_error_parameter_unsupported for everything without a GPU backend."""
 import ctypes as C
 
 import pytest
@@ -107,8 +108,10 @@ def test_context_calls_check_their_arguments(lib):
     assert lib.ZSTD_getErrorName(lib.ZSTD_compressCCtx(c, out, 64, b"hello", 5, 5)) == b"Unsupported parameter"   # greedy
     bad = lib.ZSTD_getParams(1, 5, 0); bad.cParams.windowLog = 40
     assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, bad)) == b"Parameter is out of bound"
-    ck = lib.ZSTD_getParams(1, 5, 0); ck.fParams.checksumFlag = 1
-    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, ck)) == b"Unsupported parameter"
+    nofcs = lib.ZSTD_getParams(1, 5, 0); nofcs.fParams.contentSizeFlag = 0        # frames always carry their content size here
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, nofcs)) == b"Unsupported parameter"
+    step = lib.ZSTD_getParams(1, 5, 0); step.cParams.targetLength = 4           # fast with a longer step (negative levels): no GPU parse
+    assert lib.ZSTD_getErrorName(lib.ZSTD_compress_advanced(c, out, 64, b"hello", 5, None, 0, step)) == b"Unsupported parameter"
     assert lib.ZSTD_CCtx_setParameter(c, 100, 1) == 0 and lib.ZSTD_CCtx_setParameter(c, 201, 0) == 0
     assert lib.ZSTD_isError(lib.ZSTD_CCtx_setParameter(c, 160, 1))      # ZSTD_c_enableLongDistanceMatching
     assert lib.ZSTD_isError(lib.ZSTD_decompressDCtx(None, out, 64, b"x", 1))
@@ -157,35 +160,79 @@ def test_reference_wrapper_sequence_on_the_gpu_library(eng, lib, reflib, kind):
             assert got is not None and got == want, (kind, n, level)
             assert _wrapper_decompress(lib, want, n) == data
         assert _wrapper_compress(lib, data, 5) is None                        # greedy and up: no backend
-    # a window clamp below the input size cannot be honoured by single-segment frames: refused, not ignored
+    # a window clamp below the input size (aocl_llc's optVar): smaller blocks, a window descriptor in the frame header
     data = a.corpus.make(kind, 65536, seed=22).tobytes()
-    assert _wrapper_compress(lib, data, 1, window_log=12) is None
-    assert _wrapper_compress(lib, data, 1, window_log=16) == _wrapper_compress(reflib, data, 1, window_log=16)
+    for wl in (10, 12, 15, 16):
+        assert _wrapper_compress(lib, data, 1, window_log=wl) == _wrapper_compress(reflib, data, 1, window_log=wl), wl
+    assert _wrapper_compress(lib, data, 3, window_log=12) is None                # double-fast: single-segment frames only
 
 
 @pytest.mark.gpu
-def test_inputs_above_128k_become_concatenated_frames(eng, lib, reflib):
-    """a valid stream the reference decodes (zstd_decompress.c:1113 reads frame after frame); not the reference's bytes -
-    INTEGRATION.md lists this deviation"""
-    for n in (131073, 300000, (1 << 20) + 17, 3 << 20):
+def test_inputs_above_128k(eng, lib, reflib):
+    """"fast" parameters (level 1 at every size, level 2 above 256 KiB): ONE frame of 128 KiB blocks, the reference's bytes.
+    "double-fast" (level 2 between 128 and 256 KiB, levels 3-4): 128 KiB pieces as concatenated frames - a valid stream the
+    reference decodes (zstd_decompress.c:1113 reads frame after frame), not the reference's bytes; INTEGRATION.md lists this
+    deviation."""
+    exact = 0
+    for n in (131073, 200000, 300000, (1 << 20) + 17, 3 << 20):
         data = a.corpus.make("text", n, seed=23).tobytes()
         for level in (1, 2, 3):
             blob = _wrapper_compress(lib, data, level)
             assert blob is not None and blob[:4] == b"\x28\xb5\x2f\xfd"
-            assert _wrapper_decompress(reflib, blob, n) == data            # the reference reads it
-            assert _wrapper_decompress(lib, blob, n) == data               # frames decoded in parallel on the GPU
-            # every 128 KiB piece is the reference's own frame for that piece
-            first = _wrapper_compress(reflib, data[:131072], level)
-            assert blob.startswith(first)
+            assert _wrapper_decompress(lib, blob, n) == data
+            if reflib.ZSTD_getParams(level, n, 0).cParams.strategy == 1:
+                assert blob == _wrapper_compress(reflib, data, level), (n, level)
+                exact += 1
+            else:
+                assert _wrapper_decompress(reflib, blob, n) == data        # the reference reads it
+                first = _wrapper_compress(reflib, data[:131072], level)    # every piece is the reference's frame for that piece
+                assert blob.startswith(first)
         out = C.create_string_buffer(16)
         r = lib.ZSTD_compress(out, 16, data, n, 1)
         assert lib.ZSTD_getErrorName(r) == b"Destination buffer is too small"
-    # multi-block frames of the reference (one frame, window across blocks) decode on the GPU as before
-    data = a.corpus.make("text", 1 << 20, seed=24).tobytes()
-    ref_blob = _wrapper_compress(reflib, data, 1)
-    assert _wrapper_decompress(lib, ref_blob, len(data)) == data
+        # ZSTD_compress / ZSTD_compressCCtx / ZSTD_compress2 take the same road
+        cap = lib.ZSTD_compressBound(n)
+        o1 = C.create_string_buffer(cap)
+        r1 = lib.ZSTD_compress(o1, cap, data, n, 1)
+        assert o1.raw[:r1] == _wrapper_compress(reflib, data, 1)
+    assert exact >= 8
+    # the caller may trade the reference's bytes for throughput: 128 KiB pieces as concatenated frames, side by side
+    eng.lib.aoclgpu_zstd_set_large_input_mode(1)
+    try:
+        blob = _wrapper_compress(lib, data, 1)
+        assert blob != _wrapper_compress(reflib, data, 1) and blob.startswith(_wrapper_compress(reflib, data[:131072], 1))
+        assert _wrapper_decompress(reflib, blob, n) == data and _wrapper_decompress(lib, blob, n) == data
+    finally:
+        eng.lib.aoclgpu_zstd_set_large_input_mode(0)
+    assert _wrapper_compress(lib, data, 1) == _wrapper_compress(reflib, data, 1)
     small = C.create_string_buffer(1000)
+    ref_blob = _wrapper_compress(reflib, data, 1)
     assert lib.ZSTD_isError(lib.ZSTD_decompress(small, 1000, ref_blob, len(ref_blob)))
+
+
+@pytest.mark.gpu
+def test_advanced_parameters_and_checksums(eng, lib, reflib):
+    """ZSTD_compress_advanced with explicit "fast" parameters that are no level's row, with and without the content checksum
+    (ZSTD_writeEpilogue, zstd_compress.c:4700-4706): the reference's bytes at every size"""
+    c, rc = lib.ZSTD_createCCtx(), reflib.ZSTD_createCCtx()
+    try:
+        for i, n in enumerate((0, 5, 1000, 70000, 131072, 131073, 400000, 1500000)):
+            data = a.corpus.make("jsonlog", n, seed=60 + i).tobytes() if n else b""
+            for (wl, hl, mm, tl, ck) in ((20, 12, 5, 0, 0), (11, 9, 4, 1, 1), (17, 18, 7, 0, 1), (25, 21, 3, 0, 0), (14, 15, 6, 0, 1)):
+                cap = lib.ZSTD_compressBound(n) + 8
+                outs = []
+                for (L, ctx) in ((lib, c), (reflib, rc)):
+                    p = L.ZSTD_getParams(1, n, 0)
+                    p.cParams.windowLog, p.cParams.hashLog, p.cParams.minMatch, p.cParams.targetLength = wl, hl, mm, tl
+                    p.fParams.checksumFlag = ck
+                    out = C.create_string_buffer(cap)
+                    r = L.ZSTD_compress_advanced(ctx, out, cap, data, n, None, 0, p)
+                    assert not L.ZSTD_isError(r), (n, wl, hl, mm, L.ZSTD_getErrorName(r))
+                    outs.append(out.raw[:r])
+                assert outs[0] == outs[1], (n, wl, hl, mm, tl, ck)
+                assert _wrapper_decompress(lib, outs[0], n) == data
+    finally:
+        lib.ZSTD_freeCCtx(c); reflib.ZSTD_freeCCtx(rc)
 
 
 @pytest.mark.gpu
@@ -200,7 +247,7 @@ def test_unified_api_zstd_follows_the_wrapper(eng, lib, reflib):
             assert r == -2                                                   # ERR_COMPRESSION_FAILED
     big = a.corpus.make("text", 500000, seed=26).tobytes()
     r, blob, _ = eng.llc_compress(a.ZSTD, big, 600000, level=1)
-    assert r > 0
+    assert r > 0 and blob == _wrapper_compress(reflib, big, 1)               # one frame of four blocks, the reference's bytes
     r2, back, _ = eng.llc_decompress(a.ZSTD, blob, len(big))
     assert r2 == len(big) and back == big
     assert _wrapper_decompress(reflib, blob, len(big)) == big

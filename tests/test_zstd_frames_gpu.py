@@ -15,25 +15,25 @@ pytestmark = pytest.mark.gpu
 PARAMS = ((17, 14, 6), (12, 13, 5), (19, 14, 7), (23, 12, 4), (18, 14, 6), (23, 14, 7), (20, 16, 6))
 
 
-def oracle_frame(oracle, data, wl, hl, mm):
-    f = oracle.L.orc_zstd_compress_frame
+def oracle_frame(oracle, data, wl, hl, mm, tl=0):
+    f = oracle.L.orc_zstd_compress_frame_tl
     f.restype = C.c_size_t
-    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     n = len(data)
     cap = n + (n >> 8) + 64
     out = C.create_string_buffer(cap)
-    r = f(data, n, out, cap, wl, hl, mm)
+    r = f(data, n, out, cap, wl, hl, mm, tl)
     assert r > 0
     return out.raw[:r]
 
 
-def gpu_frames(eng, inputs, wl, hl, mm, caps=None):
+def gpu_frames(eng, inputs, wl, hl, mm, caps=None, tl=0):
     t = eng.torch
     off = np.zeros(len(inputs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in inputs])
     blob = b"".join(inputs)
     src = t.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=t.uint8).to(eng.device)
-    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps)
+    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps, target_length=tl)
     host = dst.cpu().numpy().tobytes()
     return [host[doff[i]:doff[i] + lens[i]] for i in range(len(inputs))]
 
@@ -68,6 +68,17 @@ def test_frames_against_reference(eng, ref):
             assert got == want, (n, level)
 
 
+def test_target_length_one_leaves_literals_raw(eng, oracle):
+    """fast with targetLength 1 (ZSTD level -1, row 0 of the level tables): the same parse, literals never Huffman-coded
+    (ZSTD_literalsCompressionIsDisabled, zstd_compress_internal.h:609-622)"""
+    inputs = [zfc.make(k, n, seed=400 + i) for i, (k, n) in enumerate((("text", 1000), ("jsonlog", 70000), ("mixed", 400000), ("low", 131073)))]
+    for (wl, hl, mm) in ((19, 12, 6), (11, 9, 4), (19, 13, 7)):
+        got = gpu_frames(eng, inputs, wl, hl, mm, tl=1)
+        for data, g in zip(inputs, got):
+            assert g == oracle_frame(oracle, data, wl, hl, mm, tl=1), (len(data), wl, hl, mm)
+            assert g != oracle_frame(oracle, data, wl, hl, mm, tl=0) or len(data) < 100
+
+
 def test_small_capacity_reports_zero(eng, oracle):
     data = zfc.make("text", 300000, seed=9)
     want = oracle_frame(oracle, data, 19, 14, 7)
@@ -78,6 +89,8 @@ def test_small_capacity_reports_zero(eng, oracle):
 def test_bad_parameters_are_refused(eng):
     t = eng.torch
     src = t.zeros(16, dtype=t.uint8, device=eng.device)
-    for (wl, hl, mm) in ((9, 14, 6), (32, 14, 6), (19, 21, 6), (19, 14, 3), (19, 14, 8)):
+    for (wl, hl, mm) in ((9, 14, 6), (32, 14, 6), (19, 25, 6), (19, 14, 3), (19, 14, 8)):
         with pytest.raises(a.EngineError):
             eng.zstd_compress_frames(src, [0, 16], wl, hl, mm)
+    with pytest.raises(a.EngineError):
+        eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, target_length=2)
