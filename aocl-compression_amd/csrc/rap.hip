@@ -569,12 +569,12 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
 }
 
 #define HCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(#call, e_); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; } } while (0)
-// ONE frame for an input of any size below 2 GiB with explicit "fast" parameters: host buffers in and out around
+// ONE frame for an input of any size below 2 GiB with explicit "fast" or "double-fast" parameters: host buffers in and out around
 // aoclgpu_zstd_compress_frames.  checksumFlag: the frame ends with the low 32 bits of XXH64(src) and says so in its header
 // (ZSTD_writeEpilogue, zstd_compress.c:4700-4706).  Returns the frame size, 0 when it does not fit `cap`, negative on failure.
 extern "C" int64_t aoclgpu_zstd_compress_host_frame(const void* hsrc, size_t n, void* hdst, size_t cap,
-                                                    uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength,
-                                                    uint32_t checksumFlag)
+                                                    uint32_t strategy, uint32_t windowLog, uint32_t hashLog, uint32_t chainLog,
+                                                    uint32_t minMatch, uint32_t targetLength, uint32_t checksumFlag)
 {
     if ((!hsrc && n) || !hdst || n >= ((size_t)1 << 31)) { set_error_msg("zstd frame: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frame: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
@@ -590,6 +590,7 @@ extern "C" int64_t aoclgpu_zstd_compress_host_frame(const void* hsrc, size_t n, 
     f.src = (const uint8_t*)dsrc.p; f.dst = (uint8_t*)ddst.p;
     f.src_off = (const uint64_t*)dmeta.p; f.dst_off = (const uint64_t*)dmeta.p + 2; f.out_len = (int64_t*)dmeta.p + 4;
     f.nframes = 1; f.windowLog = windowLog; f.hashLog = hashLog; f.minMatch = minMatch; f.targetLength = targetLength;
+    f.strategy = strategy; f.chainLog = chainLog;
     const int rc = aoclgpu_zstd_compress_frames(&f, nullptr);
     if (rc) return AOCLGPU_HOST_FAIL + rc;
     int64_t r = 0;

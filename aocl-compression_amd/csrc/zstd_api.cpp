@@ -142,7 +142,7 @@ int gpu_level_for(const ZSTD_compressionParameters& c, size_t n)
     return 0;
 }
 
-// Inputs above 128 KiB with "fast" parameters: 0 (default) = ONE frame of blocks, the reference's bytes, one wavefront's work
+// Inputs above 128 KiB: 0 (default) = ONE frame of blocks, the reference's bytes, one wavefront's work
 // from the first block to the last (every block needs the hash table the previous one left); 1 = 128 KiB pieces as
 // concatenated frames compressed side by side (a valid stream every Zstd decoder reads, ~1000x the throughput on large
 // inputs, not the reference's bytes).  AOCLGPU_ZSTD_LARGE_INPUTS=pieces in the environment selects 1 at start-up.
@@ -164,22 +164,25 @@ size_t compress_with(const ZSTD_compressionParameters& c, const ZSTD_frameParame
     if (!f.contentSizeFlag) return zerr(kErrParamUnsupported);
     const bool covers = ((unsigned long long)1 << c.windowLog) >= n;     // single-segment frame
     const int level = gpu_level_for(c, n);
+    // what the frame kernel parses: fast with stepSize 2 (zstd_fast.c:440), double-fast; tables of at most 2^24 entries
+    const bool frameable = n < ((size_t)1 << 31) && c.hashLog <= 24 &&
+                           ((c.strategy == ZSTD_fast && c.targetLength <= 1) || (c.strategy == ZSTD_dfast && c.chainLog <= 24));
     int64_t r;
     if (n <= (128u << 10) && level && covers && !f.checksumFlag) {
-        // one block with a level's own parameters: the chunk kernels (hash table in LDS)
+        // one block with a level's own parameters: the chunk kernels (hash table in LDS for "fast")
         const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
         r = aoclgpu_compress_host_ex(AOCLGPU_ZSTD, src, n, dst, cap, flags);
-    } else if (c.strategy == ZSTD_fast && c.targetLength <= 1 && c.hashLog <= 24 && n < ((size_t)1 << 31) &&
-               !(n > (128u << 10) && large_input_mode() == 1 && level && c.windowLog >= 17 && !f.checksumFlag)) {
-        // any size, any "fast" parameters with stepSize 2 (zstd_fast.c:440): one frame of blocks, exactly the reference's.
-        // minMatch 3 runs the 4-byte hash (ZSTD_compressBlock_fast's switch, zstd_fast.c:764-790: "default: includes case 3")
-        r = aoclgpu_zstd_compress_host_frame(src, n, dst, cap, c.windowLog, c.hashLog, c.minMatch < 4 ? 4u : c.minMatch, c.targetLength, f.checksumFlag ? 1u : 0u);
-        if (r == 0) return zerr(kErrDstTooSmall);
-    } else if (n > (128u << 10) && level && c.windowLog >= 17 && !f.checksumFlag) {
-        // double-fast above 128 KiB (or "fast" when the caller asked for pieces): 128 KiB pieces, one frame each - the
-        // documented multi-frame deviation
+    } else if (n > (128u << 10) && large_input_mode() == 1 && level && c.windowLog >= 17 && !f.checksumFlag) {
+        // the caller asked for pieces: 128 KiB each, one frame per piece, side by side (the documented multi-frame stream)
         const uint32_t flags = AOCLGPU_ZSTD_LEVEL(level) | (g_aocl_table.load() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
         r = aoclgpu_zstd_compress_host_frames(src, n, dst, cap, flags);
+    } else if (frameable) {
+        // any size, any such parameters: one frame of blocks, exactly the reference's.  minMatch 3 runs the 4-byte hash
+        // (ZSTD_compressBlock_fast's switch, zstd_fast.c:764-790, and ZSTD_compressBlock_doubleFast's, zstd_double_fast.c:
+        // "default: includes case 3")
+        r = aoclgpu_zstd_compress_host_frame(src, n, dst, cap, (uint32_t)c.strategy, c.windowLog, c.hashLog, c.chainLog,
+                                             c.minMatch < 4 ? 4u : c.minMatch, c.targetLength, f.checksumFlag ? 1u : 0u);
+        if (r == 0) return zerr(kErrDstTooSmall);
     } else return zerr(kErrParamUnsupported);
     if (r > 0) return (size_t)r;
     if (r == 0) return zerr(cap < ZSTD_compressBound(n) ? kErrDstTooSmall : kErrParamUnsupported);   // 0 with room: no GPU parse for a piece

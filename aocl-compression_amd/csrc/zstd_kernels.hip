@@ -519,20 +519,35 @@ constexpr u32 kDfScratch = 1024;                // u16 slots per hash for the sl
 
 __device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }   // ZSTD_hash8
 
-template <int MLS>
-__device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlogL, const u32 hlogS, u32* tabs, lbyte* lds,
-                           Workspace* ws, u32* litSizeOut, int lane)
+// window of a frame (ZSTD_window_t): indices are position + 2
+struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
+__device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
+{   // ZSTD_getLowestPrefixIndex without a dictionary
+    return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit;
+}
+
+// FRAME = false: the only block of a fresh frame (tables cleared here, repeat offsets {1,4,8}, no window limit).
+// FRAME = true: block [bs, be) of a frame - tables, window and repeat offsets come from the frame loop (zstd_frame_wave) and
+// the offsets go back to it (:393-399, :478-486).
+template <int MLS, bool FRAME = false>
+__device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u32 hlogL, const u32 hlogS, u32* tabs, lbyte* lds,
+                           Workspace* ws, u32* litSizeOut, int lane, const u32 bs = 0, const FrameWindow* win = nullptr,
+                           u32* rep1io = nullptr, u32* rep2io = nullptr)
 {
     typedef __attribute__((address_space(1))) u32 gu32;
     typedef __attribute__((address_space(3))) uint16_t lu16;
+    const u32 n = be;                                        // iend
     gu32* L = (gu32*)tabs;
     gu32* S = L + (1u << hlogL);
-    {   // fresh tables (ZSTD_reset_matchState clears them for a new frame)
+    if constexpr (!FRAME) {   // fresh tables (ZSTD_reset_matchState clears them for a new frame)
         typedef u32 u4 __attribute__((ext_vector_type(4)));
         const u32 quads = ((1u << hlogL) + (1u << hlogS)) / 4;
         for (u32 i = (u32)lane; i < quads; i += kWave) ((__attribute__((address_space(1))) u4*)L)[i] = u4{0, 0, 0, 0};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
+    u32 prefixIdx = 2;                                       // candidates need an index above it (:438, :456)
+    if constexpr (FRAME) prefixIdx = lowest_prefix(*win, be + 2);
+    const u32 prefixPos = prefixIdx - 2;
     auto tget = [&](gu32* t, u32 h) -> u32 { return __hip_atomic_load((u32*)(t + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto tput = [&](gu32* t, u32 h, u32 v) { __hip_atomic_store((u32*)(t + h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     lu16* scrL = (lu16*)lds; lu16* scrS = scrL + kDfScratch;
@@ -558,7 +573,14 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32
         }
         return back < maxback ? back : maxback;
     };
-    u32 nbSeq = 0, litSize = 0, anchor = 0, s = 1, rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399)
+    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399)
+    u32 saved1 = 0, saved2 = 0;
+    if constexpr (FRAME) {
+        rep1 = *rep1io; rep2 = *rep2io;
+        const u32 curr0 = s + 2, maxRep = curr0 - lowest_prefix(*win, curr0);
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
     const int64_t ilimit = (int64_t)n - 8 - 19;
     u32 i0 = 0;                                              // probes of the current search already examined
     for (;;) {
@@ -576,8 +598,8 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32
         u32 idxl = 0, idxs = 0;
         if (valid) { idxl = tget(L, hl); idxs = tget(S, hs); }
         u64 cl = ~v8; u32 cs = ~(u32)v8, r4 = ~(u32)(v8 >> 8);
-        if (valid && idxl > 2) cl = ld64(src + idxl - 2);
-        if (valid && idxs > 2) cs = ld32(src + idxs - 2);
+        if (valid && idxl > prefixIdx) cl = ld64(src + idxl - 2);
+        if (valid && idxs > prefixIdx) cs = ld32(src + idxs - 2);
         if (valid && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
         const bool repHit = r4 == (u32)(v8 >> 8), longHit = cl == v8, shortHit = cs == (u32)v8;
         wave_fence();
@@ -620,14 +642,14 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32
             else {                                           // short match: a long match at ip1 wins (:495-504)
                 const u32 idxl1 = uni(tget(L, hl1));
                 u64 c1 = ~v1;
-                if (idxl1 > 2) c1 = ld64(src + idxl1 - 2);
+                if (idxl1 > prefixIdx) c1 = ld64(src + idxl1 - 2);
                 if (uni(c1 == v1 ? 1u : 0u)) { ip = ip1; mpos = idxl1 - 2; isLong = true; }
                 else mpos = lane_get(idxs, el) - 2;
             }
             const u32 base = isLong ? 8u : 4u;
             mLength = wave_count(src, ip + base, mpos + base, n, lane) + base;
             const u32 offset = ip - mpos;
-            {   const u32 a = ip - anchor, maxback = a < mpos ? a : mpos;
+            {   const u32 a = ip - anchor, b = mpos - prefixPos, maxback = a < b ? a : b;
                 const u32 back = back_count(ip, mpos, maxback);
                 ip -= back; mLength += back;
             }
@@ -659,6 +681,11 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 n, const u32
             }
         }
         s = ip; i0 = 0;
+    }
+    if constexpr (FRAME) {
+        saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;           // :478-486
+        *rep1io = rep1 ? rep1 : saved1;
+        *rep2io = rep2 ? rep2 : saved2;
     }
     flush_seq(nbSeq & ~63u, nbSeq & 63u);
     wave_fence();
@@ -1087,11 +1114,6 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
 // ================================================================================================
 constexpr u32 kFrScratch = 1024;                // u16 slots for the slot-reuse rounds
 
-struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
-__device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
-{   // ZSTD_getLowestPrefixIndex without a dictionary
-    return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit;
-}
 
 template <int MLS>
 __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, u32* tab, lbyte* scr,
@@ -1247,14 +1269,16 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
 struct FrameLds {
     EntropyLds e;
     HufCT prev;                                  // Huffman table of the last confirmed block
-    uint16_t scratch[kFrScratch];
+    uint16_t scratch[2 * kDfScratch];            // slot-reuse rounds: one table (fast) or two (double-fast)
 };
 
 // One frame: returns its size, 0 when it does not fit `cap` (dstSize_tooSmall) or the parameters have no GPU parse.
-__device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 windowLog,
-                                     const u32 hlog, const u32 mls, const u32 targetLength, FrameLds* L, Workspace* ws, u32* tab, int lane)
+__device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 strategy,
+                                     const u32 windowLog, const u32 hlog, const u32 clog, const u32 mls, const u32 targetLength,
+                                     FrameLds* L, Workspace* ws, u32* tab, int lane)
 {
-    if (n64 >= (1ull << 31) || targetLength > 1 || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
+    if (n64 >= (1ull << 31) || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
+    if (strategy == 1 ? targetLength > 1 : (strategy != 2 || clog < 6)) return 0;
     const u32 n = (u32)n64;
     const u32 blockMax = windowLog < 17 ? 1u << windowLog : kBlockMax;   // MIN(ZSTD_BLOCKSIZE_MAX, windowSize), zstd_compress.c:2129-2131
     const u32 single = ((1ull << windowLog) >= n64) ? 1u : 0u;
@@ -1273,12 +1297,12 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
     if (n == 0) { if (lane == 0) { dst[op] = 1; dst[op + 1] = 0; dst[op + 2] = 0; } return (long long)(op + 3); }   // ZSTD_writeEpilogue
     {   // fresh table (ZSTD_reset_matchState clears it for a new frame)
         typedef u32 u4 __attribute__((ext_vector_type(4)));
-        const u32 quads = (1u << hlog) / 4;
+        const u32 quads = ((1u << hlog) + (strategy == 2 ? 1u << clog : 0u)) / 4;
         for (u32 i = (u32)lane; i < quads; i += kWave) ((__attribute__((address_space(1))) u4*)tab)[i] = u4{0, 0, 0, 0};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
     FrameWindow win = { 2u, 2u, 1u << windowLog };
-    FrameHuf fh = { &L->prev, 0u, 0u, targetLength };
+    FrameHuf fh = { &L->prev, 0u, 0u, strategy == 1 ? targetLength : 0u };
     u32 rep1 = 1, rep2 = 4;
     for (u32 bs = 0; bs < n; bs += blockMax) {
         const u32 bn = n - bs < blockMax ? n - bs : blockMax;
@@ -1292,12 +1316,19 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
         if (bn >= 7) {                                                   // ZSTD_buildSeqStore :3268
             u32 litSize = 0, nbSeq, nr1 = rep1, nr2 = rep2;
             const gbyte* g = (const gbyte*)src;
-            if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+            if (strategy == 2) {
+                lbyte* sc = (lbyte*)L->scratch;
+                if (mls == 4) nbSeq = dfast_block<4, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                else if (mls == 5) nbSeq = dfast_block<5, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                else if (mls == 6) nbSeq = dfast_block<6, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                else nbSeq = dfast_block<7, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+            }
+            else if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             wave_fence();
-            cSize = entropy_compress<true>(ws->tmp, ws, litSize, nbSeq, &L->e, lane, 1u, &fh);
+            cSize = entropy_compress<true>(ws->tmp, ws, litSize, nbSeq, &L->e, lane, strategy, &fh);
             if (cSize >= bn - ((bn >> 6) + 2)) cSize = 0;                // ZSTD_minGain, zstd_compress.c:3055-3057
             if (bs != 0 && cSize < 25) {                                 // ZSTD_isRLE, never for the first block (:4372-4383)
                 const u32 b0 = src[bs];
@@ -2039,7 +2070,7 @@ __global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, u
     const int lane = lane_id();
     for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
         const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
-        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.windowLog, f.hashLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
+        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
         if (lane == 0) f.out_len[i] = r;
         wave_fence();
     }
@@ -2268,8 +2299,11 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
 extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream)
 {
     if (!f || (f->nframes && (!f->src_off || !f->dst_off || !f->out_len || !f->dst))) { aoclgpu::set_error_msg("zstd frames: bad arguments"); return AOCLGPU_ERR_ARG; }
-    if (f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 24 || f->minMatch < 4 || f->minMatch > 7 || f->targetLength > 1) {
-        aoclgpu::set_error_msg("zstd frames: parameters outside the fast strategy's GPU parse (windowLog 10-31, hashLog 6-24, minMatch 4-7, targetLength 0-1)");
+    const bool df = f->strategy == 2;
+    if ((f->strategy != 1 && !df) || f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 24 || f->minMatch < 4 || f->minMatch > 7 ||
+        (df ? (f->chainLog < 6 || f->chainLog > 24) : f->targetLength > 1)) {
+        aoclgpu::set_error_msg("zstd frames: parameters outside the GPU parses (strategy 1 fast / 2 double-fast, windowLog 10-31, hashLog 6-24, "
+                               "chainLog 6-24 for double-fast, minMatch 4-7, targetLength 0-1 for fast)");
         return AOCLGPU_ERR_ARG;
     }
     if (f->nframes == 0) return AOCLGPU_OK;
@@ -2277,7 +2311,7 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("zstd frames: device query failed"); return AOCLGPU_ERR_HIP; }
     uint32_t grid = (uint32_t)prop.multiProcessorCount * 8u;             // one wave per frame; eight frames per CU (19 KB of LDS each)
     if (grid > f->nframes) grid = f->nframes;
-    const size_t tabBytes = (size_t)4 << f->hashLog;
+    const size_t tabBytes = ((size_t)4 << f->hashLog) + (df ? (size_t)4 << f->chainLog : 0);
     if ((size_t)grid * tabBytes > ((size_t)1 << 30)) grid = (uint32_t)(((size_t)1 << 30) / tabBytes);   // at most 1 GiB of tables
     const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
     aoclgpu::WsGuard guard;

@@ -117,7 +117,7 @@ int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
 
-/* Zstd, one frame per input of ANY size below 2 GiB with the "fast" strategy: what ZSTD_compress_advanced writes for these
+/* Zstd, one frame per input of ANY size below 2 GiB with the "fast" or "double-fast" strategy: what ZSTD_compress_advanced writes for these
  * compression parameters (zstd_compress.c:5388-5470 -> ZSTD_compress_frameChunk :4504-4583): blocks of min(128 KiB, window)
  * bytes that share the hash table, the repeat offsets and the last compressed block's Huffman table; RLE blocks after the
  * first; a window descriptor instead of the single-segment flag when the window is smaller than the input.  Blocks of a frame
@@ -131,16 +131,19 @@ typedef struct {
     const uint64_t* dst_off;
     int64_t*        out_len;
     uint32_t        nframes;
-    uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters of the fast strategy */
+    uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters */
     uint32_t        targetLength;                   /* 0 or 1: both mean step 2 (zstd_fast.c:440); 1 (level -1, row 0 of the level
                                                        tables) also leaves literals uncompressed (zstd_compress_internal.h:609-622) */
+    uint32_t        strategy;                       /* 1 = fast (zstd_fast.c), 2 = double-fast (zstd_double_fast.c: hashLog = long
+                                                       table, chainLog = short table, targetLength unused) */
+    uint32_t        chainLog;
 } aoclgpu_zstd_frames;
 int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream);
 /* the same for ONE input in host memory; checksumFlag appends the frame checksum (low 32 bits of XXH64 of the input).
  * Returns the frame size, 0 when it does not fit `cap`, < 0 on failure */
 int64_t aoclgpu_zstd_compress_host_frame(const void* src_host, size_t n, void* dst_host, size_t cap,
-                                         uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength,
-                                         uint32_t checksumFlag);
+                                         uint32_t strategy, uint32_t windowLog, uint32_t hashLog, uint32_t chainLog,
+                                         uint32_t minMatch, uint32_t targetLength, uint32_t checksumFlag);
 
 /* What the native Zstd entry points (ZSTD_compress, ZSTD_compressCCtx, ZSTD_compress_advanced, ZSTD_compress2, aocl_llc_compress)
  * do with an input above 128 KiB and "fast" parameters: 0 (default) = one frame of blocks, byte-identical to the reference,

@@ -54,6 +54,9 @@ size_t orc_zstd_compress_frame(const uint8_t* src, size_t n, uint8_t* dst, size_
  * level tables) */
 size_t orc_zstd_compress_frame_tl(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap,
                                   uint32_t windowLog, uint32_t hashLog, uint32_t minMatch, uint32_t targetLength);
+/* any size, strategy 1 (fast) or 2 (double-fast: hashLog = long table, chainLog = short table) */
+size_t orc_zstd_compress_frame_cp(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, int strategy, uint32_t windowLog,
+                                  uint32_t hashLog, uint32_t chainLog, uint32_t minMatch, uint32_t targetLength);
 /* == ZSTD_decompress: returns decoded size, (size_t)-1 on error */
 size_t orc_zstd_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
 

@@ -797,13 +797,20 @@ static size_t fast_block(const u8* src, u32 n, u32 hlog, u32 mls, zseq* seqs, u8
  * ------------------------------------------------------------------------------------------ */
 static u32 z_hash8(const u8* p, u32 hlog) { return (u32)((z_rd64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hlog)); }   /* ZSTD_hash8 */
 
-static size_t dfast_block(const u8* src, u32 n, u32 hlogL, u32 hlogS, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+/* One block [bs, be) of a frame: the tables and `rep` carry over from the previous block (positions are offsets into src,
+ * table entries position + 2; a candidate is usable when its index is above the prefix start, :438, :456) */
+static size_t dfast_block_at(const u8* src, u32 bs, u32 be, u32* L, u32* S, u32 hlogL, u32 hlogS, u32 mls, const zwin* w, u32 rep[2],
+                             zseq* seqs, u8* lits, size_t* litSizeOut)
 {
-    u32* L = (u32*)calloc((size_t)1 << hlogL, sizeof(u32));
-    u32* S = (u32*)calloc((size_t)1 << hlogS, sizeof(u32));
+    const u32 n = be;
+    const u32 prefixIdx = lowest_prefix(w, be + 2), prefixPos = prefixIdx - 2;     /* :347-348 */
     size_t nbSeq = 0, litSize = 0;
-    u32 anchor = 0, ip = 1, off1 = 1, off2 = 0;                      /* rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399) */
+    u32 anchor = bs, ip = bs + (bs == prefixPos), off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
     const int64_t ilimit = (int64_t)n - 8 - 19;
+    {   const u32 curr0 = ip + 2, maxRep = curr0 - lowest_prefix(w, curr0);        /* :393-399 */
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
+    }
 #define DF_STORE(ll_, ob_, ml_) do { seqs[nbSeq].litLength = (ll_); seqs[nbSeq].offBase = (ob_); seqs[nbSeq].matchLength = (ml_); nbSeq++; \
         memcpy(lits + litSize, src + anchor, (ll_)); litSize += (ll_); } while (0)
     for (;;) {                                                        /* one iteration per sequence (:402) */
@@ -823,33 +830,33 @@ static size_t dfast_block(const u8* src, u32 n, u32 hlogL, u32 hlogS, u32 mls, z
                 goto match_stored;
             }
             hl1 = z_hash8(src + ip1, hlogL);
-            if (idxl0 > 2 && z_rd64(src + idxl0 - 2) == z_rd64(src + ip)) {             /* long match at ip (:436-449) */
+            if (idxl0 > prefixIdx && z_rd64(src + idxl0 - 2) == z_rd64(src + ip)) {     /* long match at ip (:436-449) */
                 m = idxl0 - 2;
                 mLength = z_count(src, ip + 8, m + 8, n) + 8;
                 offset = ip - m;
-                while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+                while (ip > anchor && m > prefixPos && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
                 goto match_found;
             }
             idxl1 = L[hl1];
-            if (idxs0 > 2 && z_rd32(src + idxs0 - 2) == z_rd32(src + ip)) goto search_next_long;   /* short match (:454-460) */
+            if (idxs0 > prefixIdx && z_rd32(src + idxs0 - 2) == z_rd32(src + ip)) goto search_next_long;   /* short match (:454-460) */
             if (ip1 >= nextStep) { step++; nextStep += 256; }
             ip = ip1; ip1 += step;
             hl0 = hl1; idxl0 = idxl1;
         } while ((int64_t)ip1 <= ilimit);
         goto cleanup;
 search_next_long:
-        if (idxl1 > 2 && z_rd64(src + idxl1 - 2) == z_rd64(src + ip1)) {                /* a long match one position on wins (:495-504) */
+        if (idxl1 > prefixIdx && z_rd64(src + idxl1 - 2) == z_rd64(src + ip1)) {        /* a long match one position on wins (:495-504) */
             m = idxl1 - 2;
             ip = ip1;
             mLength = z_count(src, ip + 8, m + 8, n) + 8;
             offset = ip - m;
-            while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+            while (ip > anchor && m > prefixPos && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
             goto match_found;
         }
         m = idxs0 - 2;
         mLength = z_count(src, ip + 4, m + 4, n) + 4;
         offset = ip - m;
-        while (ip > anchor && m > 0 && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
+        while (ip > anchor && m > prefixPos && src[ip - 1] == src[m - 1]) { ip--; m--; mLength++; }
 match_found:
         off2 = off1; off1 = offset;
         if (step < 4) L[hl1] = ip1 + 2;                               /* :516-526 */
@@ -874,8 +881,20 @@ match_stored:
     }
 cleanup:
 #undef DF_STORE
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;            /* :478-486 */
+    rep[0] = off1 ? off1 : saved1;
+    rep[1] = off2 ? off2 : saved2;
     memcpy(lits + litSize, src + anchor, n - anchor); litSize += n - anchor;
     *litSizeOut = litSize;
+    return nbSeq;
+}
+static size_t dfast_block(const u8* src, u32 n, u32 hlogL, u32 hlogS, u32 mls, zseq* seqs, u8* lits, size_t* litSizeOut)
+{
+    u32* L = (u32*)calloc((size_t)1 << hlogL, sizeof(u32));
+    u32* S = (u32*)calloc((size_t)1 << hlogS, sizeof(u32));
+    const zwin w = { 2, 2, 1u << 31 };
+    u32 rep[2] = { 1, 4 };                                            /* rep {1,4,8}: 4 > maxRep = 1 is parked (:393-399) */
+    const size_t nbSeq = dfast_block_at(src, 0, n, L, S, hlogL, hlogS, mls, &w, rep, seqs, lits, litSizeOut);
     free(L); free(S);
     return nbSeq;
 }
@@ -946,12 +965,14 @@ size_t orc_zstd_compress_cparams(const u8* src, size_t n, u8* dst, size_t dstCap
  * the repeat offsets and the entropy tables as they were (:4385-4387).  FSE tables are never repeated at strategies below
  * "lazy" without a dictionary (ZSTD_selectEncodingType, zstd_compress_sequences.c:166-196: set_repeat needs
  * FSE_repeat_valid, which only a dictionary sets).  Returns the frame size, 0 on failure. */
-size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch, u32 targetLength)
+size_t orc_zstd_compress_frame_cp(const u8* src, size_t n, u8* dst, size_t dstCap, int strategy, u32 windowLog, u32 hashLog, u32 chainLog,
+                                  u32 minMatch, u32 targetLength)
 {
     u8* op = dst;
     /* blockSize = MIN(ZSTD_BLOCKSIZE_MAX, windowSize) (ZSTD_resetCCtx_internal, zstd_compress.c:2129-2131) */
     const size_t blockMax = windowLog < 17 ? (size_t)1 << windowLog : 128u << 10;
-    if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31 || targetLength > 1) return 0;
+    if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31) return 0;
+    if (strategy == 1 ? targetLength > 1 : strategy != 2) return 0;
     /* ZSTD_writeFrameHeader (zstd_compress.c:4586-4632) */
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
     {   const u32 single = ((u64)1 << windowLog) >= n;
@@ -964,6 +985,7 @@ size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCa
     }
     if (n == 0) { op[0] = 1; op[1] = 0; op[2] = 0; return (size_t)(op + 3 - dst); }   /* ZSTD_writeEpilogue */
     {   u32* table = (u32*)calloc((size_t)1 << hashLog, sizeof(u32));
+        u32* tableS = strategy == 2 ? (u32*)calloc((size_t)1 << chainLog, sizeof(u32)) : NULL;
         zseq* seqs = (zseq*)malloc(sizeof(zseq) * (blockMax / 3 + 8));
         u8* lits = (u8*)malloc(blockMax + 8);
         u8* tmp = (u8*)malloc(2 * blockMax + 1024);
@@ -972,8 +994,8 @@ size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCa
         huf_state hprev, hnext;
         size_t bs;
         memset(&hprev, 0, sizeof(hprev));
-        hprev.disabled = targetLength > 0;                            /* fast with a target length: literals stay raw (zstd_compress_internal.h:609-622) */
-        g_strategy = 1;
+        hprev.disabled = strategy == 1 && targetLength > 0;           /* fast with a target length: literals stay raw (zstd_compress_internal.h:609-622) */
+        g_strategy = (u32)strategy;
         for (bs = 0; bs < n; bs += blockMax) {
             const size_t bn = n - bs < blockMax ? n - bs : blockMax;
             const u32 last = bs + bn == n;
@@ -985,7 +1007,8 @@ size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCa
             }
             if (bn >= 7) {                                            /* ZSTD_buildSeqStore :3268 */
                 size_t litSize, nbSeq; u32 nrep[2] = { rep[0], rep[1] };
-                nbSeq = fast_block_at(src, (u32)bs, (u32)(bs + bn), table, hashLog, minMatch, &w, nrep, seqs, lits, &litSize);
+                nbSeq = strategy == 1 ? fast_block_at(src, (u32)bs, (u32)(bs + bn), table, hashLog, minMatch, &w, nrep, seqs, lits, &litSize)
+                                      : dfast_block_at(src, (u32)bs, (u32)(bs + bn), table, tableS, hashLog, chainLog, minMatch, &w, nrep, seqs, lits, &litSize);
                 cSize = entropy_compress(tmp, lits, litSize, seqs, nbSeq, &hprev, &hnext);
                 if (cSize >= bn - ((bn >> 6) + 2)) cSize = 0;         /* ZSTD_minGain, zstd_compress.c:3055-3057 */
                 if (bs != 0 && cSize < 25) {                          /* ZSTD_isRLE, :4372-4383 */
@@ -1007,9 +1030,14 @@ size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCa
                 memcpy(op + 3, tmp, cSize); op += 3 + cSize;
             }
         }
-        free(table); free(seqs); free(lits); free(tmp);
+        g_strategy = 1;
+        free(table); free(tableS); free(seqs); free(lits); free(tmp);
     }
     return (size_t)(op - dst);
+}
+size_t orc_zstd_compress_frame_tl(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch, u32 targetLength)
+{
+    return orc_zstd_compress_frame_cp(src, n, dst, dstCap, 1, windowLog, hashLog, 0, minMatch, targetLength);
 }
 
 size_t orc_zstd_compress_frame(const u8* src, size_t n, u8* dst, size_t dstCap, u32 windowLog, u32 hashLog, u32 minMatch)

@@ -33,9 +33,7 @@ int main()
         if (ZSTD_decompressBound(z.data(), r) != text.size()) { std::printf("decompressBound\n"); return 1; }
         size_t pos = 0, frames = 0;
         while (pos < r) { const size_t f = ZSTD_findFrameCompressedSize(z.data() + pos, r - pos); if (ZSTD_isError(f)) { std::printf("findFrameCompressedSize\n"); return 1; } pos += f; frames++; }
-        // "fast" parameters (level 1 here): one frame of blocks like the reference; double-fast above 128 KiB: one frame per piece
-        const bool fast = ZSTD_getCParams(level, text.size(), 0).strategy == ZSTD_fast;
-        if (frames != (fast ? 1 : (text.size() + 131071) / 131072)) { std::printf("frames %zu at level %d\n", frames, level); return 1; }
+        if (frames != 1) { std::printf("frames %zu at level %d\n", frames, level); return 1; }   // one frame of blocks, like the reference
         const size_t dr = ZSTD_decompress(d.data(), d.size(), z.data(), r);
         if (dr != text.size() || std::memcmp(d.data(), text.data(), dr) != 0) { std::printf("round trip level %d\n", level); return 1; }
         sizes[level] = r;

@@ -193,3 +193,26 @@ def test_zstd_multi_block_frames_bit_exact(oracle, ref, kind):
         if i % 4 == 0:
             assert oracle.decompress(ol.ZSTD, want, n) == data
     assert checked >= 50
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
+def test_zstd_double_fast_multi_block_frames_bit_exact(oracle, ref, kind):
+    """the same for "double-fast" (zstd_double_fast.c:332-573): both tables, the window and the repeat offsets carry from block
+    to block - the levels' own rows (level 2 between 128 and 256 KiB, levels 3-4) and explicit parameters, minMatch 3 = 4"""
+    import ctypes as C
+    f = oracle.L.orc_zstd_compress_frame_cp
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int] + [C.c_uint] * 5
+    checked = 0
+    for i, n in enumerate(zfc.EDGE_SIZES + (3000000, 100000)):
+        data = zfc.make(kind, n, seed=500 + i)
+        cps = [cp for cp in (zfc.ref_level_cparams(ref, level, n) for level in (2, 3, 4)) if cp.strategy == 2]
+        cps += [zfc.CParams(*row) for row in ((17, 15, 16, 1, 5, 0, 2), (12, 10, 11, 1, 4, 0, 2), (21, 16, 17, 1, 7, 0, 2), (18, 12, 12, 1, 3, 0, 2))]
+        for cp in cps:
+            want = zfc.ref_frame(ref, data, cp)
+            cap = n + (n >> 8) + 64
+            out = C.create_string_buffer(cap)
+            r = f(data, n, out, cap, 2, cp.windowLog, cp.hashLog, cp.chainLog, max(cp.minMatch, 4), cp.targetLength)
+            assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.chainLog, cp.minMatch)
+            checked += 1
+    assert checked >= 60

@@ -164,44 +164,36 @@ def test_reference_wrapper_sequence_on_the_gpu_library(eng, lib, reflib, kind):
     data = a.corpus.make(kind, 65536, seed=22).tobytes()
     for wl in (10, 12, 15, 16):
         assert _wrapper_compress(lib, data, 1, window_log=wl) == _wrapper_compress(reflib, data, 1, window_log=wl), wl
-    assert _wrapper_compress(lib, data, 3, window_log=12) is None                # double-fast: single-segment frames only
+    assert _wrapper_compress(lib, data, 3, window_log=12) == _wrapper_compress(reflib, data, 3, window_log=12)
 
 
 @pytest.mark.gpu
 def test_inputs_above_128k(eng, lib, reflib):
-    """"fast" parameters (level 1 at every size, level 2 above 256 KiB): ONE frame of 128 KiB blocks, the reference's bytes.
-    "double-fast" (level 2 between 128 and 256 KiB, levels 3-4): 128 KiB pieces as concatenated frames - a valid stream the
-    reference decodes (zstd_decompress.c:1113 reads frame after frame), not the reference's bytes; INTEGRATION.md lists this
-    deviation."""
-    exact = 0
+    """levels 1-4 at every size: ONE frame of 128 KiB blocks, the reference's bytes ("fast" and "double-fast" rows alike).  The
+    caller may ask for 128 KiB pieces as concatenated frames instead (aoclgpu_zstd_set_large_input_mode): a valid stream the
+    reference decodes (zstd_decompress.c:1113 reads frame after frame), far faster on large inputs, not the reference's bytes."""
     for n in (131073, 200000, 300000, (1 << 20) + 17, 3 << 20):
         data = a.corpus.make("text", n, seed=23).tobytes()
-        for level in (1, 2, 3):
+        for level in (1, 2, 3, 4):
             blob = _wrapper_compress(lib, data, level)
-            assert blob is not None and blob[:4] == b"\x28\xb5\x2f\xfd"
+            if reflib.ZSTD_getParams(level, n, 0).cParams.strategy > 2:    # level 4 is "greedy" up to 256 KiB: no GPU parse
+                assert blob is None
+                continue
+            assert blob is not None and blob == _wrapper_compress(reflib, data, level), (n, level)
             assert _wrapper_decompress(lib, blob, n) == data
-            if reflib.ZSTD_getParams(level, n, 0).cParams.strategy == 1:
-                assert blob == _wrapper_compress(reflib, data, level), (n, level)
-                exact += 1
-            else:
-                assert _wrapper_decompress(reflib, blob, n) == data        # the reference reads it
-                first = _wrapper_compress(reflib, data[:131072], level)    # every piece is the reference's frame for that piece
-                assert blob.startswith(first)
         out = C.create_string_buffer(16)
         r = lib.ZSTD_compress(out, 16, data, n, 1)
         assert lib.ZSTD_getErrorName(r) == b"Destination buffer is too small"
-        # ZSTD_compress / ZSTD_compressCCtx / ZSTD_compress2 take the same road
-        cap = lib.ZSTD_compressBound(n)
+        cap = lib.ZSTD_compressBound(n)                                    # ZSTD_compress takes the same road
         o1 = C.create_string_buffer(cap)
-        r1 = lib.ZSTD_compress(o1, cap, data, n, 1)
-        assert o1.raw[:r1] == _wrapper_compress(reflib, data, 1)
-    assert exact >= 8
-    # the caller may trade the reference's bytes for throughput: 128 KiB pieces as concatenated frames, side by side
+        r1 = lib.ZSTD_compress(o1, cap, data, n, 3)
+        assert o1.raw[:r1] == _wrapper_compress(reflib, data, 3)
     eng.lib.aoclgpu_zstd_set_large_input_mode(1)
     try:
-        blob = _wrapper_compress(lib, data, 1)
-        assert blob != _wrapper_compress(reflib, data, 1) and blob.startswith(_wrapper_compress(reflib, data[:131072], 1))
-        assert _wrapper_decompress(reflib, blob, n) == data and _wrapper_decompress(lib, blob, n) == data
+        for level in (1, 3):
+            blob = _wrapper_compress(lib, data, level)
+            assert blob != _wrapper_compress(reflib, data, level) and blob.startswith(_wrapper_compress(reflib, data[:131072], level))
+            assert _wrapper_decompress(reflib, blob, n) == data and _wrapper_decompress(lib, blob, n) == data
     finally:
         eng.lib.aoclgpu_zstd_set_large_input_mode(0)
     assert _wrapper_compress(lib, data, 1) == _wrapper_compress(reflib, data, 1)
@@ -212,24 +204,26 @@ def test_inputs_above_128k(eng, lib, reflib):
 
 @pytest.mark.gpu
 def test_advanced_parameters_and_checksums(eng, lib, reflib):
-    """ZSTD_compress_advanced with explicit "fast" parameters that are no level's row, with and without the content checksum
+    """ZSTD_compress_advanced with explicit "fast" and "double-fast" parameters that are no level's row, with and without the content checksum
     (ZSTD_writeEpilogue, zstd_compress.c:4700-4706): the reference's bytes at every size"""
     c, rc = lib.ZSTD_createCCtx(), reflib.ZSTD_createCCtx()
     try:
         for i, n in enumerate((0, 5, 1000, 70000, 131072, 131073, 400000, 1500000)):
             data = a.corpus.make("jsonlog", n, seed=60 + i).tobytes() if n else b""
-            for (wl, hl, mm, tl, ck) in ((20, 12, 5, 0, 0), (11, 9, 4, 1, 1), (17, 18, 7, 0, 1), (25, 21, 3, 0, 0), (14, 15, 6, 0, 1)):
+            for (st, wl, hl, mm, tl, ck) in ((1, 20, 12, 5, 0, 0), (1, 11, 9, 4, 1, 1), (1, 17, 18, 7, 0, 1), (1, 25, 21, 3, 0, 0), (1, 14, 15, 6, 0, 1),
+                                             (2, 20, 15, 4, 0, 1), (2, 13, 12, 6, 8, 0)):
                 cap = lib.ZSTD_compressBound(n) + 8
                 outs = []
                 for (L, ctx) in ((lib, c), (reflib, rc)):
                     p = L.ZSTD_getParams(1, n, 0)
                     p.cParams.windowLog, p.cParams.hashLog, p.cParams.minMatch, p.cParams.targetLength = wl, hl, mm, tl
+                    p.cParams.strategy, p.cParams.chainLog = st, hl - 1
                     p.fParams.checksumFlag = ck
                     out = C.create_string_buffer(cap)
                     r = L.ZSTD_compress_advanced(ctx, out, cap, data, n, None, 0, p)
-                    assert not L.ZSTD_isError(r), (n, wl, hl, mm, L.ZSTD_getErrorName(r))
+                    assert not L.ZSTD_isError(r), (n, st, wl, hl, mm, L.ZSTD_getErrorName(r))
                     outs.append(out.raw[:r])
-                assert outs[0] == outs[1], (n, wl, hl, mm, tl, ck)
+                assert outs[0] == outs[1], (n, st, wl, hl, mm, tl, ck)
                 assert _wrapper_decompress(lib, outs[0], n) == data
     finally:
         lib.ZSTD_freeCCtx(c); reflib.ZSTD_freeCCtx(rc)

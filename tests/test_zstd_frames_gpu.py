@@ -27,13 +27,25 @@ def oracle_frame(oracle, data, wl, hl, mm, tl=0):
     return out.raw[:r]
 
 
-def gpu_frames(eng, inputs, wl, hl, mm, caps=None, tl=0):
+def oracle_frame_df(oracle, data, wl, hl, cl, mm):
+    f = oracle.L.orc_zstd_compress_frame_cp
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int] + [C.c_uint] * 5
+    n = len(data)
+    cap = n + (n >> 8) + 64
+    out = C.create_string_buffer(cap)
+    r = f(data, n, out, cap, 2, wl, hl, cl, mm, 0)
+    assert r > 0
+    return out.raw[:r]
+
+
+def gpu_frames(eng, inputs, wl, hl, mm, caps=None, tl=0, strategy=1, cl=0):
     t = eng.torch
     off = np.zeros(len(inputs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in inputs])
     blob = b"".join(inputs)
     src = t.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=t.uint8).to(eng.device)
-    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps, target_length=tl)
+    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps, target_length=tl, strategy=strategy, chain_log=cl)
     host = dst.cpu().numpy().tobytes()
     return [host[doff[i]:doff[i] + lens[i]] for i in range(len(inputs))]
 
@@ -55,16 +67,30 @@ def test_frames_bit_exact(eng, oracle, kind):
         assert r == len(data) and out.raw == data, (kind, len(data), r)
 
 
+DF_PARAMS = ((18, 14, 14, 5), (23, 17, 15, 5), (23, 18, 16, 5), (12, 11, 10, 4), (21, 17, 16, 7), (17, 16, 15, 6))   # (window, long, short, minMatch)
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
+def test_double_fast_frames_bit_exact(eng, oracle, kind):
+    sizes = zfc.EDGE_SIZES + (3000000, 0, 1, 7, 27, 28, 100, 70000, 131072)
+    inputs = [zfc.make(kind, n, seed=600 + i) if n else b"" for i, n in enumerate(sizes)]
+    for (wl, hl, cl, mm) in DF_PARAMS:
+        got = gpu_frames(eng, inputs, wl, hl, mm, strategy=2, cl=cl)
+        for data, g in zip(inputs, got):
+            want = oracle_frame_df(oracle, data, wl, hl, cl, mm)
+            assert g == want, (kind, len(data), wl, hl, cl, mm, len(g), len(want))
+
+
 def test_frames_against_reference(eng, ref):
     """the level's own parameters for the size (AOCL table), straight against the reference build"""
     for i, n in enumerate((131073, 262145, 400000, 1 << 20, 2500000)):
         data = zfc.make("mixed", n, seed=300 + i)
-        for level in (1, 2):
+        for level in (1, 2, 3, 4):
             cp = zfc.ref_level_cparams(ref, level, n)
-            if cp.strategy != 1:
-                continue
+            if cp.strategy > 2:
+                continue                                   # level 4 is "greedy" up to 256 KiB: no GPU parse
             want = zfc.ref_frame(ref, data, cp)
-            got = gpu_frames(eng, [data], cp.windowLog, cp.hashLog, cp.minMatch)[0]
+            got = gpu_frames(eng, [data], cp.windowLog, cp.hashLog, cp.minMatch, strategy=cp.strategy, cl=cp.chainLog)[0]
             assert got == want, (n, level)
 
 
@@ -94,3 +120,6 @@ def test_bad_parameters_are_refused(eng):
             eng.zstd_compress_frames(src, [0, 16], wl, hl, mm)
     with pytest.raises(a.EngineError):
         eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, target_length=2)
+    for (strategy, cl) in ((3, 14), (0, 14), (2, 5), (2, 25)):
+        with pytest.raises(a.EngineError):
+            eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, strategy=strategy, chain_log=cl)
