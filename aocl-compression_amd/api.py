@@ -247,6 +247,20 @@ class Engine:
         self._check(self.lib.aoclgpu_rap_pack(codec, C.byref(b), out.data_ptr(), cap, C.byref(n), self._stream()), "rap_pack")
         return out[:n.value]
 
+    def zstd_rap_compress(self, src, part_off, window_log: int, hash_log: int, min_match: int, strategy: int = 1, chain_log: int = 0,
+                          target_length: int = 0):
+        """Zstd RAP stream with partitions of any size: partition i covers src[part_off[i], part_off[i+1]) and becomes one frame
+        with the given compression parameters (what every thread of the reference's AOCL_ENABLE_THREADS build does with the
+        caller's parameters, zstd_compress.c:5447-5468), joined behind the RAP frame (aoclgpu_rap_assemble)."""
+        dst, doff, lens = self.zstd_compress_frames(src, part_off, window_log, hash_log, min_match, target_length=target_length,
+                                                    strategy=strategy, chain_log=chain_log)
+        if any(x <= 0 for x in lens):
+            raise EngineError("zstd_rap_compress: a partition failed to compress")
+        sizes = [int(part_off[i + 1]) - int(part_off[i]) for i in range(len(lens))]
+        if len(lens) == 1:
+            return dst[:lens[0]]
+        return self.rap_assemble(ZSTD, dst, doff[:-1], lens, sizes)
+
     def rap_decompress(self, codec: int, stream, max_bytes: int):
         """Decode a RAP stream (or a plain one-shot stream).  Returns (dst tensor, decoded size or negative)."""
         t = self.torch

@@ -53,6 +53,28 @@ def test_stream_is_byte_identical_to_the_reference_mt_build(eng, ref, ref_mt, co
     assert r == len(data) and bytes(dst[:r].cpu().numpy()) == data
 
 
+@pytest.mark.parametrize("kind", ["text", "jsonlog", "binary", "mixed"])
+def test_zstd_stream_is_byte_identical_to_the_reference_mt_build(eng, ref, ref_mt, kind):
+    """Zstd: the threaded reference cuts the input into num_threads partitions once it spans several windows
+    (threads/threads.c:57-97 with chunk = window, zstd_compress.c:5418-5420) and compresses each with the caller's parameters
+    as one frame (:5447-5468) - multi-block frames with a window descriptor here (window 128 KiB, partitions of 300 000 bytes)."""
+    import zstd_frame_cases as zfc
+    T, part = 4, 300000
+    data = zfc.make(kind, T * part, seed=12)
+    for cp in (zfc.CParams(17, 13, 14, 1, 6, 0, 1), zfc.CParams(17, 15, 16, 1, 5, 0, 2)):
+        ref_mt.set_threads(T)
+        want = zfc.ref_frame(ref_mt, data, cp, extra=1024)
+        ents = _entries(want, 8)
+        assert len(ents) == T and all(e[2] == part for e in ents)       # the reference really used T partitions of `part` bytes
+        src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+        got = bytes(eng.zstd_rap_compress(src, [i * part for i in range(T + 1)], cp.windowLog, cp.hashLog, cp.minMatch,
+                                          strategy=cp.strategy, chain_log=cp.chainLog).cpu().numpy())
+        assert got == want
+        assert ref.decompress(ol.ZSTD, got, len(data)) == data
+        dst, r = eng.rap_decompress(a.ZSTD, torch.frombuffer(bytearray(got), dtype=torch.uint8).to(eng.device), len(data))
+        assert r == len(data) and bytes(dst[:r].cpu().numpy()) == data
+
+
 @pytest.mark.parametrize("codec", ["lz4", "snappy", "zstd"])
 @pytest.mark.parametrize("chunk,total", [(65536, 1000003), (131072, 131072 * 9), (4096, 70000), (262144, 100)])
 def test_gpu_streams_decode_everywhere(eng, ref, ref_mt, codec, chunk, total):

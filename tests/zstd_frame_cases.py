@@ -51,7 +51,7 @@ KINDS = ("text", "mixed", "low", "rep", "zeros", "random", "jsonlog")
 EDGE_SIZES = (131073, 131078, 131079, 200000, 262144, 262145, 300000, 524288, 524289, (1 << 20) + 5)
 
 
-def ref_frame(ref, data, cp):
+def ref_frame(ref, data, cp, extra=0):
     """the reference's ZSTD_compress_advanced with these compression parameters (contentSizeFlag 1, no checksum)"""
     L = ref.L
     L.ZSTD_createCCtx.restype = C.c_void_p
@@ -59,7 +59,7 @@ def ref_frame(ref, data, cp):
     L.ZSTD_compress_advanced.restype = C.c_size_t
     L.ZSTD_compress_advanced.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, ZParams]
     n = len(data)
-    cap = n + (n >> 8) + 64
+    cap = n + (n >> 8) + 64 + extra
     out = C.create_string_buffer(cap)
     cctx = L.ZSTD_createCCtx()
     try:
