@@ -90,7 +90,7 @@ EXPORTS = [
     "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",
     "aoclgpu_zstd_compress_host_frames", "aoclgpu_zstd_decompress_host_frames", "aoclgpu_set_host_device", "aoclgpu_host_device",
     "aoclgpu_rap_assemble", "aoclgpu_zstd_compress_frames", "aoclgpu_zstd_compress_host_frame",
-    "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode",
+    "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode", "aoclgpu_lz4f_set_block_linking", "aoclgpu_lz4f_block_linking",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
 ]
 

@@ -852,6 +852,166 @@ __global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Linked blocks on the compress side: the blocks of ONE LZ4 frame written with LZ4F_blockLinked, what LZ4F_compressFrame
+// makes by default (lz4frame.c:373-419 -> LZ4F_compressBlock_continue :777-782 -> LZ4_compress_fast_continue lz4.c:3179-3256
+// in prefix mode -> LZ4_compress_generic_validated :972-1360 with byU32, withPrefix64k, noDictIssue, limitedOutput).  The hash
+// table carries over from block to block - indices are offsets from the frame's start, a match may begin up to 65535 bytes
+// back in earlier blocks, the catch-up stops at the frame's start - so the blocks of a frame are one wavefront's work, in
+// order.  Uniform batch: chunk c is block c, its output goes to slot c with room for (block size - 1) bytes as
+// LZ4F_makeBlock asks (:747-749); out_len[c] = 0 when it does not fit (the caller stores the block) - the parse of such a
+// block stopped where the output ran out and the table keeps what was written until then (lz4.c:1139), as in the reference.
+// Same exact speculation as the chunk kernel, one match per batch: lane k evaluates probe i0 + k of the schedule, the batch
+// is cut at the first in-batch reuse of a table slot, the probes up to the first hit write the table.
+// ------------------------------------------------------------------------------------------------
+__device__ uint32_t lz4_wave_count(const gbyte* __restrict__ src, uint32_t a, uint32_t b, uint32_t limit, int lane)
+{   // LZ4_count (lz4.c:656-679): common prefix of src[a..limit) and src[b..], 256 bytes per step
+    uint32_t n = 0;
+    for (;;) {
+        const uint32_t o = n + 4u * (uint32_t)lane, pa = a + o;
+        uint32_t x = 0xFFFFFFFFu;
+        if (pa + 4 <= limit) x = ld32(src + pa) ^ ld32(src + b + o);
+        else if (pa < limit) {
+            x = 0;
+            for (uint32_t t = 0; t < limit - pa; ++t) x |= (uint32_t)(src[pa + t] ^ src[b + o + t]) << (8 * t);
+            x |= 0xFFFFFFFFu << (8 * (limit - pa));
+        }
+        const int l = first_lane(ballot(x != 0));
+        if (l == 64) { n += 256; continue; }
+        return n + 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
+    }
+}
+
+// one block [b0, iend) of the frame at src; returns its compressed size, 0 when it does not fit olimit bytes
+__device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32_t b0, const uint32_t iend, uint32_t* table, const uint32_t accel,
+                                     gbyte* __restrict__ d, const uint32_t olimit, int lane)
+{
+    typedef __attribute__((address_space(3))) uint32_t L32;
+    L32* T = (L32*)table;
+    const uint32_t bn = iend - b0;
+    const uint32_t mfl1 = iend - 12 + 1, matchlimit = iend - 5;          // mflimitPlusOne, matchlimit (lz4.c:1002-1003)
+    uint32_t ip = b0, anchor = b0;
+    uint64_t op = 0;
+    if (bn >= 13) {                                                      // LZ4_minLength (:1039)
+        if (lane == 0) T[lz4_hash<false>(ld64(src + ip))] = ip;          // first byte (:1042)
+        wave_fence();
+        uint32_t s = ip + 1, i0 = 0;
+        for (;;) {
+            // ---------------- one batch of 64 speculative probes (:1077-1135) ----------------
+            const uint32_t j = i0 + (uint32_t)lane;
+            const uint64_t p64 = (uint64_t)s + sched(j, accel), nx64 = (uint64_t)s + sched(j + 1, accel);
+            const bool valid = nx64 <= mfl1;                             // forwardIp > mflimitPlusOne ends the search (:1090)
+            const uint32_t pos = (uint32_t)p64;
+            uint64_t seq = 0; uint32_t h = 0, cand = 0;
+            if (valid) { seq = ld64(src + pos); h = lz4_hash<false>(seq); cand = T[h]; }
+            uint32_t m4 = ~(uint32_t)seq;
+            if (valid && (uint64_t)cand + 65535u >= pos) m4 = ld32(src + cand);       // not "too far" (:1124-1127)
+            wave_fence();
+            const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&T[h], (uint32_t)lane, valid);
+            wave_fence();
+            if (valid) T[h] = cand;                                      // the rounds scribbled on the slots' low halves
+            wave_fence();
+            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
+            const int e = first_lane(ballot(!valid));
+            const int lim = f < e ? f : e;
+            const int el = first_lane(ballot(lane < lim && m4 == (uint32_t)seq));
+            const int ncommit = el < 64 ? el + 1 : lim;
+            if (lane < ncommit) T[h] = pos;                              // LZ4_putIndexOnHash (:1121)
+            wave_fence();
+            if (el == 64) {
+                if (e < 64 && e <= f) break;                             // _last_literals
+                i0 += (uint32_t)lim;
+                continue;
+            }
+            ip = lane_get(pos, el);
+            uint32_t match = lane_get(cand, el);
+            {   // catch up (:1139-1140): lowLimit is the frame's start
+                const uint32_t a = ip - anchor, maxback = a < match ? a : match;
+                uint32_t back = 0;
+                while (back < maxback) {
+                    const uint32_t k = back + (uint32_t)lane;
+                    bool eq = false;
+                    if (k < maxback) eq = src[ip - 1 - k] == src[match - 1 - k];
+                    const int c = first_lane(ballot(!eq));
+                    back += (uint32_t)c;
+                    if (c < 64) break;
+                }
+                if (back > maxback) back = maxback;
+                ip -= back; match -= back;
+            }
+            // literals (:1142-1167)
+            const uint32_t lit = ip - anchor;
+            uint64_t token_pos = op++;
+            if (op + lit + (2 + 1 + 5) + lit / 255 > olimit) return 0;
+            uint32_t token;
+            if (lit >= 15) { token = 15u << 4; op += put_len_bytes(d + op, lit - 15, lane); }
+            else token = lit << 4;
+            wave_copy(d + op, src + anchor, lit, lane);
+            op += lit;
+            bool again;
+            do {                                                         // _next_match (:1169-1260)
+                if (lane == 0) { d[op] = (uint8_t)(ip - match); d[op + 1] = (uint8_t)((ip - match) >> 8); }
+                op += 2;
+                uint32_t mc = lz4_wave_count(src, ip + 4, match + 4, matchlimit, lane);
+                ip += mc + 4;
+                if (op + (1 + 5) + (mc + 240) / 255 > olimit) return 0;
+                if (mc >= 15) { token += 15; op += put_len_bytes(d + op, mc - 15, lane); }
+                else token += mc;
+                if (lane == 0) d[token_pos] = (uint8_t)token;
+                anchor = ip;
+                again = false;
+                if (ip >= mfl1) break;                                   // :1274
+                {   // fill the table (:1277), test the next position (:1279-1330)
+                    const uint64_t s2 = ld64(src + ip - 2), s0 = ld64(src + ip);
+                    const uint32_t h2 = lz4_hash<false>(s2), h0 = lz4_hash<false>(s0);
+                    if (lane == 0) T[h2] = ip - 2;
+                    wave_fence();
+                    const uint32_t c0 = T[h0];
+                    wave_fence();
+                    if (lane == 0) T[h0] = ip;
+                    wave_fence();
+                    if ((uint64_t)c0 + 65535u >= ip && uni(ld32(src + c0) == (uint32_t)s0 ? 1u : 0u)) {
+                        token_pos = op++; token = 0; match = c0; again = true;
+                    }
+                }
+            } while (again);
+            if (ip >= mfl1) break;
+            s = ip + 1; i0 = 0;                                          // forwardH = hash(++ip) (:1332)
+        }
+    }
+    {   // _last_literals (:1336-1358)
+        const uint32_t lastRun = iend - anchor;
+        if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) return 0;
+        if (lastRun >= 15) { if (lane == 0) d[op] = 15u << 4; op++; op += put_len_bytes(d + op, lastRun - 15, lane); }
+        else { if (lane == 0) d[op] = (uint8_t)(lastRun << 4); op++; }
+        wave_copy(d + op, src + anchor, lastRun, lane);
+        op += lastRun;
+    }
+    return (uint32_t)op;
+}
+
+__global__ void __launch_bounds__(64) lz4_compress_linked_kernel(aoclgpu_batch b)
+{
+    __shared__ uint32_t table[4096];
+    const int lane = lane_id();
+    for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) table[i] = 0;  // LZ4_initStream
+    wave_fence();
+    const uint32_t accel = (b.reserved >> 15) + 1;
+    for (uint32_t c = 0; c < b.nchunks; ++c) {
+        const uint64_t b0 = (uint64_t)c * b.chunk_bytes;
+        const uint64_t rest = b.total_bytes - b0;
+        const uint32_t bn = (uint32_t)(rest < b.chunk_bytes ? rest : b.chunk_bytes);
+        uint32_t r = 0;
+        if (bn >= 1) {
+            const uint64_t room = b.slot_bytes < (uint64_t)bn - 1 ? b.slot_bytes : (uint64_t)bn - 1;
+            r = lz4_linked_block((const gbyte*)b.src, (uint32_t)b0, (uint32_t)b0 + bn, table, accel, (gbyte*)b.dst + (uint64_t)c * b.slot_bytes,
+                                 (uint32_t)room, lane);
+        }
+        wave_fence();
+        if (lane == 0) b.out_len[c] = (int32_t)r;
+    }
+}
+
 template <bool RAP>
 __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
 {
@@ -895,6 +1055,15 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
 {
     if (int rc = aoclgpu::check_batch(b, /*decompress=*/false)) return rc;
     if (b->nchunks == 0) return AOCLGPU_OK;
+    if (b->reserved & AOCLGPU_FLAG_LZ4_LINKED) {
+        // the blocks of one LZ4 frame with linked blocks: one wavefront, block after block
+        if (b->src_off || b->chunk_bytes < 65536 || b->total_bytes >= 0x7E000000ull) {
+            aoclgpu::set_error_msg("lz4: linked blocks need a uniform batch of blocks of at least 64 KiB, below 0x7E000000 bytes in all");
+            return AOCLGPU_ERR_ARG;
+        }
+        hipLaunchKernelGGL(aoclgpu::lz4_compress_linked_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *b);
+        return aoclgpu::check_launch("lz4_compress_linked_kernel");
+    }
     // Table mode per launch: 0 = byU16 (16 KB LDS), 1 = packed byU32 (9 KB, chunks 65547 B .. 256 KiB), 2 = u32 with
     // check bits (16 KB).  Uniform batches launch the body and the ragged tail chunk separately; explicit batches
     // (sizes only known on the device) use the per-chunk dispatching kernel.

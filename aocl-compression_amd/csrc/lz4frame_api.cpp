@@ -3,15 +3,16 @@
 // the blocks of a frame are LZ4 blocks compressed / decoded by lz4_kernels.hip, this file only does the framing
 // (header, block sizes, end mark) and the xxHash32 checksums of lz4frame.c:259-266, 758-761, 1004-1010.
 //
-//  * LZ4F_compressFrame (lz4frame.c:373-460): every block is compressed on its own, all blocks of the frame in one
-//    launch, with the reference's `srcSize - 1` output limit (LZ4F_makeBlock :740-763: a block that does not shrink is
-//    stored).  For blockMode LZ4F_blockIndependent - and for any input that fits one block, which the reference switches
-//    to independent itself (:394-395) - the frame is byte-identical to the reference's.  A multi-block frame requested
-//    with LZ4F_blockLinked (the default) is ALSO written with independent blocks and says so in its FLG byte: linked
-//    blocks chain every block to the hash table of the one before (LZ4_compress_fast_continue), i.e. a frame would be
-//    one sequential stream; the result is a valid frame every LZ4F decoder reads, a little larger than the reference's.
-//    Levels: the fast compressor at default acceleration only (compressionLevel 0..2; LZ4HC levels and negative
-//    "acceleration" levels return LZ4F_ERROR_compressionLevel_invalid).
+//  * LZ4F_compressFrame (lz4frame.c:373-460), byte-identical to the reference's frame for the fast compressor
+//    (compressionLevel < 3; negative levels are accelerations, :768).  LZ4F_blockIndependent - and any input that fits one
+//    block, which the reference switches to independent itself (:394-395): every block on its own, all blocks of the frame
+//    in one launch, with the reference's `srcSize - 1` output limit (LZ4F_makeBlock :740-763: a block that does not shrink is
+//    stored).  LZ4F_blockLinked (the default): every block continues from the hash table of the one before and may match
+//    into it (LZ4_compress_fast_continue in prefix mode), so the blocks of a frame are ONE wavefront's sequential work
+//    (lz4_compress_linked_kernel) - a few MiB/s however large the input.  Callers who prefer throughput to the reference's
+//    bytes switch that off (aoclgpu_lz4f_set_block_linking(0) or AOCLGPU_LZ4F_LINKED=independent): such frames are written
+//    with independent blocks, flagged so in the FLG byte - valid frames every LZ4F decoder reads, a little larger.
+//    LZ4HC levels (>= 3) return LZ4F_ERROR_compressionLevel_invalid.
 //  * LZ4F_compressBegin / Update / flush / End: the reference's buffering rules, one launch per call (end of this file).
 //  * LZ4F_decompress (lz4frame.c:1398-1860): a whole frame per call is decoded straight into the caller's buffer;
 //    a frame that arrives in pieces (or a destination too small for all of it) is collected in the context, decoded when
@@ -22,6 +23,7 @@
 #include "../../include/aocl_native_api.h"
 #include "../../include/aocl_gpu_codec.h"
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -150,12 +152,25 @@ struct Xxh32Stream {
     }
 };
 
+// LZ4F_blockLinked in one-shot frames: 1 (default) = honoured, the reference's bytes, serial; 0 = independent blocks instead
+std::atomic<int> g_block_linking{-1};
+bool block_linking()
+{
+    int m = g_block_linking.load();
+    if (m < 0) {
+        const char* e = getenv("AOCLGPU_LZ4F_LINKED");
+        m = (e && !strcmp(e, "independent")) ? 0 : 1;
+        g_block_linking.store(m);
+    }
+    return m != 0;
+}
+
 struct BlockRef { const uint8_t* p; uint32_t len; };
 
 // LZ4F_makeBlock (lz4frame.c:740-763) for a list of blocks, all compressed in ONE launch: each block on its own, output limit
 // len - 1, stored when it does not shrink; writes {size, data, [checksum]} per block at op.  Returns the bytes written or an
 // error code (test with LZ4F_isError).
-size_t make_blocks(const std::vector<BlockRef>& blks, size_t bs, bool blockCrc, uint8_t* op)
+size_t make_blocks(const std::vector<BlockRef>& blks, size_t bs, bool blockCrc, uint8_t* op, int acceleration = 1)
 {
     const size_t nb = blks.size();
     if (!nb) return 0;
@@ -179,6 +194,7 @@ size_t make_blocks(const std::vector<BlockRef>& blks, size_t bs, bool blockCrc, 
     aoclgpu_batch b; memset(&b, 0, sizeof(b));
     b.src = d_src; b.dst = d_dst;
     if (!upload_geometry(D, b, so, sl, dofs, dc)) return err(E_allocation_failed);
+    b.reserved = AOCLGPU_LZ4_ACCELERATION(acceleration);
     if (aoclgpu_lz4_compress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
     std::vector<int32_t> ol(nb);
     std::vector<uint8_t> slots(nb * slot);
@@ -194,13 +210,44 @@ size_t make_blocks(const std::vector<BlockRef>& blks, size_t bs, bool blockCrc, 
     return (size_t)(op - op0);
 }
 
-// frame header (lz4frame.c:670-699); blocks are always independent here.  Returns its size.
-size_t write_header(uint8_t* dst, const LZ4F_preferences_t& prefs)
+// The blocks of a frame with LZ4F_blockLinked, one-shot (lz4frame.c:373-419): compressed in order by one wavefront that keeps
+// the hash table from block to block (aoclgpu_lz4_compress_chunks with AOCLGPU_FLAG_LZ4_LINKED).  Same output layout as
+// make_blocks.
+size_t make_linked_blocks(const uint8_t* src, size_t n, size_t bs, bool blockCrc, int acceleration, uint8_t* op)
+{
+    if (!n) return 0;
+    uint8_t* const op0 = op;
+    const size_t nb = (n + bs - 1) / bs, slot = (bs + 15) & ~(size_t)15;
+    DevBuf D;
+    uint8_t* d_src = (uint8_t*)D.get(n); uint8_t* d_dst = (uint8_t*)D.get(nb * slot); int32_t* d_len = (int32_t*)D.get(nb * 4);
+    if (!d_src || !d_dst || !d_len) return err(E_allocation_failed);
+    if (hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) return err(E_allocation_failed);
+    aoclgpu_batch b; memset(&b, 0, sizeof(b));
+    b.src = d_src; b.dst = d_dst; b.out_len = d_len; b.nchunks = (uint32_t)nb; b.total_bytes = n; b.chunk_bytes = bs; b.slot_bytes = slot;
+    b.reserved = AOCLGPU_FLAG_LZ4_LINKED | AOCLGPU_LZ4_ACCELERATION(acceleration);
+    if (aoclgpu_lz4_compress_chunks(&b, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+    std::vector<int32_t> ol(nb);
+    std::vector<uint8_t> slots(nb * slot);
+    if (hipMemcpy(ol.data(), d_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(slots.data(), d_dst, nb * slot, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+    for (size_t i = 0; i < nb; ++i) {
+        const uint32_t len = (uint32_t)(n - i * bs < bs ? n - i * bs : bs);
+        uint32_t c = ol[i] > 0 ? (uint32_t)ol[i] : 0;
+        if (c == 0) { c = len; wr32(op, c | kStored); memcpy(op + kBH, src + i * bs, c); }                    // stored block
+        else { wr32(op, c); memcpy(op + kBH, slots.data() + i * slot, c); }
+        if (blockCrc) wr32(op + kBH + c, xxh32(op + kBH, c, 0));
+        op += kBH + c + (blockCrc ? kBF : 0);
+    }
+    return (size_t)(op - op0);
+}
+
+// frame header (lz4frame.c:670-699).  Returns its size.
+size_t write_header(uint8_t* dst, const LZ4F_preferences_t& prefs, bool independent = true)
 {
     uint8_t* op = dst;
     wr32(op, kMagic); op += 4;
     uint8_t* const hs = op;
-    *op++ = (uint8_t)((1 << 6) | (1 << 5) | ((prefs.frameInfo.blockChecksumFlag & 1) << 4) | ((prefs.frameInfo.contentSize > 0) << 3) |
+    *op++ = (uint8_t)((1 << 6) | ((independent ? 1 : 0) << 5) | ((prefs.frameInfo.blockChecksumFlag & 1) << 4) | ((prefs.frameInfo.contentSize > 0) << 3) |
                       ((prefs.frameInfo.contentChecksumFlag & 1) << 2) | (prefs.frameInfo.dictID > 0));
     *op++ = (uint8_t)(((int)prefs.frameInfo.blockSizeID & 7) << 4);
     if (prefs.frameInfo.contentSize) { wr64(op, prefs.frameInfo.contentSize); op += 8; }
@@ -260,6 +307,8 @@ struct LZ4F_dctx_s {
 };
 
 extern "C" {
+void aoclgpu_lz4f_set_block_linking(int linked) { g_block_linking.store(linked ? 1 : 0); }
+int aoclgpu_lz4f_block_linking(void) { return block_linking() ? 1 : 0; }
 
 unsigned LZ4F_isError(size_t code) { return code > err(E_maxCode); }          // lz4frame.c:270-273
 const char* LZ4F_getErrorName(size_t code)
@@ -286,7 +335,8 @@ static size_t LZ4F_compressFrame_impl(void* dstBuffer, size_t dstCapacity, const
     LZ4F_preferences_t prefs;
     if (prefsPtr) prefs = *prefsPtr; else memset(&prefs, 0, sizeof(prefs));
     if (!dstBuffer || (!srcBuffer && srcSize)) return err(E_GENERIC);
-    if (prefs.compressionLevel < 0 || prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);   // only the fast compressor
+    if (prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);                                  // only the fast compressor
+    const int acceleration = prefs.compressionLevel < 0 ? -prefs.compressionLevel + 1 : 1;                    // LZ4F_compressBlock :768
     if (prefs.frameInfo.contentSize != 0) prefs.frameInfo.contentSize = srcSize;                              // :389-390
     prefs.frameInfo.blockSizeID = (LZ4F_blockSizeID_t)optimal_bsid((int)prefs.frameInfo.blockSizeID, srcSize);
     if (!block_size((int)prefs.frameInfo.blockSizeID)) return err(E_maxBlockSize_invalid);
@@ -295,12 +345,18 @@ static size_t LZ4F_compressFrame_impl(void* dstBuffer, size_t dstCapacity, const
     const size_t bs = block_size((int)prefs.frameInfo.blockSizeID);
     if (srcSize > ((size_t)0xFFFFFFFFu - 64) * 1) return err(E_srcSize_tooLarge);
     uint8_t* const dst = (uint8_t*)dstBuffer; uint8_t* op = dst;
-    op += write_header(op, prefs);
+    // one block => independent (:394-395); linked blocks unless the caller switched them off
+    const bool linked = prefs.frameInfo.blockMode == LZ4F_blockLinked && srcSize > bs && block_linking() && srcSize < 0x7E000000ull;
+    op += write_header(op, prefs, !linked);
     // ---- blocks: one launch for the whole frame ----
-    {
+    if (linked) {
+        const size_t w = make_linked_blocks((const uint8_t*)srcBuffer, srcSize, bs, prefs.frameInfo.blockChecksumFlag != 0, acceleration, op);
+        if (LZ4F_isError(w)) return w;
+        op += w;
+    } else {
         std::vector<BlockRef> blks;
         for (size_t o = 0; o < srcSize; o += bs) blks.push_back(BlockRef{(const uint8_t*)srcBuffer + o, (uint32_t)(srcSize - o < bs ? srcSize - o : bs)});
-        const size_t w = make_blocks(blks, bs, prefs.frameInfo.blockChecksumFlag != 0, op);
+        const size_t w = make_blocks(blks, bs, prefs.frameInfo.blockChecksumFlag != 0, op, acceleration);
         if (LZ4F_isError(w)) return w;
         op += w;
     }

@@ -69,9 +69,14 @@ typedef struct {
  * may end right after a match (lz4.c:3935,4147-4181); Snappy: chunks carry no varint length prefix and dst_cap[i] is the
  * exact decoded size (snappy.cc:2567-2654); Zstd: no effect (partitions are whole frames). */
 #define AOCLGPU_FLAG_RAP_PARTITIONS 0x100u
-/* LZ4 decompress, explicit batch: the chunks are the blocks of ONE stream with linked blocks (LZ4 frame format, lz4frame.h
- * LZ4F_blockLinked): decoded in order into dst back to back (dst_off is ignored, total_bytes = capacity of dst), every block
- * may copy from what was decoded before it; src_len[i] bit 31 marks a stored block. */
+/* LZ4, the blocks of ONE stream with linked blocks (LZ4 frame format, lz4frame.h LZ4F_blockLinked), handled in order by one
+ * wavefront.
+ * Decompress, explicit batch: decoded into dst back to back (dst_off is ignored, total_bytes = capacity of dst), every block
+ * may copy from what was decoded before it; src_len[i] bit 31 marks a stored block.
+ * Compress, uniform batch (chunk_bytes = block size >= 64 KiB): block i is compressed with the hash table the blocks before it
+ * left and may match up to 65535 bytes back into them (LZ4_compress_fast_continue in prefix mode, lz4.c:3179-3223); its output
+ * goes to slot i with room for block size - 1 bytes (LZ4F_makeBlock, lz4frame.c:747-749); out_len[i] = 0: does not fit, the
+ * caller stores the block.  Byte-identical to the blocks of the reference's LZ4F_compressFrame. */
 #define AOCLGPU_FLAG_LZ4_LINKED 0x200u
 /* Zstd compress: level 2 instead of level 1 (clevels.h:82,108: still the "fast" strategy for chunks <= 128 KiB, with a 2^15-slot
  * table - 68 KB of LDS, 2 chunks per CU - and minMatch 5 / 4); frames byte-identical to ZSTD_compress(.., 2). */
@@ -152,6 +157,13 @@ int64_t aoclgpu_zstd_compress_host_frame(const void* src_host, size_t n, void* d
  * AOCLGPU_ZSTD_LARGE_INPUTS=pieces selects 1 at start-up. */
 void aoclgpu_zstd_set_large_input_mode(int pieces);
 int aoclgpu_zstd_large_input_mode(void);
+
+/* LZ4F_compressFrame with LZ4F_blockLinked (the format's default) on an input of several blocks: 1 (default) = linked blocks,
+ * byte-identical to the reference, one wavefront's sequential work (a few MiB/s); 0 = the blocks are written independent
+ * instead (flagged so in the frame header; all blocks in one launch, GiB/s; every LZ4F decoder reads it; not the reference's
+ * bytes).  AOCLGPU_LZ4F_LINKED=independent in the environment selects 0 at start-up. */
+void aoclgpu_lz4f_set_block_linking(int linked);
+int aoclgpu_lz4f_block_linking(void);
 
 /* Compaction: gather the used prefix of every slot into one contiguous stream (the serial memcpy join
  * of the reference's MT path, lz4.c:2736-2906 / snappy.cc:2567-2654 / zstd_compress.c:5499-5517).

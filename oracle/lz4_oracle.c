@@ -170,6 +170,122 @@ fail:
     return result;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Linked blocks of an LZ4 frame: LZ4F_compressFrame with LZ4F_blockLinked (lz4frame.c:373-419 -> LZ4F_compressUpdate
+ * :825-929 -> LZ4F_makeBlock :740-763 -> LZ4F_compressBlock_continue :777-782 -> LZ4_compress_fast_continue lz4.c:3179-3256).
+ * The blocks of a one-shot frame lie back to back in the caller's buffer, so every block after the first runs in "prefix
+ * mode" (:3217-3223): LZ4_compress_generic_validated (lz4.c:972-1360) with tableType byU32, withPrefix64k, noDictIssue
+ * (the prefix is never shorter than 64 KiB: blocks are 64 KiB - 4 MiB), limitedOutput with room for blockSize - 1 bytes.
+ * The context carries over: table indices are offsets from the frame's start (currentOffset accumulates, :1033), matches
+ * reach at most 65535 bytes back (:1124-1127) - into the previous blocks too - and the catch-up stops at the frame's start
+ * (lowLimit = source - dictSize, :1029).  A block that does not fit is stored raw by the caller; its parse stopped where the
+ * output ran out and the table keeps what was written until then (:1139).
+ * dst receives the blocks back to back; blockLen[k] = compressed size, or size | 0x80000000 for a stored block.
+ * Returns the number of blocks, -1 on bad arguments. */
+int orc_lz4_compress_linked_blocks(const uint8_t* src, size_t n, size_t blockSize, int acceleration, uint8_t* dst, size_t dstCap,
+                                   uint32_t* blockLen)
+{
+    uint32_t* table;
+    size_t bs, out = 0; int nb = 0;
+    if (acceleration < 1) acceleration = 1;
+    if (acceleration > 65537) acceleration = 65537;
+    if (!src || !dst || blockSize < 65536 || n >= 0x7E000000u || dstCap < n) return -1;
+    table = (uint32_t*)calloc(4096, sizeof(uint32_t));
+    if (!table) return -1;
+    for (bs = 0; bs < n; bs += blockSize) {
+        const uint32_t b0 = (uint32_t)bs, bn = (uint32_t)(n - bs < blockSize ? n - bs : blockSize), iend = b0 + bn;
+        const uint32_t mflimitPlusOne = iend - LZ4_MFLIMIT + 1, matchlimit = iend - LZ4_LASTLITERALS;
+        uint8_t* const d = dst + out;
+        const int64_t olimit = (int64_t)bn - 1;
+        uint32_t ip = b0, anchor = b0;
+        int64_t op = 0; int ok = 0;
+        if (bn < LZ4_MINLENGTH) goto last_literals;
+        table[lz4_hash(src + ip, 0)] = ip;                                    /* first byte of the block */
+        ip++;
+        for (;;) {
+            uint32_t match, token_pos;
+            {
+                uint32_t fwd = ip, step = 1, nbp = (uint32_t)acceleration << LZ4_SKIPTRIGGER;
+                uint32_t fwdH = lz4_hash(src + fwd, 0);
+                for (;;) {
+                    const uint32_t h = fwdH, cur = fwd;
+                    const uint32_t cand = table[h];
+                    ip = fwd;
+                    fwd += step;
+                    step = nbp++ >> LZ4_SKIPTRIGGER;
+                    if (fwd > mflimitPlusOne) goto last_literals;
+                    fwdH = lz4_hash(src + fwd, 0);
+                    table[h] = cur;
+                    if (cand + LZ4_DIST_MAX < cur) continue;                  /* too far */
+                    if (rd32(src + cand) == rd32(src + ip)) { match = cand; break; }
+                }
+            }
+            while (ip > anchor && match > 0 && src[ip - 1] == src[match - 1]) { ip--; match--; }
+            {
+                const uint32_t lit = ip - anchor;
+                token_pos = (uint32_t)op++;
+                if (op + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit) goto done;
+                if (lit >= LZ4_RUN_MASK) {
+                    uint32_t len = lit - LZ4_RUN_MASK;
+                    d[token_pos] = LZ4_RUN_MASK << LZ4_ML_BITS;
+                    for (; len >= 255; len -= 255) d[op++] = 255;
+                    d[op++] = (uint8_t)len;
+                } else d[token_pos] = (uint8_t)(lit << LZ4_ML_BITS);
+                memcpy(d + op, src + anchor, lit);
+                op += lit;
+            }
+next_match:
+            d[op++] = (uint8_t)(ip - match);
+            d[op++] = (uint8_t)((ip - match) >> 8);
+            {
+                uint32_t mc = lz4_count(src, ip + LZ4_MINMATCH, match + LZ4_MINMATCH, matchlimit);
+                ip += mc + LZ4_MINMATCH;
+                if (op + (1 + LZ4_LASTLITERALS) + (mc + 240) / 255 > olimit) goto done;
+                if (mc >= LZ4_ML_MASK) {
+                    d[token_pos] += LZ4_ML_MASK;
+                    mc -= LZ4_ML_MASK;
+                    for (; mc >= 255; mc -= 255) d[op++] = 255;
+                    d[op++] = (uint8_t)mc;
+                } else d[token_pos] += (uint8_t)mc;
+            }
+            anchor = ip;
+            if (ip >= mflimitPlusOne) break;
+            table[lz4_hash(src + ip - 2, 0)] = ip - 2;
+            {
+                const uint32_t h = lz4_hash(src + ip, 0);
+                const uint32_t cand = table[h];
+                table[h] = ip;
+                if (cand + LZ4_DIST_MAX >= ip && rd32(src + cand) == rd32(src + ip)) {
+                    token_pos = (uint32_t)op++;
+                    d[token_pos] = 0;
+                    match = cand;
+                    goto next_match;
+                }
+            }
+            ip++;
+        }
+last_literals:
+        {
+            const uint32_t lastRun = iend - anchor;
+            if (op + lastRun + 1 + (lastRun + 255 - LZ4_RUN_MASK) / 255 > olimit) goto done;
+            if (lastRun >= LZ4_RUN_MASK) {
+                uint32_t acc = lastRun - LZ4_RUN_MASK;
+                d[op++] = LZ4_RUN_MASK << LZ4_ML_BITS;
+                for (; acc >= 255; acc -= 255) d[op++] = 255;
+                d[op++] = (uint8_t)acc;
+            } else d[op++] = (uint8_t)(lastRun << LZ4_ML_BITS);
+            memcpy(d + op, src + anchor, lastRun);
+            op += lastRun;
+            ok = 1;
+        }
+done:
+        if (ok) { blockLen[nb++] = (uint32_t)op; out += (size_t)op; }
+        else { memcpy(d, src + b0, bn); blockLen[nb++] = bn | 0x80000000u; out += bn; }   /* LZ4F_makeBlock :750-755 */
+    }
+    free(table);
+    return nb;
+}
+
 /* LZ4_decompress_safe: decode_full_block + endOnInputSize rules of the reference's safe loop
  * (lz4.c:3563-3790): literal run either obeys the parsing restrictions (ends <= oend-MFLIMIT and
  * <= iend-8) and is followed by a match, or is the last run and must end exactly at iend; a match must

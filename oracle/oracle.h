@@ -24,6 +24,9 @@ int orc_lz4_compress_bound(int srcSize);                               /* lz4.h:
 int orc_lz4_compress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap);
 /* == LZ4_compress_fast (lz4.c:2937-2965) */
 int orc_lz4_compress_fast(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap, int acceleration);
+/* the blocks of LZ4F_compressFrame with linked blocks (lz4frame.c:373-419, lz4.c:3179-3256 in prefix mode): see lz4_oracle.c */
+int orc_lz4_compress_linked_blocks(const uint8_t* src, size_t n, size_t blockSize, int acceleration, uint8_t* dst, size_t dstCap,
+                                   uint32_t* blockLen);
 /* == LZ4_decompress_safe (lz4.c:4898-4923): returns decoded size, <0 on malformed input. */
 int orc_lz4_decompress(const uint8_t* src, int srcSize, uint8_t* dst, int dstCap);
 

@@ -1,6 +1,6 @@
 """LZ4 frame format on the GPU block codec (csrc/lz4frame_api.cpp) against the reference's lz4frame.c (oracle/_ref):
 SURVEY 8f row 3.  CPU part: bounds, header parsing, error codes (no codec call).  GPU part: frames byte-identical to
-LZ4F_compressFrame for independent blocks, every frame readable by the reference, reference frames (linked and independent
+LZ4F_compressFrame for independent and linked blocks, every frame readable by the reference, reference frames (linked and independent
 blocks, stored blocks, all checksum options) decoded on the GPU, corrupted frames rejected."""
 import ctypes as C
 import os
@@ -82,10 +82,39 @@ def test_compress_frames(eng, G, R, kind):
             assert isinstance(got, bytes), (n, o, got)
             back = lf.decompress(R, got, n)
             assert back == (data, len(got)), (n, o, back if isinstance(back, str) else "bytes differ")
-            bs = 1 << (8 + 2 * max(p.frameInfo.blockSizeID, 4))
-            if o.get("independent") or n <= 65536 or (o.get("bsid", 0) >= 5 and n <= 262144) or (o.get("bsid", 0) >= 6 and n <= (1 << 20)) or (o.get("bsid", 0) >= 7 and n <= (4 << 20)):
-                assert got == lf.compress(R, data, p), (n, o)        # independent blocks / one block: the reference's bytes
+            assert got == lf.compress(R, data, p), (n, o)            # independent or linked blocks: the reference's bytes
     assert lf.compress(G, base[:1000], lf.prefs(level=5)) == "ERROR_compressionLevel_invalid"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text", "mixed", "low", "rep", "random", "jsonlog", "zeros"])
+def test_linked_block_frames(eng, G, R, oracle, kind):
+    """LZ4F_blockLinked, the format's default: every block continues from the hash table of the one before and may match up to
+    65535 bytes back into it (LZ4_compress_fast_continue in prefix mode, lz4.c:3179-3223) - one wavefront walks the blocks in
+    order (lz4_compress_linked_kernel).  Block sizes 64 KiB - 4 MiB, stored blocks in the middle of a frame (their parse stops
+    where the output ran out, the table keeps what was written), negative levels = accelerations, all checksum options."""
+    import zstd_frame_cases as zfc
+    cases = ((4, 65537), (4, 200000), (4, 1 << 20), (5, 262145), (5, 900000), (6, (1 << 20) + 77), (7, (4 << 20) + 5),
+             (4, 65536 * 3), (4, 65536 * 2 + 12), (4, 65536 + 5), (0, 300000))
+    for i, (bsid, n) in enumerate(cases):
+        data = zfc.make(kind, n, seed=700 + i)
+        for o in (dict(), dict(level=-1), dict(level=-7, content_checksum=True, block_checksum=True, content_size=True)):
+            p = lf.prefs(bsid=bsid, **o)
+            got = lf.compress(G, data, p)
+            want = lf.compress(R, data, p)
+            assert isinstance(got, bytes) and got == want, (kind, bsid, n, o)
+            assert not (got[4] >> 5) & 1                             # the header says linked
+        back = lf.decompress(G, got, n)
+        assert back == (data, len(got))
+    # the caller may trade the reference's bytes for throughput: independent blocks, all in one launch
+    eng.lib.aoclgpu_lz4f_set_block_linking(0)
+    try:
+        p = lf.prefs(bsid=4)
+        got = lf.compress(G, data, p)
+        assert (got[4] >> 5) & 1 and got != lf.compress(R, data, p) and got == lf.compress(R, data, lf.prefs(bsid=4, independent=True))
+        assert lf.decompress(R, got, len(data)) == (data, len(got))
+    finally:
+        eng.lib.aoclgpu_lz4f_set_block_linking(1)
 
 
 @pytest.mark.gpu

@@ -216,3 +216,45 @@ def test_zstd_double_fast_multi_block_frames_bit_exact(oracle, ref, kind):
             assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.chainLog, cp.minMatch)
             checked += 1
     assert checked >= 60
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
+def test_lz4_linked_blocks_bit_exact(oracle, ref, kind):
+    """the blocks of LZ4F_compressFrame with linked blocks (the frame format's default): orc_lz4_compress_linked_blocks restates
+    LZ4_compress_fast_continue in prefix mode (lz4.c:3179-3223, :972-1360) block after block; the reference's own frame is cut
+    at its block headers and compared block by block (stored blocks included), three accelerations"""
+    import ctypes as C
+    import os
+    import struct
+    import lz4f_lib as lf
+    if not hasattr(ref.L, "LZ4F_compressFrame"):
+        pytest.skip("reference build without lz4frame.c")
+    R = lf.bind(ref.L)
+    f = oracle.L.orc_lz4_compress_linked_blocks
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    BS = {4: 65536, 5: 262144, 6: 1 << 20, 7: 4 << 20}
+    cases = ((4, 65537), (4, 200000), (4, 1 << 20), (5, 262145), (5, 900000), (6, (1 << 20) + 77), (6, 3500000), (7, (4 << 20) + 5),
+             (4, 65536 * 3), (4, 65536 * 2 + 12), (4, 65536 + 5))
+    for i, (bsid, n) in enumerate(cases):
+        data = zfc.make(kind, n, seed=800 + i)
+        for level in (0, -1, -5):
+            frame = lf.compress(R, data, lf.prefs(bsid=bsid, level=level))
+            assert isinstance(frame, bytes) and not (frame[4] >> 5) & 1
+            pos, blocks = 7, []
+            while True:
+                (h,) = struct.unpack_from("<I", frame, pos)
+                pos += 4
+                if h == 0:
+                    break
+                blocks.append((h, frame[pos:pos + (h & 0x7FFFFFFF)]))
+                pos += h & 0x7FFFFFFF
+            out = C.create_string_buffer(n + 16)
+            lens = (C.c_uint32 * (n // BS[bsid] + 2))()
+            nb = f(data, n, BS[bsid], -level + 1 if level < 0 else 1, out, n + 16, lens)
+            assert nb == len(blocks), (kind, bsid, n, level)
+            at = 0
+            for k in range(nb):
+                sz = lens[k] & 0x7FFFFFFF
+                assert lens[k] == blocks[k][0] and out.raw[at:at + sz] == blocks[k][1], (kind, bsid, n, level, k)
+                at += sz
