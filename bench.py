@@ -195,6 +195,67 @@ def cpu_baseline(codec_name, base_np, total, chunk, slot, sample_gib, reps):
     return rec, out_len
 
 
+def whole_input_frames(eng):
+    """Zstd inputs above 128 KiB are frames of several blocks: one wavefront per frame.  Reported next to
+    the headline, never part of it: 512 frames of 1 MiB side by side (data already in HBM), one 1 MiB frame alone, and the
+    same two for an LZ4 frame with linked blocks through LZ4F_compressFrame (host buffers).  A sample of the frames is
+    compared with the reference's ZSTD_compress / LZ4F_compressFrame when the reference build is present."""
+    import aocl_compression_amd as a
+    import numpy as np
+    import torch
+    import oracle_lib as ol
+    out = {}
+    fb, k = 1 << 20, 512
+    base = a.corpus.silesia_mix(64 << 20, seed=0x5EED)
+    src = torch.from_numpy(base).to(eng.device).repeat(k * fb // base.size + 1)[:k * fb].contiguous()
+    off = np.arange(k + 1, dtype=np.uint64) * fb
+    w, h, m = 20, 14, 7                                        # ZSTD_getCParams(1, 1 MiB, 0) under the AOCL level table
+    best = None
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dst, doff, lens = eng.zstd_compress_frames(src, off, w, h, m)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None or (it and dt < best) else best
+    assert all(x > 0 for x in lens)
+    out["zstd_level1_frames_1MiB_x512"] = {"GiBps": round(k * fb / best / 2**30, 2), "ms": round(best * 1e3, 1), "ratio": round(k * fb / sum(lens), 3)}
+    one = src[:fb].contiguous()
+    best = None
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        d1, do1, l1 = eng.zstd_compress_frames(one, [0, fb], w, h, m)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None or (it and dt < best) else best
+    out["zstd_level1_one_frame_1MiB"] = {"MiBps": round(fb / best / 2**20, 1), "ms": round(best * 1e3, 1)}
+    if os.path.exists(ol.REF_SO):
+        ref = C.CDLL(ol.REF_SO)
+        ref.ZSTD_compress.restype = C.c_size_t
+        ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        host = dst.cpu().numpy()
+        same = True
+        for i in (0, 1, k // 2, k - 1):
+            data = src[i * fb:(i + 1) * fb].cpu().numpy().tobytes()
+            cap = fb + (fb >> 8) + 64
+            ob = C.create_string_buffer(cap)
+            r = ref.ZSTD_compress(ob, cap, data, fb, 1)
+            same = same and host[doff[i]:doff[i] + lens[i]].tobytes() == ob.raw[:r]
+        out["zstd_frames_identical_to_reference_ZSTD_compress"] = bool(same)
+    try:                                                       # LZ4 frame with linked blocks (the format's default), host buffers
+        import lz4f_lib as lf
+        G = lf.bind(eng.lib)
+        data = base.tobytes()[:4 << 20]
+        p = lf.prefs()
+        t0 = time.perf_counter(); frame = lf.compress(G, data, p); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); frame = lf.compress(G, data, p); dt = min(dt, time.perf_counter() - t0)
+        res = {"MiBps": round(len(data) / dt / 2**20, 1), "ms": round(dt * 1e3, 1), "ratio": round(len(data) / len(frame), 3)}
+        if os.path.exists(ol.REF_SO) and hasattr(C.CDLL(ol.REF_SO), "LZ4F_compressFrame"):
+            res["identical_to_reference_LZ4F_compressFrame"] = bool(frame == lf.compress(lf.bind(C.CDLL(ol.REF_SO)), data, p))
+        out["lz4f_linked_one_frame_4MiB_host"] = res
+    except Exception as e:
+        out["lz4f_linked_one_frame_4MiB_host"] = {"error": repr(e)}
+    out["note"] = "one wavefront per frame (blocks of a frame depend on each other in order); never the reported value"
+    return out
+
+
 def config1_latency(eng, reps=20):
     """BASELINE config 1: one 64 KiB text block through aocl_llc_compress / aocl_llc_decompress on HOST buffers
     (PCIe both ways included), next to the reference's own aocl_llc_* on one host core.  Microseconds, best of `reps`."""
@@ -583,6 +644,10 @@ def main():
                 out["config1_latency_us"] = config1_latency(eng)
             except Exception as e:
                 out["config1_latency_us"] = {"error": repr(e)}
+            try:
+                out["whole_input_frames"] = whole_input_frames(eng)
+            except Exception as e:
+                out["whole_input_frames"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     for f in _BASE_FILES.values():
         try:
