@@ -3,7 +3,7 @@
 Prints one JSON line per case.  Data already in HBM, level-1 parameters of the size (AOCL table)."""
 import json, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import aocl_compression_amd as a
 
 eng = a.engine(0)
