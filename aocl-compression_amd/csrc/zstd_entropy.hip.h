@@ -378,7 +378,7 @@ struct HufScratch {
     FseCT wct;            // FSE table of the weights
     FseScratch fs;
     u32 wbits[2][128];    // weight chain output: value << 8 | bits
-    short todo[11][64];   // per-bucket work lists of the tie-order sort
+    short todo[12][64];   // per-bucket work lists of the tie-order sort
 };
 
 constexpr u32 kHufCutoff = 165;      // RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) (huf_compress.c:552)
@@ -447,11 +447,14 @@ __device__ u32 huf_build_wave(HufCT* ct, const u32* hist, const u32 maxSym, cons
     wave_fence();
     const u32 nonNull = wsum((c[0] ? 1u : 0u) + (c[1] ? 1u : 0u) + (c[2] ? 1u : 0u) + (c[3] ? 1u : 0u));   // leaves 0..nonNull-1
     {   // power-of-two buckets: lane b owns bucket hb = 7 + b (counts 165.. fall into hb >= 7); sorted[] is count-descending,
-        // so a bucket is one contiguous range
+        // so a bucket is one contiguous range.  The reference's sorting loop starts one bucket early (its bucket n holds the
+        // symbols of index n - 1, huf_compress.c:649-664): the symbols whose count is exactly 164 are quicksorted as well -
+        // all ties, so nine or more of them come out permuted.  Lane 11 owns that bucket.
         const u32 hbv = 7u + (u32)lane;
         int lo = -1, hi = -2;
-        if (lane < 11) {
-            const u32 cmin = hbv == 7 ? kHufCutoff : (1u << hbv), cmax = (2u << hbv) - 1;
+        if (lane < 12) {
+            const u32 cmin = lane == 11 ? kHufCutoff - 1 : (hbv == 7 ? kHufCutoff : (1u << hbv));
+            const u32 cmax = lane == 11 ? kHufCutoff - 1 : (2u << hbv) - 1;
             // entries with count in [cmin, cmax]: binary search on the descending array
             int a = 0, b = (int)nonNull;                     // first index with count <= cmax
             while (a < b) { const int m = (a + b) >> 1; if ((sc->tmp[m] >> 8) > cmax) a = m + 1; else b = m; }

@@ -1437,6 +1437,16 @@ unsigned orc_dbg_huf_build(uint8_t* nbBitsOut, const unsigned* count, unsigned m
 { huf_ct ct; unsigned r = huf_build(&ct, count, maxSym, maxNbBits); memcpy(nbBitsOut, ct.nbBits, 256); return r; }
 size_t orc_dbg_write_ncount(uint8_t* out, const int16_t* norm, unsigned maxSym, unsigned tableLog)
 { return fse_write_ncount(out, norm, maxSym, tableLog); }
+/* code length per symbol of a Huffman table description (debugging aid of tools/debug): returns the table log, 0 on error */
+unsigned orc_dbg_huf_lengths(const uint8_t* desc, size_t n, uint8_t* lens256)
+{
+    huf_dt* dt = (huf_dt*)malloc(sizeof(huf_dt)); u32 i, tl;
+    memset(lens256, 0, 256);
+    if (!dt || huf_read_table(dt, desc, n) == ZERR) { free(dt); return 0; }
+    for (i = 0; i < (1u << dt->tableLog); i++) lens256[dt->symbol[i]] = dt->nbBits[i];
+    tl = dt->tableLog; free(dt);
+    return tl;
+}
 size_t orc_dbg_huf_write(uint8_t* out, const unsigned* count, unsigned maxSym, unsigned maxNbBits)
 { huf_ct ct; unsigned r = huf_build(&ct, count, maxSym, maxNbBits); return huf_write_ctable(out, &ct, maxSym, r); }
 /* sequences of the match finder: out[4*i] = {litLength, offBase, matchLength, 0}; returns nbSeq */

@@ -258,3 +258,11 @@ def test_lz4_linked_blocks_bit_exact(oracle, ref, kind):
                 sz = lens[k] & 0x7FFFFFFF
                 assert lens[k] == blocks[k][0] and out.raw[at:at + sz] == blocks[k][1], (kind, bsid, n, level, k)
                 at += sz
+
+
+def test_huffman_sort_bucket_of_count_164(oracle, ref):
+    """nine or more literal symbols with a count of exactly 164: the reference's HUF_sort permutes them (zstd_frame_cases.
+    count164_case); found by tools/fuzz_frames_campaign.py on the GPU, pinned here for the oracle"""
+    for seed in range(12):
+        data = zfc.count164_case(seed, ties=9 + seed)
+        assert oracle.compress(ol.ZSTD, data) == ref.compress(ol.ZSTD, data), seed

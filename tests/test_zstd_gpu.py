@@ -239,3 +239,16 @@ def test_slots_smaller_than_the_bound(eng, oracle):
         out = C.create_string_buffer(len(want))
         assert lib.ZSTD_compress(out, len(want), data, n, 1) == len(want) and out.raw == want
         assert lib.ZSTD_isError(lib.ZSTD_compress(out, len(want) - 1, data, n, 1))
+
+
+def test_huffman_sort_bucket_of_count_164(eng, oracle):
+    """the reference quicksorts the bucket of count 164 as well (huf_compress.c:649-664, one bucket below the log2 buckets): nine
+    or more symbols with that count come out permuted, and with them their code lengths (found by tools/fuzz_frames_campaign.py)"""
+    import zstd_frame_cases as zfc
+    t = eng.torch
+    for seed in range(24):
+        data = zfc.count164_case(seed, ties=9 + seed % 14)
+        src = t.frombuffer(bytearray(data), dtype=t.uint8).to(eng.device)
+        slots, lens, slot = eng.compress_chunks(a.ZSTD, src, len(data))
+        got = slots[:int(lens[0])].cpu().numpy().tobytes()
+        assert got == oracle.compress(ol.ZSTD, data), seed

@@ -78,3 +78,14 @@ def ref_level_cparams(ref, level, n):
     L.ZSTD_getCParams.restype = CParams
     L.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
     return L.ZSTD_getCParams(level, n, 0)
+
+
+def count164_case(seed, ties=12):
+    """bytes whose histogram has `ties` symbols with a count of exactly 164 (shuffled, so almost no matches): the reference's
+    Huffman sort quicksorts that bucket too (its loop starts one bucket below the log2 buckets, huf_compress.c:649-664) and
+    permutes nine or more equal counts - which symbol of them gets the shorter code is part of the output"""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(100, 900, 256)
+    counts[rng.choice(256, ties, replace=False)] = 164
+    counts[counts == 164] = 164                          # (others that drew 164 by chance simply join the bucket)
+    return rng.permutation(np.repeat(np.arange(256, dtype=np.uint8), counts)).tobytes()
