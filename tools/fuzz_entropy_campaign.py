@@ -54,12 +54,35 @@ def counts_for(rng, n):
     return full
 
 
+def seq_shaped(rng, n):
+    """a chunk whose parse is (mostly) prescribed: fresh random literals of a few fixed run lengths, each followed by a copy of a
+    few fixed lengths at a few fixed distances - sequence-code histograms with one to four symbols per stream (RLE / predefined /
+    compressed tables with ties, the `mostFrequent` thresholds of ZSTD_selectEncodingType)"""
+    lls = rng.choice([0, 1, 2, 3, 5, 8, 15, 16, 17, 24, 40, 64, 130, 600], int(rng.integers(1, 5)))
+    mls = rng.choice([5, 6, 7, 8, 9, 12, 18, 34, 35, 36, 40, 66, 67, 130, 131, 259, 1000], int(rng.integers(1, 5)))
+    ofs = rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 31, 32, 33, 100, 255, 256, 1000, 4096, 20000, 65536], int(rng.integers(1, 5)))
+    out = bytearray(rng.integers(0, 256, int(rng.integers(8, 3000)), dtype=np.uint8).tobytes())
+    while len(out) < n:
+        out += rng.integers(0, 256, int(rng.choice(lls)), dtype=np.uint8).tobytes()
+        d = min(int(rng.choice(ofs)), len(out)); m = int(rng.choice(mls))
+        if d >= m: out += out[len(out) - d:len(out) - d + m]
+        else:
+            seg = bytes(out[-d:]); out += (seg * (m // d + 1))[:m]
+    return bytes(out[:n])
+
+
 t0 = time.time(); it = 0; chunks = 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed0 + it); it += 1
-    n_target = int(rng.choice([2000, 20000, 50000, 131072]))
+    # sizes: a few bulk ones and the neighbourhoods of the literal-section thresholds (raw below 64, one stream below 256,
+    # header formats at 1 KiB and 16 KiB, table reuse preference at 1 KiB, sampling of suspected-incompressible input from
+    # 40 960, 4-stream segments of 64 KiB)
+    near = int(rng.choice([64, 256, 1024, 4096, 16384, 40960, 65536, 65792, 131072]))
+    n_target = int(rng.choice([2000, 20000, 50000, 131072, max(8, min(131072, near + int(rng.integers(-12, 13))))]))
     parts = []
     for _ in range(32):
+        if rng.random() < 0.35:
+            parts.append(seq_shaped(rng, n_target)); continue
         full = counts_for(rng, n_target)
         data = rng.permutation(np.repeat(np.arange(256, dtype=np.uint8), full))
         if len(data) < n_target:                  # top up with copies of the most frequent symbol: counts stay tied elsewhere
