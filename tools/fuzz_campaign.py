@@ -53,6 +53,23 @@ def build(rng, target):
     return bytes(out[:target])
 
 
+def seq_shaped(rng, n):
+    """a prescribed parse: fresh random literals of a few fixed run lengths, each followed by a copy of a few fixed lengths at a
+    few fixed distances (overlapping copies, distances 1..4, lengths at the formats' token boundaries: LZ4 15 / 19 / 270+,
+    Snappy 4..11 / 64 / 65, 1-byte / 2-byte offsets) - the speculation's special paths with sharp edges instead of random ones"""
+    lls = rng.choice([0, 1, 2, 3, 5, 14, 15, 16, 17, 59, 60, 61, 270, 271, 600], int(rng.integers(1, 5)))
+    mls = rng.choice([4, 5, 6, 7, 8, 11, 12, 18, 19, 20, 34, 63, 64, 65, 66, 67, 68, 130, 259, 273, 274, 1000, 70000], int(rng.integers(1, 5)))
+    ofs = rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 31, 32, 33, 100, 255, 256, 2047, 2048, 2049, 4096, 20000, 65535, 65536], int(rng.integers(1, 5)))
+    out = bytearray(rng.integers(0, 256, int(rng.integers(8, 3000)), dtype=np.uint8).tobytes())
+    while len(out) < n:
+        out += rng.integers(0, 256, int(rng.choice(lls)), dtype=np.uint8).tobytes()
+        d = min(int(rng.choice(ofs)), len(out)); m = int(rng.choice(mls))
+        if d >= m: out += out[len(out) - d:len(out) - d + m]
+        else:
+            seg = bytes(out[-d:]); out += (seg * (m // d + 1))[:m]
+    return bytes(out[:n])
+
+
 def want_lz4(part, acc):
     cap = ol.bound(ol.LZ4, len(part)); w = C.create_string_buffer(max(cap, 1))
     r = L.orc_lz4_compress_fast(part, len(part), w, cap, acc)
@@ -74,7 +91,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed0 + it); it += 1
     codec = ["lz4", "snappy", "zstd"][it % 3]
     size = int(rng.choice([300, 5000, 40000, 65536 + 11, 70000, 140000, 262144, 300000, 400000]))
-    raw = build(rng, size)
+    raw = seq_shaped(rng, size) if rng.random() < 0.4 else build(rng, size)
     chunk = int(rng.choice([0, 97, 1000, 4096, 65536, 65547, 131072, 262144]))
     upstream = False
     if codec == "lz4":
