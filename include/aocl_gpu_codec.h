@@ -21,7 +21,11 @@
  *   aoclgpu_zstd_compress_chunks     ZSTD_compress(level 1)          algos/zstd/lib/compress/zstd_compress.c:5388
  *                                    (-> zstd_fast.c:427-706 + entropy stage zstd_compress.c:2910-3064)
  *   aoclgpu_zstd_decompress_chunks   ZSTD_decompress                 algos/zstd/lib/decompress/zstd_decompress.c:1252
- * Output bytes are identical to those functions' output on the same chunk.
+ *   aoclgpu_zstd_compress_frames     ZSTD_compress_advanced, any size algos/zstd/lib/compress/zstd_compress.c:5388-5470
+ *                                    (-> ZSTD_compress_frameChunk :4504-4583: one frame of several blocks; fast / double-fast)
+ *   aoclgpu_lz4_compress_chunks      the blocks of LZ4F_compressFrame algos/lz4/lz4frame.c:373-419, lz4.c:3179-3256
+ *     with AOCLGPU_FLAG_LZ4_LINKED   with LZ4F_blockLinked (LZ4_compress_fast_continue in prefix mode)
+ * Output bytes are identical to those functions' output on the same chunk / input.
  */
 #ifndef AOCL_GPU_CODEC_H
 #define AOCL_GPU_CODEC_H
