@@ -1228,18 +1228,35 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
                 rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
                 const u32 a = ip0 - anchor, b = match0 - prefixPos; maxback = a < b ? a : b;
             }
-            {
-                u32 back = 0;
-                while (back < maxback) {
-                    const u32 k = back + (u32)lane;
-                    bool eq = false;
-                    if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
-                    const int c = first_lane(ballot(!eq));
-                    back += (u32)c;
-                    if (c < 64) break;
+            {   // catch-up and forward extension: the first round of both compares (64 bytes back, 256 bytes forward) is
+                // issued together, one global round trip instead of two; longer runs continue with the loops
+                const u32 fa = ip0 + 4, fb = match0 + 4;
+                bool eqb = false;
+                if ((u32)lane < maxback) eqb = src[ip0 - 1 - (u32)lane] == src[match0 - 1 - (u32)lane];
+                const u32 o = 4u * (u32)lane, pa = fa + o;
+                u32 x = 0xFFFFFFFFu;
+                if (pa + 4 <= n) x = ld32(src + pa) ^ ld32(src + fb + o);
+                else if (pa < n) {
+                    x = 0;
+                    for (u32 t = 0; t < n - pa; ++t) x |= (u32)(src[pa + t] ^ src[fb + o + t]) << (8 * t);
+                    x |= 0xFFFFFFFFu << (8 * (n - pa));
+                }
+                u32 back = (u32)first_lane(ballot(!eqb));               // <= maxback for maxback <= 64
+                if (back == 64) {
+                    while (back < maxback) {
+                        const u32 k = back + (u32)lane;
+                        bool eq = false;
+                        if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
+                        const int c = first_lane(ballot(!eq));
+                        back += (u32)c;
+                        if (c < 64) break;
+                    }
                 }
                 if (back > maxback) back = maxback;
-                const u32 fwd = wave_count(src, ip0 + 4, match0 + 4, n, lane);
+                u32 fwd;
+                const int l = first_lane(ballot(x != 0));
+                if (l == 64) fwd = 256 + wave_count(src, fa + 256, fb + 256, n, lane);
+                else fwd = 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
                 ip0 -= back; match0 -= back; mLength = 4 + back + fwd;   // _match (:669)
             }
             {
@@ -1267,9 +1284,11 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
 }
 
 struct FrameLds {
-    EntropyLds e;
+    union {                                      // never live at the same time: a block is parsed, then coded
+        EntropyLds e;
+        uint16_t scratch[2 * kDfScratch];        // slot-reuse rounds of the match finder: one table (fast) or two (double-fast)
+    };
     HufCT prev;                                  // Huffman table of the last confirmed block
-    uint16_t scratch[2 * kDfScratch];            // slot-reuse rounds: one table (fast) or two (double-fast)
 };
 
 // One frame: returns its size, 0 when it does not fit `cap` (dstSize_tooSmall) or the parameters have no GPU parse.
@@ -2077,6 +2096,7 @@ __global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, u
 }
 
 size_t zstd_workspace_bytes() { return sizeof(Workspace); }
+size_t zstd_frame_lds_bytes() { return sizeof(FrameLds); }
 uint32_t zstd_decoder_lds_bytes() { return (uint32_t)sizeof(DecLds); }
 size_t zstd_entropy_lds_bytes() { return sizeof(EntropyLds); }
 
@@ -2309,7 +2329,10 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     if (f->nframes == 0) return AOCLGPU_OK;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("zstd frames: device query failed"); return AOCLGPU_ERR_HIP; }
-    uint32_t grid = (uint32_t)prop.multiProcessorCount * 8u;             // one wave per frame; eight frames per CU (19 KB of LDS each)
+    // one wave per frame; as many frames per CU as its LDS holds (granules of 1280 bytes, 128 per CU), at most 12 (163 VGPRs)
+    uint32_t perCU = 128u / (uint32_t)((aoclgpu::zstd_frame_lds_bytes() + 1279) / 1280);
+    if (perCU > 12) perCU = 12;
+    uint32_t grid = (uint32_t)prop.multiProcessorCount * perCU;
     if (grid > f->nframes) grid = f->nframes;
     const size_t tabBytes = ((size_t)4 << f->hashLog) + (df ? (size_t)4 << f->chainLog : 0);
     if ((size_t)grid * tabBytes > ((size_t)1 << 30)) grid = (uint32_t)(((size_t)1 << 30) / tabBytes);   // at most 1 GiB of tables
