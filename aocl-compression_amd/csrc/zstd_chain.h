@@ -51,6 +51,7 @@ ZC_FN uint64_t map_from_window(uint32_t eqb, int j)
 // per-lane record of a table candidate, packed for one readlane: candidate position (17 bits) | forward length beyond
 // the 4 match bytes, 0..24 (24 = runs out of the window) << 17 | catch-up bytes 0..4 (7 = needs the exact path) << 22
 ZC_FN uint32_t pack_info(uint32_t c, uint32_t fw, uint32_t bk4) { return c | (fw << 17) | (bk4 << 22); }
+ZC_FN uint64_t pack_info_wide(uint32_t c, uint32_t fw, uint32_t bk4) { return ((uint64_t)c << 32) | (fw << 17) | (bk4 << 22); }
 
 enum { ZC_RESTART = 0, ZC_SPECIAL = 1, ZC_CONTINUE = 2, ZC_REFRESH = 3 };
 
@@ -95,7 +96,8 @@ ZC_FN void finish(WalkOut& o, uint64_t& commit, int w1, int w2, int w3, int lim,
 // emit(litLength, offBase, matchLength, anchorPosition) stores one sequence.
 template <class Info, class Eqb, class Emit>
 ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, int32_t arel, uint32_t rep1, uint32_t rep2,
-                   uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit, const int S0 = 0, const uint64_t commit0 = 0)
+                   uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit, const int S0 = 0, const uint64_t commit0 = 0,
+                   const uint32_t lowPos = 0)
 {
     WalkOut o;
     int S = S0;
@@ -140,10 +142,15 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             commit |= lane_bit(k + 1) | lane_bit(k + 2) | lane_bit(E - 2);
         } else {
             const int j = jm;
-            const uint32_t in = info(j);
-            const uint32_t c = in & 0x1FFFFu, fw = (in >> 17) & 31u, bk4 = (in >> 22) & 7u;
+            const auto in = info(j);
+            // a 64-bit record carries a full-width candidate position in its upper half (frames: positions are offsets into
+            // the frame, the catch-up stops at lowPos, the prefix start); the 32-bit record of the chunk kernels holds 17 bits
+            uint32_t c, cl;
+            if constexpr (sizeof(in) == 8) { c = (uint32_t)((uint64_t)in >> 32); cl = c - lowPos; }
+            else { c = (uint32_t)in & 0x1FFFFu; cl = c; }
+            const uint32_t fw = ((uint32_t)in >> 17) & 31u, bk4 = ((uint32_t)in >> 22) & 7u;
             const uint32_t room = (uint32_t)(j - arel);
-            const uint32_t maxback = room < c ? room : c;
+            const uint32_t maxback = room < cl ? room : cl;
             const uint32_t back = bk4 < maxback ? bk4 : maxback;
             const int E = j + 4 + (int)fw;
             const bool tails = E - 2 >= lim;
