@@ -66,7 +66,7 @@ class ZstdFrames(C.Structure):
     """aoclgpu_zstd_frames (include/aocl_gpu_codec.h)"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_off", C.c_void_p), ("dst_off", C.c_void_p), ("out_len", C.c_void_p),
                 ("nframes", C.c_uint32), ("windowLog", C.c_uint32), ("hashLog", C.c_uint32), ("minMatch", C.c_uint32), ("targetLength", C.c_uint32),
-                ("strategy", C.c_uint32), ("chainLog", C.c_uint32)]
+                ("strategy", C.c_uint32), ("chainLog", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class LlcDesc(C.Structure):
@@ -289,7 +289,7 @@ class Engine:
         return out[:n.value]
 
     def zstd_compress_frames(self, src, src_off, window_log: int, hash_log: int, min_match: int, caps=None, target_length: int = 0,
-                             strategy: int = 1, chain_log: int = 0):
+                             strategy: int = 1, chain_log: int = 0, flags: int = 0):
         """One Zstd frame per input of any size (aoclgpu_zstd_compress_frames): `src` is a device uint8 tensor, `src_off` a
         host sequence of nframes + 1 offsets into it.  Returns (dst tensor, dst offsets as a list, frame sizes as a list)."""
         import numpy as np
@@ -306,7 +306,7 @@ class Engine:
         d_do = t.from_numpy(do.view(np.int64)).to(self.device)
         out_len = t.zeros(max(k, 1), dtype=t.int64, device=self.device)
         f = ZstdFrames(src.data_ptr(), dst.data_ptr(), d_so.data_ptr(), d_do.data_ptr(), out_len.data_ptr(), k,
-                       window_log, hash_log, min_match, target_length, strategy, chain_log)
+                       window_log, hash_log, min_match, target_length, strategy, chain_log, flags)
         self._check(self.lib.aoclgpu_zstd_compress_frames(C.byref(f), self._stream()), "zstd_compress_frames")
         return dst, [int(x) for x in do], [int(x) for x in out_len[:k].cpu().tolist()]
 

@@ -1283,6 +1283,281 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
     return nbSeq;
 }
 
+// The chunk kernels' finder for a block of a frame: hash table AND source ring in LDS, chain batches that resolve several
+// sequences per batch (zstd_chain.h) - the table is 2^hashLog u32 entries (position + 2, offsets into the frame), so this
+// variant serves hashLog <= 14 (64 KB of LDS: one frame per CU) and is what a lone frame or a small batch of frames runs on;
+// fast_frame_block above (table in HBM, 9 frames per CU) is the bulk variant.  Same output, both driven by the same tests.
+template <int MLS>
+__device__ u32 fast_frame_block_lds(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, lbyte* lds,
+                                    const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane)
+{
+    typedef __attribute__((address_space(3))) u32 L32;
+    const u32 tsize = 1u << hlog;
+    L32* table = (L32*)lds;
+    lbyte* ring = lds + 4 * tsize;
+    auto tget = [&](u32 h) -> u32 { return table[h]; };
+    auto tput = [&](u32 h, u32 v) { table[h] = v; };
+    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;
+    auto flush_seq = [&](u32 first, u32 count) {
+        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
+    };
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
+        const bool me = (u32)lane == (idx & 63u);
+        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
+        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
+    };
+    const u32 n = be;
+    const u32 prefixIdx = lowest_prefix(win, be + 2), prefixPos = prefixIdx - 2;
+    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u);
+    u32 rep1 = rep1io, rep2 = rep2io, saved1 = 0, saved2 = 0;
+    {   const u32 curr = s + 2, maxRep = curr - lowest_prefix(win, curr);
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
+    if (n >= 20) {
+        const u32 ilimit = n - 16;
+        // source ring: 240-byte blocks counted from the block's start (see fast_block)
+        int32_t rb = -4;
+        u32 pend = 0; bool have_pend = false;
+        auto blk_load = [&](int32_t b) -> u32 {
+            const u32 a = bs + kRingBlk * (u32)b + 4u * (u32)lane;
+            u32 v = 0;
+            if (lane < 60 && a + 4 <= n) v = ld32(src + a);
+            return v;
+        };
+        auto blk_store = [&](int32_t b, u32 v) {
+            if (lane < 60) *(L32*)(ring + ((u32)b & 1u) * kRingBlk + 4u * (u32)lane) = v;
+            if (!(b & 1) && lane < 8) *(L32*)(ring + 2 * kRingBlk + 4u * (u32)lane) = v;
+        };
+        auto rep_loop = [&](u32 ip0) -> u32 {
+            bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            while (hit) {
+                const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
+                const u32 t = rep2; rep2 = rep1; rep1 = t;
+                const u32 hc = z_hash<MLS>(ld64(src + ip0), hlog);
+                if (lane == 0) tput(hc, ip0 + 2);
+                put_seq(nbSeq, 0, 1, rLength, ip0);
+                wave_fence();
+                nbSeq++;
+                ip0 += rLength;
+                hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
+            }
+            return ip0;
+        };
+        for (;;) {                                                      // _start
+            u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
+            u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
+            bool e_ok1 = false, e_ok2 = false;
+            if (s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit) {
+                // ---------------- chain batch (see fast_block) ----------------
+                const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
+                typedef u32x4 __attribute__((aligned(1))) U4;
+                typedef const __attribute__((address_space(1))) U4* GP4;
+                const u32 rel0 = pos0 - 4 - bs;
+                const int32_t bl = (int32_t)(((u64)rel0 * 17895698ull) >> 32), bh = (int32_t)(((u64)(rel0 + 94) * 17895698ull) >> 32);   // / 240
+                if (!(bh <= rb && rb <= bl + 1)) {
+                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
+                    else {
+                        const u32 v0 = blk_load(bl), v1 = blk_load(bh);
+                        blk_store(bl, v0);
+                        if (bh != bl) blk_store(bh, v1);
+                        rb = bh;
+                    }
+                    pend = blk_load(rb + 1); have_pend = true;
+                    wave_fence();
+                }
+                u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
+                if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
+                const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
+                const u32 b1 = src[pos - rep1];
+                u32 b2 = 0x100;
+                if (rep2) b2 = src[pos - rep2];
+                const u64 seq = pa.y | ((u64)pa.z << 32);
+                const u32 h = z_hash<MLS>(seq, hlog);
+                const u32 ent = tget(h);
+                const bool has = ent >= prefixIdx;
+                const u32 c = ent - 2;
+                const bool near0 = c - prefixPos < 4;                   // candidate within 4 bytes of the prefix start: exact path
+                u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+                if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }
+                wave_fence();
+                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
+                wave_fence();
+                table[h] = ent;                                         // the rounds scribbled on the slots' low halves
+                wave_fence();
+                const int lim = first_lane(ballot(w != (u32)lane));
+                using zchain::zero_bytes;
+                const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
+                                (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
+                const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
+                const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
+                const u32 infoLo = near0 ? zchain::pack_info(0, 0, 7) : zchain::pack_info(0, fw, bk4);
+                const u64 okmask = ballot(lane < lim && ok);
+                const u32 pb0 = pa.y & 0xFFu;
+                zchain::WalkOut wo;
+                {
+                    u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
+                    int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
+                    for (;;) {
+                        wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
+                            [&](int j) -> u64 { return ((u64)lane_get(c, j) << 32) | lane_get(infoLo, j); }, [&](int j) { return lane_get(eqb, j); },
+                            [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0, prefixPos);
+                        if (wo.outcome != zchain::ZC_REFRESH) break;
+                        u32 nb1 = 0x100, nb2 = 0x100;
+                        if (pos - prefixPos >= wo.rep1) nb1 = src[pos - wo.rep1];
+                        if (wo.rep2 && pos - prefixPos >= wo.rep2) nb2 = src[pos - wo.rep2];
+                        e1 = ballot(pb0 == nb1); e2 = ballot(pb0 == nb2);
+                        S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
+                    }
+                }
+                if ((wo.commit >> lane) & 1) tput(h, pos + 2);
+                wave_fence();
+                anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
+                if (wo.outcome == zchain::ZC_RESTART) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (t >= 3 - wo.ntail) {
+                            const int idx = wo.tail[t];
+                            const u32 hh = idx < 64 ? lane_get(h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
+                            if (lane == 0) tput(hh, pos0 + (u32)idx + 2);
+                            wave_fence();
+                        }
+                    }
+                    if (wo.post) { s = rep_loop(s); anchor = s; }
+                    continue;
+                }
+                if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(wo.R - wo.S);
+                else {
+                    const int el = wo.el;
+                    ev = wo.ev;
+                    e_pos = pos0 + (u32)el; e_cand = lane_get(ent, el); e_sig = 2; e_st = 2; e_half = (u32)(el - wo.S) & 1u;
+                    e_ok1 = el + 1 < 64; e_p1 = e_pos + 1; e_h1 = lane_get(h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64; e_h2 = lane_get(h, (el + 2) & 63);
+                }
+            }
+            if (!ev) for (;;) {
+                const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
+                u32 am, sg, st;
+                if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
+                else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
+                else { am = 0x40000000u; sg = 2; st = 2; }
+                const bool valid = (u64)s + am + sg + 1 < ilimit;
+                const u32 pos = s + am + half;
+                u64 seq = 0;
+                if (valid) seq = ld64(src + pos);
+                const u32 h = z_hash<MLS>(seq, hlog);
+                u32 ent = 0;
+                if (valid) ent = tget(h);
+                bool rep_hit = false;
+                if (valid && half == 0 && rep1 > 0) {
+                    const u32 r = pos + sg;
+                    rep_hit = ld32(src + r) == ld32(src + r - rep1);
+                }
+                u32 m4 = ~(u32)seq;
+                if (valid && ent >= prefixIdx) m4 = ld32(src + ent - 2);
+                wave_fence();
+                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane, valid);
+                wave_fence();
+                if (valid) table[h] = ent;
+                wave_fence();
+                const int f = first_lane(ballot(valid && w != (u32)lane));
+                const int e = first_lane(ballot(!valid));
+                const int lim = f < e ? f : e;
+                const bool mat_hit = m4 == (u32)seq;
+                const int el = first_lane(ballot(lane < lim && (rep_hit || mat_hit)));
+                const int ncommit = (el < 64) ? el + 1 : lim;
+                if (lane < ncommit) tput(h, pos + 2);
+                wave_fence();
+                if (el < 64) {
+                    ev = lane_get((u32)rep_hit, el) ? 2 : 1;
+                    e_pos = lane_get(pos, el); e_cand = lane_get(ent, el);
+                    e_sig = lane_get(sg, el); e_st = lane_get(st, el); e_half = lane_get(half, el);
+                    e_ok1 = el + 1 < 64 && lane_get((u32)valid, (el + 1) & 63) != 0;
+                    e_p1 = lane_get(pos, (el + 1) & 63); e_h1 = lane_get(h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64 && lane_get((u32)valid, (el + 2) & 63) != 0 && lane_get(pos, (el + 2) & 63) == e_pos + 2;
+                    e_h2 = lane_get(h, (el + 2) & 63);
+                    break;
+                }
+                if (e < 64 && e <= f) break;
+                i0 += (u32)lim;
+            }
+            if (!ev) break;                                             // _cleanup
+            {
+                const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
+                if (e_half == 0 || e_st <= 4) {
+                    const u32 h1 = (e_ok1 && e_p1 == ip1) ? e_h1 : z_hash<MLS>(ld64(src + ip1), hlog);
+                    if (lane == 0) tput(h1, ip1 + 2);
+                    wave_fence();
+                }
+            }
+            const u32 current0 = e_pos;
+            u32 ip0, match0, offcode, mLength, maxback;
+            if (ev == 2) { ip0 = e_pos + e_sig; match0 = ip0 - rep1; offcode = 1; maxback = 1; }
+            else {
+                ip0 = e_pos; match0 = e_cand - 2;
+                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
+                const u32 a = ip0 - anchor, b = match0 - prefixPos; maxback = a < b ? a : b;
+            }
+            {
+                const u32 fa = ip0 + 4, fb = match0 + 4;
+                bool eqb = false;
+                if ((u32)lane < maxback) eqb = src[ip0 - 1 - (u32)lane] == src[match0 - 1 - (u32)lane];
+                const u32 o = 4u * (u32)lane, pa = fa + o;
+                u32 x = 0xFFFFFFFFu;
+                if (pa + 4 <= n) x = ld32(src + pa) ^ ld32(src + fb + o);
+                else if (pa < n) {
+                    x = 0;
+                    for (u32 t = 0; t < n - pa; ++t) x |= (u32)(src[pa + t] ^ src[fb + o + t]) << (8 * t);
+                    x |= 0xFFFFFFFFu << (8 * (n - pa));
+                }
+                u32 back = (u32)first_lane(ballot(!eqb));
+                if (back == 64) {
+                    while (back < maxback) {
+                        const u32 k = back + (u32)lane;
+                        bool eq = false;
+                        if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
+                        const int c = first_lane(ballot(!eq));
+                        back += (u32)c;
+                        if (c < 64) break;
+                    }
+                }
+                if (back > maxback) back = maxback;
+                u32 fwd;
+                const int l = first_lane(ballot(x != 0));
+                if (l == 64) fwd = 256 + wave_count(src, fa + 256, fb + 256, n, lane);
+                else fwd = 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
+                ip0 -= back; match0 -= back; mLength = 4 + back + fwd;
+            }
+            {
+                const u32 ll = ip0 - anchor;
+                put_seq(nbSeq, ll, offcode, mLength, anchor);
+                litSize += ll; nbSeq++;
+            }
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {
+                const bool chk = rep2 > 0;
+                u64 va = 0;
+                if (!e_ok2) va = ld64(src + current0 + 2);
+                const u64 vb = ld64(src + ip0 - 2);
+                u32 r0 = 0, r1 = 1;
+                if (chk) { r0 = ld32(src + ip0); r1 = ld32(src + ip0 - rep2); }
+                const u32 ha = e_ok2 ? e_h2 : z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
+                if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
+                wave_fence();
+                if (chk && uni(r0 == r1 ? 1u : 0u) != 0) { ip0 = rep_loop(ip0); anchor = ip0; }
+            }
+            s = ip0;
+        }
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep1io = rep1 ? rep1 : saved1;
+    rep2io = rep2 ? rep2 : saved2;
+    flush_seq(nbSeq & ~63u, nbSeq & 63u);
+    wave_fence();
+    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    return nbSeq;
+}
+
 struct FrameLds {
     union {                                      // never live at the same time: a block is parsed, then coded
         EntropyLds e;
@@ -1292,6 +1567,9 @@ struct FrameLds {
 };
 
 // One frame: returns its size, 0 when it does not fit `cap` (dstSize_tooSmall) or the parameters have no GPU parse.
+// LT: the fast finder with its table in LDS (`tab` = 2^hlog u32 entries followed by the 512-byte source ring, both LDS);
+// otherwise `tab` is this workgroup's slice of the HBM workspace.
+template <bool LT>
 __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 strategy,
                                      const u32 windowLog, const u32 hlog, const u32 clog, const u32 mls, const u32 targetLength,
                                      FrameLds* L, Workspace* ws, u32* tab, int lane)
@@ -1314,7 +1592,12 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
         else st32(dst + p, n);
     }
     if (n == 0) { if (lane == 0) { dst[op] = 1; dst[op + 1] = 0; dst[op + 2] = 0; } return (long long)(op + 3); }   // ZSTD_writeEpilogue
-    {   // fresh table (ZSTD_reset_matchState clears it for a new frame)
+    if constexpr (LT) {                                                  // fresh table (ZSTD_reset_matchState clears it for a new frame)
+        if (strategy != 1) return 0;
+        typedef __attribute__((address_space(3))) u32 L32;
+        for (u32 i = (u32)lane; i < (1u << hlog); i += kWave) ((L32*)tab)[i] = 0;
+        wave_fence();
+    } else {
         typedef u32 u4 __attribute__((ext_vector_type(4)));
         const u32 quads = ((1u << hlog) + (strategy == 2 ? 1u << clog : 0u)) / 4;
         for (u32 i = (u32)lane; i < quads; i += kWave) ((__attribute__((address_space(1))) u4*)tab)[i] = u4{0, 0, 0, 0};
@@ -1335,17 +1618,25 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
         if (bn >= 7) {                                                   // ZSTD_buildSeqStore :3268
             u32 litSize = 0, nbSeq, nr1 = rep1, nr2 = rep2;
             const gbyte* g = (const gbyte*)src;
-            if (strategy == 2) {
-                lbyte* sc = (lbyte*)L->scratch;
-                if (mls == 4) nbSeq = dfast_block<4, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
-                else if (mls == 5) nbSeq = dfast_block<5, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
-                else if (mls == 6) nbSeq = dfast_block<6, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
-                else nbSeq = dfast_block<7, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+            if constexpr (LT) {
+                lbyte* lt = (lbyte*)tab;
+                if (mls == 4) nbSeq = fast_frame_block_lds<4>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
+                else if (mls == 5) nbSeq = fast_frame_block_lds<5>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
+                else if (mls == 6) nbSeq = fast_frame_block_lds<6>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
+                else nbSeq = fast_frame_block_lds<7>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
+            } else {
+                if (strategy == 2) {
+                    lbyte* sc = (lbyte*)L->scratch;
+                    if (mls == 4) nbSeq = dfast_block<4, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                    else if (mls == 5) nbSeq = dfast_block<5, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                    else if (mls == 6) nbSeq = dfast_block<6, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                    else nbSeq = dfast_block<7, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
+                }
+                else if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+                else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+                else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+                else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             }
-            else if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-            else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-            else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-            else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
             wave_fence();
             cSize = entropy_compress<true>(ws->tmp, ws, litSize, nbSeq, &L->e, lane, strategy, &fh);
             if (cSize >= bn - ((bn >> 6) + 2)) cSize = 0;                // ZSTD_minGain, zstd_compress.c:3055-3057
@@ -2089,7 +2380,23 @@ __global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, u
     const int lane = lane_id();
     for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
         const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
-        const long long r = zstd_frame_wave(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
+        const long long r = zstd_frame_wave<false>(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
+        if (lane == 0) f.out_len[i] = r;
+        wave_fence();
+    }
+}
+
+// the same with the fast finder's table and source ring in LDS (dynamic: 4 << hashLog bytes + ring + FrameLds): one frame per CU
+__global__ void __launch_bounds__(64) zstd_frame_lds_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
+    FrameLds* L = reinterpret_cast<FrameLds*>(lds + ((size_t)4 << f.hashLog) + kSrcRingBytes);
+    const int lane = lane_id();
+    for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
+        const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
+        const long long r = zstd_frame_wave<true>(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, L, ws,
+                                                  reinterpret_cast<u32*>(lds), lane);
         if (lane == 0) f.out_len[i] = r;
         wave_fence();
     }
@@ -2329,6 +2636,26 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     if (f->nframes == 0) return AOCLGPU_OK;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { aoclgpu::set_error_msg("zstd frames: device query failed"); return AOCLGPU_ERR_HIP; }
+    // Two finders for the fast strategy, same bytes: table + source ring in LDS with chain batches (one frame per CU, ~2.4x
+    // the speed per frame) for a lone frame or a small batch, table in HBM (9 frames per CU) for the bulk.
+    const bool canLds = !df && f->hashLog <= 14;
+    const bool useLds = (f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_LDS) ? canLds
+                      : ((f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_HBM) ? false : (canLds && f->nframes <= 2u * (uint32_t)prop.multiProcessorCount));
+    if ((f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_LDS) && !canLds) { aoclgpu::set_error_msg("zstd frames: the LDS finder serves the fast strategy with hashLog <= 14"); return AOCLGPU_ERR_ARG; }
+    aoclgpu::WsGuard guard;
+    if (useLds) {
+        const uint32_t ldsBytes = (uint32_t)(((size_t)4 << f->hashLog) + aoclgpu::kSrcRingBytes + aoclgpu::zstd_frame_lds_bytes());
+        uint32_t grid = (uint32_t)prop.multiProcessorCount * ((160u << 10) / ldsBytes ? (160u << 10) / (((ldsBytes + 1279u) / 1280u) * 1280u) : 1u);
+        if (grid > f->nframes) grid = f->nframes;
+        void* ws = get_workspace(guard, (size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
+        if (!ws) { aoclgpu::set_error_msg("zstd frames: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+        if (ldsBytes > 65536u) {
+            hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_frame_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+            if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
+        }
+        hipLaunchKernelGGL(aoclgpu::zstd_frame_lds_kernel, dim3(grid), dim3(64), ldsBytes, (hipStream_t)stream, *f, (uint8_t*)ws);
+        return aoclgpu::check_launch("zstd_frame_lds_kernel");
+    }
     // one wave per frame; as many frames per CU as its LDS holds (granules of 1280 bytes, 128 per CU), at most 12 (163 VGPRs)
     uint32_t perCU = 128u / (uint32_t)((aoclgpu::zstd_frame_lds_bytes() + 1279) / 1280);
     if (perCU > 12) perCU = 12;
@@ -2337,7 +2664,6 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     const size_t tabBytes = ((size_t)4 << f->hashLog) + (df ? (size_t)4 << f->chainLog : 0);
     if ((size_t)grid * tabBytes > ((size_t)1 << 30)) grid = (uint32_t)(((size_t)1 << 30) / tabBytes);   // at most 1 GiB of tables
     const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
-    aoclgpu::WsGuard guard;
     void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);
     if (!ws) { aoclgpu::set_error_msg("zstd frames: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
     hipLaunchKernelGGL(aoclgpu::zstd_frame_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *f, (uint8_t*)ws, (uint8_t*)ws + seqBytes, (uint32_t)tabBytes);

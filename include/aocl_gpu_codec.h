@@ -146,7 +146,14 @@ typedef struct {
     uint32_t        strategy;                       /* 1 = fast (zstd_fast.c), 2 = double-fast (zstd_double_fast.c: hashLog = long
                                                        table, chainLog = short table, targetLength unused) */
     uint32_t        chainLog;
+    uint32_t        flags;                          /* 0, or AOCLGPU_ZSTD_FRAMES_FINDER_* : pins the choice the launcher otherwise makes
+                                                       from the batch size (never changes an output byte; for tests and measurements) */
 } aoclgpu_zstd_frames;
+/* the fast strategy has two match finders: hash table in the HBM workspace, 9 frames resident per CU (the bulk variant), or hash
+ * table and source ring in LDS with several sequences resolved per batch (hashLog <= 14, one frame per CU, ~2.4x faster per
+ * frame: chosen for batches of at most two frames per CU) */
+#define AOCLGPU_ZSTD_FRAMES_FINDER_HBM 1u
+#define AOCLGPU_ZSTD_FRAMES_FINDER_LDS 2u
 int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* stream);
 /* the same for ONE input in host memory; checksumFlag appends the frame checksum (low 32 bits of XXH64 of the input).
  * Returns the frame size, 0 when it does not fit `cap`, < 0 on failure */

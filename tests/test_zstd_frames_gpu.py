@@ -39,13 +39,13 @@ def oracle_frame_df(oracle, data, wl, hl, cl, mm):
     return out.raw[:r]
 
 
-def gpu_frames(eng, inputs, wl, hl, mm, caps=None, tl=0, strategy=1, cl=0):
+def gpu_frames(eng, inputs, wl, hl, mm, caps=None, tl=0, strategy=1, cl=0, flags=0):
     t = eng.torch
     off = np.zeros(len(inputs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(x) for x in inputs])
     blob = b"".join(inputs)
     src = t.frombuffer(bytearray(blob) if blob else bytearray(1), dtype=t.uint8).to(eng.device)
-    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps, target_length=tl, strategy=strategy, chain_log=cl)
+    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, caps=caps, target_length=tl, strategy=strategy, chain_log=cl, flags=flags)
     host = dst.cpu().numpy().tobytes()
     return [host[doff[i]:doff[i] + lens[i]] for i in range(len(inputs))]
 
@@ -56,10 +56,12 @@ def test_frames_bit_exact(eng, oracle, kind):
     sizes = zfc.EDGE_SIZES + (3000000, 0, 1, 6, 7, 100, 70000, 131072)
     inputs = [zfc.make(kind, n, seed=200 + i) if n else b"" for i, n in enumerate(sizes)]
     for (wl, hl, mm) in PARAMS:
-        got = gpu_frames(eng, inputs, wl, hl, mm)
-        for data, g in zip(inputs, got):
-            want = oracle_frame(oracle, data, wl, hl, mm)
-            assert g == want, (kind, len(data), wl, hl, mm, len(g), len(want))
+        # both finders of the fast strategy (table in HBM / table and source ring in LDS, hashLog <= 14), then the launcher's choice
+        for flags in ((1, 2, 0) if hl <= 14 else (1,)):
+            got = gpu_frames(eng, inputs, wl, hl, mm, flags=flags)
+            for data, g in zip(inputs, got):
+                want = oracle_frame(oracle, data, wl, hl, mm)
+                assert g == want, (kind, len(data), wl, hl, mm, flags, len(g), len(want))
     # the frames decode on the GPU too (multi-block frames, treeless literal blocks, RLE and raw blocks)
     for data, g in zip(inputs[:6], got[:6]):
         out = C.create_string_buffer(len(data))
@@ -99,10 +101,11 @@ def test_target_length_one_leaves_literals_raw(eng, oracle):
     (ZSTD_literalsCompressionIsDisabled, zstd_compress_internal.h:609-622)"""
     inputs = [zfc.make(k, n, seed=400 + i) for i, (k, n) in enumerate((("text", 1000), ("jsonlog", 70000), ("mixed", 400000), ("low", 131073)))]
     for (wl, hl, mm) in ((19, 12, 6), (11, 9, 4), (19, 13, 7)):
-        got = gpu_frames(eng, inputs, wl, hl, mm, tl=1)
-        for data, g in zip(inputs, got):
-            assert g == oracle_frame(oracle, data, wl, hl, mm, tl=1), (len(data), wl, hl, mm)
-            assert g != oracle_frame(oracle, data, wl, hl, mm, tl=0) or len(data) < 100
+        for flags in (1, 2):
+            got = gpu_frames(eng, inputs, wl, hl, mm, tl=1, flags=flags)
+            for data, g in zip(inputs, got):
+                assert g == oracle_frame(oracle, data, wl, hl, mm, tl=1), (len(data), wl, hl, mm, flags)
+                assert g != oracle_frame(oracle, data, wl, hl, mm, tl=0) or len(data) < 100
 
 
 def test_small_capacity_reports_zero(eng, oracle):
@@ -120,6 +123,8 @@ def test_bad_parameters_are_refused(eng):
             eng.zstd_compress_frames(src, [0, 16], wl, hl, mm)
     with pytest.raises(a.EngineError):
         eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, target_length=2)
+    with pytest.raises(a.EngineError):
+        eng.zstd_compress_frames(src, [0, 16], 19, 15, 6, flags=2)          # the LDS finder serves hashLog <= 14
     for (strategy, cl) in ((3, 14), (0, 14), (2, 5), (2, 25)):
         with pytest.raises(a.EngineError):
             eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, strategy=strategy, chain_log=cl)

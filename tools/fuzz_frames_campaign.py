@@ -62,7 +62,8 @@ while time.time() - t0 < budget:
     tl = int(rng.integers(0, 2)) if strategy == 1 else 0
     off = np.zeros(len(inputs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(x) for x in inputs])
     src = torch.frombuffer(bytearray(b"".join(inputs)), dtype=torch.uint8).to(eng.device)
-    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, target_length=tl, strategy=strategy, chain_log=cl)
+    flags = int(rng.choice([1, 2])) if strategy == 1 and hl <= 14 else 0         # both finders of the fast strategy
+    dst, doff, lens = eng.zstd_compress_frames(src, off, wl, hl, mm, target_length=tl, strategy=strategy, chain_log=cl, flags=flags)
     host = dst.cpu().numpy()
     for i, data in enumerate(inputs):
         n = len(data); cap = n + (n >> 8) + 64
@@ -70,7 +71,7 @@ while time.time() - t0 < budget:
         r = L.orc_zstd_compress_frame_cp(data, n, w, cap, strategy, wl, hl, cl, mm, tl)
         got = host[doff[i]:doff[i] + lens[i]].tobytes()
         if got != w.raw[:r]:
-            print("ZSTD FRAME MISMATCH seed", seed0 + it - 1, "input", i, "n", n, (strategy, wl, hl, cl, mm, tl), len(got), r); sys.exit(1)
+            print("ZSTD FRAME MISMATCH seed", seed0 + it - 1, "input", i, "n", n, (strategy, wl, hl, cl, mm, tl), "flags", flags, len(got), r); sys.exit(1)
         back = C.create_string_buffer(max(n, 1))
         rr = lib.aoclgpu_zstd_decompress_host_frames(got, len(got), back, n)
         if rr != n or back.raw[:n] != data:
