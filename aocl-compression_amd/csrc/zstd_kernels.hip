@@ -1404,8 +1404,10 @@ __device__ u32 fast_frame_block_lds(const gbyte* __restrict__ src, const u32 bs,
                             [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0, prefixPos);
                         if (wo.outcome != zchain::ZC_REFRESH) break;
                         u32 nb1 = 0x100, nb2 = 0x100;
-                        if (pos - prefixPos >= wo.rep1) nb1 = src[pos - wo.rep1];
-                        if (wo.rep2 && pos - prefixPos >= wo.rep2) nb2 = src[pos - wo.rep2];
+                        // (a repeat offset may reach below the prefix start - the reference's repcode tests are not bounded by it,
+                        //  only table candidates are - so the guard is the frame's first byte)
+                        if (pos >= wo.rep1) nb1 = src[pos - wo.rep1];
+                        if (wo.rep2 && pos >= wo.rep2) nb2 = src[pos - wo.rep2];
                         e1 = ballot(pb0 == nb1); e2 = ballot(pb0 == nb2);
                         S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
                     }
