@@ -152,20 +152,38 @@ __device__ unsigned long long g_zstd_prof[16];
 #else
 #define ZSTAGE(k) do { } while (0)
 #endif
-template <int MLS, typename T, bool HI>
+// window of a frame (ZSTD_window_t): indices are position + 2
+struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
+__device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
+{   // ZSTD_getLowestPrefixIndex without a dictionary
+    return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit;
+}
+// FRAME = false: the only block of a fresh frame (a chunk): table cleared here, u16 slots (+ 1 bit), repeat offsets {1,4,8}.
+// FRAME = true: block [bs, n) of a frame whose bytes start at src[0] (zstd_frame_wave): T = u32 slots holding position + 2 as
+// offsets into the frame, the table persists, candidates below the prefix start (ZSTD_getLowestPrefixIndex) are ignored and
+// the catch-up stops there, the repeat offsets come in and go out (zstd_fast.c:481-489, :614-634); the source ring counts its
+// 240-byte blocks from bs.
+template <int MLS, typename T, bool HI, bool FRAME = false>
 __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
-                          u32* litSizeOut, int lane, const u32 expf)
+                          u32* litSizeOut, int lane, const u32 expf, const u32 bs_ = 0, const FrameWindow* win = nullptr,
+                          u32* rep1io = nullptr, u32* rep2io = nullptr)
 {
-    static_assert(sizeof(T) == 2, "u16 slots");
+    static_assert(FRAME ? (sizeof(T) == 4 && !HI) : sizeof(T) == 2, "u16 slots for chunks, u32 slots for frames");
+    const u32 bs = FRAME ? bs_ : 0u;                                    // (a compile-time zero for chunks)
     typedef __attribute__((address_space(3))) T LT;
     typedef __attribute__((address_space(3))) u32 L32;
     constexpr bool kHi = HI;                                            // positions need 17 bits (chunks above 16 KiB)
     const u32 tsize = 1u << hlog;
     LT* table = (LT*)lds;
-    L32* hib = (L32*)(lds + 2 * tsize);                                 // kHi: tsize/32 words
-    for (u32 i = (u32)lane; i < tsize / 2; i += kWave) ((L32*)lds)[i] = 0;
-    if (kHi) for (u32 i = (u32)lane; i < tsize / 32; i += kWave) hib[i] = 0;
-    wave_fence();
+    L32* hib = (L32*)(lds + sizeof(T) * tsize);                         // kHi: tsize/32 words
+    if constexpr (!FRAME) {
+        for (u32 i = (u32)lane; i < tsize / 2; i += kWave) ((L32*)lds)[i] = 0;
+        if (kHi) for (u32 i = (u32)lane; i < tsize / 32; i += kWave) hib[i] = 0;
+        wave_fence();
+    }
+    u32 prefixIdx = 2;                                                   // table entries below it are not candidates
+    if constexpr (FRAME) prefixIdx = lowest_prefix(*win, n + 2);        // (:443-446)
+    const u32 prefixPos = prefixIdx - 2;
     auto tget = [&](u32 h) -> u32 {
         u32 v = table[h];
         if (kHi) v |= ((hib[h >> 5] >> (h & 31)) & 1u) << 16;
@@ -194,7 +212,14 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
         q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
         if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
     };
-    u32 nbSeq = 0, litSize = 0, anchor = 0, s = 1, rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
+    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
+    u32 saved1 = 0, saved2 = 0;
+    if constexpr (FRAME) {
+        rep1 = *rep1io; rep2 = *rep2io;
+        const u32 curr = s + 2, maxRep = curr - lowest_prefix(*win, curr);
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
+    }
 #ifdef ZSTD_PROF
     unsigned long long zacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zprev = __builtin_amdgcn_s_memtime(), zbatches = 0;
 #endif
@@ -209,11 +234,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
         // 32 bytes of the even block are mirrored behind the odd one so that a 32-byte read never wraps; the block after
         // the newest one is always in flight in a register (requested a block of parsing ahead of its use), so the 64
         // probe windows of a batch are LDS reads instead of a global round trip.
-        lbyte* ring = lds + 2 * tsize + (kHi ? tsize / 8 : 0);
+        lbyte* ring = lds + sizeof(T) * tsize + (kHi ? tsize / 8 : 0);
         int32_t rb = -4;                                                // newest block in the ring (rb-1 and rb are valid)
         u32 pend = 0; bool have_pend = false;                           // block rb+1, in flight
         auto blk_load = [&](int32_t b) -> u32 {
-            const u32 a = kRingBlk * (u32)b + 4u * (u32)lane;
+            const u32 a = bs + kRingBlk * (u32)b + 4u * (u32)lane;     // (blocks of the ring are counted from the block's start)
             u32 v = 0;
             if (lane < 60 && a + 4 <= n) v = ld32(src + a);             // (the chain never looks at the chunk's last 25 bytes)
             return v;
@@ -243,14 +268,15 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
             u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
             bool e_ok1 = false, e_ok2 = false;
-            if (chain && s >= 4 && (u64)s + 100 < ilimit) {
+            if (chain && s >= bs + 4 && (!FRAME || rep1 > 0) && (u64)s + 100 < ilimit) {
                 // ---------------- chain batch: the 64 consecutive probes a search starts with; every sequence they
                 //                  hold is resolved from registers by the scalar walk of zstd_chain.h ----------------
                 const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
                 typedef u32x4 __attribute__((aligned(1))) U4;
                 typedef const __attribute__((address_space(1))) U4* GP4;
                 // probe windows [pos-4, pos+28) from the source ring
-                const int32_t bl = (int32_t)(((u64)(pos0 - 4) * 17895698ull) >> 32), bh = (int32_t)(((u64)(pos0 + 90) * 17895698ull) >> 32);   // / 240
+                const u32 rel0 = pos0 - 4 - bs;
+                const int32_t bl = (int32_t)(((u64)rel0 * 17895698ull) >> 32), bh = (int32_t)(((u64)(rel0 + 94) * 17895698ull) >> 32);   // / 240
                 if (!(bh <= rb && rb <= bl + 1)) {
                     if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
                     else {
@@ -262,7 +288,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                     pend = blk_load(rb + 1); have_pend = true;
                     wave_fence();
                 }
-                u32 ro = (pos0 - 4) - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
+                u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
                 if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
                 const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
                 // byte equality at the two repcode distances over the 64 lanes: one byte load per lane each
@@ -276,9 +302,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u64 seq = pa.y | ((u64)pa.z << 32);
                 const u32 h = z_hash<MLS>(seq, hlog);
                 const u32 ent = tget(h);
-                const bool has = ent >= 2;
+                const bool has = ent >= prefixIdx;
                 const u32 c = ent - 2;
-                const bool near0 = c < 4;                               // candidate within 4 bytes of the chunk start: exact path
+                const bool near0 = c - prefixPos < 4;                   // candidate within 4 bytes of the chunk / prefix start: exact path
                 u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
                 if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }   // candidate window [c-4, c+28)
                 wave_fence();
@@ -294,7 +320,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                                 (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
                 const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
                 const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
-                const u32 infoV = near0 ? zchain::pack_info(c, 0, 7) : zchain::pack_info(c, fw, bk4);
+                const u32 infoV = near0 ? zchain::pack_info(FRAME ? 0u : c, 0, 7) : zchain::pack_info(FRAME ? 0u : c, fw, bk4);   // (frames: the position travels apart)
                 const u64 okmask = ballot(lane < lim && ok);
                 const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
                 zchain::WalkOut wo;
@@ -302,9 +328,14 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                     u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
                     int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
                     for (;;) {
-                        wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
-                            [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
-                            [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0);
+                        if constexpr (FRAME)
+                            wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
+                                [&](int j) -> u64 { return ((u64)lane_get(c, j) << 32) | lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
+                                [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0, prefixPos);
+                        else
+                            wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
+                                [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
+                                [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0);
                         if (wo.outcome != zchain::ZC_REFRESH) break;
                         // the map of the current rep1 came from a match's window and ends too early: one load round for full-width
                         // maps of both repcodes instead of a whole new batch (lanes below the repcode's reach are not needed)
@@ -367,15 +398,15 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u32 h = z_hash<MLS>(seq, hlog);
                 u32 ent = 0;
                 if (valid) ent = tget(h);
-                const u32 cand = ent & kPosMask;
+                const u32 cand = FRAME ? ent : (ent & kPosMask);
                 const u32 mychk = chk((u32)seq);
                 bool rep_hit = false;
-                if (valid && half == 0) {                               // repcode at ip2 (:519-542)
+                if (valid && half == 0 && (!FRAME || rep1 > 0)) {       // repcode at ip2 (:519-542)
                     const u32 r = pos + sg;
                     rep_hit = ld32(src + r) == ld32(src + r - rep1);
                 }
                 u32 m4 = ~(u32)seq;
-                if (valid && cand >= 2 && ((ent ^ mychk) & ~kPosMask) == 0) m4 = ld32(src + cand - 2);
+                if (valid && cand >= prefixIdx && (FRAME || ((ent ^ mychk) & ~kPosMask) == 0)) m4 = ld32(src + cand - 2);
                 wave_fence();
                 ZSTAGE(1);
                 const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane, valid);
@@ -425,7 +456,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
             else {                                                      // _offset (:651-665)
                 ip0 = e_pos; match0 = e_cand - 2;
                 rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
-                const u32 a = ip0 - anchor; maxback = a < match0 ? a : match0;
+                const u32 a = ip0 - anchor, b = match0 - prefixPos; maxback = a < b ? a : b;
             }
             u32 fwd;
             {
@@ -482,6 +513,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
 #ifdef ZSTD_PROF
     if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq); }
 #endif
+    if constexpr (FRAME) {
+        saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;           // :614-630
+        *rep1io = rep1 ? rep1 : saved1;
+        *rep2io = rep2 ? rep2 : saved2;
+    }
     flush_seq(nbSeq & ~63u, nbSeq & 63u);
     wave_fence();
     *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
@@ -519,12 +555,6 @@ constexpr u32 kDfScratch = 1024;                // u16 slots per hash for the sl
 
 __device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }   // ZSTD_hash8
 
-// window of a frame (ZSTD_window_t): indices are position + 2
-struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
-__device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
-{   // ZSTD_getLowestPrefixIndex without a dictionary
-    return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit;
-}
 
 // FRAME = false: the only block of a fresh frame (tables cleared here, repeat offsets {1,4,8}, no window limit).
 // FRAME = true: block [bs, be) of a frame - tables, window and repeat offsets come from the frame loop (zstd_frame_wave) and
@@ -1283,283 +1313,10 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
     return nbSeq;
 }
 
-// The chunk kernels' finder for a block of a frame: hash table AND source ring in LDS, chain batches that resolve several
-// sequences per batch (zstd_chain.h) - the table is 2^hashLog u32 entries (position + 2, offsets into the frame), so this
-// variant serves hashLog <= 14 (64 KB of LDS: one frame per CU) and is what a lone frame or a small batch of frames runs on;
-// fast_frame_block above (table in HBM, 9 frames per CU) is the bulk variant.  Same output, both driven by the same tests.
-template <int MLS>
-__device__ u32 fast_frame_block_lds(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, lbyte* lds,
-                                    const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane)
-{
-    typedef __attribute__((address_space(3))) u32 L32;
-    const u32 tsize = 1u << hlog;
-    L32* table = (L32*)lds;
-    lbyte* ring = lds + 4 * tsize;
-    auto tget = [&](u32 h) -> u32 { return table[h]; };
-    auto tput = [&](u32 h, u32 v) { table[h] = v; };
-    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;
-    auto flush_seq = [&](u32 first, u32 count) {
-        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
-    };
-    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
-        const bool me = (u32)lane == (idx & 63u);
-        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
-        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
-    };
-    const u32 n = be;
-    const u32 prefixIdx = lowest_prefix(win, be + 2), prefixPos = prefixIdx - 2;
-    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u);
-    u32 rep1 = rep1io, rep2 = rep2io, saved1 = 0, saved2 = 0;
-    {   const u32 curr = s + 2, maxRep = curr - lowest_prefix(win, curr);
-        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
-        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
-    }
-    if (n >= 20) {
-        const u32 ilimit = n - 16;
-        // source ring: 240-byte blocks counted from the block's start (see fast_block)
-        int32_t rb = -4;
-        u32 pend = 0; bool have_pend = false;
-        auto blk_load = [&](int32_t b) -> u32 {
-            const u32 a = bs + kRingBlk * (u32)b + 4u * (u32)lane;
-            u32 v = 0;
-            if (lane < 60 && a + 4 <= n) v = ld32(src + a);
-            return v;
-        };
-        auto blk_store = [&](int32_t b, u32 v) {
-            if (lane < 60) *(L32*)(ring + ((u32)b & 1u) * kRingBlk + 4u * (u32)lane) = v;
-            if (!(b & 1) && lane < 8) *(L32*)(ring + 2 * kRingBlk + 4u * (u32)lane) = v;
-        };
-        auto rep_loop = [&](u32 ip0) -> u32 {
-            bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
-            while (hit) {
-                const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
-                const u32 t = rep2; rep2 = rep1; rep1 = t;
-                const u32 hc = z_hash<MLS>(ld64(src + ip0), hlog);
-                if (lane == 0) tput(hc, ip0 + 2);
-                put_seq(nbSeq, 0, 1, rLength, ip0);
-                wave_fence();
-                nbSeq++;
-                ip0 += rLength;
-                hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
-            }
-            return ip0;
-        };
-        for (;;) {                                                      // _start
-            u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
-            u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
-            bool e_ok1 = false, e_ok2 = false;
-            if (s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit) {
-                // ---------------- chain batch (see fast_block) ----------------
-                const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
-                typedef u32x4 __attribute__((aligned(1))) U4;
-                typedef const __attribute__((address_space(1))) U4* GP4;
-                const u32 rel0 = pos0 - 4 - bs;
-                const int32_t bl = (int32_t)(((u64)rel0 * 17895698ull) >> 32), bh = (int32_t)(((u64)(rel0 + 94) * 17895698ull) >> 32);   // / 240
-                if (!(bh <= rb && rb <= bl + 1)) {
-                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
-                    else {
-                        const u32 v0 = blk_load(bl), v1 = blk_load(bh);
-                        blk_store(bl, v0);
-                        if (bh != bl) blk_store(bh, v1);
-                        rb = bh;
-                    }
-                    pend = blk_load(rb + 1); have_pend = true;
-                    wave_fence();
-                }
-                u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
-                if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
-                const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
-                const u32 b1 = src[pos - rep1];
-                u32 b2 = 0x100;
-                if (rep2) b2 = src[pos - rep2];
-                const u64 seq = pa.y | ((u64)pa.z << 32);
-                const u32 h = z_hash<MLS>(seq, hlog);
-                const u32 ent = tget(h);
-                const bool has = ent >= prefixIdx;
-                const u32 c = ent - 2;
-                const bool near0 = c - prefixPos < 4;                   // candidate within 4 bytes of the prefix start: exact path
-                u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
-                if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }
-                wave_fence();
-                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
-                wave_fence();
-                table[h] = ent;                                         // the rounds scribbled on the slots' low halves
-                wave_fence();
-                const int lim = first_lane(ballot(w != (u32)lane));
-                using zchain::zero_bytes;
-                const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
-                                (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
-                const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
-                const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
-                const u32 infoLo = near0 ? zchain::pack_info(0, 0, 7) : zchain::pack_info(0, fw, bk4);
-                const u64 okmask = ballot(lane < lim && ok);
-                const u32 pb0 = pa.y & 0xFFu;
-                zchain::WalkOut wo;
-                {
-                    u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
-                    int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
-                    for (;;) {
-                        wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
-                            [&](int j) -> u64 { return ((u64)lane_get(c, j) << 32) | lane_get(infoLo, j); }, [&](int j) { return lane_get(eqb, j); },
-                            [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0, prefixPos);
-                        if (wo.outcome != zchain::ZC_REFRESH) break;
-                        u32 nb1 = 0x100, nb2 = 0x100;
-                        // (a repeat offset may reach below the prefix start - the reference's repcode tests are not bounded by it,
-                        //  only table candidates are - so the guard is the frame's first byte)
-                        if (pos >= wo.rep1) nb1 = src[pos - wo.rep1];
-                        if (wo.rep2 && pos >= wo.rep2) nb2 = src[pos - wo.rep2];
-                        e1 = ballot(pb0 == nb1); e2 = ballot(pb0 == nb2);
-                        S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
-                    }
-                }
-                if ((wo.commit >> lane) & 1) tput(h, pos + 2);
-                wave_fence();
-                anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
-                if (wo.outcome == zchain::ZC_RESTART) {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        if (t >= 3 - wo.ntail) {
-                            const int idx = wo.tail[t];
-                            const u32 hh = idx < 64 ? lane_get(h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
-                            if (lane == 0) tput(hh, pos0 + (u32)idx + 2);
-                            wave_fence();
-                        }
-                    }
-                    if (wo.post) { s = rep_loop(s); anchor = s; }
-                    continue;
-                }
-                if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(wo.R - wo.S);
-                else {
-                    const int el = wo.el;
-                    ev = wo.ev;
-                    e_pos = pos0 + (u32)el; e_cand = lane_get(ent, el); e_sig = 2; e_st = 2; e_half = (u32)(el - wo.S) & 1u;
-                    e_ok1 = el + 1 < 64; e_p1 = e_pos + 1; e_h1 = lane_get(h, (el + 1) & 63);
-                    e_ok2 = el + 2 < 64; e_h2 = lane_get(h, (el + 2) & 63);
-                }
-            }
-            if (!ev) for (;;) {
-                const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
-                u32 am, sg, st;
-                if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
-                else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
-                else { am = 0x40000000u; sg = 2; st = 2; }
-                const bool valid = (u64)s + am + sg + 1 < ilimit;
-                const u32 pos = s + am + half;
-                u64 seq = 0;
-                if (valid) seq = ld64(src + pos);
-                const u32 h = z_hash<MLS>(seq, hlog);
-                u32 ent = 0;
-                if (valid) ent = tget(h);
-                bool rep_hit = false;
-                if (valid && half == 0 && rep1 > 0) {
-                    const u32 r = pos + sg;
-                    rep_hit = ld32(src + r) == ld32(src + r - rep1);
-                }
-                u32 m4 = ~(u32)seq;
-                if (valid && ent >= prefixIdx) m4 = ld32(src + ent - 2);
-                wave_fence();
-                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane, valid);
-                wave_fence();
-                if (valid) table[h] = ent;
-                wave_fence();
-                const int f = first_lane(ballot(valid && w != (u32)lane));
-                const int e = first_lane(ballot(!valid));
-                const int lim = f < e ? f : e;
-                const bool mat_hit = m4 == (u32)seq;
-                const int el = first_lane(ballot(lane < lim && (rep_hit || mat_hit)));
-                const int ncommit = (el < 64) ? el + 1 : lim;
-                if (lane < ncommit) tput(h, pos + 2);
-                wave_fence();
-                if (el < 64) {
-                    ev = lane_get((u32)rep_hit, el) ? 2 : 1;
-                    e_pos = lane_get(pos, el); e_cand = lane_get(ent, el);
-                    e_sig = lane_get(sg, el); e_st = lane_get(st, el); e_half = lane_get(half, el);
-                    e_ok1 = el + 1 < 64 && lane_get((u32)valid, (el + 1) & 63) != 0;
-                    e_p1 = lane_get(pos, (el + 1) & 63); e_h1 = lane_get(h, (el + 1) & 63);
-                    e_ok2 = el + 2 < 64 && lane_get((u32)valid, (el + 2) & 63) != 0 && lane_get(pos, (el + 2) & 63) == e_pos + 2;
-                    e_h2 = lane_get(h, (el + 2) & 63);
-                    break;
-                }
-                if (e < 64 && e <= f) break;
-                i0 += (u32)lim;
-            }
-            if (!ev) break;                                             // _cleanup
-            {
-                const u32 ip1 = e_half == 0 ? e_pos + 1 : e_pos - 1 + e_sig;
-                if (e_half == 0 || e_st <= 4) {
-                    const u32 h1 = (e_ok1 && e_p1 == ip1) ? e_h1 : z_hash<MLS>(ld64(src + ip1), hlog);
-                    if (lane == 0) tput(h1, ip1 + 2);
-                    wave_fence();
-                }
-            }
-            const u32 current0 = e_pos;
-            u32 ip0, match0, offcode, mLength, maxback;
-            if (ev == 2) { ip0 = e_pos + e_sig; match0 = ip0 - rep1; offcode = 1; maxback = 1; }
-            else {
-                ip0 = e_pos; match0 = e_cand - 2;
-                rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3;
-                const u32 a = ip0 - anchor, b = match0 - prefixPos; maxback = a < b ? a : b;
-            }
-            {
-                const u32 fa = ip0 + 4, fb = match0 + 4;
-                bool eqb = false;
-                if ((u32)lane < maxback) eqb = src[ip0 - 1 - (u32)lane] == src[match0 - 1 - (u32)lane];
-                const u32 o = 4u * (u32)lane, pa = fa + o;
-                u32 x = 0xFFFFFFFFu;
-                if (pa + 4 <= n) x = ld32(src + pa) ^ ld32(src + fb + o);
-                else if (pa < n) {
-                    x = 0;
-                    for (u32 t = 0; t < n - pa; ++t) x |= (u32)(src[pa + t] ^ src[fb + o + t]) << (8 * t);
-                    x |= 0xFFFFFFFFu << (8 * (n - pa));
-                }
-                u32 back = (u32)first_lane(ballot(!eqb));
-                if (back == 64) {
-                    while (back < maxback) {
-                        const u32 k = back + (u32)lane;
-                        bool eq = false;
-                        if (k < maxback) eq = src[ip0 - 1 - k] == src[match0 - 1 - k];
-                        const int c = first_lane(ballot(!eq));
-                        back += (u32)c;
-                        if (c < 64) break;
-                    }
-                }
-                if (back > maxback) back = maxback;
-                u32 fwd;
-                const int l = first_lane(ballot(x != 0));
-                if (l == 64) fwd = 256 + wave_count(src, fa + 256, fb + 256, n, lane);
-                else fwd = 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
-                ip0 -= back; match0 -= back; mLength = 4 + back + fwd;
-            }
-            {
-                const u32 ll = ip0 - anchor;
-                put_seq(nbSeq, ll, offcode, mLength, anchor);
-                litSize += ll; nbSeq++;
-            }
-            ip0 += mLength; anchor = ip0;
-            if (ip0 <= ilimit) {
-                const bool chk = rep2 > 0;
-                u64 va = 0;
-                if (!e_ok2) va = ld64(src + current0 + 2);
-                const u64 vb = ld64(src + ip0 - 2);
-                u32 r0 = 0, r1 = 1;
-                if (chk) { r0 = ld32(src + ip0); r1 = ld32(src + ip0 - rep2); }
-                const u32 ha = e_ok2 ? e_h2 : z_hash<MLS>(va, hlog), hb2 = z_hash<MLS>(vb, hlog);
-                if (lane == 0) { tput(ha, current0 + 2 + 2); tput(hb2, ip0 - 2 + 2); }
-                wave_fence();
-                if (chk && uni(r0 == r1 ? 1u : 0u) != 0) { ip0 = rep_loop(ip0); anchor = ip0; }
-            }
-            s = ip0;
-        }
-    }
-    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
-    rep1io = rep1 ? rep1 : saved1;
-    rep2io = rep2 ? rep2 : saved2;
-    flush_seq(nbSeq & ~63u, nbSeq & 63u);
-    wave_fence();
-    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
-    return nbSeq;
-}
-
+// The fast strategy has a second finder for lone frames and small batches: fast_block<MLS, u32, false, true>, the chunk kernels'
+// finder (hash table AND source ring in LDS, chain batches that resolve several sequences per batch, zstd_chain.h) on offsets
+// into the frame - 2^hashLog u32 entries, so hashLog <= 14 (64 KB of LDS: one frame per CU); fast_frame_block above (table in
+// HBM, 9 frames per CU) is the bulk variant.  Same output, both driven by the same tests.
 struct FrameLds {
     union {                                      // never live at the same time: a block is parsed, then coded
         EntropyLds e;
@@ -1622,10 +1379,10 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
             const gbyte* g = (const gbyte*)src;
             if constexpr (LT) {
                 lbyte* lt = (lbyte*)tab;
-                if (mls == 4) nbSeq = fast_frame_block_lds<4>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
-                else if (mls == 5) nbSeq = fast_frame_block_lds<5>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
-                else if (mls == 6) nbSeq = fast_frame_block_lds<6>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
-                else nbSeq = fast_frame_block_lds<7>(g, bs, bs + bn, hlog, lt, win, nr1, nr2, ws, &litSize, lane);
+                if (mls == 4) nbSeq = fast_block<4, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
+                else if (mls == 5) nbSeq = fast_block<5, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
+                else if (mls == 6) nbSeq = fast_block<6, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
+                else nbSeq = fast_block<7, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
             } else {
                 if (strategy == 2) {
                     lbyte* sc = (lbyte*)L->scratch;
@@ -2374,7 +2131,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 }
 
-__global__ void __launch_bounds__(64) zstd_frame_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, uint8_t* tabBase, uint32_t tabBytes)
+// (9 frames per CU by LDS need a SIMD to hold three waves: at most 170 VGPRs)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) zstd_frame_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, uint8_t* tabBase, uint32_t tabBytes)
 {
     __shared__ FrameLds L;
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
