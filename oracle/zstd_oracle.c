@@ -1437,6 +1437,33 @@ unsigned orc_dbg_huf_build(uint8_t* nbBitsOut, const unsigned* count, unsigned m
 { huf_ct ct; unsigned r = huf_build(&ct, count, maxSym, maxNbBits); memcpy(nbBitsOut, ct.nbBits, 256); return r; }
 size_t orc_dbg_write_ncount(uint8_t* out, const int16_t* norm, unsigned maxSym, unsigned tableLog)
 { return fse_write_ncount(out, norm, maxSym, tableLog); }
+/* the fast parser's sequences of every block of a frame (debugging aid and reference of tests/test_zstd_chain_model.py): rows
+ * {litLength, offBase, matchLength, 0}, and {0xFFFFFFFF, block, last literals, 0} after every block; every block counts as
+ * confirmed (repeat offsets carried on).  Returns the number of rows. */
+size_t orc_dbg_zstd_frame_sequences(const uint8_t* src, size_t n, unsigned windowLog, unsigned hashLog, unsigned minMatch, uint32_t* out)
+{
+    const size_t blockMax = windowLog < 17 ? (size_t)1 << windowLog : 128u << 10;
+    u32* table = (u32*)calloc((size_t)1 << hashLog, sizeof(u32));
+    zseq* seqs = (zseq*)malloc(sizeof(zseq) * (blockMax / 3 + 8));
+    u8* lits = (u8*)malloc(blockMax + 8);
+    zwin w = { 2, 2, 1u << windowLog };
+    u32 rep[2] = { 1, 4 }, blk = 0; size_t rows = 0, bs, i;
+    for (bs = 0; bs < n; bs += blockMax, blk++) {
+        const size_t bn = n - bs < blockMax ? n - bs : blockMax;
+        size_t litSize = bn, nbSeq = 0, sum = 0;
+        if ((u32)bs + 2 > w.maxDist) {
+            const u32 low = (u32)bs + 2 - w.maxDist;
+            if (w.lowLimit < low) w.lowLimit = low;
+            if (w.dictLimit < w.lowLimit) w.dictLimit = w.lowLimit;
+        }
+        if (bn >= 7) nbSeq = fast_block_at(src, (u32)bs, (u32)(bs + bn), table, hashLog, minMatch, &w, rep, seqs, lits, &litSize);
+        for (i = 0; i < nbSeq; i++) { out[4 * rows] = seqs[i].litLength; out[4 * rows + 1] = seqs[i].offBase; out[4 * rows + 2] = seqs[i].matchLength; out[4 * rows + 3] = 0; rows++; sum += seqs[i].litLength; }
+        out[4 * rows] = 0xFFFFFFFFu; out[4 * rows + 1] = blk; out[4 * rows + 2] = (u32)(litSize - sum); out[4 * rows + 3] = 0; rows++;
+    }
+    free(table); free(seqs); free(lits);
+    return rows;
+}
+
 /* code length per symbol of a Huffman table description (debugging aid of tools/debug): returns the table log, 0 on error */
 unsigned orc_dbg_huf_lengths(const uint8_t* desc, size_t n, uint8_t* lens256)
 {

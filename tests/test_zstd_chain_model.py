@@ -114,3 +114,47 @@ def test_record_like_inputs(model, orc):
             for _ in range(int(rng.integers(0, 3))):
                 rows[k, int(rng.integers(0, rec))] = int(rng.integers(0, 256))
         check(model, orc, rows.tobytes())
+
+
+# ---- frames: blocks that continue from the table, window and repeat offsets of the block before (fast_block<.., FRAME>) ----
+def frame_rows(fn, data: bytes, wl, hl, mm, *extra):
+    n = len(data)
+    out = np.zeros(4 * (n // 3 + n // 1024 + 64), dtype=np.uint32)
+    buf = C.create_string_buffer(data, n + 1)
+    rows = fn(buf, n, wl, hl, mm, out.ctypes.data, *extra)
+    return out[:4 * rows].reshape(-1, 4)[:, :3].copy()
+
+
+def check_frame(model, orc, data: bytes, wl, hl, mm):
+    model.zchain_model_frame_sequences.restype = C.c_size_t
+    model.zchain_model_frame_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_int]
+    orc.orc_dbg_zstd_frame_sequences.restype = C.c_size_t
+    orc.orc_dbg_zstd_frame_sequences.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
+    want = frame_rows(orc.orc_dbg_zstd_frame_sequences, data, wl, hl, mm)
+    for use_chain in (1, 0):
+        got = frame_rows(model.zchain_model_frame_sequences, data, wl, hl, mm, use_chain)
+        if got.shape != want.shape or not np.array_equal(got, want):
+            k = 0
+            while k < min(len(got), len(want)) and np.array_equal(got[k], want[k]):
+                k += 1
+            raise AssertionError(f"frame (wl {wl}, hl {hl}, mm {mm}, chain {use_chain}): first difference at row {k}: "
+                                 f"model {got[k:k+3].tolist()} oracle {want[k:k+3].tolist()} (n={len(data)})")
+
+
+@pytest.mark.parametrize("kind", ["text", "mixed", "low", "rep", "jsonlog"])
+def test_frames(model, orc, kind):
+    """the lane model of the frame instantiation of the finder against the oracle's block-after-block parser: windows above the
+    input, below it, equal to the block size (the prefix start moves, repeat offsets reach below it), every minMatch"""
+    import zstd_frame_cases as zfc
+    for i, n in enumerate((131073, 200000, 300000, 524289, 1000000)):
+        data = zfc.make(kind, n, seed=900 + i)
+        for (wl, hl, mm) in ((20, 14, 7), (18, 14, 6), (17, 13, 5), (12, 11, 4), (10, 11, 7), (15, 9, 6)):
+            check_frame(model, orc, data, wl, hl, mm)
+
+
+def test_frames_grammar(model, orc):
+    rng = np.random.default_rng(99)
+    for it in range(30):
+        n = int(rng.integers(1000, 400000))
+        data = lz_grammar(rng, n, int(rng.choice([2, 4, 16, 256])))
+        check_frame(model, orc, data, int(rng.integers(10, 21)), int(rng.integers(6, 15)), int(rng.integers(4, 8)))

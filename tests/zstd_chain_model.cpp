@@ -17,8 +17,10 @@ u64 rd64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 u32 zhash(const u8* p, u32 hlog, u32 mls)
 {
     const u64 v = rd64(p);
+    if (mls == 4) return ((u32)v * 2654435761u) >> (32 - hlog);
     if (mls == 5) return (u32)(((v << 24) * 889523592379ull) >> (64 - hlog));
-    return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    if (mls == 6) return (u32)(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    return (u32)(((v << 8) * 58295818150454627ull) >> (64 - hlog));
 }
 u32 zcount(const u8* s, u32 a, u32 b, u32 end) { u32 n = 0; while (a + n < end && s[a + n] == s[b + n]) n++; return n; }
 int hb(u32 v) { int r = 0; while (v >>= 1) r++; return r; }
@@ -47,6 +49,7 @@ struct Model {
     std::vector<u32> table;
     std::vector<Seq> seqs;
     u64 litSize = 0;
+    u32 lastLits = 0;
     u64 stat[40] = {0};   // batches, fast sequences, specials, restarts, continues, sequential searches, tails, post checks; [8+why] specials by reason
     void put(u32 pos) { table[zhash(src + pos, hlog, mls)] = pos + 2; }
 };
@@ -56,17 +59,19 @@ struct Model {
 extern "C" void zchain_model_trace(u64* buf) { g_trace = buf; g_trace_n = 0; }
 extern "C" u32 zchain_model_trace_count(void) { return g_trace_n; }
 
-extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, size_t* litSizeOut, u64* stats, int useChain)
+struct Win { u32 dictLimit, lowLimit, maxDist; };
+static u32 lowest_prefix(const Win& w, u32 curr) { return (curr - w.dictLimit > w.maxDist) ? curr - w.maxDist : w.dictLimit; }
+
+// one block [bs, n) of the frame at M.src: the kernel's fast_block<.., FRAME> lane by lane (a chunk is the frame's only block)
+static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32& rep1io, u32& rep2io, int useChain)
 {
-    Model M; M.src = src; M.n = (u32)n_;
-    const u32 n = M.n;
-    {   // level1_params (oracle/zstd_oracle.c)
-        const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
-        if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; M.hlog = (15 < w + 1) ? 15 : w + 1; M.mls = 5; }
-        else { const u32 w = srcLog < 17 ? srcLog : 17; M.hlog = (13 < w + 1) ? 13 : w + 1; M.mls = 6; }
+    const u8* src = M.src;
+    const u32 prefixIdx = lowest_prefix(win, n + 2), prefixPos = prefixIdx - 2;
+    u32 anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = rep1io, rep2 = rep2io, saved1 = 0, saved2 = 0, i0 = 0;
+    {   const u32 curr = s + 2, maxRep = curr - lowest_prefix(win, curr);
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; }
     }
-    M.table.assign((size_t)1 << M.hlog, 0);
-    u32 anchor = 0, s = 1, rep1 = 1, rep2 = 0, i0 = 0;
     if (n >= 20) {
         const u32 ilimit = n - 16;
         // immediate rep2 matches after a sequence that ends at ip0 (oracle fast_block :713-722)
@@ -84,30 +89,30 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
         };
         for (;;) {
             int ev = 0; u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
-            if (useChain && i0 == 0 && s >= 4 && (u64)s + 100 < ilimit) {
+            if (useChain && i0 == 0 && s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit) {
                 // ---------------- chain batch: 64 consecutive probes ----------------
                 M.stat[0]++;
                 const u32 pos0 = s;
-                u32 h[64], ent[64], eqbv[64], infov[64]; bool ok[64];
+                u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64];
                 for (int j = 0; j < 64; ++j) {
                     const u32 p = pos0 + (u32)j;
                     h[j] = zhash(src + p, M.hlog, M.mls);
                     ent[j] = M.table[h[j]];
                     ok[j] = false; eqbv[j] = 0; infov[j] = 0;
-                    if (ent[j] >= 2) {
+                    if (ent[j] >= prefixIdx) {
                         const u32 c = ent[j] - 2;
-                        if (c >= 4) {
+                        if (c - prefixPos >= 4) {
                             u32 e = 0;
                             for (int i = 0; i < 32; ++i) if (src[p - 4 + i] == src[c - 4 + i]) e |= 1u << i;
                             const u32 fwm = ~(e >> 8);
                             const u32 fw = (u32)__builtin_ctz(fwm);                       // <= 24
                             const u32 bkm = ~(e << 28);
                             const u32 bk4 = (u32)__builtin_clz(bkm);                      // <= 4
-                            eqbv[j] = e; infov[j] = zchain::pack_info(c, fw, bk4);
+                            eqbv[j] = e; infov[j] = zchain::pack_info_wide(c, fw, bk4);
                             ok[j] = ((e >> 4) & 15u) == 15u;
                         } else {
                             ok[j] = rd32(src + c) == rd32(src + p);
-                            infov[j] = zchain::pack_info(c, 0, 7);
+                            infov[j] = zchain::pack_info_wide(c, 0, 7);
                         }
                     }
                 }
@@ -126,7 +131,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                     M.seqs.push_back({ll, off, ml}); M.litSize += ll; M.stat[1]++;
                 };
                 zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
-                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit);
+                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, 0, 0, prefixPos);
                 while (w.outcome == zchain::ZC_REFRESH) {                                 // fresh full-width maps for the current repcodes
                     M.stat[33]++;
                     u64 e1 = 0, e2 = 0;
@@ -136,7 +141,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                         if (w.rep2 && p >= w.rep2 && src[p] == src[p - w.rep2]) e2 |= 1ull << j;
                     }
                     w = zchain::walk(okmask, lim, pos0, w.arel, w.rep1, w.rep2, e1, e2,
-                        [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit);
+                        [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit, prefixPos);
                 }
                 for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
                 if (g_trace && g_trace_n < 4096) {
@@ -169,8 +174,8 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
                     const u32 hh = zhash(src + pos, M.hlog, M.mls);
                     const u32 idx = M.table[hh];
                     M.table[hh] = pos + 2;
-                    if (half == 0 && rd32(src + pos + sg) == rd32(src + pos + sg - rep1)) { ev = 2; e_pos = pos; e_sig = sg; e_st = st; e_half = 0; break; }
-                    if (idx >= 2 && rd32(src + idx - 2) == rd32(src + pos)) { ev = 1; e_pos = pos; e_cand = idx; e_sig = sg; e_st = st; e_half = half; break; }
+                    if (half == 0 && rep1 > 0 && rd32(src + pos + sg) == rd32(src + pos + sg - rep1)) { ev = 2; e_pos = pos; e_sig = sg; e_st = st; e_half = 0; break; }
+                    if (idx >= prefixIdx && rd32(src + idx - 2) == rd32(src + pos)) { ev = 1; e_pos = pos; e_cand = idx; e_sig = sg; e_st = st; e_half = half; break; }
                 }
                 i0 = 0;
                 if (!ev) break;
@@ -189,7 +194,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
             } else {
                 ip0 = e_pos; match0 = e_cand - 2;
                 rep2 = rep1; rep1 = ip0 - match0; offcode = rep1 + 3; mLength = 4;
-                while (ip0 > anchor && match0 > 0 && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
+                while (ip0 > anchor && match0 > prefixPos && src[ip0 - 1] == src[match0 - 1]) { ip0--; match0--; mLength++; }
             }
             mLength += zcount(src, ip0 + mLength, match0 + mLength, n);
             M.seqs.push_back({ip0 - anchor, offcode, mLength}); M.litSize += ip0 - anchor;
@@ -202,10 +207,54 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
             s = ip0;
         }
     }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep1io = rep1 ? rep1 : saved1;
+    rep2io = rep2 ? rep2 : saved2;
     M.litSize += n - anchor;
+    M.lastLits = n - anchor;
+}
+
+extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, size_t* litSizeOut, u64* stats, int useChain)
+{
+    Model M; M.src = src; M.n = (u32)n_;
+    const u32 n = M.n;
+    {   // level1_params (oracle/zstd_oracle.c)
+        const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
+        if (n <= 16384) { const u32 w = srcLog < 14 ? srcLog : 14; M.hlog = (15 < w + 1) ? 15 : w + 1; M.mls = 5; }
+        else { const u32 w = srcLog < 17 ? srcLog : 17; M.hlog = (13 < w + 1) ? 13 : w + 1; M.mls = 6; }
+    }
+    M.table.assign((size_t)1 << M.hlog, 0);
+    {   const Win win = { 2, 2, 1u << 31 };
+        u32 r1 = 1, r2 = 4;
+        model_block(M, 0, n, win, r1, r2, useChain);
+    }
     for (size_t i = 0; i < M.seqs.size(); ++i) { out[4 * i] = M.seqs[i].ll; out[4 * i + 1] = M.seqs[i].off; out[4 * i + 2] = M.seqs[i].ml; out[4 * i + 3] = 0; }
     *litSizeOut = (size_t)M.litSize;
     if (stats) memcpy(stats, M.stat, 8 * sizeof(u64));
     if (stats && useChain == 2) memcpy(stats, M.stat, sizeof(M.stat));
     return M.seqs.size();
+}
+
+// all blocks of a frame (fast strategy): rows {ll, off, ml, 0}, and {0xFFFFFFFF, block, last literals, 0} after every block.
+// Every block counts as confirmed (repeat offsets carried on), as in orc_dbg_zstd_frame_sequences.
+extern "C" size_t zchain_model_frame_sequences(const u8* src, size_t n_, u32 windowLog, u32 hashLog, u32 mls, u32* out, int useChain)
+{
+    Model M; M.src = src; M.n = (u32)n_; M.hlog = hashLog; M.mls = mls;
+    M.table.assign((size_t)1 << hashLog, 0);
+    const u32 n = M.n, blockMax = windowLog < 17 ? 1u << windowLog : 128u << 10;
+    Win win = { 2, 2, 1u << windowLog };
+    u32 r1 = 1, r2 = 4; size_t rows = 0; u32 blk = 0;
+    for (u32 bs = 0; bs < n; bs += blockMax, ++blk) {
+        const u32 bn = n - bs < blockMax ? n - bs : blockMax;
+        if (bs + 2 > win.maxDist) {
+            const u32 low = bs + 2 - win.maxDist;
+            if (win.lowLimit < low) win.lowLimit = low;
+            if (win.dictLimit < win.lowLimit) win.dictLimit = win.lowLimit;
+        }
+        M.seqs.clear();
+        if (bn >= 7) model_block(M, bs, bs + bn, win, r1, r2, useChain); else M.lastLits = bn;
+        for (const Seq& q : M.seqs) { out[4 * rows] = q.ll; out[4 * rows + 1] = q.off; out[4 * rows + 2] = q.ml; out[4 * rows + 3] = 0; rows++; }
+        out[4 * rows] = 0xFFFFFFFFu; out[4 * rows + 1] = blk; out[4 * rows + 2] = M.lastLits; out[4 * rows + 3] = 0; rows++;
+    }
+    return rows;
 }
