@@ -56,6 +56,33 @@ def test_argument_checks_without_gpu():
     assert lib.aocl_llc_setup(C.byref(d), 2) == -3                     # LZMA: ERR_EXCLUDED_METHOD (no backend)
 
 
+def test_frame_entry_points_check_their_arguments_without_gpu():
+    """aoclgpu_zstd_compress_frames validates the parameters before it touches the device; the mode switches are plain host state"""
+    lib = api.load_library()
+    one = (C.c_uint64 * 2)(0, 16)
+    out = (C.c_int64 * 1)(0)
+    buf = C.create_string_buffer(64)
+
+    def frames(**kw):
+        f = api.ZstdFrames(C.addressof(buf), C.addressof(buf), C.addressof(one), C.addressof(one), C.addressof(out), 1, 19, 14, 6, 0, 1, 0, 0)
+        for k, v in kw.items():
+            setattr(f, k, v)
+        return lib.aoclgpu_zstd_compress_frames(C.byref(f), None)
+
+    for bad in (dict(windowLog=9), dict(windowLog=32), dict(hashLog=5), dict(hashLog=25), dict(minMatch=3), dict(minMatch=8), dict(targetLength=2),
+                dict(strategy=0), dict(strategy=3), dict(strategy=2, chainLog=5), dict(strategy=2, chainLog=25), dict(src_off=None), dict(out_len=None)):
+        assert frames(**bad) == -1, bad                                    # AOCLGPU_ERR_ARG
+        assert b"zstd frames" in lib.aoclgpu_last_error()
+    assert frames(nframes=0) == 0                                          # nothing to do: no device needed
+    assert lib.aoclgpu_zstd_compress_frames(None, None) == -1
+    lib.aoclgpu_zstd_large_input_mode.restype = C.c_int
+    lib.aoclgpu_lz4f_block_linking.restype = C.c_int
+    assert lib.aoclgpu_zstd_large_input_mode() == 0 and lib.aoclgpu_lz4f_block_linking() == 1     # the reference's bytes by default
+    lib.aoclgpu_zstd_set_large_input_mode(1); lib.aoclgpu_lz4f_set_block_linking(0)
+    assert lib.aoclgpu_zstd_large_input_mode() == 1 and lib.aoclgpu_lz4f_block_linking() == 0
+    lib.aoclgpu_zstd_set_large_input_mode(0); lib.aoclgpu_lz4f_set_block_linking(1)
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
