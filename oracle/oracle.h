@@ -8,7 +8,9 @@
  * Parity status: PINNED.  Every function here is checked byte-for-byte against the real reference
  * compiled in place (oracle/_ref/libaocl_ref.so, see build_ref.sh) by tests/test_oracle_vs_ref.py,
  * and against the committed golden vectors in tests/golden/ (generated from that reference build by
- * tests/golden/make_golden.py).
+ * tests/golden/make_golden*.py).  That includes the whole-input paths: Zstd frames of several blocks
+ * (orc_zstd_compress_frame_cp against ZSTD_compress_advanced, fast and double-fast, any window) and the blocks of an
+ * LZ4 frame with linked blocks (orc_lz4_compress_linked_blocks against LZ4F_compressFrame).
  */
 #ifndef AOCL_GPU_ORACLE_H
 #define AOCL_GPU_ORACLE_H
