@@ -81,23 +81,28 @@ def study(stream, nb, tl, trials=200):
     return res, top
 
 
-rows = []
-for kind in sorted(a.corpus.KINDS):
-    data = a.corpus.make(kind, per_kind * 131072, seed=3).tobytes()
-    allb, alls = [], []
-    for i in range(per_kind):
-        part = data[i * 131072:(i + 1) * 131072]
-        ls = literal_streams(orc.compress(ol.ZSTD, part), len(part))
-        if ls is None: continue
-        lens, tl, streams = ls
-        nb = decode_table(lens, tl)
-        for st in streams:
-            if len(st) < 64: continue
-            r, total_bits = study(st, nb, tl, trials=60)
-            allb += [x[0] for x in r]; alls += [x[1] for x in r]
-    if allb:
-        b = np.array(allb); s = np.array(alls)
-        rows.append((kind, len(b), float(np.median(b)), float(np.percentile(b, 90)), float(np.percentile(b, 99)), int(b.max()), float(np.median(s)), float(np.percentile(s, 99))))
-print("kind            trials  bits-to-sync median / p90 / p99 / max      symbols median / p99")
-for r in rows:
-    print(f"{r[0]:14s} {r[1]:7d}  {r[2]:8.0f} {r[3]:6.0f} {r[4]:6.0f} {r[5]:6d}      {r[6]:6.0f} {r[7]:6.0f}")
+def main():
+    rows = []
+    for kind in sorted(a.corpus.KINDS):
+        data = a.corpus.make(kind, per_kind * 131072, seed=3).tobytes()
+        allb, alls = [], []
+        for i in range(per_kind):
+            part = data[i * 131072:(i + 1) * 131072]
+            ls = literal_streams(orc.compress(ol.ZSTD, part), len(part))
+            if ls is None: continue
+            lens, tl, streams = ls
+            nb = decode_table(lens, tl)
+            for st in streams:
+                if len(st) < 64: continue
+                r, total_bits = study(st, nb, tl, trials=60)
+                allb += [x[0] for x in r]; alls += [x[1] for x in r]
+        if allb:
+            b = np.array(allb); s = np.array(alls)
+            rows.append((kind, len(b), float(np.median(b)), float(np.percentile(b, 90)), float(np.percentile(b, 99)), int(b.max()), float(np.median(s)), float(np.percentile(s, 99))))
+    print("kind            trials  bits-to-sync median / p90 / p99 / max      symbols median / p99")
+    for r in rows:
+        print(f"{r[0]:14s} {r[1]:7d}  {r[2]:8.0f} {r[3]:6.0f} {r[4]:6.0f} {r[5]:6d}      {r[6]:6.0f} {r[7]:6.0f}")
+
+
+if __name__ == "__main__":
+    main()
