@@ -24,6 +24,7 @@
 // (inherently serial) run on three lanes, one per symbol stream, 64 sequences per tile.
 #include "zstd_entropy.hip.h"
 #include "zstd_chain.h"
+#include "zstd_hufspec.h"
 #include "host_util.h"
 #include <mutex>
 #include <stdlib.h>
@@ -1749,6 +1750,54 @@ __device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout,
     return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane);
 }
 
+// The four Huffman streams of a literals section, 16 lanes per stream (zstd_hufspec.h): every lane runs its segment from a
+// guessed start, lanes whose predecessor left somewhere else run again until nothing changes (lane 0 of a stream is exact, so
+// round r settles lane r; prefix codes fall into step within a few symbols, so two or three rounds are the rule), then the
+// symbol counts become write positions by a prefix sum and one more run writes.  so / sl: this lane's stream inside src,
+// oo / no: where its symbols go and how many there must be.  Accepts exactly what the one-lane-per-stream decoder accepts:
+// `no` symbols that end on bit 0 of the stream.  Table logs <= 11 (table in LDS).
+__device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* src_, const u32 so, const u32 sl, const u32 oo, const u32 no,
+                                                const u32 tl, int lane)
+{
+    typedef __attribute__((address_space(3))) const u16 LT;
+    const gbyte* sp = (const gbyte*)src_ + so;
+    gbyte* out = (gbyte*)out_;
+    const int sub = lane & 15;
+    int top = bit_stream_bits(src_ + so, sl);
+    bool ok = top >= 0;
+    if (!ok) top = 0;
+    const int seg = hufspec::seg_bits(top, 16);
+    int start = hufspec::seg_start(top, seg, sub);
+    const int limit = hufspec::seg_start(top, seg, sub + 1);
+    auto ld = [&](int off) -> u64 {
+        if (off >= 0 && (u32)off + 8 <= sl) return ld64(sp + off);
+        u64 v = 0;
+        for (int i = 0; i < 8; ++i) { const int a = off + i; if (a >= 0 && (u32)a < sl) v |= (u64)sp[a] << (8 * i); }
+        return v;
+    };
+    LT* tabp = (LT*)L->huf;
+    auto tab = [&](u32 i) -> u32 { return tabp[i]; };
+    u32 cnt = 0; int ex = start;
+    bool dirty = true;
+    for (int round = 0; ; ++round) {
+        if (dirty) ex = hufspec::run_count(ld, tab, tl, start, limit, &cnt);
+        const int prev = __shfl_up(ex, 1);
+        dirty = sub != 0 && prev != start;
+        if (dirty) start = prev;
+        if (!any_lane(dirty)) break;
+        if (round > 20) return false;                                    // (cannot happen: round r settles lane r of every stream)
+    }
+    u32 inc = cnt;
+    for (int d = 1; d < 16; d <<= 1) { const u32 t = (u32)__shfl_up((int)inc, d, 16); if (sub >= d) inc += t; }
+    const u32 total = (u32)__shfl((int)inc, 15, 16);
+    const int lastex = __shfl(ex, 15, 16);
+    ok = ok && lastex == 0 && total == no;
+    if (ballot(!ok) != 0) return false;
+    const u32 off = oo + inc - cnt;
+    hufspec::run_write(ld, tab, tl, start, limit, [&](u32 i, u32 v) { st32(out + off + i, v); }, [&](u32 i, u32 v) { out[off + i] = (u8)v; });
+    return true;
+}
+
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705).  All lanes call it: lane 0 reads a transmitted description (the bit
 // positions of its values depend on the values before them), the table itself is built by the wave, one symbol per lane.
 __device__ __attribute__((noinline)) bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
@@ -1864,6 +1913,12 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 const u32 so = j == 0 ? 0 : (j == 1 ? s1 : (j == 2 ? s1 + s2 : s1 + s2 + s3));
                 const u32 sl = j == 0 ? s1 : (j == 1 ? s2 : (j == 2 ? s3 : s4));
                 const u32 no = j < 3 ? seg : litSize - 3 * seg;
+                if (uni(L->hufLog) <= 11) {                                   // 16 lanes per stream
+                    const u32 j4 = (u32)lane >> 4;
+                    const u32 so4 = j4 == 0 ? 0 : (j4 == 1 ? s1 : (j4 == 2 ? s1 + s2 : s1 + s2 + s3));
+                    const u32 sl4 = j4 == 0 ? s1 : (j4 == 1 ? s2 : (j4 == 2 ? s3 : s4));
+                    if (!huf_decode_spec(L, litBuf, src + hoff + 6, so4, sl4, j4 * seg, j4 < 3 ? seg : litSize - 3 * seg, uni(L->hufLog), lane)) return 0xFFFFFFFFu;
+                } else
                 ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane);
             }
             if (ballot(!ok) != 0) return 0xFFFFFFFFu;
@@ -2104,13 +2159,20 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
 
 template <bool DF>
 __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
-                                                           uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes)
+                                                           uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes, uint32_t* counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
     u32* tabs = tabBase ? reinterpret_cast<u32*>(tabBase + (size_t)blockIdx.x * tabBytes) : nullptr;   // double-fast: this workgroup's two tables
     const int lane = lane_id();
-    for (uint32_t c = first + blockIdx.x; c < first + count; c += gridDim.x) {
+    // chunks are handed out through a counter (zeroed by the launcher): a chunk's duration varies by a factor of several with
+    // its content, and a static stride leaves the workgroups that drew the short ones idle at the end of the launch
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        c = uni(c);
+        if (c >= count) break;
+        c += first;
         const ChunkView v = compress_view(b, c);
         const int r = zstd_compress_wave<DF>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, tabs, lane, b.reserved);
         if (lane == 0) b.out_len[c] = r;
@@ -2118,12 +2180,16 @@ __global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint
     }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase, uint32_t* counter)
 {
     __shared__ DecLds L;
     uint8_t* litBuf = litBase + (size_t)blockIdx.x * kDecWs;       // literals, then room for a 12-bit Huffman table
     const int lane = lane_id();
-    for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
+    for (;;) {                                                     // dynamic hand-out, as in zstd_compress_kernel
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        c = uni(c);
+        if (c >= b.nchunks) break;
         const ChunkView v = decompress_view(b, c);
         const int r = zstd_decompress_wave((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, &L, litBuf, lane);
         if (lane == 0) b.out_len[c] = r;
@@ -2333,17 +2399,21 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
         if (grid > L[i].count) grid = L[i].count;
         const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
-        void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);
+        // (one hand-out counter per launch of this call, behind the scratch: the launches of a call run back to back on the stream)
+        const size_t ctrOff = (seqBytes + (size_t)grid * tabBytes + 255) & ~(size_t)255;
+        void* ws = get_workspace(guard, ctrOff + 256, stream);
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         uint8_t* tabBase = tabBytes ? (uint8_t*)ws + seqBytes : nullptr;
+        uint32_t* counter = (uint32_t*)((uint8_t*)ws + ctrOff);
+        if (hipMemsetAsync(counter, 0, 4, s) != hipSuccess) { aoclgpu::set_error_msg("zstd: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
         if (L[i].lds > 65536u) {
             hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
             if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
         }
         if (level >= 3) hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<true>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
-                                           tabBase, (uint32_t)tabBytes);
+                                           tabBase, (uint32_t)tabBytes, counter);
         else hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<false>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
-                                tabBase, (uint32_t)tabBytes);
+                                tabBase, (uint32_t)tabBytes, counter);
         if (int rc = aoclgpu::check_launch("zstd_compress_kernel")) return rc;
     }
     return AOCLGPU_OK;
@@ -2376,9 +2446,12 @@ extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stre
     uint32_t grid = (uint32_t)(perCU * nCU);
     if (grid > b->nchunks) grid = b->nchunks;
     // the decoder's literal buffers share the stream's workspace with the compressor's (same stream order)
-    void* ws = get_workspace(guard, (size_t)grid * aoclgpu::kDecWs, stream);
+    const size_t ctrOff = ((size_t)grid * aoclgpu::kDecWs + 255) & ~(size_t)255;
+    void* ws = get_workspace(guard, ctrOff + 256, stream);
     if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
-    hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws);
+    uint32_t* counter = (uint32_t*)((uint8_t*)ws + ctrOff);
+    if (hipMemsetAsync(counter, 0, 4, (hipStream_t)stream) != hipSuccess) { aoclgpu::set_error_msg("zstd: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
+    hipLaunchKernelGGL(aoclgpu::zstd_decompress_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, (uint8_t*)ws, counter);
     return aoclgpu::check_launch("zstd_decompress_kernel");
 }
 
