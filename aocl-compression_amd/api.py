@@ -23,7 +23,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libaocl_compression_gpu.so")
+    # AOCLGPU_LIB: development hook of tools/ (experiment / profiling builds made by build.py --variant); tests and bench.py
+    # run without it and load the product library
+    return os.environ.get("AOCLGPU_LIB") or os.path.join(_HERE, "libaocl_compression_gpu.so")
 
 
 class EngineError(RuntimeError):

@@ -47,6 +47,40 @@ def _run(cmd):
     return r
 
 
+def build_variant(name: str, cflags, verbose: bool = False) -> str:
+    """Development builds next to the product (kernel experiments, profiling instantiations): the same sources with extra
+    flags -> libaocl_compression_gpu_<name>.so, objects under build/<name>/.  Loaded by tools/ through AOCLGPU_LIB (api.lib_path)."""
+    objdir = os.path.join(OBJDIR, name)
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(HERE, f"libaocl_compression_gpu_{name}.so")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    stamp = os.path.join(objdir, "flags.txt")
+    flags = " ".join(cflags)
+    same = os.path.exists(stamp) and open(stamp).read() == flags
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if not same or _newer(src, obj, headers):
+            cmd = [HIPCC, f"--offload-arch={ARCH}", *CFLAGS, *cflags, "-I" + os.path.join(HERE, "..", "include")]
+            if s.endswith(".cpp"):
+                cmd += ["-x", "hip"]
+            jobs.append(cmd + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    stubdir = os.path.join(OBJDIR, "stub")
+    if jobs or not os.path.exists(out):
+        _run(["g++", "-shared", "-fPIC", *objs, "-o", out, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    with open(stamp, "w") as f:
+        f.write(flags)
+    if verbose:
+        print("built", out)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -91,3 +125,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    # python build.py --variant prof -DAOCLGPU_EXPERIMENTS -DZSTD_PROF
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True)

@@ -1538,11 +1538,10 @@ __device__ u32 fse_read_ncount(s16* norm, u32* maxSym, u32* tableLog, const u8* 
     u32 bp = 0, charnum = 0, nbBits; int previous0 = 0, remaining, threshold;
     const u32 maxSV1 = *maxSym + 1;
     auto peek32 = [&](u32 bitpos) -> u32 {
-        u32 v = 0; const u32 by = bitpos >> 3;
-        for (u32 i = 0; i < 5; ++i) if (by + i < n) v |= 0;   // placeholder to keep structure simple
+        const u32 by = bitpos >> 3;
         u64 w = 0;
         for (u32 i = 0; i < 5; ++i) if (by + i < n) w |= (u64)src[by + i] << (8 * i);
-        return (u32)(w >> (bitpos & 7)) | v;
+        return (u32)(w >> (bitpos & 7));
     };
     for (u32 i = 0; i < maxSV1; ++i) norm[i] = 0;
     if (n < 1) return 0xFFFFFFFFu;
@@ -1632,57 +1631,111 @@ __device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tabl
     return true;
 }
 
-// HUF_readStats + X1 table (entropy_common.c:234-310, huf_decompress.c:380-470); lane-serial; bytes used or 0xFFFFFFFF
-// (noinline: the table builders run once per block on lane 0 but need ~200 VGPRs when inlined, which held the whole decoder
-//  at 2 waves per SIMD = 8 blocks per CU; as separate functions the kernel needs 103 and LDS bounds it at 10 per CU)
-__device__ __attribute__((noinline)) u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big)
+// HUF_readStats + X1 table (entropy_common.c:234-310, huf_decompress.c:380-470); all lanes call it; bytes used or 0xFFFFFFFF.
+// What is serial by format stays on lane 0 - the FSE-coded weights (two interleaved states in one bitstream), read from a copy
+// of the description (< 130 bytes) that the wave stages in LDS first, so the chain never waits on global memory.  Everything
+// after the weights is the wave's: four symbols per lane (symbol = 64 k + lane), the weight histogram and each symbol's rank
+// inside its weight class from ballots, the class starts from an unrolled scan over the 12 weights (no indexed local array:
+// those live in scratch memory), the cells of short codes by whole-wave fills and those of long codes by their own lanes.
+// (noinline: inlined, the table builders held the whole decoder at 2 waves per SIMD)
+__device__ __attribute__((noinline)) u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big, int lane)
 {
-    u8* w = L->weights; u32 nsym, total = 0, used, rank[14];
-    for (int i = 0; i < 14; ++i) rank[i] = 0;
+    u8* w = L->weights;
     if (!n) return 0xFFFFFFFFu;
-    if (src[0] >= 128) {
-        nsym = src[0] - 127; used = 1 + (nsym + 1) / 2;
+    const u32 h0 = uni(src[0]);
+    u32 nsym = 0, used = 0;
+    if (h0 >= 128) {
+        nsym = h0 - 127; used = 1 + (nsym + 1) / 2;
         if (used > n) return 0xFFFFFFFFu;
-        for (u32 i = 0; i < nsym; i += 2) { w[i] = src[1 + i / 2] >> 4; w[i + 1] = src[1 + i / 2] & 15; }
+        for (u32 b = (u32)lane; b < (nsym + 1) / 2; b += kWave) { const u32 v = src[1 + b]; w[2 * b] = (u8)(v >> 4); w[2 * b + 1] = (u8)(v & 15); }
     } else {
-        u32 maxSym = 255, tl; BitR b;
-        const u32 isz = src[0];
+        const u32 isz = h0;
         used = 1 + isz;
         if (used > n || isz < 2) return 0xFFFFFFFFu;
-        const u32 h = fse_read_ncount(L->norm, &maxSym, &tl, src + 1, isz, 6);
-        if (h == 0xFFFFFFFFu || h >= isz) return 0xFFFFFFFFu;
-        if (!fse_build_dtable(L->wdt, L->norm, maxSym, tl, L->next)) return 0xFFFFFFFFu;
-        if (!b.init(src + 1 + h, isz - h)) return 0xFFFFFFFFu;
-        u32 s1 = b.read((int)tl), s2 = b.read((int)tl);
-        nsym = 0;
-        for (;;) {                                                       // FSE_decompress_usingDTable tail (fse_decompress.c:220-245)
-            if (nsym > 253) return 0xFFFFFFFFu;
-            w[nsym++] = L->wdt[s1].symbol; s1 = L->wdt[s1].newState + b.read(L->wdt[s1].nbBits);
-            if (b.pos < 0) { w[nsym++] = L->wdt[s2].symbol; break; }
-            if (nsym > 253) return 0xFFFFFFFFu;
-            w[nsym++] = L->wdt[s2].symbol; s2 = L->wdt[s2].newState + b.read(L->wdt[s2].nbBits);
-            if (b.pos < 0) { w[nsym++] = L->wdt[s1].symbol; break; }
+        u8* stg = L->bswin;                                                  // (the sequence bitstream's window: not in use yet)
+        for (u32 b = (u32)lane; b < isz; b += kWave) stg[b] = src[1 + b];
+        wave_fence();
+        u32 res = 0;
+        if (lane == 0) {
+            u32 maxSym = 255, tl; BitR b;
+            res = 0xFFFFFFFFu;
+            const u32 h = fse_read_ncount(L->norm, &maxSym, &tl, stg, isz, 6);
+            if (h != 0xFFFFFFFFu && h < isz && fse_build_dtable(L->wdt, L->norm, maxSym, tl, L->next) && b.init(stg + h, isz - h)) {
+                u32 s1 = b.read((int)tl), s2 = b.read((int)tl), k = 0;
+                for (;;) {                                                   // FSE_decompress_usingDTable tail (fse_decompress.c:220-245)
+                    if (k > 253) { k = 0xFFFFFFFFu; break; }
+                    w[k++] = L->wdt[s1].symbol; s1 = L->wdt[s1].newState + b.read(L->wdt[s1].nbBits);
+                    if (b.pos < 0) { w[k++] = L->wdt[s2].symbol; break; }
+                    if (k > 253) { k = 0xFFFFFFFFu; break; }
+                    w[k++] = L->wdt[s2].symbol; s2 = L->wdt[s2].newState + b.read(L->wdt[s2].nbBits);
+                    if (b.pos < 0) { w[k++] = L->wdt[s1].symbol; break; }
+                }
+                res = k;
+            }
         }
+        wave_fence();
+        nsym = uni(res);
+        if (nsym == 0xFFFFFFFFu) return 0xFFFFFFFFu;
     }
-    for (u32 i = 0; i < nsym; ++i) { if (w[i] > 12) return 0xFFFFFFFFu; rank[w[i]]++; total += (1u << w[i]) >> 1; }
+    wave_fence();
+    // ---- the wave's part: symbol 64 k + lane in slot k ----
+    u32 wk[4]; u32 part = 0; bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 i = 64u * k + (u32)lane;
+        wk[k] = i < nsym ? (u32)w[i] : 0u;
+        bad = bad || wk[k] > 12;
+        part += (1u << (wk[k] & 15)) >> 1;
+    }
+    if (ballot(bad) != 0) return 0xFFFFFFFFu;
+    const u32 total = wsum(part);
     if (total == 0) return 0xFFFFFFFFu;
     const u32 tableLog = (u32)hb(total) + 1;
     if (tableLog > 12) return 0xFFFFFFFFu;
-    {   const u32 rest = (1u << tableLog) - total;
+    {   // the last symbol's weight is implied: what is left must be a power of two (entropy_common.c:290-300)
+        const u32 rest = (1u << tableLog) - total;
         if ((1u << hb(rest)) != rest) return 0xFFFFFFFFu;
-        w[nsym] = (u8)(hb(rest) + 1); rank[w[nsym]]++; nsym++;
+        const u32 lastW = (u32)hb(rest) + 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (64u * k + (u32)lane == nsym) wk[k] = lastW;
+        nsym++;
     }
-    if (rank[1] < 2 || (rank[1] & 1)) return 0xFFFFFFFFu;
-    u32 start[14], cur = 0;
-    for (u32 wg = 1; wg <= tableLog; ++wg) { start[wg] = cur; cur += rank[wg] << (wg - 1); }
-    for (u32 i = 0; i < nsym; ++i) if (w[i]) {
-        const u32 len = 1u << (w[i] - 1), nb = tableLog + 1 - w[i];
-        const u16 cell = (u16)(i | (nb << 8));
-        if (tableLog == 12) for (u32 k = 0; k < len; ++k) big[start[w[i]] + k] = cell;
-        else for (u32 k = 0; k < len; ++k) L->huf[start[w[i]] + k] = cell;
-        start[w[i]] += len;
+    u32 pos[4] = {0, 0, 0, 0};
+    u32 cur = 0;
+#pragma unroll
+    for (u32 wv = 1; wv <= 12; ++wv) {                                       // class starts: weight ascending, symbols ascending inside
+        const u64 m0 = ballot(wk[0] == wv), m1 = ballot(wk[1] == wv), m2 = ballot(wk[2] == wv), m3 = ballot(wk[3] == wv);
+        const u32 c0 = (u32)__builtin_popcountll(m0), c1 = (u32)__builtin_popcountll(m1), c2 = (u32)__builtin_popcountll(m2), c3 = (u32)__builtin_popcountll(m3);
+        const u32 sh = wv - 1;
+        if (wk[0] == wv) pos[0] = cur + (below(m0) << sh);
+        if (wk[1] == wv) pos[1] = cur + ((c0 + below(m1)) << sh);
+        if (wk[2] == wv) pos[2] = cur + ((c0 + c1 + below(m2)) << sh);
+        if (wk[3] == wv) pos[3] = cur + ((c0 + c1 + c2 + below(m3)) << sh);
+        const u32 rank = c0 + c1 + c2 + c3;
+        if (wv == 1 && (rank < 2 || (rank & 1))) return 0xFFFFFFFFu;          // by construction there are at least two weight-1 symbols
+        cur += rank << sh;
     }
-    L->hufLog = tableLog;
+    typedef __attribute__((address_space(3))) u16 LT;
+    typedef __attribute__((address_space(1))) u16 GT;
+    LT* lt = (LT*)L->huf; GT* gt = (GT*)big;
+    const bool toBig = tableLog == 12;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 wv = wk[k], len = wv ? 1u << (wv - 1) : 0u;
+        const u32 cell = (64u * k + (u32)lane) | ((tableLog + 1 - wv) << 8);
+        if (len && len <= 8) {                                               // long codes: the symbol's own lane
+            if (toBig) for (u32 t = 0; t < len; ++t) gt[pos[k] + t] = (u16)cell;
+            else for (u32 t = 0; t < len; ++t) lt[pos[k] + t] = (u16)cell;
+        }
+        for (u64 m = ballot(len > 8); m; m &= m - 1) {                        // short codes (few symbols, many cells): the whole wave
+            const int j = (int)__builtin_ctzll(m);
+            const u32 p0 = lane_get(pos[k], j), ln = lane_get(len, j), cl = lane_get(cell, j);
+            if (toBig) for (u32 t = (u32)lane; t < ln; t += kWave) gt[p0 + t] = (u16)cl;
+            else for (u32 t = (u32)lane; t < ln; t += kWave) lt[p0 + t] = (u16)cl;
+        }
+    }
+    if (lane == 0) L->hufLog = tableLog;
+    wave_fence();
     return used;
 }
 // one Huffman stream, executed by ONE lane
@@ -1750,6 +1803,13 @@ __device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout,
     return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane);
 }
 
+#ifdef ZSTD_PROF
+__device__ unsigned long long g_zstd_dprof[16];
+#define DSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dacc[k] += t_ - dprev; dprev = t_; } while (0)
+#else
+#define DSTAGE(k) do { } while (0)
+#endif
 // The four Huffman streams of a literals section, 16 lanes per stream (zstd_hufspec.h): every lane runs its segment from a
 // guessed start, lanes whose predecessor left somewhere else run again until nothing changes (lane 0 of a stream is exact, so
 // round r settles lane r; prefix codes fall into step within a few symbols, so two or three rounds are the rule), then the
@@ -1757,9 +1817,14 @@ __device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout,
 // oo / no: where its symbols go and how many there must be.  Accepts exactly what the one-lane-per-stream decoder accepts:
 // `no` symbols that end on bit 0 of the stream.  Table logs <= 11 (table in LDS).
 __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* src_, const u32 so, const u32 sl, const u32 oo, const u32 no,
-                                                const u32 tl, int lane)
+                                                const u32 tl, int lane
+#ifdef ZSTD_PROF
+                                                , unsigned long long* dacc, unsigned long long& dprev
+#endif
+                                                )
 {
     typedef __attribute__((address_space(3))) const u16 LT;
+    DSTAGE(5);
     const gbyte* sp = (const gbyte*)src_ + so;
     gbyte* out = (gbyte*)out_;
     const int sub = lane & 15;
@@ -1787,6 +1852,7 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
         if (!any_lane(dirty)) break;
         if (round > 20) return false;                                    // (cannot happen: round r settles lane r of every stream)
     }
+    DSTAGE(6);
     u32 inc = cnt;
     for (int d = 1; d < 16; d <<= 1) { const u32 t = (u32)__shfl_up((int)inc, d, 16); if (sub >= d) inc += t; }
     const u32 total = (u32)__shfl((int)inc, 15, 16);
@@ -1795,6 +1861,7 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
     if (ballot(!ok) != 0) return false;
     const u32 off = oo + inc - cnt;
     hufspec::run_write(ld, tab, tl, start, limit, [&](u32 i, u32 v) { st32(out + off + i, v); }, [&](u32 i, u32 v) { out[off + i] = (u8)v; });
+    DSTAGE(7);
     return true;
 }
 
@@ -1852,13 +1919,6 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int 
 }
 
 // one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
-#ifdef ZSTD_PROF
-__device__ unsigned long long g_zstd_dprof[16];
-#define DSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dacc[k] += t_ - dprev; dprev = t_; } while (0)
-#else
-#define DSTAGE(k) do { } while (0)
-#endif
 __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
                             u8* litBuf, int lane)
 {
@@ -1892,10 +1952,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             if (litSize > blockMax || litSize == 0 || lh + csize > n) return 0xFFFFFFFFu;
             u32 hoff = lh, hsz = csize;
             if (type == 2) {
-                u32 used = 0;
-                if (lane == 0) used = huf_read_table(L, src + hoff, hsz, (u16*)(litBuf + kBlockMax + 64));
-                wave_fence();
-                used = uni(used);
+                const u32 used = huf_read_table(L, src + hoff, hsz, (u16*)(litBuf + kBlockMax + 64), lane);
                 if (used == 0xFFFFFFFFu) return 0xFFFFFFFFu;
                 if (lane == 0) L->haveHuf = 1;
                 hoff += used; hsz -= used;
@@ -1917,7 +1974,11 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     const u32 j4 = (u32)lane >> 4;
                     const u32 so4 = j4 == 0 ? 0 : (j4 == 1 ? s1 : (j4 == 2 ? s1 + s2 : s1 + s2 + s3));
                     const u32 sl4 = j4 == 0 ? s1 : (j4 == 1 ? s2 : (j4 == 2 ? s3 : s4));
-                    if (!huf_decode_spec(L, litBuf, src + hoff + 6, so4, sl4, j4 * seg, j4 < 3 ? seg : litSize - 3 * seg, uni(L->hufLog), lane)) return 0xFFFFFFFFu;
+                    if (!huf_decode_spec(L, litBuf, src + hoff + 6, so4, sl4, j4 * seg, j4 < 3 ? seg : litSize - 3 * seg, uni(L->hufLog), lane
+#ifdef ZSTD_PROF
+                                         , dacc, dprev
+#endif
+                                         )) return 0xFFFFFFFFu;
                 } else
                 ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane);
             }

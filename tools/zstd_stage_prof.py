@@ -22,7 +22,8 @@ dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, src.numel(), 13107
 torch.cuda.synchronize()
 eng.lib.aoclgpu_debug_zstd_dprof(buf)
 dn = ["literals section (Huffman table + 4 streams)", "sequence tables + bitstream init", "FSE sequence decode (lane 0)", "prefix sums + literal copies", "match copies (in order)"]
-tot = sum(buf[:5])
+tot = sum(buf[:8])
+dn += ["lit: before the streams (table)", "lit: speculative count rounds", "lit: writing run"]
 print("---- decoder (entropy stage skipped on the compress side -> raw blocks!)" if ZEXP == 16 else "---- decoder")
-for n, v in zip(dn, buf[:5]):
+for n, v in zip(dn, buf[:8]):
     print(f"{n:48s} {v/tot*100:6.2f}%")
