@@ -1518,7 +1518,7 @@ struct DecLds {                     // 12.4 KB = 10 LDS granules of 1280 bytes: 
     u32 haveLL, haveOF, haveML, haveHuf;
     u32 rep[3];
     u32 seqLL[64], seqML[64], seqOff[64];
-    u32 streamOk[4];
+    u32 zeroWord, dumpWord, pad_[2];                          // a cell of zeros / a sink for the idle lanes of the sequence loop
     u8 bswin[768] __attribute__((aligned(16)));             // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes + the 8-byte container)
     union {                                                  // never live at the same time
         u8 hwin[4][480] __attribute__((aligned(16)));       // decoding the literals: windows of the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
@@ -2010,68 +2010,106 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             else L->mlTab[i - 36] = kMLbase[i - 36] | ((u32)kMLbits[i - 36] << 24);
         }
         wave_fence();
-        // lane 0 decodes 64 sequences (ZSTD_decodeSequence :1339-1460), the wave executes them (:1007-1108)
+        // The FSE cells carry, in the spare bits of newState (values < 512), how many additional bits their symbol reads, so the
+        // serial chain below needs one table read per state, not two (idempotent: a repeated table is already marked).
+        {
+            typedef __attribute__((address_space(3))) u16 L16;
+            typedef __attribute__((address_space(3))) u8 L8;
+            typedef __attribute__((address_space(3))) u32 L32;
+            auto mark = [&](FseD* dt, u32 log, int kind) {
+                lbyte* t = (lbyte*)dt;
+                for (u32 u = (u32)lane; u < (1u << log); u += kWave) {
+                    const u32 sym = *(L8*)(t + 4 * u + 2);
+                    const u32 eb = kind == 0 ? sym : (kind == 1 ? *(L32*)((lbyte*)&L->mlTab[sym]) >> 24 : *(L32*)((lbyte*)&L->llTab[sym]) >> 24);
+                    *(L16*)(t + 4 * u) = (u16)((*(L16*)(t + 4 * u) & 0x3FFu) | (eb << 10));
+                }
+            };
+            mark(L->of, uni(L->ofLog), 0); mark(L->ml, uni(L->mlLog), 1); mark(L->ll, uni(L->llLog), 2);
+            if (lane == 0) { L->zeroWord = 0; }
+            wave_fence();
+        }
+        // Sequences (ZSTD_decodeSequence :1339-1460), 64 per tile, then the wave executes the tile (:1007-1108).  The three FSE
+        // states advance in lock step on three lanes - lane 0 offsets, 1 match lengths, 2 literal lengths (lanes 3-7 idle on a
+        // cell of zeros so that every row shift reads a defined value) - instead of one after the other on one lane: one table
+        // read, one additional-bits field and one state field per lane and sequence, the fields' bit positions from row-shift
+        // prefix sums (additional bits are stored offset, match, literal; state bits literal, match, offset), branch-free.
+        // Over-reading a damaged stream reads the zeros the window holds below bit 0, as BIT_reloadDStream leaves them.
         BitL b; b.pos = 0; b.wb = 0; b.c = 0; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
         u32 r0 = 0, r1 = 0, r2 = 0;                                              // repcodes live in lane 0's registers
         const gbyte* bsp = (const gbyte*)(src + ip); const u32 bsn = n - ip;      // the sequence bitstream
         const lbyte* win = (const lbyte*)&L->bswin[0];
+        int pos;                                                                 // unread bits of the sequence bitstream (wave-uniform)
+        int wbase = 0;                                                           // stream byte offset of window byte 0
         auto refill = [&]() {                                                    // 48 lanes: the 768 bytes that end with the byte holding bit pos-1
-            const int e = ((int)lane_get((u32)b.pos, 0) + 7) >> 3, wb = e - 768;
+            const int e = (pos + 7) >> 3, wb = e - 768;
             typedef __attribute__((address_space(3))) u32x4 LV;
             if (lane < 48) *(LV*)((lbyte*)&L->bswin[0] + 16 * lane) = stream16(bsp, bsn, wb + 16 * lane);
-            b.wb = wb;
+            wbase = wb;
             wave_fence();
         };
         {
             const int bits = bit_stream_bits(src + ip, n - ip);
             if (bits < 0) return 0xFFFFFFFFu;
-            b.pos = bits;
+            pos = bits;
             refill();
         }
         if (lane == 0) {
+            b.pos = pos; b.wb = wbase;
             b.grab(win); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0;
             r0 = L->rep[0]; r1 = L->rep[1]; r2 = L->rep[2];
         }
         if (!uni(okB)) return 0xFFFFFFFFu;
+        pos = (int)lane_get((u32)b.pos, 0);
+        // per-lane roles of the sequence loop
+        typedef __attribute__((address_space(3))) u32 L32;
+        const u32 zeroA = (u32)(uintptr_t)(lbyte*)&L->zeroWord;
+        const u32 tabA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->of[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->ml[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->ll[0] : zeroA;
+        const u32 auxA = lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->llTab[0] : lane < 2 ? (u32)(uintptr_t)(lbyte*)&L->mlTab[0] : zeroA;
+        const u32 outA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->seqOff[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->seqML[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->seqLL[0]
+                                   : (u32)(uintptr_t)(lbyte*)&L->dumpWord;
+        const u32 outStride = lane < 3 ? 4u : 0u;
+        const u32 winA = (u32)(uintptr_t)win;
+        u32 st = lane == 0 ? lane_get(sOF, 0) : lane == 1 ? lane_get(sML, 0) : lane == 2 ? lane_get(sLL, 0) : 0u;
         DSTAGE(1);
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
-            u32 okS = 1;
             if (q0) refill();
-            if (lane == 0) {
+            if (lane < 8) {
+                const bool isOF = lane == 0;
+                const u32 winRel = winA - (u32)wbase;                            // LDS address of stream byte 0 (may lie below the window)
+                auto field = [&](int p, u32 nb) -> u32 {                         // the nb (<= 32) bits right below stream bit p
+                    const int q = p - (int)nb;
+                    const uint64_t w = lds_ld64((const lbyte*)(uintptr_t)(winRel + (u32)(q >> 3)));
+                    return __builtin_amdgcn_ubfe((u32)(w >> (q & 7)), 0u, nb);
+                };
                 for (u32 k = 0; k < cnt; ++k) {
-                    const FseD dl = L->ll[sLL], dof = L->of[sOF], dm = L->ml[sML];
-                    const u32 tLL = L->llTab[dl.symbol], tML = L->mlTab[dm.symbol], ofc = dof.symbol;
-                    b.grab(win);                                                 // >= 57 bits
-                    const u32 ofv = (1u << ofc) + b.take(ofc);
-                    if (ofc > 24) b.grab(win);                                   // offset (<= 31) + lengths (<= 16 + 16) may exceed one container
-                    const u32 ml = (tML & 0xFFFFFFu) + b.take(tML >> 24);
-                    const u32 ll = (tLL & 0xFFFFFFu) + b.take(tLL >> 24);
-                    u32 offset;
-                    if (ofv > 3) { offset = ofv - 3; r2 = r1; r1 = r0; r0 = offset; }
-                    else {
-                        const u32 idx = ofv - 1 + (ll == 0);
-                        if (idx == 0) offset = r0;
-                        else {
-                            u32 t = (idx == 3) ? r0 - 1 : (idx == 1 ? r1 : r2);
-                            t += !t;
-                            if (idx != 1) r2 = r1;
-                            r1 = r0; r0 = t; offset = t;
-                        }
-                    }
-                    if (q0 + k + 1 < nbSeq) {
-                        b.grab(win);                                             // the three state updates: <= 9 + 9 + 8 bits
-                        sLL = dl.newState + b.take(dl.nbBits);
-                        sML = dm.newState + b.take(dm.nbBits);
-                        sOF = dof.newState + b.take(dof.nbBits);
-                    }
-                    L->seqLL[k] = ll; L->seqML[k] = ml; L->seqOff[k] = offset;
+                    const u32 cell = *(L32*)(uintptr_t)(tabA + 4u * st);
+                    const u32 nbE = (cell >> 10) & 31u, nbS = cell >> 24, ns = cell & 0x3FFu, sym = (cell >> 16) & 0xFFu;
+                    const u32 offE = (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x111, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x112, 0xF, 0xF, true);
+                    const u32 offS = (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x102, 0xF, 0xF, true);
+                    const int Etot = (int)lane_get(offE + nbE, 2), Stot = (int)lane_get(offS + nbS, 0);
+                    const u32 t = *(L32*)(uintptr_t)(auxA + 4u * sym);
+                    const u32 val = (isOF ? 1u << sym : t & 0xFFFFFFu) + field(pos - (int)offE, nbE);
+                    const u32 fs = field(pos - Etot - (int)offS, nbS);
+                    // offset history (ZSTD_decodeSequence :1370-1400), meaningful on lane 0 where val is the offset value
+                    const u32 ll0 = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0x102, 0xF, 0xF, true) == 0 ? 1u : 0u;
+                    const bool isRep = val <= 3;
+                    const u32 idx = val - 1 + ll0;
+                    u32 tt = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                    tt += tt == 0 ? 1u : 0u;
+                    const u32 offset = isRep ? (idx == 0 ? r0 : tt) : val - 3;
+                    const bool shift = !(isRep && idx == 0);
+                    const bool shift2 = !isRep || idx >= 2;
+                    r2 = shift2 ? r1 : r2; r1 = shift ? r0 : r1; r0 = shift ? offset : r0;
+                    *(L32*)(uintptr_t)(outA + k * outStride) = isOF ? offset : val;
+                    st = ns + fs;
+                    pos -= Etot + (q0 + k + 1 < nbSeq ? Stot : 0);
                 }
-                if (q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
+                if (lane == 0 && q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
             }
+            pos = (int)uni((u32)pos);
             wave_fence();
             DSTAGE(2);
-            if (!uni(okS)) return 0xFFFFFFFFu;
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;
             if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
@@ -2133,9 +2171,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             litPos += totL; out += totO;
             DSTAGE(4);
         }
-        u32 endOk = 1;
-        if (lane == 0) endOk = b.pos <= 0 ? 1u : 0u;                             // bitstream fully consumed
-        if (!uni(endOk)) return 0xFFFFFFFFu;
+        if (pos > 0) return 0xFFFFFFFFu;                                         // bitstream not fully consumed
     }
     const u32 rest = litSize - litPos;
     if ((u64)out + rest > cap || (u64)(out - opos) + rest > blockMax) return 0xFFFFFFFFu;
