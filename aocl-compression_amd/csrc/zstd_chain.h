@@ -78,69 +78,56 @@ ZC_FN uint64_t lane_range(int a, int b)   // bits [a, b), 0 <= a < 64, b <= 64
 }
 ZC_FN uint64_t lane_bit(int i) { return (i >= 0 && i < 64) ? 1ull << i : 0; }
 
-// the last sequence of a chain: its three table writes w1 <= w2 <= w3; those below lim join the commit mask, the others
-// (a suffix, because the lanes are ordered) are left to the caller
-ZC_FN void finish(WalkOut& o, uint64_t& commit, int w1, int w2, int w3, int lim, bool post)
-{
-    o.tail[0] = w1; o.tail[1] = w2; o.tail[2] = w3;
-    o.ntail = (w1 >= lim) + (w2 >= lim) + (w3 >= lim);
-    if (w1 < lim) commit |= lane_bit(w1);
-    if (w2 < lim) commit |= lane_bit(w2);
-    if (w3 < lim) commit |= lane_bit(w3);
-    o.post = post;
-    o.outcome = ZC_RESTART;
-}
+// bits [a, b) for 0 <= a <= 63, a < b <= 64 (two shifts instead of a guarded one: b - 1 <= 63)
+ZC_FN uint64_t span(int a, int b) { return (~0ull << a) & ~((~0ull << (b - 1)) << 1); }
 
 // okmask: lanes below lim with a matching table candidate.  eq1 / eq2: equality maps at distance rep1 / rep2 over all 64
 // lanes (eq2 is ignored while rep2 == 0).  info(j), eqb(j): per-lane inputs of lane j;
 // emit(litLength, offBase, matchLength, anchorPosition) stores one sequence.
+//
+// Written for the scalar unit: every shift amount is kept below 64 by construction (S <= 63 inside the loop, event lanes
+// below lim <= 64) instead of being guarded, the loop carries only what the next sequence needs, and whatever describes HOW
+// the chain ended (the three pending table writes, the special event) is assembled once, after the loop.
 template <class Info, class Eqb, class Emit>
 ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, int32_t arel, uint32_t rep1, uint32_t rep2,
                    uint64_t eq1, const uint64_t eq2, Info info, Eqb eqb, Emit emit, const int S0 = 0, const uint64_t commit0 = 0,
                    const uint32_t lowPos = 0)
 {
-    WalkOut o;
     int S = S0;
     uint64_t commit = commit0;
     uint64_t q1 = quad(eq1), q2 = quad(eq2);
     int end1 = 64, end2 = 64;                            // the maps are known for lanes below end
-    o.ev = 0; o.el = 0; o.R = 0; o.why = 0; o.ntail = 0; o.post = false; o.tail[0] = o.tail[1] = o.tail[2] = 0;
-    for (;;) {
-        if (S >= lim) { o.outcome = ZC_RESTART; break; }
-        const int jm = S + ctz64(okmask >> S);                                                   // first M event, >= 64: none
-        const uint64_t t = shr64(q1, S + 2) & 0x5555555555555555ull;
-        const int kr = S + ctz64(t);                                                             // first R event
-        const int U = t ? 1000 : end1 - 5;               // even probes below U have a known repcode test (k + 6 <= end1)
-        int ev;
-        if (t && kr <= jm) {
-            if (kr >= lim) { commit |= lane_range(S, lim); o.R = lim; o.outcome = ZC_CONTINUE; break; }
-            ev = 2;
-        } else if (jm < 64 && jm < U) ev = 1;
-        else {
-            const int R = lim < U ? lim : U;             // no event in [S, R)
-            if (R < lim && S > 0) { o.outcome = end1 < 64 ? ZC_REFRESH : ZC_RESTART; break; }   // fresh maps / a fresh batch see further
-            commit |= lane_range(S, R); o.R = R; o.outcome = ZC_CONTINUE; break;
-        }
-        if (ev == 2) {
-            const int k = kr, q = k + 2;
-            const uint32_t back1 = (uint32_t)(eq1 >> (q - 1)) & 1u;                              // :533
-            const int f = ctz64(~shr64(eq1, q + 4));
-            const int E = q + 4 + f;
-            // table writes at k+1, k+2 and E-2 (:537, :680-681): lanes below lim join the batch commit; from the first one
-            // at or beyond lim on they follow one by one (`tail`, in order) and the chain ends with this sequence
-            const bool tails = E - 2 >= lim;
-            // (straight-line on purpose: every branch costs the wave far more than the few scalar operations it would skip)
-            const bool imm = rep2 != 0 && E + 4 <= end2;                                          // :690 immediate rep2 test decidable here
-            const int why = (E < end1 ? 0 : 1)           // the comparison ran into the end of what is known
-                          | ((imm & (int)((q2 >> (E & 63)) & 1)) ? 16 : 0);
-            const bool post = why == 0 && rep2 != 0 && !imm;                                      // else by two loads after the walk
-            commit |= lane_range(S, k + 1);
-            if (why) { o.outcome = ZC_SPECIAL; o.ev = 2; o.el = k; o.why = why; break; }
-            emit((uint32_t)(q - (int)back1 - arel), 1u, back1 + 4u + (uint32_t)f, (uint32_t)((int32_t)pos0 + arel));
+    int outcome = ZC_RESTART, R = 0, ev = 0, el = 0, why = 0, E = 0;
+    bool fin = false, post = false;                      // the chain ended with a sequence whose table writes / rep2 test are pending
+    while (S < lim) {                                    // (S <= 63 in the body)
+        const uint64_t okS = okmask >> S;
+        const uint64_t t = ((q1 >> 1) >> (S + 1)) & 0x5555555555555555ull;           // R events of this search, relative to S
+        const int jm = S + ctz64(okS);                                                // first M event, >= 64: none
+        const int kr = S + ctz64(t);                                                  // first R event
+        if (t != 0 && kr <= jm) {
+            if (kr >= lim) { commit |= span(S, lim); R = lim; outcome = ZC_CONTINUE; break; }
+            // ---- repcode found by even probe k at k + 2 (:519-542) ----
+            const int k = kr;
+            const uint64_t e1k = eq1 >> (k + 1);                                      // bit 0 <-> lane k + 1 = q - 1 (:533)
+            const uint32_t back1 = (uint32_t)e1k & 1u;
+            const int f = ctz64(~(e1k >> 5));                                         // equality run from q + 4
+            E = k + 6 + f;
+            const bool imm = rep2 != 0 && E + 4 <= end2;                              // :690 immediate rep2 test decidable here
+            why = (E < end1 ? 0 : 1) | ((imm && ((q2 >> (E & 63)) & 1)) ? 16 : 0);
+            commit |= span(S, k + 1);
+            ev = 2; el = k;
+            if (why) { outcome = ZC_SPECIAL; break; }
+            emit((uint32_t)(k + 2 - (int)back1 - arel), 1u, back1 + 4u + (uint32_t)f, (uint32_t)((int32_t)pos0 + arel));
             arel = E; S = E;
-            if (tails || post) { finish(o, commit, k + 1, k + 2, E - 2, lim, post); break; }
-            commit |= lane_bit(k + 1) | lane_bit(k + 2) | lane_bit(E - 2);
+            post = rep2 != 0 && !imm;                                                 // else by two loads after the walk
         } else {
+            const int U = t ? 1000 : end1 - 5;           // even probes below U have a known repcode test (k + 6 <= end1)
+            if (!(okS != 0 && jm < U)) {
+                R = lim < U ? lim : U;                   // no event in [S, R)
+                if (R < lim && S > 0) { outcome = end1 < 64 ? ZC_REFRESH : ZC_RESTART; break; }    // fresh maps / a fresh batch see further
+                commit |= span(S, R); outcome = ZC_CONTINUE; break;                   // (R > S: lim > S, and U > S or S == 0 ... see below)
+            }
+            // ---- table match at lane j (:546-598, :651-669) ----
             const int j = jm;
             const auto in = info(j);
             // a 64-bit record carries a full-width candidate position in its upper half (frames: positions are offsets into
@@ -152,25 +139,42 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
             const uint32_t room = (uint32_t)(j - arel);
             const uint32_t maxback = room < cl ? room : cl;
             const uint32_t back = bk4 < maxback ? bk4 : maxback;
-            const int E = j + 4 + (int)fw;
-            const bool tails = E - 2 >= lim;
-            const bool imm = E + 4 <= end1;                                                       // rep2 becomes the old rep1
-            const int why = (fw < 24 ? 0 : 1) | (bk4 != 7 && !(bk4 == 4 && maxback > 4) ? 0 : 2) | (tails && j + 2 >= 64 ? 4 : 0)
-                          | ((imm & (int)((q1 >> (E & 63)) & 1)) ? 16 : 0);
-            const bool post = why == 0 && !imm;
-            commit |= lane_range(S, j + 1);
-            if (why) { o.outcome = ZC_SPECIAL; o.ev = 1; o.el = j; o.why = why; break; }
+            E = j + 4 + (int)fw;
+            const bool imm = E + 4 <= end1;                                           // rep2 becomes the old rep1
+            why = (fw < 24 ? 0 : 1) | (bk4 != 7 && !(bk4 == 4 && maxback > 4) ? 0 : 2) | (E - 2 >= lim && j + 2 >= 64 ? 4 : 0)
+                | ((imm && ((q1 >> (E & 63)) & 1)) ? 16 : 0);
+            commit |= span(S, j + 1);
+            ev = 1; el = j;
+            if (why) { outcome = ZC_SPECIAL; break; }
             const uint32_t off = pos0 + (uint32_t)j - c;
             emit((uint32_t)(j - (int)back - arel), off + 3u, 4u + back + fw, (uint32_t)((int32_t)pos0 + arel));
             rep2 = rep1; rep1 = off;
             arel = E; S = E;
-            if (tails || post) { finish(o, commit, j + 1, j + 2, E - 2, lim, post); break; }
-            commit |= lane_bit(j + 1) | lane_bit(j + 2) | lane_bit(E - 2);
+            post = !imm;
             q2 = q1; end2 = end1;
-            eq1 = map_from_window(eqb(j), j); q1 = quad(eq1); end1 = j + 28 < 64 ? j + 28 : 64;
+            eq1 = (uint64_t)(eqb(j) >> 4) << j;                                       // = map_from_window(eqb(j), j)
+            q1 = quad(eq1); end1 = j + 28 < 64 ? j + 28 : 64;
         }
+        // table writes at el+1, el+2 and E-2 (:537, :680-681): lanes below lim join the batch commit; from the first one at or
+        // beyond lim on they follow one by one, in order, and the chain ends with this sequence - as it does when the immediate
+        // rep2 test (:690) could not be decided from the maps
+        if (E - 2 >= lim || post) { fin = true; break; }
+        commit |= (3ull << (el + 1)) | (1ull << (E - 2));
     }
-    o.S = S; o.arel = arel; o.rep1 = rep1; o.rep2 = rep2; o.commit = commit;
+    WalkOut o;
+    o.outcome = outcome; o.S = S; o.R = R; o.ev = 0; o.el = 0; o.why = 0; o.arel = arel; o.rep1 = rep1; o.rep2 = rep2;
+    o.ntail = 0; o.tail[0] = o.tail[1] = o.tail[2] = 0; o.post = false;
+    if (outcome == ZC_SPECIAL) { o.ev = ev; o.el = el; o.why = why; }
+    if (fin) {
+        const int w1 = el + 1, w2 = el + 2, w3 = E - 2;
+        o.tail[0] = w1; o.tail[1] = w2; o.tail[2] = w3;
+        o.ntail = (w1 >= lim) + (w2 >= lim) + (w3 >= lim);
+        if (w1 < lim) commit |= lane_bit(w1);
+        if (w2 < lim) commit |= lane_bit(w2);
+        if (w3 < lim) commit |= lane_bit(w3);
+        o.post = post;
+    }
+    o.commit = commit;
     return o;
 }
 

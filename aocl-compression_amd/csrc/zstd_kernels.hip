@@ -148,8 +148,13 @@ __device__ unsigned int g_ztrace_n;
 #endif
 #ifdef ZSTD_PROF
 __device__ unsigned long long g_zstd_prof[16];
+#ifdef ZSTD_PROF_NOWAIT   /* stamps without draining the global loads: a stage is charged the waits the compiler placed in it */
+#define ZSTAGE(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); zacc[k] += t_ - zprev; zprev = t_; } while (0)
+#else
 #define ZSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); zacc[k] += t_ - zprev; zprev = t_; } while (0)
+#endif
 #else
 #define ZSTAGE(k) do { } while (0)
 #endif
@@ -215,6 +220,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     };
     u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
     u32 saved1 = 0, saved2 = 0;
+#ifdef ZSTD_PREFETCH
+    u32 pfacc = 0, pfv = 0;
+#endif
     if constexpr (FRAME) {
         rep1 = *rep1io; rep2 = *rep2io;
         const u32 curr = s + 2, maxRep = curr - lowest_prefix(*win, curr);
@@ -315,6 +323,17 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 table[h] = (T)ent;                                        // low halves only: the extra bits were not touched
                 wave_fence();
                 ZSTAGE(2);
+#ifdef ZSTD_PREFETCH
+                {   // warm the cache with the NEXT batch's candidates (positions pos0+64 ..): their table entries are known now
+                    // (bar the few slots this batch commits), and the line is then on its way while this batch is resolved
+                    pfacc ^= pfv;
+                    const u32 pn = pos + 64;
+                    if (pn + 8 <= n) {
+                        const u32 en = tget(z_hash<MLS>(ld64(src + pn), hlog));
+                        if (en >= prefixIdx + 2) pfv = src[en - 2];
+                    }
+                }
+#endif
                 const int lim = first_lane(ballot(w != (u32)lane));
                 using zchain::zero_bytes;
                 const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
@@ -324,6 +343,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 const u32 infoV = near0 ? zchain::pack_info(FRAME ? 0u : c, 0, 7) : zchain::pack_info(FRAME ? 0u : c, fw, bk4);   // (frames: the position travels apart)
                 const u64 okmask = ballot(lane < lim && ok);
                 const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
+                ZSTAGE(6);
                 zchain::WalkOut wo;
                 {
                     u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
@@ -520,6 +540,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
         *rep2io = rep2 ? rep2 : saved2;
     }
     flush_seq(nbSeq & ~63u, nbSeq & 63u);
+#ifdef ZSTD_PREFETCH
+    if ((pfacc ^ pfv) == 0x5A17C0DEu) ws->pad[0] = 1;                    // (keeps the prefetch loads alive)
+#endif
     wave_fence();
     *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
     return nbSeq;

@@ -14,8 +14,9 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_zstd_prof(buf)
 names = ["probe loads (ld64 at pos)", "hash + table + cand/rep loads", "slot-reuse rounds", "decision + commit (+ no-hit batches)", "ip1 write + catch-up + extension", "store seq + post writes + rep2 / loop top"]
-tot = sum(buf[:6]); nseq = buf[9]
-for n, v in zip(names, buf[:6]):
+names += ["chain batch: equality masks (waits for the candidates)", "-"]
+tot = sum(buf[:8]); nseq = buf[9]
+for n, v in zip(names, buf[:8]):
     print(f"{n:44s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
 print("total cyc/seq", tot / nseq, "batches", buf[8], "seqs", nseq, "batches/seq", buf[8] / nseq)
 dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, src.numel(), 131072)
