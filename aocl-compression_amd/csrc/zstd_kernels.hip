@@ -213,9 +213,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     auto flush_seq = [&](u32 first, u32 count) {
         if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
     };
-    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {
-        const bool me = (u32)lane == (idx & 63u);
-        q_ll = me ? ll : q_ll; q_off = me ? off : q_off; q_ml = me ? ml : q_ml; q_src = me ? srcpos : q_src;
+    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {         // (wave-uniform arguments: one v_writelane per field)
+        const u32 l = uni(idx & 63u);
+        asm("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+            : "+v"(q_ll), "+v"(q_off), "+v"(q_ml), "+v"(q_src) : "s"(uni(ll)), "s"(uni(off)), "s"(uni(ml)), "s"(uni(srcpos)), "s"(l) : "m0");
         if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
     };
     u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
@@ -367,6 +368,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                         S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
                     }
                 }
+                ZSTAGE(7);
                 if ((wo.commit >> lane) & 1) tput(h, pos + 2);
                 wave_fence();
 #ifdef ZSTD_TRACE

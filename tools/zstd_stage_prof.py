@@ -14,7 +14,7 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_zstd_prof(buf)
 names = ["probe loads (ld64 at pos)", "hash + table + cand/rep loads", "slot-reuse rounds", "decision + commit (+ no-hit batches)", "ip1 write + catch-up + extension", "store seq + post writes + rep2 / loop top"]
-names += ["chain batch: equality masks (waits for the candidates)", "-"]
+names += ["chain batch: equality masks (waits for the candidates)", "chain batch: the scalar walk alone"]
 tot = sum(buf[:8]); nseq = buf[9]
 for n, v in zip(names, buf[:8]):
     print(f"{n:44s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
