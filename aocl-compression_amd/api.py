@@ -94,6 +94,7 @@ EXPORTS = [
     "aoclgpu_rap_assemble", "aoclgpu_zstd_compress_frames", "aoclgpu_zstd_compress_host_frame",
     "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode", "aoclgpu_lz4f_set_block_linking", "aoclgpu_lz4f_block_linking",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
+    "aoclgpu_probe_copy", "aoclgpu_probe_scatter8",
 ]
 
 
@@ -115,6 +116,10 @@ def load_library() -> C.CDLL:
     lib.aoclgpu_compact_slots.restype = C.c_int
     lib.aoclgpu_compact_slots.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.aoclgpu_time_batch.restype = C.c_double
+    lib.aoclgpu_probe_copy.restype = C.c_double
+    lib.aoclgpu_probe_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    lib.aoclgpu_probe_scatter8.restype = C.c_double
+    lib.aoclgpu_probe_scatter8.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p]
     lib.aoclgpu_time_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Batch), C.c_int, C.c_void_p]
     for n in ("aoclgpu_compress_host", "aoclgpu_decompress_host"):
         f = getattr(lib, n)

@@ -186,6 +186,74 @@ extern "C" int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, 
     return check_launch("gather_slots_kernel");
 }
 
+// ---------------- memory-system probes (bench.py: the measured ceiling next to the 8 TB/s of the data sheet) ----------------
+// probe_copy_kernel: every lane moves 16 bytes per step, consecutive lanes consecutive addresses - the access pattern HBM
+// likes best; 2 * bytes / time is what a kernel of this chip can get out of its memory.
+// probe_scatter8_kernel: every lane issues dependent-free 8-byte loads at pseudo-random 8-byte-aligned addresses of a large
+// buffer (the codecs' candidate-window pattern); run under rocprofv3 --pmc FETCH_SIZE it calibrates that counter for
+// scattered loads (bytes fetched per load).
+__global__ void __launch_bounds__(256) probe_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) probe_scatter8_kernel(const uint64_t* __restrict__ src, size_t n8, uint32_t loads_per_lane, uint64_t* __restrict__ sink)
+{
+    uint64_t x = 0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1), acc = 0;
+    for (uint32_t k = 0; k < loads_per_lane; ++k) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                   // xorshift64: addresses do not depend on loaded data
+        acc += src[x % n8];
+    }
+    if (acc == 0x1234567887654321ull) *sink = acc;                 // (keeps the loads alive)
+}
+
+extern "C" double aoclgpu_probe_copy(void* dst, const void* src, size_t bytes, int iters, void* stream)
+{
+    if (!dst || !src || bytes < 16 || iters <= 0) { set_error_msg("probe_copy: bad arguments"); return -1.0; }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { set_error_msg("hipEventCreate failed"); return -1.0; }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error_msg("probe_copy: device query failed"); return -1.0; }
+    const dim3 g((unsigned)prop.multiProcessorCount * 8), t(256);
+    hipLaunchKernelGGL(probe_copy_kernel, g, t, 0, s, (uint4*)dst, (const uint4*)src, bytes / 16);       // warm-up
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(probe_copy_kernel, g, t, 0, s, (uint4*)dst, (const uint4*)src, bytes / 16);
+    hipEventRecord(e1, s);
+    double ms = -1.0;
+    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) {
+        float f = 0.f;
+        if (hipEventElapsedTime(&f, e0, e1) == hipSuccess) ms = (double)f / iters;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms;
+}
+
+extern "C" double aoclgpu_probe_scatter8(const void* src, size_t bytes, uint32_t loads_per_lane, uint64_t* total_loads, void* stream)
+{
+    if (!src || bytes < 64 || !loads_per_lane) { set_error_msg("probe_scatter8: bad arguments"); return -1.0; }
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error_msg("probe_scatter8: device query failed"); return -1.0; }
+    uint64_t* sink = nullptr;
+    if (hipMalloc((void**)&sink, 8) != hipSuccess) { set_error_msg("probe_scatter8: hipMalloc failed"); return -1.0; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); set_error_msg("hipEventCreate failed"); return -1.0; }
+    const dim3 g((unsigned)prop.multiProcessorCount * 8), t(256);
+    hipEventRecord(e0, s);
+    hipLaunchKernelGGL(probe_scatter8_kernel, g, t, 0, s, (const uint64_t*)src, bytes / 8, loads_per_lane, sink);
+    hipEventRecord(e1, s);
+    double ms = -1.0;
+    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) {
+        float f = 0.f;
+        if (hipEventElapsedTime(&f, e0, e1) == hipSuccess) ms = (double)f;
+    }
+    if (total_loads) *total_loads = (uint64_t)g.x * t.x * loads_per_lane;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return ms;
+}
+
 typedef int (*batch_fn)(const aoclgpu_batch*, void*);
 static batch_fn pick(aoclgpu_codec codec, int op)
 {

@@ -256,6 +256,35 @@ def whole_input_frames(eng):
     return out
 
 
+def memory_probes(eng):
+    """The memory system's own numbers on this box, next to the data-sheet peak the roofline is priced against:
+    a device-to-device copy (coalesced 16-byte lanes, 2 GiB) and a scattered 8-byte-load kernel (the codecs' candidate-window
+    pattern; profiles/ holds the FETCH_SIZE pass of this same kernel = bytes the counter reports per scattered load)."""
+    import torch
+    n = 2 << 30
+    a_ = torch.empty(n, dtype=torch.uint8, device=eng.device)
+    b_ = torch.ones(n, dtype=torch.uint8, device=eng.device)
+    ms = eng.lib.aoclgpu_probe_copy(a_.data_ptr(), b_.data_ptr(), n, 5, eng._stream())
+    out = {"hbm_copy_GBps": round(2.0 * n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None, "hbm_copy_bytes": n}
+    tot = C.c_uint64(0)
+    ms2 = eng.lib.aoclgpu_probe_scatter8(b_.data_ptr(), n, 256, C.byref(tot), eng._stream())
+    if ms2 > 0:
+        cal = {"kernel": "probe_scatter8_kernel", "loads": tot.value, "requested_bytes": 8 * tot.value, "ms": round(ms2, 3),
+               "Gloads_per_s": round(tot.value / (ms2 * 1e-3) / 1e9, 2)}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                t = json.load(f).get("scatter8_calibration")
+            if t:
+                cal["fetch_size_bytes_per_load_measured"] = t["fetch_bytes_per_load"]
+                cal["source"] = t["source"]
+        except (OSError, ValueError, KeyError):
+            pass
+        out["fetch_calibration"] = cal
+    del a_, b_
+    torch.cuda.empty_cache()
+    return out
+
+
 def config1_latency(eng, reps=20):
     """BASELINE config 1: one 64 KiB text block through aocl_llc_compress / aocl_llc_decompress on HOST buffers
     (PCIe both ways included), next to the reference's own aocl_llc_* on one host core.  Microseconds, best of `reps`."""
@@ -639,6 +668,18 @@ def main():
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
         out["codecs"] = results
+        if world == 1:
+            try:
+                probes = memory_probes(eng)
+                out["hbm_copy_GBps"] = probes.get("hbm_copy_GBps")
+                out["fetch_calibration"] = probes.get("fetch_calibration")
+                for r in [out["roofline"]] + [v["roofline"] for v in results.values()]:
+                    r["measured_copy_GBps"] = probes.get("hbm_copy_GBps")
+                    if probes.get("hbm_copy_GBps"):
+                        r["frac_of_measured_copy"] = round(r["achieved"] / probes["hbm_copy_GBps"], 5)
+            except Exception as e:
+                out["hbm_copy_GBps"] = None
+                out["fetch_calibration"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and args.codec in ("all", "lz4"):
             try:
                 out["config1_latency_us"] = config1_latency(eng)

@@ -228,6 +228,14 @@ int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* host_src, s
  * (negative on error).  op: 0 = compress, 1 = decompress. */
 double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, int iters, void* stream);
 
+/* Memory-system probes for bench.py's roofline ("a device-to-device copy kernel gives the achievable ceiling").
+ * aoclgpu_probe_copy: average milliseconds of one device-to-device copy of `bytes` (16-byte lanes, coalesced); the achievable
+ * HBM rate is 2 * bytes / time.  aoclgpu_probe_scatter8: one launch of `loads_per_lane` independent 8-byte loads per lane at
+ * pseudo-random addresses of src[0, bytes) - the codecs' candidate-window pattern; returns its milliseconds, *total_loads =
+ * loads issued (under rocprofv3 --pmc FETCH_SIZE this calibrates the counter for scattered loads).  Negative on error. */
+double aoclgpu_probe_copy(void* dst_dev, const void* src_dev, size_t bytes, int iters, void* stream);
+double aoclgpu_probe_scatter8(const void* src_dev, size_t bytes, uint32_t loads_per_lane, uint64_t* total_loads, void* stream);
+
 /* Host-buffer convenience (H2D, one launch of ONE chunk, D2H).  Return value = the per-chunk result of the
  * native one-shot API (compress: size, 0 = does not fit; decompress: size, small negative = malformed),
  * or a value <= AOCLGPU_HOST_FAIL/2 when the GPU path itself failed (AOCLGPU_HOST_FAIL + AOCLGPU_ERR_*). */

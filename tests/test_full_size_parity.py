@@ -1,0 +1,67 @@
+"""Byte parity at BASELINE's full size: the ENTIRE 8 GiB stream bench.py measures (same base corpus, same seed, same tiling,
+same chunk size, one launch for all chunks) is compressed on the GPU and compared with the CPU checker chunk by chunk, byte
+for byte - every one of the 32 768 / 131 072 / 65 536 chunks (they are all distinct: the 202 MiB base is not a multiple of the
+chunk size).  The checker is the real reference's one-shot function when oracle/_ref is there (16 OpenMP threads,
+oracle/chunk_driver.c), this repo's C restatement otherwise; the host side works through the stream in 1 GiB slabs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import aocl_compression_amd as a
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SILESIA_BYTES = 211_938_580
+TOTAL = 8 << 30
+CASES = [("lz4", a.LZ4, ol.LZ4, 262144, "LZ4_compress_default"), ("snappy", a.SNAPPY, ol.SNAPPY, 65536, "snappy_compress"),
+         ("zstd", a.ZSTD, ol.ZSTD, 131072, "ZSTD_compress")]
+
+
+@pytest.mark.parametrize("name,gc,oc,chunk,ref_fn", CASES)
+def test_whole_bench_stream_equals_the_checker(eng, oracle, name, gc, oc, chunk, ref_fn):
+    free, _ = torch.cuda.mem_get_info()
+    if free < (20 << 30):
+        pytest.skip("needs 20 GiB of free HBM")
+    base_np = a.corpus.make("jsonlog", SILESIA_BYTES, seed=0xA0C3) if name == "snappy" else a.corpus.silesia_mix(SILESIA_BYTES, seed=0xA0C1)
+    base = torch.from_numpy(base_np).to(eng.device)
+    src = base.repeat(-(-TOTAL // base.numel()))[:TOTAL].contiguous()          # bench.py Run.shard_of(0)
+    del base
+    slots, out_len, slot = eng.compress_chunks(gc, src, chunk)                 # ONE launch, as in the bench
+    torch.cuda.synchronize()
+    nchunks = TOTAL // chunk
+    glen = out_len.cpu().numpy().astype(np.int32)
+    assert (glen > 0).all()
+    fn = None
+    if os.path.exists(ol.REF_SO):
+        fn = C.cast(getattr(C.CDLL(ol.REF_SO), ref_fn), C.c_void_p)
+    L = oracle.L
+    L.orc_compress_chunks_fn.restype = C.c_int
+    L.orc_compress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    slab_chunks = (1 << 30) // chunk
+    host = np.empty(slab_chunks * chunk, np.uint8)
+    want = np.zeros(slab_chunks * slot, np.uint8)
+    wlen = np.zeros(slab_chunks, np.int32)
+    nb = len(base_np)
+    col = np.arange(slot, dtype=np.uint32)[None, :]
+    for s0 in range(0, nchunks, slab_chunks):
+        o = (s0 * chunk) % nb                                                  # the slab's bytes: the base corpus, wrapped
+        k = 0
+        while k < host.size:
+            m = min(nb - o, host.size - k)
+            host[k:k + m] = base_np[o:o + m]
+            k += m
+            o = (o + m) % nb
+        fails = L.orc_compress_chunks_fn(oc, fn, host.ctypes.data, host.size, chunk, want.ctypes.data, slot, wlen.ctypes.data, 16)
+        assert fails == 0
+        g = glen[s0:s0 + slab_chunks]
+        assert np.array_equal(g, wlen), f"{name}: sizes differ in chunks {s0 + np.nonzero(g != wlen)[0][:5]}"
+        got = slots[s0 * slot:(s0 + slab_chunks) * slot].cpu().numpy().reshape(slab_chunks, slot)
+        w2 = want.reshape(slab_chunks, slot)
+        for c0 in range(0, slab_chunks, 512):                                  # (bounded temporaries)
+            used = col < wlen[c0:c0 + 512, None].astype(np.uint32)
+            bad = np.nonzero((got[c0:c0 + 512] != w2[c0:c0 + 512]) & used)
+            assert bad[0].size == 0, f"{name}: first differing byte in chunk {s0 + c0 + bad[0][0]} at {bad[1][0]}"
+    assert torch.equal(src[:chunk], torch.from_numpy(base_np[:chunk]).to(eng.device))
