@@ -94,7 +94,7 @@ EXPORTS = [
     "aoclgpu_rap_assemble", "aoclgpu_zstd_compress_frames", "aoclgpu_zstd_compress_host_frame",
     "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode", "aoclgpu_lz4f_set_block_linking", "aoclgpu_lz4f_block_linking",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
-    "aoclgpu_probe_copy", "aoclgpu_probe_scatter8",
+    "aoclgpu_probe_copy", "aoclgpu_probe_scatter8", "aoclgpu_host_trim",
 ]
 
 

@@ -47,7 +47,21 @@ def _run(cmd):
     return r
 
 
-def build_variant(name: str, cflags, verbose: bool = False) -> str:
+def build_sanitized(verbose: bool = False) -> str:
+    """AOCLGPU_SANITIZE=1 / `python build.py --sanitize`: the HOST side of the library (the .cpp shims and the host halves of
+    the .hip files) with AddressSanitizer + UndefinedBehaviorSanitizer -> libaocl_compression_gpu_asan.so.  Device code is
+    compiled as always (the GPU sanitizers need xnack+ boxes this pool does not have).  CPU-only use: tests/test_sanitized.py
+    preloads the clang ASan runtime and drives the host logic (ABI structs, level tables, frame-header parsing, error paths)."""
+    return build_variant("asan", ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-Wno-option-ignored"], verbose=verbose,
+                         linker=[os.path.join(ROCM, "lib", "llvm", "bin", "clang++"), "-fsanitize=address,undefined", "-shared-libsan"])
+
+
+def asan_runtime() -> str:
+    r = subprocess.run([os.path.join(ROCM, "lib", "llvm", "bin", "clang++"), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    return r.stdout.strip()
+
+
+def build_variant(name: str, cflags, verbose: bool = False, linker=None) -> str:
     """Development builds next to the product (kernel experiments, profiling instantiations): the same sources with extra
     flags -> libaocl_compression_gpu_<name>.so, objects under build/<name>/.  Loaded by tools/ through AOCLGPU_LIB (api.lib_path)."""
     objdir = os.path.join(OBJDIR, name)
@@ -72,7 +86,7 @@ def build_variant(name: str, cflags, verbose: bool = False) -> str:
             list(ex.map(_run, jobs))
     stubdir = os.path.join(OBJDIR, "stub")
     if jobs or not os.path.exists(out):
-        _run(["g++", "-shared", "-fPIC", *objs, "-o", out, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
+        _run([*(linker or ["g++"]), "-shared", "-fPIC", *objs, "-o", out, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
               "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
     with open(stamp, "w") as f:
         f.write(flags)
@@ -106,7 +120,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             f.write("/* link-time stand-in so the engine records NEEDED libamdhip64.so (no version) */\n")
         _run(["gcc", "-shared", "-fPIC", stub_c, "-o", os.path.join(stubdir, "libamdhip64.so")])
         _run(["g++", "-shared", "-fPIC", *objs, "-o", LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
-              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-Wl,-Bsymbolic-functions"])
         vmap = os.path.join(stubdir, "core.map")
         with open(vmap, "w") as f:
             f.write("{ global: aoclgpu_*; aocl_llc_*; aocl_get_rap_frame_bound_mt; aocl_skip_rap_frame_mt; local: *; };\n")
@@ -125,6 +139,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--sanitize" in sys.argv or os.environ.get("AOCLGPU_SANITIZE") == "1":
+        build_sanitized(verbose=True)
     # python build.py --variant prof -DAOCLGPU_EXPERIMENTS -DZSTD_PROF
     if "--variant" in sys.argv:
         i = sys.argv.index("--variant")

@@ -9,9 +9,12 @@
 #include "../../include/aocl_compression.h"
 #include "../../include/aocl_gpu_codec.h"
 #include "../../include/aocl_native_api.h"
+#include <atomic>
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
+
+extern "C" int aoclgpu_zstd_level_table(void);     // zstd_api.cpp
 
 namespace {
 
@@ -24,7 +27,22 @@ uint64_t now_ns()
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
-bool gpu_codec(aocl_compression_type t, aoclgpu_codec* out)
+// numThreads > 1: 0 (default) = GPU geometry, the codec's chunk (128 KiB for Zstd) is the partition; 1 = the reference's
+// own partition geometry for Zstd (few partitions of at least a window each: byte-identical to its threaded build for the
+// same thread count, one wavefront per partition).  aoclgpu_set_rap_geometry / AOCLGPU_RAP_GEOMETRY=reference.
+std::atomic<int> g_rap_geometry{-1};
+int rap_geometry()
+{
+    int m = g_rap_geometry.load();
+    if (m < 0) { const char* e = getenv("AOCLGPU_RAP_GEOMETRY"); m = (e && !strcmp(e, "reference")) ? 1 : 0; g_rap_geometry.store(m); }
+    return m;
+}
+
+// The codec type arrives as an enum a caller may have filled with anything (the reference's own tests pass out-of-range
+// values, gtest/api/api_gtest.cpp): it is read as the integer it is, never through the enum type.
+int raw_type(const aocl_compression_type& t) { int v; memcpy(&v, &t, sizeof(v)); return v; }
+
+bool gpu_codec(int t, aoclgpu_codec* out)
 {
     switch (t) {
     case LZ4: *out = AOCLGPU_LZ4; return true;
@@ -35,7 +53,7 @@ bool gpu_codec(aocl_compression_type t, aoclgpu_codec* out)
     }
 }
 
-int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
+int64_t wrap_compress(int t, const aocl_compression_desc* h)
 {
     aoclgpu_codec c;
     if (!gpu_codec(t, &c)) return kCodecError;
@@ -45,8 +63,34 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
         // The reference's AOCL_ENABLE_THREADS build partitions the input inside this call and returns a RAP stream
         // (lz4.c:2655-2909, snappy.cc:2505-2654, zstd_compress.c:5388-5534; callers add aocl_get_rap_frame_bound_mt()
         // to outSize).  Here `numThreads > 1` asks for the same with GPU chunks as the partitions.
-        if (h->inSize > 0x7FFFFFFFu || (t == ZSTD && h->level != 1)) return kCodecError;
-        int64_t r = aoclgpu_rap_compress_host(c, h->inBuf, h->inSize, h->outBuf, h->outSize, 0);
+        if (h->inSize > 0x7FFFFFFFu) return kCodecError;
+        uint32_t flags = 0;
+        if (t == ZSTD) {
+            // every partition is compressed with the level's parameters for ITS size, as each thread of the reference does
+            // with the caller's parameters (zstd_compress.c:5447-5468); levels with a GPU parse: 1-4 (0 = the default, 3)
+            const int level = h->level == 0 ? 3 : (int)h->level;
+            if (level < 1 || level > 4) return kCodecError;
+            flags = AOCLGPU_ZSTD_LEVEL((uint32_t)level) | (aoclgpu_zstd_level_table() ? 0u : AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE);
+            if (rap_geometry() == 1) {
+                // the reference's own geometry: min(numThreads, partitions of window size) frames (threads/threads.c:46-118)
+                ZSTD_parameters zp = ZSTD_getParams((int)h->level, h->inSize, 0);
+                if (h->optVar && zp.cParams.windowLog > h->optVar) zp.cParams.windowLog = (unsigned)h->optVar;
+                const uint64_t wf = h->inSize < (100ull << 20) ? 1 : (h->inSize > (400ull << 20) ? 4 : h->inSize / (100ull << 20));
+                const uint64_t chunk = ((uint64_t)1 << zp.cParams.windowLog) * wf;
+                uint64_t parts = 1;
+                if (h->inSize >= chunk) {
+                    parts = h->inSize / chunk;
+                    if (h->inSize % chunk >= (wf > 1 ? chunk >> 1 : ((uint64_t)1 << zp.cParams.windowLog) >> 1)) parts++;
+                    if (parts > (uint64_t)h->numThreads) parts = (uint64_t)h->numThreads;
+                }
+                const int64_t r = aoclgpu_zstd_rap_compress_host_parts(h->inBuf, h->inSize, h->outBuf, h->outSize, (uint32_t)parts,
+                                                                       (uint32_t)zp.cParams.strategy, zp.cParams.windowLog, zp.cParams.hashLog,
+                                                                       zp.cParams.chainLog, zp.cParams.minMatch < 4 ? 4u : zp.cParams.minMatch,
+                                                                       zp.cParams.targetLength);
+                return r > 0 ? r : kCodecError;
+            }
+        }
+        int64_t r = aoclgpu_rap_compress_host_ex(c, h->inBuf, h->inSize, h->outBuf, h->outSize, 0, flags);
         return r > 0 ? r : kCodecError;
     }
     if (t == LZ4) {                                   // api/codec.cpp:126-134: LZ4_compress_default takes int sizes
@@ -76,7 +120,7 @@ int64_t wrap_compress(aocl_compression_type t, const aocl_compression_desc* h)
     return ZSTD_isError(r) ? kCodecError : (int64_t)r;
 }
 
-int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
+int64_t wrap_decompress(int t, const aocl_compression_desc* h)
 {
     aoclgpu_codec c;
     if (!gpu_codec(t, &c)) return kCodecError;
@@ -94,11 +138,14 @@ int64_t wrap_decompress(aocl_compression_type t, const aocl_compression_desc* h)
 
 }  // namespace
 
+extern "C" void aoclgpu_set_rap_geometry(int reference) { g_rap_geometry.store(reference ? 1 : 0); }
+extern "C" int aoclgpu_rap_geometry(void) { return rap_geometry(); }
+
 extern "C" int64_t aocl_llc_compress(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     if (!handle) return ERR_COMPRESSION_FAILED;
     const uint64_t t0 = now_ns();
-    const int64_t ret = wrap_compress(codec_type, handle);
+    const int64_t ret = wrap_compress(raw_type(codec_type), handle);
     const uint64_t t1 = now_ns();
     if (handle->measureStats == 1) {                  // api/api.cpp:70-75
         handle->cSize = (uint64_t)ret;
@@ -112,7 +159,7 @@ extern "C" int64_t aocl_llc_decompress(aocl_compression_desc* handle, aocl_compr
 {
     if (!handle) return ERR_COMPRESSION_FAILED;
     const uint64_t t0 = now_ns();
-    const int64_t ret = wrap_decompress(codec_type, handle);
+    const int64_t ret = wrap_decompress(raw_type(codec_type), handle);
     const uint64_t t1 = now_ns();
     if (handle->measureStats == 1) {                  // api/api.cpp:111-116
         handle->dSize = (uint64_t)ret;
@@ -124,10 +171,11 @@ extern "C" int64_t aocl_llc_decompress(aocl_compression_desc* handle, aocl_compr
 
 extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
-    if ((int)codec_type < (int)LZ4 || (int)codec_type >= (int)AOCL_COMPRESSOR_ALGOS_NUM)
+    const int ct = raw_type(codec_type);
+    if (ct < (int)LZ4 || ct >= (int)AOCL_COMPRESSOR_ALGOS_NUM)
         return ERR_UNSUPPORTED_METHOD;                // api/api.cpp:133-138
     aoclgpu_codec c;
-    if (!gpu_codec(codec_type, &c)) return ERR_EXCLUDED_METHOD;   // api/api.cpp:155-161 (no backend in this build)
+    if (!gpu_codec(ct, &c)) return ERR_EXCLUDED_METHOD;   // api/api.cpp:155-161 (no backend in this build)
     if (handle) {
         // utils/utils.cpp:148-175 derives optLevel from CPUID; host ISA levels are meaningless for the GPU
         // backend, so it reports 0 ("no host SIMD path selected").  workBuf: LZ4/Snappy keep no context
@@ -136,14 +184,14 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
         // LZ4 / Snappy keep no context (workBuf NULL, api/codec.cpp:118-122,262-266); Zstd's setup hands back a context block
         // (api/codec.cpp:354-376; gtest/api/api_gtest.cpp:771-778 checks it is not NULL) - it is freed by aocl_llc_destroy
         handle->workBuf = NULL;
-        if (codec_type == ZSTD) {
+        if (ct == (int)ZSTD) {
             void** ctx = (void**)malloc(2 * sizeof(void*));
             if (ctx) { ctx[0] = ZSTD_createCCtx(); ctx[1] = ZSTD_createDCtx(); }
             handle->workBuf = (char*)ctx;
         }
         // the reference's setup runs the codec's dispatcher (api/codec.cpp:354-376); for Zstd that also selects the level
         // table (optOff -> upstream parameters, zstd_compress.c:7390-7425)
-        if (codec_type == ZSTD) (void)aocl_setup_zstd_encode(handle->optOff, 0, handle->inSize, handle->level, handle->optVar);
+        if (ct == (int)ZSTD) (void)aocl_setup_zstd_encode(handle->optOff, 0, handle->inSize, handle->level, handle->optVar);
     }
     if (aoclgpu_init(aoclgpu_host_device()) != AOCLGPU_OK) return ERR_EXCLUDED_METHOD;   // AOCLGPU_DEVICE / aoclgpu_set_host_device
     return 0;
@@ -152,13 +200,14 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
 extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     if (!handle) return;
-    if (codec_type == ZSTD && handle->workBuf) {          // api/codec.cpp:378-394
+    if (raw_type(codec_type) == (int)ZSTD && handle->workBuf) {          // api/codec.cpp:378-394
         void** ctx = (void**)handle->workBuf;
         ZSTD_freeCCtx((ZSTD_CCtx*)ctx[0]); ZSTD_freeDCtx((ZSTD_DCtx*)ctx[1]);
         free(ctx);
         aocl_destroy_zstd_encode(); aocl_destroy_zstd_decode();
     }
     handle->workBuf = NULL;
+    aoclgpu_host_trim();                                  // staging buffers of idle host contexts go back to the device
 }
 
 extern "C" const char* aocl_llc_version(void)

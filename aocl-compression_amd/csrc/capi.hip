@@ -332,7 +332,15 @@ HostCtx* host_acquire(int dev)
     g_host_ctx.push_back(c);
     return c;
 }
-void host_release(HostCtx* c) { std::lock_guard<std::mutex> lk(g_host_mu); c->busy = false; }
+// A context keeps its buffers for the next call of the same size class; what a single huge call needed is given back at
+// once (a co-resident process should not find several GiB of HBM pinned by a call that returned long ago).
+constexpr size_t kHostCtxKeepBytes = (size_t)256 << 20;
+void host_release(HostCtx* c)
+{
+    if (c->srcCap > kHostCtxKeepBytes) { (void)hipFree(c->dsrc); c->dsrc = nullptr; c->srcCap = 0; }
+    if (c->dstCap > kHostCtxKeepBytes) { (void)hipFree(c->ddst); c->ddst = nullptr; c->dstCap = 0; }
+    std::lock_guard<std::mutex> lk(g_host_mu); c->busy = false;
+}
 
 bool host_grow(uint8_t** p, size_t* cap, size_t need)
 {
@@ -347,6 +355,18 @@ bool host_grow(uint8_t** p, size_t* cap, size_t need)
     return true;
 }
 }  // namespace
+
+// Frees the device buffers of every idle host context (aocl_llc_destroy calls it); contexts in use keep theirs.
+extern "C" void aoclgpu_host_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (HostCtx* c : g_host_ctx) {
+        if (c->busy) continue;
+        DeviceScope ds(c->dev);
+        if (c->dsrc) { (void)hipFree(c->dsrc); c->dsrc = nullptr; c->srcCap = 0; }
+        if (c->ddst) { (void)hipFree(c->ddst); c->ddst = nullptr; c->dstCap = 0; }
+    }
+}
 
 extern "C" int aoclgpu_set_host_device(int device)
 {
@@ -364,8 +384,9 @@ static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_
     if ((!hsrc && n) || !hdst || n > 0xFFFFFFFFull) { set_error_msg("host one-shot: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     if (cap > 0xFFFFFFFFull) cap = 0xFFFFFFFFull;
     const int dev = host_device();
-    hipError_t e = hipSetDevice(dev);
-    if (e != hipSuccess) { set_error("hipSetDevice", e); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    DeviceScope devScope(dev);
+    hipError_t e = hipSuccess;
+    if (!devScope.ok) { set_error_msg("host one-shot: hipSetDevice failed"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     HostCtx* c = host_acquire(dev);
     if (!c) { set_error_msg("host one-shot: no context (stream / pinned memory allocation failed)"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
     int64_t result = AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;

@@ -12,4 +12,12 @@ int check_launch(const char* kernel);
 // The caller holds a WsGuard from before this call until its kernel is enqueued (see capi.hip).
 struct WsGuard { WsGuard(); ~WsGuard(); WsGuard(const WsGuard&) = delete; WsGuard& operator=(const WsGuard&) = delete; };
 void* get_workspace(const WsGuard& held, size_t bytes, void* stream);
+// The host-buffer entry points work on aoclgpu_host_device(); the calling thread's current device is put back when they
+// return (a caller that drives another GPU with its own HIP code must not find it changed under its feet).
+struct DeviceScope {
+    int prev = -1; bool ok = false;
+    explicit DeviceScope(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; ok = hipSetDevice(dev) == hipSuccess; if (prev == dev) prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete; DeviceScope& operator=(const DeviceScope&) = delete;
+};
 }  // namespace aoclgpu

@@ -266,6 +266,41 @@ extern "C" int aoclgpu_rap_assemble(aoclgpu_codec codec, const uint8_t* gathered
     return rap_join(codec, nchunks, chunk_len, chunk_src_len, chunk_aux, chunk_off, gathered, out, cap, stream_bytes, s);
 }
 
+// The whole sharded stream as the SEQUENCE of RAP streams the formats allow: a RAP frame holds 32-bit offsets and a 16-bit
+// partition count (threads/threads.h:77-106), and the reference's own bench feeds its codecs slabs of at most 1 GiB
+// (MAX_MEM_SIZE_FOR_FILE_READ, test/codec_bench.h:58).  Consecutive chunks are grouped into slabs of at most `slab_src_bytes`
+// source bytes (0 = 1 GiB; at most 2 GiB - 1) and 65535 partitions; every slab is one aoclgpu_rap_assemble stream, the
+// streams are written back to back into `out`.  slab_off[0 .. *nslabs] (host, room for max_slabs + 1 entries) = their
+// offsets in `out`; slab_first[0 .. *nslabs] = the first chunk of each slab.  A decoder walks the slabs with
+// aoclgpu_rap_unpack / the reference's MT decoders, one call per slab.
+extern "C" int aoclgpu_rap_assemble_slabs(aoclgpu_codec codec, const uint8_t* gathered, const uint64_t* chunk_off, const int32_t* chunk_len,
+                                          const uint32_t* chunk_src_len, const uint32_t* chunk_aux, uint64_t nchunks, uint64_t slab_src_bytes,
+                                          uint8_t* out, uint64_t cap, uint64_t* slab_off, uint64_t* slab_first, uint32_t max_slabs, uint32_t* nslabs,
+                                          void* stream)
+{
+    if (!gathered || !chunk_off || !chunk_len || !chunk_src_len || !out || !slab_off || !slab_first || !nslabs || nchunks == 0) {
+        set_error_msg("rap_assemble_slabs: NULL argument / no chunks"); return AOCLGPU_ERR_ARG;
+    }
+    if (slab_src_bytes == 0) slab_src_bytes = 1ull << 30;
+    if (slab_src_bytes > 0x7FFFFFFFull) { set_error_msg("rap_assemble_slabs: a slab holds at most 2 GiB - 1 of source (32-bit RAP fields)"); return AOCLGPU_ERR_ARG; }
+    uint64_t pos = 0, first = 0; uint32_t k = 0;
+    while (first < nchunks) {
+        uint64_t last = first, bytes = 0;
+        while (last < nchunks && last - first < 65535 && bytes + chunk_src_len[last] <= slab_src_bytes) { bytes += chunk_src_len[last]; ++last; }
+        if (last == first) { set_error_msg("rap_assemble_slabs: a chunk is larger than a slab"); return AOCLGPU_ERR_ARG; }
+        if (k >= max_slabs) { set_error_msg("rap_assemble_slabs: more slabs than max_slabs"); return AOCLGPU_ERR_ARG; }
+        uint64_t sb = 0;
+        const int rc = aoclgpu_rap_assemble(codec, gathered, chunk_off + first, chunk_len + first, chunk_src_len + first,
+                                            chunk_aux ? chunk_aux + first : nullptr, (uint32_t)(last - first), out + pos, cap - pos, &sb, stream);
+        if (rc) return rc;
+        slab_off[k] = pos; slab_first[k] = first;
+        pos += sb; first = last; ++k;
+    }
+    slab_off[k] = pos; slab_first[k] = nchunks;
+    *nslabs = k;
+    return AOCLGPU_OK;
+}
+
 extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream);
 extern "C" int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
 extern "C" int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
@@ -348,8 +383,16 @@ extern "C" uint64_t aoclgpu_rap_default_chunk(aoclgpu_codec codec)
     return codec == AOCLGPU_LZ4 ? (256u << 10) : (codec == AOCLGPU_SNAPPY ? (64u << 10) : (128u << 10));
 }
 
+extern "C" int64_t aoclgpu_rap_compress_host_ex(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap,
+                                                uint64_t chunk_bytes, uint32_t flags);
 extern "C" int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap,
                                              uint64_t chunk_bytes)
+{
+    return aoclgpu_rap_compress_host_ex(codec, hsrc, n, hdst, cap, chunk_bytes, 0);
+}
+// flags: the codec's AOCLGPU_FLAG_* / AOCLGPU_ZSTD_LEVEL(l) / AOCLGPU_LZ4_ACCELERATION(a) for every partition
+extern "C" int64_t aoclgpu_rap_compress_host_ex(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap,
+                                                uint64_t chunk_bytes, uint32_t flags)
 {
     if ((!hsrc && n) || !hdst || n > 0x7FFFFFFFull) { set_error_msg("rap_compress_host: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     if (chunk_bytes == 0) chunk_bytes = aoclgpu_rap_default_chunk(codec);
@@ -367,7 +410,7 @@ extern "C" int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* hs
     if (n) HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
     aoclgpu_batch b; memset(&b, 0, sizeof(b));
     b.src = (const uint8_t*)dsrc.p; b.dst = (uint8_t*)dslots.p; b.out_len = (int32_t*)dlen.p; b.aux = (uint32_t*)daux.p;
-    b.nchunks = (uint32_t)K; b.total_bytes = n; b.chunk_bytes = chunk_bytes; b.slot_bytes = slot;
+    b.nchunks = (uint32_t)K; b.total_bytes = n; b.chunk_bytes = chunk_bytes; b.slot_bytes = slot; b.reserved = flags;
     int rc = codec == AOCLGPU_LZ4 ? aoclgpu_lz4_compress_chunks(&b, nullptr)
            : codec == AOCLGPU_SNAPPY ? aoclgpu_snappy_compress_chunks(&b, nullptr) : aoclgpu_zstd_compress_chunks(&b, nullptr);
     if (rc) return AOCLGPU_HOST_FAIL + rc;
@@ -409,7 +452,8 @@ extern "C" int64_t aoclgpu_zstd_compress_host_frames(const void* hsrc, size_t n,
     const uint64_t K = (n + chunk - 1) / chunk;
     if (K > 0xFFFFFFFFull) { set_error_msg("zstd frames: input too large"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     const uint64_t slot = (aoclgpu_compress_bound(AOCLGPU_ZSTD, chunk) + 15) & ~(uint64_t)15;
-    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     DevBuf dsrc, dslots, dlen, doff, dout;
     if (!dsrc.alloc(n) || !dslots.alloc(K * slot) || !dlen.alloc(K * 4) || !doff.alloc((K + 1) * 8) || !dout.alloc(K * slot)) {
         set_error_msg("zstd frames: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
@@ -535,6 +579,11 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     bool sized = split && fr.size() >= 2;
     if (sized) for (const FrameSpan& f : fr) sized = sized && f.content >= 0;
     if (!sized) {                                             // one wavefront walks the stream
+        if (split && !fr.empty()) {                           // a known content size that does not fit: dstSize_tooSmall, as the reference says
+            bool known = true; uint64_t tot = 0;
+            for (const FrameSpan& f : fr) { known = known && f.content >= 0; tot += f.content >= 0 ? (uint64_t)f.content : 0; }
+            if (known && tot > cap) return -2;
+        }
         const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
         if (r >= 0 && split && !checksums_ok(fr, (const uint8_t*)hdst, (size_t)r)) return -1;   // checksum_wrong (zstd_decompress.c:1094)
         return r;
@@ -544,7 +593,8 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     std::vector<uint64_t> soff(K), doff(K); std::vector<uint32_t> slen(K), dcap(K);
     for (size_t k = 0; k < K; ++k) { soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = total; dcap[k] = (uint32_t)fr[k].content; total += (uint64_t)fr[k].content; }
     if (total > cap) return -2;
-    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     DevBuf dsrc, ddst, a, bq, c, d, o;
     if (!dsrc.alloc(n) || !ddst.alloc(total) || !a.alloc(K * 8) || !bq.alloc(K * 4) || !c.alloc(K * 8) || !d.alloc(K * 4) || !o.alloc(K * 4)) {
         set_error_msg("zstd frames: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
@@ -577,7 +627,8 @@ extern "C" int64_t aoclgpu_zstd_compress_host_frame(const void* hsrc, size_t n, 
                                                     uint32_t minMatch, uint32_t targetLength, uint32_t checksumFlag)
 {
     if ((!hsrc && n) || !hdst || n >= ((size_t)1 << 31)) { set_error_msg("zstd frame: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
-    if (hipSetDevice(aoclgpu_host_device()) != hipSuccess) { set_error_msg("zstd frame: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("zstd frame: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     const size_t tail = checksumFlag ? 4 : 0;
     if (cap < tail) return 0;
     const size_t bound = aoclgpu_compress_bound(AOCLGPU_ZSTD, n) + 32, room = cap - tail < bound ? cap - tail : bound;
@@ -604,6 +655,57 @@ extern "C" int64_t aoclgpu_zstd_compress_host_frame(const void* hsrc, size_t n, 
         r += 4;
     }
     return r;
+}
+
+
+// Zstd RAP stream in the REFERENCE'S partition geometry, host buffers: what ZSTD_compress_advanced of the AOCL_ENABLE_THREADS build
+// writes when `nparts` threads take part (zstd_compress.c:5410-5522): partition t covers src[t * (n / nparts), ...) and the last
+// one takes the n % nparts leftover bytes (threads/threads.c:121-136), every partition becomes one frame with the caller's
+// compression parameters (one wavefront each, side by side), the frames travel behind the RAP frame in a skippable frame.
+// nparts = 1: a plain frame, no RAP frame (:5429-5437).  Returns the stream size, 0 when it does not fit, < 0 on failure.
+extern "C" int64_t aoclgpu_zstd_rap_compress_host_parts(const void* hsrc, size_t n, void* hdst, size_t cap, uint32_t nparts,
+                                                        uint32_t strategy, uint32_t windowLog, uint32_t hashLog, uint32_t chainLog,
+                                                        uint32_t minMatch, uint32_t targetLength)
+{
+    if ((!hsrc && n) || !hdst || n >= ((size_t)1 << 31) || nparts == 0 || nparts > 65535 || nparts > (n ? n : 1)) {
+        set_error_msg("zstd rap parts: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG;
+    }
+    if (nparts == 1) return aoclgpu_zstd_compress_host_frame(hsrc, n, hdst, cap, strategy, windowLog, hashLog, chainLog, minMatch, targetLength, 0);
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("zstd rap parts: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    const uint32_t K = nparts;
+    const uint64_t common = n / K, left = n % K;
+    std::vector<uint64_t> soff(K + 1), doff(K + 1);
+    std::vector<uint32_t> slen(K);
+    uint64_t dpos = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        soff[k] = common * k; slen[k] = (uint32_t)(common + (k == K - 1 ? left : 0));
+        doff[k] = dpos; dpos += (aoclgpu_compress_bound(AOCLGPU_ZSTD, slen[k]) + 32 + 15) & ~(uint64_t)15;
+    }
+    soff[K] = n; doff[K] = dpos;
+    const uint64_t scap = aoclgpu_rap_frame_bytes(AOCLGPU_ZSTD, K) + dpos + 64;
+    DevBuf dsrc, dfr, dmeta, dout;
+    if (!dsrc.alloc(n) || !dfr.alloc(dpos) || !dmeta.alloc((size_t)(3 * K + 2) * 8) || !dout.alloc(scap)) { set_error_msg("zstd rap parts: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    HCK(hipMemcpy(dmeta.p, soff.data(), (size_t)(K + 1) * 8, hipMemcpyHostToDevice));
+    HCK(hipMemcpy((uint64_t*)dmeta.p + K + 1, doff.data(), (size_t)(K + 1) * 8, hipMemcpyHostToDevice));
+    aoclgpu_zstd_frames f; memset(&f, 0, sizeof(f));
+    f.src = (const uint8_t*)dsrc.p; f.dst = (uint8_t*)dfr.p;
+    f.src_off = (const uint64_t*)dmeta.p; f.dst_off = (const uint64_t*)dmeta.p + K + 1; f.out_len = (int64_t*)dmeta.p + 2 * K + 2;
+    f.nframes = K; f.windowLog = windowLog; f.hashLog = hashLog; f.minMatch = minMatch; f.targetLength = targetLength;
+    f.strategy = strategy; f.chainLog = chainLog;
+    int rc = aoclgpu_zstd_compress_frames(&f, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    std::vector<int64_t> ol(K);
+    HCK(hipMemcpy(ol.data(), (const int64_t*)dmeta.p + 2 * K + 2, (size_t)K * 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> clen(K);
+    for (uint32_t k = 0; k < K; ++k) { if (ol[k] <= 0) { set_error_msg("zstd rap parts: a partition did not compress"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; } clen[k] = (int32_t)ol[k]; }
+    uint64_t bytes = 0;
+    rc = aoclgpu_rap_assemble(AOCLGPU_ZSTD, (const uint8_t*)dfr.p, doff.data(), clen.data(), slen.data(), nullptr, K, (uint8_t*)dout.p, scap, &bytes, nullptr);
+    if (rc) return AOCLGPU_HOST_FAIL + rc;
+    if (bytes > cap) return 0;
+    HCK(hipMemcpy(hdst, dout.p, bytes, hipMemcpyDeviceToHost));
+    return (int64_t)bytes;
 }
 
 #undef HCK

@@ -3,16 +3,24 @@
 // ZSTD_getParams / ZSTD_CCtx_setParameter / ZSTD_compress_advanced / ZSTD_decompressDCtx) and the parameter tables.
 // Host buffers, no CPU fallback.
 //
-// What has a GPU backend: the "fast" and "double-fast" strategies with the parameters of levels 1-4 (clevels.h:24-130,
-// 155-262; level 0 is the default, 3), single-segment frames with a content size and no checksum.  Inputs of at most 128 KiB give the reference's bytes (one block per
-// frame).  Larger inputs are cut into 128 KiB pieces that become independent frames, concatenated: a valid Zstandard
-// stream that every decoder reads (ZSTD_decompress handles multi-frame input, zstd_decompress.c:1113), but NOT the
-// reference's bytes, which come from one multi-block frame with a window across blocks (deviations).
-// Anything else (other strategies, dictionaries, checksums, window below the input size) returns
-// ZSTD_error_parameter_unsupported instead of silently compressing differently.
+// What has a GPU backend: the "fast" and "double-fast" strategies (the parameters of levels 1-4 and of level -1, clevels.h:24-130,
+// 155-262, or any explicit parameter set of those strategies: hashLog / chainLog <= 24, minMatch 3-7, fast with targetLength
+// 0-1), with or without a content checksum, windows above or below the input size.  Inputs of at most 128 KiB with a
+// level's own parameters are one block per frame on the chunk kernels; everything else - above all inputs LARGER than
+// 128 KiB - is ONE frame of blocks, byte-identical to the reference's ZSTD_compress_advanced, written by one wavefront
+// (aoclgpu_zstd_compress_frames): correct and slow, a few MiB/s for a lone input.  The opt-out for bulk callers is
+// aoclgpu_zstd_set_large_input_mode(1) / AOCLGPU_ZSTD_LARGE_INPUTS=pieces: 128 KiB pieces as concatenated frames side by
+// side (a valid stream for every Zstd decoder, not the reference's bytes).  Other strategies, dictionaries and frames without a
+// content size return ZSTD_error_parameter_unsupported instead of silently compressing differently.
+//
+// Level tables as in the reference (zstd_compress.c:72, 7390-7463, clevels.h:262): a process starts on the UPSTREAM table;
+// the first compress-side entry point (or aocl_setup_zstd_encode) runs the dispatcher once, which installs the AOCL table
+// unless optimisations are off (optOff / AOCL_DISABLE_OPT=ON); later setups are ignored until aocl_destroy_zstd_encode
+// clears the "set up" flag - which leaves the table where it was.
 #include "../../include/aocl_native_api.h"
 #include "../../include/aocl_gpu_codec.h"
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -20,7 +28,7 @@
 
 namespace {
 size_t zerr(int code) { return (size_t)0 - (size_t)code; }
-enum { kErrGeneric = 1, kErrPrefix = 10, kErrCorrupt = 20, kErrParamUnsupported = 40, kErrParamOutOfBound = 42,
+enum { kErrGeneric = 1, kErrPrefix = 10, kErrFrameParamUnsupported = 14, kErrFrameWindowTooLarge = 16, kErrCorrupt = 20, kErrParamUnsupported = 40, kErrParamOutOfBound = 42,
        kErrMemory = 64, kErrDstTooSmall = 70, kErrSrcSize = 72, kErrDstNull = 74, kErrMax = 120 };   // zstd_errors.h:58-100
 
 // {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy} for level rows 0..22 of the four size
@@ -81,7 +89,24 @@ const uint16_t kLevelRows[2][4][23][7] = {
     },
   },
 };
-std::atomic<int> g_aocl_table{1};      // aocl_setup_zstd_encode(optOff = 1, ..) selects the upstream table, as in the reference
+std::atomic<int> g_aocl_table{0};      // AOCL_ZSTD_defaultCParameters_used: starts on the upstream table (clevels.h:262)
+std::atomic<int> g_setup_ok{0};        // setup_ok_zstd_encode (zstd_compress.c:72)
+std::mutex g_setup_mu;
+
+bool disable_opt_env()
+{   // get_disable_opt_flags (utils/utils.cpp:207-219)
+    const char* e = getenv("AOCL_DISABLE_OPT");
+    return e && strcmp(e, "ON") == 0;
+}
+void dispatcher_setup(int optOff)
+{   // aocl_setup_zstd_encode / aocl_setup_native (zstd_compress.c:7429-7457): once, until aocl_destroy_zstd_encode
+    std::lock_guard<std::mutex> lk(g_setup_mu);
+    if (g_setup_ok.load()) return;
+    const bool off = optOff ? true : disable_opt_env();
+    g_aocl_table.store(off ? 0 : 1);   // aocl_register_zstd_compress_fmv (:7390-7425), a build with AOCL_ZSTD_OPT
+    g_setup_ok.store(1);
+}
+void setup_native() { dispatcher_setup(0); }       // AOCL_SETUP_NATIVE() at the top of every compress-side entry point
 
 unsigned highbit(uint32_t v) { unsigned r = 0; while (v >>= 1) r++; return r; }
 
@@ -195,6 +220,10 @@ struct ZSTD_DCtx_s { int unused; };
 
 extern "C" {
 
+// for the unified API's threaded branch (aocl_api.cpp): run the dispatcher as a compress entry point does, and tell which
+// level table is installed (1 = AOCL, 0 = upstream)
+int aoclgpu_zstd_level_table(void) { setup_native(); return g_aocl_table.load(); }
+
 void aoclgpu_zstd_set_large_input_mode(int pieces) { g_large_input_mode.store(pieces ? 1 : 0); }
 int aoclgpu_zstd_large_input_mode(void) { return large_input_mode(); }
 
@@ -214,6 +243,8 @@ const char* ZSTD_getErrorName(size_t code)
     if (!ZSTD_isError(code)) return "No error detected";
     switch ((int)((size_t)0 - code)) {
     case kErrPrefix: return "Unknown frame descriptor";
+    case kErrFrameParamUnsupported: return "Unsupported frame parameter";
+    case kErrFrameWindowTooLarge: return "Frame requires too much memory for decoding";
     case kErrCorrupt: return "Data corruption detected";
     case kErrParamUnsupported: return "Unsupported parameter";
     case kErrParamOutOfBound: return "Parameter is out of bound";
@@ -263,6 +294,7 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, ZSTD_cParameter param, int value)
 size_t ZSTD_compress_advanced(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                               const void* dict, size_t dictSize, ZSTD_parameters params)
 {   // zstd_compress.c:5388-5408
+    setup_native();
     if (!cctx || (!src && srcSize > 0)) return zerr(kErrGeneric);
     if (!dst) return zerr(kErrDstNull);
     if (dict && dictSize) return zerr(kErrParamUnsupported);
@@ -271,6 +303,7 @@ size_t ZSTD_compress_advanced(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, co
 
 size_t ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
 {   // zstd_compress.c:5519-5531
+    setup_native();
     if (!cctx || (!src && srcSize > 0)) return zerr(kErrGeneric);
     if (!dst) return zerr(kErrDstNull);
     const ZSTD_parameters p = ZSTD_getParams(level, srcSize, 0);
@@ -279,6 +312,7 @@ size_t ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const v
 
 size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
 {   // zstd_compress.c:5534-5560
+    setup_native();
     if (!src && srcSize > 0) return zerr(kErrGeneric);
     if (!dst) return zerr(kErrDstNull);
     const ZSTD_parameters p = ZSTD_getParams(level, srcSize, 0);
@@ -290,6 +324,7 @@ size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t co
     if ((!dst && dstCapacity) || !src) return zerr(kErrGeneric);
     const int64_t r = aoclgpu_zstd_decompress_host_frames(src, compressedSize, dst ? dst : (void*)"", dstCapacity);
     if (r >= 0) return (size_t)r;
+    if (r <= AOCLGPU_HOST_FAIL / 2) return zerr(kErrGeneric);         // the GPU path itself failed (no device, allocation, launch)
     return zerr(r == -2 ? kErrDstTooSmall : kErrCorrupt);
 }
 size_t ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
@@ -312,6 +347,7 @@ unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
     const size_t fl = (fcsID == 0) ? (single ? 1 : 0) : fcs[fcsID];
     if (fhd & 0x08) return kError;                                    // reserved bit
     if (srcSize < pos + fl) return kError;
+    if (!single && (uint32_t)(p[5] >> 3) + 10 > 31) return kError;    // windowLog above ZSTD_WINDOWLOG_MAX (zstd_decompress.c:516-521)
     if (fl == 0) return kUnknown;
     unsigned long long v = 0;
     for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
@@ -336,6 +372,8 @@ static size_t first_frame_size(const uint8_t* p, size_t n, unsigned long long* c
     size_t pos = 5 + (single ? 0 : 1) + (did == 3 ? 4 : did);
     const size_t fl = fcsId == 0 ? (single ? 1 : 0) : (fcsId == 1 ? 2 : (fcsId == 2 ? 4 : 8));
     if (pos + fl > n) return zerr(kErrSrcSize);
+    if (fhd & 0x08) return zerr(kErrFrameParamUnsupported);           // reserved bit (ZSTD_getFrameHeader_advanced, zstd_decompress.c:500-502)
+    if (!single && (uint32_t)(p[5] >> 3) + 10 > 31) return zerr(kErrFrameWindowTooLarge);   // (:516-521)
     if (content && fl) {
         unsigned long long v = 0;
         for (size_t i = 0; i < fl; ++i) v |= (unsigned long long)p[pos + i] << (8 * i);
@@ -392,17 +430,18 @@ size_t ZSTD_CCtx_reset(ZSTD_CCtx* c, ZSTD_ResetDirective reset)
 size_t ZSTD_DCtx_reset(ZSTD_DCtx* d, ZSTD_ResetDirective) { return d ? 0 : zerr(kErrGeneric); }
 size_t ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {   // zstd_compress.c:6333-6360
+    setup_native();
     if (!cctx || (!src && srcSize > 0)) return zerr(kErrGeneric);
     if (!dst) return zerr(kErrDstNull);
     const ZSTD_parameters p = ZSTD_getParams(cctx->level, srcSize, 0);
     return compress_with(p.cParams, cctx->f, dst, dstCapacity, src, srcSize);
 }
 
-// the reference's dispatcher hooks (zstd.h:423-452): there is no host ISA variant to pick here; optOff selects the
-// upstream parameter table instead of the AOCL one exactly as zstd_compress.c:7390-7425 does
-char* aocl_setup_zstd_encode(int optOff, int, size_t, size_t, size_t) { g_aocl_table.store(optOff ? 0 : 1); return nullptr; }
+// the reference's dispatcher hooks (zstd.h:423-452): there is no host ISA variant to pick here; the dispatcher's one
+// visible effect - which level table ZSTD_getCParams reads - follows zstd_compress.c:7390-7463 (see the top of this file)
+char* aocl_setup_zstd_encode(int optOff, int, size_t, size_t, size_t) { dispatcher_setup(optOff); return nullptr; }
 char* aocl_setup_zstd_decode(int, int, size_t, size_t, size_t) { return nullptr; }
-void aocl_destroy_zstd_encode(void) { g_aocl_table.store(1); }
+void aocl_destroy_zstd_encode(void) { std::lock_guard<std::mutex> lk(g_setup_mu); g_setup_ok.store(0); }   // (the table stays, :7459-7463)
 void aocl_destroy_zstd_decode(void) {}
 
 }  // extern "C"

@@ -222,6 +222,33 @@ uint64_t aoclgpu_rap_default_chunk(aoclgpu_codec codec);
 int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap,
                                   uint64_t chunk_bytes);
 int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);
+/* the same with the codec's per-launch flags for every partition (AOCLGPU_ZSTD_LEVEL(2..4), AOCLGPU_LZ4_ACCELERATION(a), ...) */
+int64_t aoclgpu_rap_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap,
+                                     uint64_t chunk_bytes, uint32_t flags);
+/* Zstd RAP stream in the REFERENCE'S partition geometry (host buffers): the bytes ZSTD_compress_advanced of the reference's
+ * AOCL_ENABLE_THREADS build writes when `nparts` threads take part (zstd_compress.c:5410-5522, threads/threads.c:46-136):
+ * nparts partitions of n / nparts bytes, the last one with the leftover, each ONE frame with the given parameters (one
+ * wavefront per partition), joined behind the RAP frame.  Correct for every fast / double-fast parameter set, slow by
+ * construction (few, large partitions): bulk callers use aoclgpu_rap_compress_host_ex (128 KiB partitions).
+ * Returns the stream size, 0 when it does not fit `cap`, <= AOCLGPU_HOST_FAIL / 2 on a GPU failure. */
+int64_t aoclgpu_zstd_rap_compress_host_parts(const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t nparts,
+                                             uint32_t strategy, uint32_t windowLog, uint32_t hashLog, uint32_t chainLog,
+                                             uint32_t minMatch, uint32_t targetLength);
+/* aoclgpu_rap_assemble_slabs: a stream of ANY length as the sequence of RAP streams the container allows (32-bit offsets,
+ * 16-bit partition count: threads/threads.h:77-106; the reference's bench cuts its input into slabs the same way,
+ * test/codec_bench.h:58).  Consecutive chunks are grouped into slabs of at most slab_src_bytes source bytes (0 = 1 GiB, at
+ * most 2 GiB - 1) and 65535 partitions; every slab is one aoclgpu_rap_assemble stream, written back to back into stream_out.
+ * slab_off[0 .. *nslabs] = their offsets in stream_out, slab_first[0 .. *nslabs] = the first chunk of each (host arrays with
+ * room for max_slabs + 1 entries).  The per-chunk arrays are host arrays as for aoclgpu_rap_assemble. */
+/* aocl_llc_compress(ZSTD) with numThreads > 1: 0 (default) = 128 KiB partitions (the GPU's geometry), 1 = the reference's
+ * geometry (aoclgpu_zstd_rap_compress_host_parts with the partition count threads/threads.c computes for numThreads);
+ * the environment variable AOCLGPU_RAP_GEOMETRY=reference selects 1 at start-up. */
+void aoclgpu_set_rap_geometry(int reference);
+int aoclgpu_rap_geometry(void);
+int aoclgpu_rap_assemble_slabs(aoclgpu_codec codec, const uint8_t* gathered, const uint64_t* chunk_off, const int32_t* chunk_len,
+                               const uint32_t* chunk_src_len, const uint32_t* chunk_aux, uint64_t nchunks, uint64_t slab_src_bytes,
+                               uint8_t* stream_out, uint64_t stream_cap, uint64_t* slab_off, uint64_t* slab_first, uint32_t max_slabs,
+                               uint32_t* nslabs, void* stream);
 
 /* Timing helper used by bench.py: runs `iters` back-to-back launches of one batch op on `stream`
  * bracketed by HIP events recorded on that same stream; returns the average milliseconds per launch
@@ -259,6 +286,9 @@ int64_t aoclgpu_zstd_decompress_host_frames(const void* host_src, size_t n, void
  * or the environment variable AOCLGPU_DEVICE read at first use. */
 int aoclgpu_set_host_device(int device);
 int aoclgpu_host_device(void);
+/* The host-buffer entry points keep their device staging buffers between calls (up to 256 MiB each; larger ones are freed when
+ * the call returns).  aoclgpu_host_trim frees those of every idle context; aocl_llc_destroy calls it. */
+void aoclgpu_host_trim(void);
 
 int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);

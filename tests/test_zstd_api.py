@@ -314,3 +314,54 @@ def test_frame_inspection_equals_the_reference(lib, reflib):
                 assert lib.ZSTD_isError(got), (name, len(blob))                    # both refuse (error codes may differ)
             else:
                 assert got == want, (name, len(blob), got, want)
+
+
+# ---- the dispatcher's state machine, in FRESH processes, against the reference (zstd_compress.c:72, 7429-7463) ----
+_SEQ_DRIVER = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import test_zstd_api as t
+L = t._bind(C.CDLL(sys.argv[2]))
+out = []
+buf = C.create_string_buffer(4096); src = b"abcdefgh" * 64
+def probe():
+    p3 = L.ZSTD_getCParams(3, 1 << 20, 0); p4 = L.ZSTD_getCParams(4, 100 << 20, 0)
+    out.append([p3.chainLog, p4.windowLog, p4.chainLog])
+for op in json.loads(sys.argv[3]):
+    if op == "probe": probe()
+    elif op == "compress": L.ZSTD_compress(buf, 4096, src, len(src), 1)           # (may fail without a GPU: the dispatcher ran first)
+    elif op == "cctx": c = L.ZSTD_createCCtx(); L.ZSTD_compressCCtx(c, buf, 4096, src, len(src), 1); L.ZSTD_freeCCtx(c)
+    elif op == "setup0": L.aocl_setup_zstd_encode(0, 0, 0, 0, 0)
+    elif op == "setup1": L.aocl_setup_zstd_encode(1, 0, 0, 0, 0)
+    elif op == "destroy": L.aocl_destroy_zstd_encode()
+print(json.dumps(out))
+'''
+
+SEQUENCES = [
+    ["probe"],                                                     # a fresh process reads the upstream table
+    ["probe", "compress", "probe"],                                # the first compress entry installs the AOCL table
+    ["setup1", "probe", "setup0", "probe"],                        # a second setup is ignored while set up
+    ["setup1", "destroy", "probe", "setup0", "probe"],             # destroy clears the flag, not the table
+    ["compress", "setup1", "probe", "destroy", "setup1", "probe"], # setup after a native compress is ignored until destroy
+    ["cctx", "probe", "destroy", "probe"],
+]
+
+
+@pytest.mark.parametrize("seq", SEQUENCES, ids=["-".join(s) for s in SEQUENCES])
+@pytest.mark.parametrize("env_off", [False, True], ids=["opt", "AOCL_DISABLE_OPT"])
+def test_level_table_state_follows_the_reference(seq, env_off):
+    import json, os, subprocess, sys
+    if not ol.have_ref():
+        pytest.skip("reference build (oracle/_ref) not available")
+    env = dict(os.environ)
+    env.pop("AOCL_DISABLE_OPT", None)
+    if env_off:
+        env["AOCL_DISABLE_OPT"] = "ON"
+    env["HIP_VISIBLE_DEVICES"] = ""                                 # host logic only: same result with or without a GPU
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for so in (api.lib_path(), ol.REF_SO):
+        p = subprocess.run([sys.executable, "-c", _SEQ_DRIVER, root, so, json.dumps(seq)], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-500:]
+        res.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1], f"{seq}: library {res[0]} reference {res[1]}"
