@@ -95,6 +95,8 @@ EXPORTS = [
     "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode", "aoclgpu_lz4f_set_block_linking", "aoclgpu_lz4f_block_linking",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
     "aoclgpu_probe_copy", "aoclgpu_probe_scatter8", "aoclgpu_host_trim",
+    "aoclgpu_rap_compress_host_ex", "aoclgpu_zstd_rap_compress_host_parts", "aoclgpu_rap_assemble_slabs", "aoclgpu_set_rap_geometry", "aoclgpu_rap_geometry",
+    "aoclgpu_comm_unique_id", "aoclgpu_comm_create", "aoclgpu_comm_destroy", "aoclgpu_exchange_segments", "aoclgpu_allgather_words",
 ]
 
 
@@ -116,6 +118,17 @@ def load_library() -> C.CDLL:
     lib.aoclgpu_compact_slots.restype = C.c_int
     lib.aoclgpu_compact_slots.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.aoclgpu_time_batch.restype = C.c_double
+    lib.aoclgpu_comm_unique_id.argtypes = [C.c_void_p]
+    lib.aoclgpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.aoclgpu_comm_destroy.argtypes = [C.c_void_p]
+    lib.aoclgpu_exchange_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.aoclgpu_allgather_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    lib.aoclgpu_rap_assemble_slabs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    lib.aoclgpu_rap_compress_host_ex.restype = C.c_int64
+    lib.aoclgpu_rap_compress_host_ex.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32]
+    lib.aoclgpu_zstd_rap_compress_host_parts.restype = C.c_int64
+    lib.aoclgpu_zstd_rap_compress_host_parts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.c_uint32] * 7
     lib.aoclgpu_probe_copy.restype = C.c_double
     lib.aoclgpu_probe_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     lib.aoclgpu_probe_scatter8.restype = C.c_double
@@ -295,6 +308,29 @@ class Engine:
                                                   C.byref(n), self._stream()), "rap_assemble")
         return out[:n.value]
 
+    def rap_assemble_slabs(self, codec: int, gathered, chunk_off, chunk_len, chunk_src_len, chunk_aux=None, slab_src_bytes: int = 0):
+        """A stream of any length as the sequence of RAP streams the container allows (aoclgpu_rap_assemble_slabs).
+        Returns (device tensor holding the slab streams back to back, slab offsets (nslabs + 1), first chunk of each slab)."""
+        import numpy as np
+        t = self.torch
+        k = len(chunk_len)
+        off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        ln = np.ascontiguousarray(chunk_len, dtype=np.int32)
+        sl = np.ascontiguousarray(chunk_src_len, dtype=np.uint32)
+        ax = np.ascontiguousarray(chunk_aux, dtype=np.uint32) if chunk_aux is not None else None
+        slab = slab_src_bytes or (1 << 30)
+        max_slabs = int(sl.astype(np.uint64).sum() // max(1, slab - int(sl.max()))) + k // 65535 + 4
+        cap = int(ln.clip(min=0).astype(np.int64).sum()) + 16 * k + (64 + int(self.lib.aoclgpu_rap_frame_bytes(codec, 65535))) * max_slabs
+        out = t.empty(cap, dtype=t.uint8, device=self.device)
+        so = np.zeros(max_slabs + 1, np.uint64)
+        sf = np.zeros(max_slabs + 1, np.uint64)
+        ns = C.c_uint32(0)
+        self._check(self.lib.aoclgpu_rap_assemble_slabs(codec, gathered.data_ptr(), off.ctypes.data, ln.ctypes.data, sl.ctypes.data,
+                                                        ax.ctypes.data if ax is not None else None, k, slab, out.data_ptr(), cap,
+                                                        so.ctypes.data, sf.ctypes.data, max_slabs, C.byref(ns), self._stream()), "rap_assemble_slabs")
+        n = ns.value
+        return out[:int(so[n])], [int(x) for x in so[:n + 1]], [int(x) for x in sf[:n + 1]]
+
     def zstd_compress_frames(self, src, src_off, window_log: int, hash_log: int, min_match: int, caps=None, target_length: int = 0,
                              strategy: int = 1, chain_log: int = 0, flags: int = 0):
         """One Zstd frame per input of any size (aoclgpu_zstd_compress_frames): `src` is a device uint8 tensor, `src_off` a
@@ -351,11 +387,11 @@ class Engine:
         return out.raw[:r] if r >= 0 else None
 
     # ---- unified API (aocl_llc_*) on host buffers ----
-    def llc_compress(self, codec: int, data: bytes, cap: int, level: int = 1, stats: bool = False):
+    def llc_compress(self, codec: int, data: bytes, cap: int, level: int = 1, stats: bool = False, num_threads: int = 0, opt_var: int = 0):
         out = C.create_string_buffer(max(cap, 1))
         inb = C.create_string_buffer(data, len(data)) if data else None
         d = LlcDesc(inBuf=C.cast(inb, C.c_void_p) if inb else None, outBuf=C.cast(out, C.c_void_p), inSize=len(data),
-                    outSize=cap, level=level, measureStats=1 if stats else 0)
+                    outSize=cap, level=level, measureStats=1 if stats else 0, numThreads=num_threads, optVar=opt_var)
         r = self.lib.aocl_llc_compress(C.byref(d), _LLC_ENUM[codec])
         return r, (out.raw[:r] if r > 0 else b""), d
 

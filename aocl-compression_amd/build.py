@@ -27,7 +27,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 CLI_SOURCE = "bench_cli.cpp"
-SOURCES = ["capi.hip", "lz4_kernels.hip", "snappy_kernels.hip", "zstd_kernels.hip", "rap.hip", "aocl_api.cpp", "native_api.cpp", "zstd_api.cpp", "lz4frame_api.cpp"]
+SOURCES = ["capi.hip", "lz4_kernels.hip", "snappy_kernels.hip", "zstd_kernels.hip", "rap.hip", "aocl_api.cpp", "native_api.cpp", "zstd_api.cpp", "lz4frame_api.cpp", "exchange.cpp"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-function",
           *os.environ.get("AOCLGPU_CFLAGS", "").split()]
 
@@ -87,7 +87,7 @@ def build_variant(name: str, cflags, verbose: bool = False, linker=None) -> str:
     stubdir = os.path.join(OBJDIR, "stub")
     if jobs or not os.path.exists(out):
         _run([*(linker or ["g++"]), "-shared", "-fPIC", *objs, "-o", out, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
-              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-ldl"])
     with open(stamp, "w") as f:
         f.write(flags)
     if verbose:
@@ -120,12 +120,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             f.write("/* link-time stand-in so the engine records NEEDED libamdhip64.so (no version) */\n")
         _run(["gcc", "-shared", "-fPIC", stub_c, "-o", os.path.join(stubdir, "libamdhip64.so")])
         _run(["g++", "-shared", "-fPIC", *objs, "-o", LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
-              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-Wl,-Bsymbolic-functions"])
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-ldl", "-Wl,-Bsymbolic-functions"])
         vmap = os.path.join(stubdir, "core.map")
         with open(vmap, "w") as f:
             f.write("{ global: aoclgpu_*; aocl_llc_*; aocl_get_rap_frame_bound_mt; aocl_skip_rap_frame_mt; local: *; };\n")
         _run(["g++", "-shared", "-fPIC", *objs, "-o", CORE_LIB, "-L" + stubdir, "-Wl,--no-as-needed", "-lamdhip64",
-              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-Wl,--version-script=" + vmap])
+              "-Wl,--as-needed", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-ldl", "-Wl,--version-script=" + vmap])
     # the bench CLI (counterpart of the reference's aocl_compression_bench, test/codec_bench.c)
     cli_src = os.path.join(CSRC, "bench_cli.cpp")
     if force or not os.path.exists(CLI) or _newer(cli_src, CLI, headers + [LIB]):

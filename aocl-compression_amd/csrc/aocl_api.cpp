@@ -105,9 +105,9 @@ int64_t wrap_compress(int t, const aocl_compression_desc* h)
         return r > 0 ? r : kCodecError;
     }
     // ZSTD: the call sequence of the reference's wrapper (api/codec.cpp:388-422) on this library's own Zstd entry points:
-    // parameters from the level table, optVar clamps windowLog, ZSTD_compress_advanced.  Levels whose parameters are not
-    // the "fast" strategy (level 0 = default 3 and up: double-fast, greedy, ...) and windows below the input size come
-    // back as ZSTD_error_parameter_unsupported -> CODEC_ERROR, never as different bytes.
+    // parameters from the level table, optVar clamps windowLog, ZSTD_compress_advanced.  Levels -1 and 0-4 (fast and double-fast,
+    // windows below the input size included) are compressed; greedy and above come back as
+    // ZSTD_error_parameter_unsupported -> CODEC_ERROR, never as different bytes.
     ZSTD_parameters zp = ZSTD_getParams((int)h->level, h->inSize, 0);
     zp.fParams.contentSizeFlag = 1;
     if (h->optVar && zp.cParams.windowLog > h->optVar) {

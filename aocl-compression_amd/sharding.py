@@ -1,6 +1,62 @@
 """Chunk sharding across ranks (the GPU counterpart of the reference's RAP partition split,
-threads/threads.c:57-80,121-153): contiguous chunk ranges, ordered gather of compressed segments."""
+threads/threads.c:57-80,121-153): contiguous chunk ranges, ordered gather of compressed segments.
+
+The exchange itself is the C library's (csrc/exchange.cpp: aoclgpu_comm_create / aoclgpu_exchange_segments /
+aoclgpu_allgather_words over RCCL, bound at run time); `CExchange` below is its thin binding.  The torch.distributed
+functions that follow are the fallbacks bench.py keeps (a grouped isend / irecv, a padded all-gather) and the host-staged
+gloo transport of the 1-GPU / CPU validation runs."""
 from __future__ import annotations
+
+import ctypes as C
+
+
+class _StreamWait:
+    """what `exchange` hands back: wait() makes the caller's current stream wait for the exchange stream"""
+
+    def __init__(self, torch, side):
+        self.torch, self.side = torch, side
+
+    def wait(self):
+        self.torch.cuda.current_stream().wait_stream(self.side)
+
+
+class CExchange:
+    """The C exchange (include/aocl_gpu_codec.h, config 5): an RCCL communicator created through the library on this rank's
+    device - the 128-byte id travels from rank 0 over whatever torch.distributed backend is up - and the two data-path calls,
+    enqueued on a side stream so that they overlap with the rank's own decompression."""
+
+    def __init__(self, eng, dist, rank: int, world: int):
+        import torch
+        self.torch, self.eng, self.rank, self.world = torch, eng, rank, world
+        lib = eng.lib
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            eng._check(lib.aoclgpu_comm_unique_id(ident), "comm_unique_id")
+        obj = [bytes(ident)]
+        dist.broadcast_object_list(obj, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(obj[0])
+        comm = C.c_void_p()
+        eng._check(lib.aoclgpu_comm_create(ident, world, rank, C.byref(comm)), "comm_create")
+        self.comm = comm
+        self.side = torch.cuda.Stream(device=eng.device)
+
+    def exchange(self, gather_buf, seg_sizes, seg_off):
+        sz = (C.c_uint64 * self.world)(*[int(x) for x in seg_sizes])
+        of = (C.c_uint64 * self.world)(*[int(x) for x in seg_off])
+        self.side.wait_stream(self.torch.cuda.current_stream())          # the compaction into gather_buf comes first
+        self.eng._check(self.eng.lib.aoclgpu_exchange_segments(self.comm, gather_buf.data_ptr(), sz, of, self.world, self.rank,
+                                                               self.side.cuda_stream), "exchange_segments")
+        return [_StreamWait(self.torch, self.side)]
+
+    def allgather_words(self, out, mine):
+        """out[r * n ..] = rank r's `mine` (int32 / uint32 device tensors)"""
+        self.eng._check(self.eng.lib.aoclgpu_allgather_words(self.comm, mine.data_ptr(), out.data_ptr(), int(mine.numel()), self.world, self.rank,
+                                                             self.torch.cuda.current_stream().cuda_stream), "allgather_words")
+
+    def close(self):
+        if self.comm:
+            self.eng.lib.aoclgpu_comm_destroy(self.comm)
+            self.comm = None
 
 
 def chunk_range(nchunks: int, rank: int, world: int) -> tuple[int, int]:

@@ -58,8 +58,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
-    p.add_argument("--exchange", default="sendrecv", choices=["sendrecv", "allgather"],
-                   help="N>1: exact-size grouped send/recv (default) or all-gather of segments padded to the largest")
+    p.add_argument("--exchange", default="c", choices=["c", "sendrecv", "allgather"],
+                   help="N>1: the C library's exchange (aoclgpu_exchange_segments over its own RCCL communicator, default), "
+                        "torch.distributed's grouped send/recv of exact sizes, or an all-gather of segments padded to the largest")
     return p.parse_args()
 
 
@@ -372,6 +373,8 @@ class Run:
     # ---- N > 1: exchange of the compacted compressed segments ----
     def all_gather_vec(self, out, mine):
         """all-gather of one device vector per rank (gloo, the 1-GPU validation backend, only moves host tensors)"""
+        if getattr(self, "cx", None) and mine.dtype == self.torch.int32:
+            return self.cx.allgather_words(out, mine)
         if not self.gloo:
             return self.dist.all_gather_into_tensor(out, mine)
         parts = [self.torch.zeros(mine.numel(), dtype=mine.dtype) for _ in range(self.world)]
@@ -392,6 +395,24 @@ class Run:
         self.len_all = torch.zeros(self.world * self.nchunks, dtype=torch.int32, device=dev)
         self.aux_all = torch.zeros(self.world * self.nchunks, dtype=torch.int32, device=dev)
         self.all_gather_vec(self.aux_all, self.aux)
+        if self.args.exchange == "c" and self.gloo:
+            self.args.exchange = "sendrecv"           # host-staged validation runs (1 GPU / CPU) have no RCCL communicator
+        if self.args.exchange == "c" and not getattr(self, "cx", None):
+            # the product path: the communicator and the exchange are the C library's (csrc/exchange.cpp).  Every rank learns
+            # together whether it came up; if not, all of them use torch.distributed's grouped send / recv instead.
+            from aocl_compression_amd import sharding
+            ok = 1
+            try:
+                self.cx = sharding.CExchange(eng, dist, self.rank, self.world)
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                if self.rank == 0:
+                    print(f"bench: C exchange unavailable ({e!r}); using torch.distributed send/recv", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                self.cx = None
+                self.args.exchange = "sendrecv"
         if self.args.exchange == "allgather":
             # RCCL has no all-gatherv: every segment is padded to the largest one (the ring moves the padding too)
             self.seg_cap = (max(self.seg) + (1 << 20)) & ~0xFFFFF
@@ -412,9 +433,11 @@ class Run:
                     w.wait()
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
+                nxt = "sendrecv" if self.args.exchange == "c" else "allgather"
                 if self.rank == 0:
-                    print(f"bench: grouped send/recv exchange failed ({e!r}); using the padded all-gather", file=sys.stderr)
-                self.args.exchange = "allgather"
+                    print(f"bench: {self.args.exchange} exchange failed ({e!r}); using {nxt}", file=sys.stderr)
+                self.args.exchange = nxt
+                self.cx = None
                 self.setup_exchange()
 
     def exchange(self):
@@ -426,6 +449,8 @@ class Run:
                 self.gather_buf.copy_(torch.cat(parts))
                 return []
             return [dist.all_gather_into_tensor(self.gather_buf, self.packed, async_op=True)]
+        if self.args.exchange == "c":
+            return self.cx.exchange(self.gather_buf, self.seg, self.seg_off)
         from aocl_compression_amd import sharding
         return sharding.exchange_segments(dist, self.rank, self.world, self.gather_buf, self.seg, self.seg_off, host_staged=self.gloo)
 
@@ -526,6 +551,27 @@ class Run:
         assert torch.equal(got[:r], want), f"rank {self.rank}: assembled RAP stream does not decode to the two ranks' bytes"
         return int(stream.numel()), 2 * half
 
+    def verify_slabs(self):
+        """The WHOLE sharded stream as a product: every chunk of every rank, in stream order, assembled into the sequence of
+        RAP streams the container allows (aoclgpu_rap_assemble_slabs: 1 GiB of source per slab), from the gathered buffer and
+        size tables alone; the first and the last slab are decoded and compared with the ranks' bytes."""
+        import numpy as np
+        torch, eng = self.torch, self.eng
+        lens = self.len_all.cpu().numpy().reshape(self.world, self.nchunks)
+        auxs = self.aux_all.cpu().numpy().reshape(self.world, self.nchunks)
+        off = np.concatenate([np.cumsum(lens[r].astype(np.int64)) - lens[r] + self.seg_off[r] for r in range(self.world)]).astype(np.uint64)
+        ln = lens.reshape(-1)
+        sl = np.full(len(ln), self.chunk, np.uint32)
+        stream, soff, sfirst = eng.rap_assemble_slabs(self.codec, self.gather_buf, off, ln, sl, auxs.reshape(-1).astype(np.uint32) if self.name == "lz4" else None)
+        nslabs = len(soff) - 1
+        for k in sorted({0, nslabs - 1}):
+            c0, c1 = sfirst[k], sfirst[k + 1]
+            want = torch.cat([self.shard_of(c // self.nchunks)[(c % self.nchunks) * self.chunk:(c % self.nchunks + 1) * self.chunk] for c in (c0, c1 - 1)])
+            got, r = eng.rap_decompress(self.codec, stream[soff[k]:soff[k + 1]], (c1 - c0) * self.chunk)
+            assert r == (c1 - c0) * self.chunk, f"slab {k} decodes to {r} bytes"
+            assert torch.equal(got[:self.chunk], want[:self.chunk]) and torch.equal(got[r - self.chunk:r], want[self.chunk:]), f"slab {k} differs from the source"
+        return nslabs, int(stream.numel())
+
     def result(self, elapsed):
         """Per-codec record (rank 0 prints it); collective when world > 1."""
         torch, dist, args = self.torch, self.dist, self.args
@@ -556,7 +602,7 @@ class Run:
                 "workload": f"{self.name} level-1, {chunk // 1024} KiB independent chunks, {self.corpus_name} "
                             f"({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
                 "codec": self.name, "chunk_bytes": chunk, "chunks_per_gpu": self.nchunks, "gib_per_gpu": args.gib,
-                "step": "compress" + (f" -> compact -> exchange of compressed segments between all ranks ({args.exchange}, "
+                "step": "compress" + (f" -> compact -> exchange of compressed segments between all ranks ({'aoclgpu_exchange_segments (C, RCCL)' if args.exchange == 'c' else args.exchange}, "
                                       "overlapped with) " if world > 1 else " -> ") + "decompress",
                 "parallelism": f"chunks sharded over {world} GPU(s), one wavefront per chunk",
             },
@@ -640,6 +686,13 @@ def main():
                 nbytes, parts = run.verify_assemble()
                 checks["rap_assemble"] = (f"one RAP stream of {parts} partitions across the rank boundary ({nbytes} bytes) assembled "
                                           "from the gathered segments, decoded by aoclgpu_rap_unpack, equal to both ranks' bytes")
+                if rank == 0:
+                    try:
+                        nsl, sbytes = run.verify_slabs()
+                        checks["rap_slabs"] = (f"the whole sharded stream ({world} x {run.nchunks} chunks) assembled into {nsl} RAP slab streams "
+                                               f"({sbytes} bytes) by aoclgpu_rap_assemble_slabs; first and last slab decoded and compared")
+                    except Exception as e:  # noqa: BLE001  (memory on small configurations)
+                        checks["rap_slabs"] = {"error": repr(e)}
         res = run.result(elapsed)
         res["checks"] = checks
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

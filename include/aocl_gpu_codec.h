@@ -240,6 +240,26 @@ int64_t aoclgpu_zstd_rap_compress_host_parts(const void* host_src, size_t n, voi
  * most 2 GiB - 1) and 65535 partitions; every slab is one aoclgpu_rap_assemble stream, written back to back into stream_out.
  * slab_off[0 .. *nslabs] = their offsets in stream_out, slab_first[0 .. *nslabs] = the first chunk of each (host arrays with
  * room for max_slabs + 1 entries).  The per-chunk arrays are host arrays as for aoclgpu_rap_assemble. */
+/* ---- BASELINE config 5 from C: the stream sharded over the GPUs of a node, compressed segments exchanged over RCCL / xGMI ----
+ * One process (or thread) per GPU.  Rank 0 makes an id (aoclgpu_comm_unique_id) and hands it to the other ranks by whatever
+ * the host program uses (MPI, a file, torch.distributed ...); every rank calls aoclgpu_comm_create on ITS current device.
+ * `comm` is an ncclComm_t: one created by the caller with ncclCommInitRank works as well.  RCCL (librccl.so.1) is bound at
+ * run time on first use; without it these calls fail with AOCLGPU_ERR_HIP and the rest of the library is unaffected.
+ *   per step and rank:  aoclgpu_<codec>_compress_chunks  ->  aoclgpu_compact_slots straight into gather_buf + seg_off[rank]
+ *                       ->  aoclgpu_allgather_words (per-chunk sizes; LZ4 also the aux[] run lengths)
+ *                       ->  aoclgpu_exchange_segments  ->  aoclgpu_rap_assemble_slabs on the rank(s) that write the stream.
+ * aoclgpu_exchange_segments: afterwards gather_buf[seg_off[r], +seg_bytes[r]) holds rank r's segment on every rank (this
+ * rank's own must already be there); one group of exact-size ncclSend / ncclRecv pairs on `stream`, every pair of ranks over
+ * its own xGMI link.  seg_bytes / seg_off: host arrays of nranks entries, the same on all ranks.
+ * aoclgpu_allgather_words: all_dev[r * nwords ..] = rank r's mine_dev[0 .. nwords) (32-bit words, ncclAllGather). */
+#define AOCLGPU_COMM_ID_BYTES 128
+int aoclgpu_comm_unique_id(uint8_t id[AOCLGPU_COMM_ID_BYTES]);
+int aoclgpu_comm_create(const uint8_t id[AOCLGPU_COMM_ID_BYTES], int nranks, int rank, void** comm);
+int aoclgpu_comm_destroy(void* comm);
+int aoclgpu_exchange_segments(void* comm, void* gather_buf, const uint64_t* seg_bytes, const uint64_t* seg_off,
+                              int nranks, int rank, void* stream);
+int aoclgpu_allgather_words(void* comm, const void* mine_dev, void* all_dev, size_t nwords, int nranks, int rank, void* stream);
+
 /* aocl_llc_compress(ZSTD) with numThreads > 1: 0 (default) = 128 KiB partitions (the GPU's geometry), 1 = the reference's
  * geometry (aoclgpu_zstd_rap_compress_host_parts with the partition count threads/threads.c computes for numThreads);
  * the environment variable AOCLGPU_RAP_GEOMETRY=reference selects 1 at start-up. */
