@@ -38,9 +38,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GIB = float(1 << 30)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SILESIA_BYTES = 211_938_580     # size of the real Silesia corpus; the synthetic base matches it
-CODECS = {"lz4": (0, 262144), "snappy": (1, 65536), "zstd": (2, 131072)}
+CODECS = {"lz4": (0, 262144), "snappy": (1, 65536), "zstd": (2, 131072), "zstd3": (2, 131072)}
+ZSTD_LEVEL = {"zstd": 1, "zstd3": 3}            # zstd3 = BASELINE's Zstd chunk shape at level 3 ("double-fast")
 REF_FUNCS = {"lz4": ("LZ4_compress_default", "LZ4_decompress_safe"), "snappy": ("snappy_compress", "snappy_uncompress"),
-             "zstd": ("ZSTD_compress", "ZSTD_decompress")}
+             "zstd": ("ZSTD_compress", "ZSTD_decompress"), "zstd3": ("ZSTD_compress", "ZSTD_decompress")}
 
 
 def parse():
@@ -49,7 +50,7 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--codec", default="all", choices=["all", *CODECS],
-                   help="all = lz4 (headline) + snappy + zstd at N=1, lz4 + zstd at N>1")
+                   help="all = lz4 (headline) + snappy + zstd + zstd3 (Zstd level 3) at N=1, lz4 + zstd at N>1")
     p.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU and codec")
     p.add_argument("--chunk", type=int, default=0, help="chunk bytes (default: the codec's BASELINE chunk)")
     p.add_argument("--base-mib", type=float, default=SILESIA_BYTES / (1 << 20), help="size of the synthetic base corpus")
@@ -113,7 +114,7 @@ def cpu_worker(spec):
     base_np = np.load(spec["base"], mmap_mode="r")
     codec = CODECS[name][0]
     orc = ol.Oracle()
-    kind, fc, fd = "port", None, None
+    kind, fc, fd, ref = "port", None, None, None
     cname, dname = REF_FUNCS[name]
     if os.path.exists(ol.REF_SO):
         ref = C.CDLL(ol.REF_SO)
@@ -121,6 +122,12 @@ def cpu_worker(spec):
         fd = C.cast(getattr(ref, dname), C.c_void_p)
         kind = "reference"
     L = orc.L
+    if name in ZSTD_LEVEL:
+        L.orc_set_zstd_level(ZSTD_LEVEL[name])
+        if ref is not None:                            # the level table the reference's dispatcher installs (AOCL rows)
+            ref.aocl_setup_zstd_encode.restype = C.c_void_p
+            ref.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+            ref.aocl_setup_zstd_encode(0, 0, 0, 0, 0)
     L.orc_bench_chunks.restype = C.c_int
     L.orc_bench_chunks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -159,7 +166,7 @@ def cpu_worker(spec):
         "method": f"child process; buffers first-touched by their threads, 1 warm-up pass, best of {reps} passes (median "
                   "alongside), schedule(static,1) over chunks (oracle/chunk_driver.c orc_bench_chunks)",
         "sample": f"first {allt['sample_GiB']:.2f} GiB (all threads) / {one['sample_GiB'] * 1024:.0f} MiB (1 thread) of the same "
-                  f"{chunk // 1024} KiB chunk stream, {cname} + {dname}",
+                  f"{chunk // 1024} KiB chunk stream, {cname}" + (f"(level {ZSTD_LEVEL[name]})" if name in ZSTD_LEVEL else "") + f" + {dname}",
     }), flush=True)
 
 
@@ -240,6 +247,25 @@ def whole_input_frames(eng):
             r = ref.ZSTD_compress(ob, cap, data, fb, 1)
             same = same and host[doff[i]:doff[i] + lens[i]].tobytes() == ob.raw[:r]
         out["zstd_frames_identical_to_reference_ZSTD_compress"] = bool(same)
+        # the reference on ONE host core for the same frames (cpu_baseline of this report; best of 3 passes over 32 frames)
+        datas = [src[i * fb:(i + 1) * fb].cpu().numpy().tobytes() for i in range(32)]
+        ob = C.create_string_buffer(fb + (fb >> 8) + 64)
+        bestc = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for d_ in datas:
+                ref.ZSTD_compress(ob, len(ob), d_, fb, 1)
+            dt = time.perf_counter() - t0
+            bestc = dt if bestc is None or dt < bestc else bestc
+        out["cpu_baseline"] = {"kind": "reference", "cores": 1, "unit": "MB/s", "value": round(32 * fb / bestc / 1e6, 1),
+                               "ms_per_1MiB_frame": round(bestc / 32 * 1e3, 3), "sample": "32 frames of 1 MiB, ZSTD_compress(.., 1), best of 3"}
+    for key, ms_key, nb in (("zstd_level1_frames_1MiB_x512", "ms", k * fb), ("zstd_level1_one_frame_1MiB", "ms", fb)):
+        if key in out:                                     # roofline of the frame kernels: N + C bytes per launch over the wall time
+            rec = out[key]
+            comp = nb / rec["ratio"] if "ratio" in rec else nb / out["zstd_level1_frames_1MiB_x512"]["ratio"]
+            ach = (nb + comp) / (rec[ms_key] * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "kernel": "zstd_frame_kernel" if key.endswith("x512") else "zstd_frame_lds_kernel",
+                               "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 7)}
     try:                                                       # LZ4 frame with linked blocks (the format's default), host buffers
         import lz4f_lib as lf
         G = lf.bind(eng.lib)
@@ -249,7 +275,11 @@ def whole_input_frames(eng):
         t0 = time.perf_counter(); frame = lf.compress(G, data, p); dt = min(dt, time.perf_counter() - t0)
         res = {"MiBps": round(len(data) / dt / 2**20, 1), "ms": round(dt * 1e3, 1), "ratio": round(len(data) / len(frame), 3)}
         if os.path.exists(ol.REF_SO) and hasattr(C.CDLL(ol.REF_SO), "LZ4F_compressFrame"):
-            res["identical_to_reference_LZ4F_compressFrame"] = bool(frame == lf.compress(lf.bind(C.CDLL(ol.REF_SO)), data, p))
+            R = lf.bind(C.CDLL(ol.REF_SO))
+            t0 = time.perf_counter(); rf = lf.compress(R, data, p); dtr = time.perf_counter() - t0
+            t0 = time.perf_counter(); rf = lf.compress(R, data, p); dtr = min(dtr, time.perf_counter() - t0)
+            res["identical_to_reference_LZ4F_compressFrame"] = bool(frame == rf)
+            res["cpu_baseline"] = {"kind": "reference", "cores": 1, "unit": "MB/s", "value": round(len(data) / dtr / 1e6, 1), "ms": round(dtr * 1e3, 3)}
         out["lz4f_linked_one_frame_4MiB_host"] = res
     except Exception as e:
         out["lz4f_linked_one_frame_4MiB_host"] = {"error": repr(e)}
@@ -357,6 +387,8 @@ class Run:
         self.aux = torch.zeros(nchunks, dtype=torch.int32, device=dev)     # LZ4: final literal run per chunk (RAP join)
         self.cb = eng.uniform_compress_batch(self.src, chunk, self.slots, self.clen, slot)
         self.cb.aux = self.aux.data_ptr()
+        if ZSTD_LEVEL.get(name, 1) != 1:
+            self.cb.reserved |= a.api.zstd_level(ZSTD_LEVEL[name])
         self.db = eng.uniform_decompress_batch(self.slots, self.clen, slot, self.dst, chunk, self.dlen)
         self.kt = {"c": [], "d": []}
         if world > 1:
@@ -594,12 +626,13 @@ class Run:
         alg_bytes = float(total) + float(comp_bytes)
         dom_ms = ms_c if dom == "compress" else ms_d
         ach = alg_bytes / (dom_ms * 1e-3) / 1e9
+        fam = "zstd" if self.name == "zstd3" else self.name
         kernel = ("snappy_compress_mix_kernel" if (self.name, dom) == ("snappy", "compress") and self.nchunks > 16 * 256
-                  else f"{self.name}_{dom}_kernel")
+                  else f"{fam}_{dom}_kernel" + ("<double-fast>" if (self.name, dom) == ("zstd3", "compress") else ""))
         out = {
             "value": round(unc_total / GIB / (elapsed / args.steps), 3), "unit": "GiB/s", "ms_per_step": round(ms_step, 3),
             "config": {
-                "workload": f"{self.name} level-1, {chunk // 1024} KiB independent chunks, {self.corpus_name} "
+                "workload": f"{fam} level-{ZSTD_LEVEL.get(self.name, 1)}, {chunk // 1024} KiB independent chunks, {self.corpus_name} "
                             f"({int(args.base_mib)} MiB base) concatenated to {args.gib:g} GiB per GPU, HBM-resident",
                 "codec": self.name, "chunk_bytes": chunk, "chunks_per_gpu": self.nchunks, "gib_per_gpu": args.gib,
                 "step": "compress" + (f" -> compact -> exchange of compressed segments between all ranks ({'aoclgpu_exchange_segments (C, RCCL)' if args.exchange == 'c' else args.exchange}, "
@@ -612,7 +645,7 @@ class Run:
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": round(dom_ms, 4), "other_kernel": f"{self.name}_{'decompress' if dom == 'compress' else 'compress'}_kernel",
+                "avg_launch_ms": round(dom_ms, 4), "other_kernel": f"{fam}_{'decompress' if dom == 'compress' else 'compress'}_kernel",
                 "other_kernel_ms": round(ms_d if dom == "compress" else ms_c, 4),
                 "other_kernel_frac": round(alg_bytes / ((ms_d if dom == "compress" else ms_c) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
             },
@@ -659,7 +692,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     eng = a.Engine(local)
-    names = [args.codec] if args.codec != "all" else (["lz4", "snappy", "zstd"] if world == 1 else ["lz4", "zstd"])
+    names = [args.codec] if args.codec != "all" else (["lz4", "snappy", "zstd", "zstd3"] if world == 1 else ["lz4", "zstd"])
     nbase = int(args.base_mib * (1 << 20))
     corpora = {}
 

@@ -18,6 +18,11 @@ typedef int (*snappy_fn)(const char*, size_t, char*, size_t*);
 typedef size_t (*zstd_c_fn)(void*, size_t, const void*, size_t, int);
 typedef size_t (*zstd_d_fn)(void*, size_t, const void*, size_t);
 
+/* Zstd level of the reference function in the drivers below (bench.py's zstd3 line: ZSTD_compress(.., 3)); the C restatement
+ * only covers levels 1-2 as a one-shot (levels 3-4 through orc_zstd_compress_cparams), so a level above 2 needs `fn`. */
+static int g_zstd_level = 1;
+void orc_set_zstd_level(int level) { g_zstd_level = level; }
+
 static int64_t comp_one(int codec, void* fn, const uint8_t* s, size_t n, uint8_t* d, size_t cap)
 {
     if (codec == 0) return fn ? ((lz4_fn)fn)((const char*)s, (char*)d, (int)n, (int)cap) : orc_lz4_compress(s, (int)n, d, (int)cap);
@@ -25,8 +30,8 @@ static int64_t comp_one(int codec, void* fn, const uint8_t* s, size_t n, uint8_t
         if (fn) { size_t l = cap; return ((snappy_fn)fn)((const char*)s, n, (char*)d, &l) == 0 ? (int64_t)l : 0; }
         return (int64_t)orc_snappy_compress(s, n, d);
     }
-    if (fn) { size_t r = ((zstd_c_fn)fn)(d, cap, s, n, 1); return r > cap ? 0 : (int64_t)r; }
-    return (int64_t)orc_zstd_compress(s, n, d, cap);
+    if (fn) { size_t r = ((zstd_c_fn)fn)(d, cap, s, n, g_zstd_level); return r > cap ? 0 : (int64_t)r; }
+    return (int64_t)(g_zstd_level <= 1 ? orc_zstd_compress(s, n, d, cap) : orc_zstd_compress_level(s, n, d, cap, g_zstd_level));
 }
 static int64_t decomp_one(int codec, void* fn, const uint8_t* s, size_t n, uint8_t* d, size_t cap)
 {

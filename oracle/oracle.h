@@ -47,6 +47,7 @@ size_t orc_zstd_compress_bound(size_t n);                              /* zstd.h
  * returns compressed size, 0 on failure */
 size_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap);
 size_t orc_zstd_compress_level(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, int level);   /* level 1 or 2 */
+void orc_set_zstd_level(int level);                                      /* chunk_driver.c: the Zstd level of the chunk drivers */
 /* == ZSTD_compress_advanced with these cParams on n <= 128 KiB: strategy 1 "fast" (zstd_fast.c:427-706) or 2 "double-fast"
  * (zstd_double_fast.c:332-573; hashLog = long table, chainLog = short table, minMatch = short-hash bytes) */
 size_t orc_zstd_compress_cparams(const uint8_t* src, size_t n, uint8_t* dst, size_t dstCap, int strategy,
