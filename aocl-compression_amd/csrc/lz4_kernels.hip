@@ -124,8 +124,13 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PROF: batches, sequences, stop: beyond-batch, lim, more_fwd, nomatch, sum(lim), -
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
+#ifdef LZ4_PROF_NOWAIT   /* stamps without draining the global loads: a stage is charged the waits the compiler placed in it */
+#define STAGE(k) do { if (PROF) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
 #define STAGE(k) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[k] += t_ - tprev; tprev = t_; } } while (0)
+#endif
 
     // Table entries of the u32 table carry, above the position, a few "check" bits derived from the 4 bytes at
     // that position.  They never change a decision (a probe whose check bits differ cannot pass the 4-byte test);

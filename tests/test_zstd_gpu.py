@@ -197,6 +197,7 @@ def test_double_fast_levels_bit_exact(eng, oracle, level, upstream):
     lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
     oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
     oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    lib.aocl_destroy_zstd_encode()                       # (a setup is ignored while the dispatcher counts as set up, as in the reference)
     lib.aocl_setup_zstd_encode(1 if upstream else 0, 0, 0, level, 0)
     try:
         for kind, chunk in (("text", 131072), ("binary", 65536), ("jsonlog", 20000), ("database", 100000), ("random", 40000),
@@ -220,6 +221,7 @@ def test_double_fast_levels_bit_exact(eng, oracle, level, upstream):
                 dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, len(raw), chunk)
                 assert torch.equal(dst, src)
     finally:
+        lib.aocl_destroy_zstd_encode()
         lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
 
 

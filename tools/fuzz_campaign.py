@@ -102,6 +102,7 @@ while time.time() < t_end:
         want = lambda p: orc.compress(ol.SNAPPY, p)
     else:
         level = int(rng.choice([1, 1, 2, 3, 4])); upstream = bool(rng.integers(0, 2)); gc = a.ZSTD
+        lib.aocl_destroy_zstd_encode()
         lib.aocl_setup_zstd_encode(1 if upstream else 0, 0, 0, level, 0)
         flags = a.api.zstd_level(level, upstream)
         if chunk == 0 or chunk > 131072: chunk = 131072
@@ -128,5 +129,6 @@ while time.time() < t_end:
             dst, dl = eng.decompress_chunks(gc, slots, out_len, slot, len(raw), chunk)
             assert torch.equal(dst, src), tag
     n_ex += 1
+lib.aocl_destroy_zstd_encode()
 lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
 print(f"fuzz campaign OK: {n_ex} inputs, {n_chunks} chunks compared byte for byte, seeds {seed0}..{seed0 + it - 1}")
