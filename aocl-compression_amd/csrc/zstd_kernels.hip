@@ -81,7 +81,9 @@ struct EntropyLds {
     u32 tile[WavePacker::kTileWords];
     u32 fseBits[3][64];      // per tile: (value << 8) | nbBits from the three state chains
     u32 misc[16];
+    int fsePre[3][64][2];    // per tile: {deltaNbBits, deltaFindState} of every sequence's code, looked up by all lanes before the chains run
 };
+static_assert(sizeof(EntropyLds) <= 17920, "the entropy stage's LDS overlays the hash table of a 128 KiB chunk (17 920 bytes)");
 
 template <int MLS>
 __device__ __forceinline__ u32 z_hash(u64 v, u32 hlog)
@@ -124,7 +126,25 @@ __device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Works
         u32 inc = ll;
         for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
         const u32 dp = lpos + inc - ll;
-        if (ll <= 24) for (u32 i = 0; i < ll; ++i) ws->lits[dp + i] = src[sp + i];
+        if (ll && ll <= 24) {
+            // short runs, one per lane: three 8-byte loads in ONE round trip and exact-length overlapping stores (a byte loop is a
+            // load -> store round trip per byte)
+            gbyte* d = (gbyte*)ws->lits + dp;
+            if (sp + 24 <= n) {
+                const u64 v0 = ld64(src + sp), v1 = ld64(src + sp + 8), v2 = ld64(src + sp + 16);
+                auto ext = [&](u32 o) -> u64 {                           // bytes [o, o + 8) of v0|v1|v2, o <= 16
+                    const u64 a = o < 8 ? v0 : (o < 16 ? v1 : v2), bb = o < 8 ? v1 : v2;
+                    const u32 sh = (o & 7) * 8;
+                    return sh ? (a >> sh) | (bb << (64 - sh)) : a;
+                };
+                if (ll >= 8) {
+                    st64(d, v0);
+                    if (ll > 8) st64(d + (ll > 16 ? 8 : ll - 8), ext(ll > 16 ? 8 : ll - 8));
+                    if (ll > 16) st64(d + ll - 8, ext(ll - 8));
+                } else if (ll >= 4) { st32(d, (u32)v0); st32(d + ll - 4, (u32)(v0 >> (8 * (ll - 4)))); }
+                else for (u32 i = 0; i < ll; ++i) d[i] = (u8)(v0 >> (8 * i));
+            } else for (u32 i = 0; i < ll; ++i) d[i] = src[sp + i];
+        }
         for (u64 lm = ballot(ll > 24); lm; lm &= lm - 1) {
             const int k = (int)__builtin_ctzll(lm);
             wave_copy(ws->lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
@@ -1002,15 +1022,26 @@ __device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, 
     if (lane < 3) state = fse_init_state(myct, mycodes[nbSeq - 1]);
     for (u32 e0 = 0; e0 < nbSeq; e0 += kWave) {
         const u32 cnt = nbSeq - e0 < kWave ? nbSeq - e0 : kWave;
+        // what a chain step needs besides the state - the code's deltaNbBits / deltaFindState - is looked up for the tile's 64
+        // sequences by all lanes first: the serial loop below is then one LDS round trip per step (the state table), not a
+        // global byte load + two table reads
+        if ((u32)lane < cnt) {
+            const u32 i = nbSeq - 1 - (e0 + (u32)lane);
+            const u32 cl = ws->llc[i], cm = ws->mlc[i], co = ws->ofc[i];
+            L->fsePre[0][lane][0] = L->ctLL.deltaNbBits[cl]; L->fsePre[0][lane][1] = L->ctLL.deltaFindState[cl];
+            L->fsePre[1][lane][0] = L->ctML.deltaNbBits[cm]; L->fsePre[1][lane][1] = L->ctML.deltaFindState[cm];
+            L->fsePre[2][lane][0] = L->ctOF.deltaNbBits[co]; L->fsePre[2][lane][1] = L->ctOF.deltaFindState[co];
+        }
+        wave_fence();
         if (lane < 3) {
             for (u32 k = 0; k < cnt; ++k) {
                 const u32 e = e0 + k;
                 u32 out = 0;
                 if (e > 0) {
-                    const u32 sym = mycodes[nbSeq - 1 - e];
-                    const u32 nb = (state + (u32)myct->deltaNbBits[sym]) >> 16;
+                    const int dnb = L->fsePre[lane][k][0], dfs = L->fsePre[lane][k][1];
+                    const u32 nb = (state + (u32)dnb) >> 16;
                     out = ((state & ((1u << nb) - 1)) << 8) | nb;
-                    state = myct->stateTable[(int)(state >> nb) + myct->deltaFindState[sym]];
+                    state = myct->stateTable[(int)(state >> nb) + dfs];
                 }
                 L->fseBits[lane][k] = out;
             }
