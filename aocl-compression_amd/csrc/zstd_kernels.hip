@@ -786,11 +786,27 @@ __device__ u32 lit_raw(u8* dst, const u8* src, u32 n, u32 type, int lane)
 }
 
 // byte histogram of src[0..n) into hist[256] (LDS)
-__device__ void wave_hist(u32* hist, const u8* src, u32 n, int lane)
-{
+__device__ void wave_hist(u32* hist_, const u8* src_, u32 n, int lane)
+{   // 16 bytes per lane and step (one load instead of sixteen round trips of one byte each), counts by LDS atomics
+    typedef __attribute__((address_space(3))) u32 L32;
+    L32* hist = (L32*)hist_;
+    const gbyte* src = (const gbyte*)src_;
     for (u32 i = (u32)lane; i < 256; i += kWave) hist[i] = 0;
     wave_fence();
-    for (u32 i = (u32)lane; i < n; i += kWave) atomicAdd(&hist[src[i]], 1u);
+    const u32 nv = n >> 4;
+    for (u32 i = (u32)lane; i < nv; i += kWave) {
+        typedef u32x4 __attribute__((aligned(1))) U;
+        const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + 16u * i);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __hip_atomic_fetch_add(&hist[w[k] & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[(w[k] >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[(w[k] >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&hist[w[k] >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    for (u32 i = 16u * nv + (u32)lane; i < n; i += kWave) __hip_atomic_fetch_add(&hist[src[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     wave_fence();
 }
 
