@@ -1958,7 +1958,12 @@ __device__ __attribute__((noinline)) bool seq_table(FseD* dt, u32* log, u32* hav
     }
     if (mode == 2) {
         u32 ms = maxSym, tl = 0, h = 0;
-        if (lane == 0) h = fse_read_ncount(L->norm, &ms, &tl, src + *ip, iend - *ip, maxLog);
+        // the description is parsed bit by bit on one lane: from a copy the wave stages in LDS (a table of <= 53 symbols and
+        // table log <= 9 takes at most 62 bytes), not byte by byte from global memory
+        const u32 avail = iend - *ip, stg = avail < 128u ? avail : 128u;
+        for (u32 b = (u32)lane; b < stg; b += kWave) L->weights[b] = src[*ip + b];
+        wave_fence();
+        if (lane == 0) h = fse_read_ncount(L->norm, &ms, &tl, L->weights, stg, maxLog);
         wave_fence();
         h = uni(h); ms = uni(ms); tl = uni(tl);
         if (h == 0xFFFFFFFFu) return false;
