@@ -701,43 +701,75 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
             continue;
         }
         // ---------------- the event, wave-uniform from here ----------------
+        // Every dependent global round trip below is a microsecond of this wave's life, so what one trip can fetch it does:
+        // the probe after the event lane already holds ip1's bytes, long-table entry and candidate; the first rounds of the
+        // forward and the backward compare travel together; so do the post-match insertions' bytes and the rep2 test's.
         const u32 curr = lane_get(pos, el), ip1 = s + lane_get(am1, el), stepE = lane_get(am1, el) - lane_get(am, el);
         const int kind = lane_get((u32)repHit, el) ? 2 : (lane_get((u32)longHit, el) ? 1 : 3);
-        u32 ip = curr, mLength;
-        if (kind == 2) {                                     // repcode at ip+1 (:425-431)
-            ip = curr + 1;
-            mLength = wave_count(src, ip + 4, ip + 4 - rep1, n, lane) + 4;
-            put_seq(nbSeq, ip - anchor, 1u, mLength, anchor);
-            litSize += ip - anchor; nbSeq++;
-        } else {
-            const u64 v1 = ld64(src + ip1);
-            const u32 hl1 = uni(z_hash8(v1, hlogL));
-            u32 mpos;
+        const bool nextOk = el + 1 < lim;                    // lane el+1 probed ip1 and no earlier lane of the batch names its slots
+        const int eln = (el + 1) & 63;
+        u32 ip = curr, mLength, mpos = 0, base = 4, offBase = 1;
+        u32 hl1 = 0; bool insert1 = false;
+        if (kind == 2) ip = curr + 1;                        // repcode at ip+1 (:425-431)
+        else {
+            u64 v1;
+            if (nextOk) { v1 = ((u64)lane_get((u32)(v8 >> 32), eln) << 32) | lane_get((u32)v8, eln); hl1 = lane_get(hl, eln); }
+            else { v1 = ld64(src + ip1); hl1 = uni(z_hash8(v1, hlogL)); }
             bool isLong = kind == 1;
             if (kind == 1) mpos = lane_get(idxl, el) - 2;    // long match at ip (:436-449)
             else {                                           // short match: a long match at ip1 wins (:495-504)
-                const u32 idxl1 = uni(tget(L, hl1));
-                u64 c1 = ~v1;
-                if (idxl1 > prefixIdx) c1 = ld64(src + idxl1 - 2);
-                if (uni(c1 == v1 ? 1u : 0u)) { ip = ip1; mpos = idxl1 - 2; isLong = true; }
+                u32 idxl1; u64 c1;
+                if (nextOk) { idxl1 = lane_get(idxl, eln); c1 = ((u64)lane_get((u32)(cl >> 32), eln) << 32) | lane_get((u32)cl, eln); }
+                else {
+                    idxl1 = uni(tget(L, hl1));
+                    c1 = ~v1;
+                    if (idxl1 > prefixIdx) c1 = ld64(src + idxl1 - 2);
+                }
+                if (idxl1 > prefixIdx && uni(c1 == v1 ? 1u : 0u)) { ip = ip1; mpos = idxl1 - 2; isLong = true; }
                 else mpos = lane_get(idxs, el) - 2;
             }
-            const u32 base = isLong ? 8u : 4u;
-            mLength = wave_count(src, ip + base, mpos + base, n, lane) + base;
-            const u32 offset = ip - mpos;
-            {   const u32 a = ip - anchor, b = mpos - prefixPos, maxback = a < b ? a : b;
-                const u32 back = back_count(ip, mpos, maxback);
-                ip -= back; mLength += back;
-            }
-            rep2 = rep1; rep1 = offset;
-            if (stepE < 4) { if (lane == 0) tput(L, hl1, ip1 + 2); }         // :516-526
-            put_seq(nbSeq, ip - anchor, offset + 3u, mLength, anchor);
-            litSize += ip - anchor; nbSeq++;
+            base = isLong ? 8u : 4u;
+            insert1 = stepE < 4;
         }
+        {   // forward extension (ZSTD_count) and catch-up: first rounds together
+            const u32 m0 = kind == 2 ? ip - rep1 : mpos;
+            const u32 fa = ip + base, fb = m0 + base;
+            u32 maxback = 0;
+            if (kind != 2) { const u32 a = ip - anchor, b2 = mpos - prefixPos; maxback = a < b2 ? a : b2; }
+            bool eqb = false;
+            if ((u32)lane < maxback) eqb = src[ip - 1 - (u32)lane] == src[m0 - 1 - (u32)lane];
+            const u32 o = 4u * (u32)lane, pa = fa + o;
+            u32 x = 0xFFFFFFFFu;
+            if (pa + 4 <= n) x = ld32(src + pa) ^ ld32(src + fb + o);
+            else if (pa < n) {
+                x = 0;
+                for (u32 t = 0; t < n - pa; ++t) x |= (u32)(src[pa + t] ^ src[fb + o + t]) << (8 * t);
+                x |= 0xFFFFFFFFu << (8 * (n - pa));
+            }
+            u32 back = (u32)first_lane(ballot(!eqb));        // <= maxback for maxback <= 64
+            if (back > maxback) back = maxback;
+            if (back == 64 && maxback > 64) back = 64 + back_count(ip - 64, m0 - 64, maxback - 64);
+            const int l = first_lane(ballot(x != 0));
+            u32 fwd;
+            if (l == 64) fwd = 256 + wave_count(src, fa + 256, fb + 256, n, lane);
+            else fwd = 4u * (u32)l + ((u32)__builtin_ctz(lane_get(x, l)) >> 3);
+            mLength = base + fwd + back;
+            if (kind != 2) {
+                const u32 offset = ip - mpos;
+                ip -= back;
+                rep2 = rep1; rep1 = offset; offBase = offset + 3u;
+            }
+        }
+        if (insert1) { if (lane == 0) tput(L, hl1, ip1 + 2); }               // :516-526
+        put_seq(nbSeq, ip - anchor, offBase, mLength, anchor);
+        litSize += ip - anchor; nbSeq++;
         ip += mLength; anchor = ip;                          // _match_stored
         if ((int64_t)ip <= ilimit) {
             const u32 ins = curr + 2;                        // complementary insertions (:550-554), in the reference's order
+            const bool chk = rep2 > 0;
             const u64 va = ld64(src + ins), vb = ld64(src + ip - 2), vc = ld64(src + ip - 1);
+            u32 r0 = 0, r1 = 1;
+            if (chk) { r0 = ld32(src + ip); r1 = ld32(src + ip - rep2); }   // the immediate rep2 test's bytes ride along
             if (lane == 0) {
                 tput(L, z_hash8(va, hlogL), ins + 2);
                 tput(L, z_hash8(vb, hlogL), ip - 2 + 2);
@@ -745,7 +777,8 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
                 tput(S, z_hash<MLS>(vc, hlogS), ip - 1 + 2);
             }
             wave_fence();
-            while ((int64_t)ip <= ilimit && rep2 > 0 && uni(ld32(src + ip) == ld32(src + ip - rep2) ? 1u : 0u)) {   // :558-572
+            bool hit = chk && uni(r0 == r1 ? 1u : 0u) != 0;
+            while (hit) {                                    // :558-572
                 const u32 rLength = wave_count(src, ip + 4, ip + 4 - rep2, n, lane) + 4;
                 const u32 t = rep2; rep2 = rep1; rep1 = t;
                 const u64 vi = ld64(src + ip);
@@ -754,6 +787,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
                 wave_fence();
                 nbSeq++;
                 ip += rLength; anchor = ip;
+                hit = (int64_t)ip <= ilimit && rep2 > 0 && uni(ld32(src + ip) == ld32(src + ip - rep2) ? 1u : 0u) != 0;
             }
         }
         s = ip; i0 = 0;
@@ -2332,7 +2366,7 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
 }  // namespace
 
 template <bool DF>
-__global__ void __launch_bounds__(64) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DF ? 4 : 1, DF ? 4 : 8))) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
                                                            uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes, uint32_t* counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
