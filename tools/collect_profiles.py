@@ -40,5 +40,18 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
         traffic[c] = {"kernel": dom, "gib_per_gpu": bench["config"]["gib_per_gpu"], "chunk_bytes": bench["config"]["chunk_bytes"],
                       "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
                       "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, raw KB per launch)"}
+# scattered-load calibration of FETCH_SIZE (tools/probe_scatter.py under --pmc FETCH_SIZE)
+try:
+    rec = json.loads([l for l in open(os.path.join(O, "scatter8.json")) if l.startswith("{")][-1])
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, "pmc_scatter8"), "probe_scatter8"], capture_output=True, text=True).stdout
+    kbv = [float(l.split()[1]) for l in txt.splitlines() if "FETCH_SIZE" in l]
+    if kbv:
+        name = f"{RND}_scatter8_fetch_calibration.txt"
+        open(os.path.join(P, name), "w").write(f"# rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/probe_scatter.py   ({rec['loads']} independent 8-byte loads at random addresses of a 2 GiB buffer)\n" + txt +
+                                                  f"# FETCH_SIZE is in KB: {kbv[0] * 1000.0 / rec['loads']:.1f} bytes fetched per 8-byte load\n")
+        traffic["scatter8_calibration"] = {"loads": rec["loads"], "fetch_kb": kbv[0], "fetch_bytes_per_load": round(kbv[0] * 1000.0 / rec["loads"], 2),
+                                           "source": f"profiles/{name}"}
+except (OSError, ValueError, IndexError, KeyError):
+    pass
 json.dump(traffic, open(tpath, "w"), indent=2)
 print(json.dumps(traffic, indent=1))

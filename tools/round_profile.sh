@@ -20,4 +20,6 @@ for c in $codecs; do
     timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${c}_$ctr -o p -- python3 $R/bench.py --codec $c --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_${c}_$ctr.json 2> $out/pmc_${c}_$ctr.err
   done
 done
+# FETCH_SIZE calibration for scattered 8-byte loads (bench.py `fetch_calibration`)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_scatter8 -o p -- python3 $R/tools/probe_scatter.py > $out/scatter8.json 2> $out/scatter8.err
 ls -R $out | head -80
