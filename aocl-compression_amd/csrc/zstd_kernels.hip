@@ -2235,15 +2235,27 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             const u32 myLit = litPos + incL - ll, myOut = out + incO - (ll + ml);
             // offsets must point inside what is already produced
             if (ballot((u32)lane < cnt && off > myOut + ll) != 0) return 0xFFFFFFFFu;
-            {   // literals: short runs one sequence per lane (two 8-byte loads, exact-length stores), long runs by the wave
+            // exact-length copy of len <= 32 bytes held in v0..v3 (overlapping stores, never past d + len)
+            auto put32 = [&](gbyte* d, u32 len, u64 v0, u64 v1, u64 v2, u64 v3) {
+                auto ext = [&](u32 o) -> u64 {                                    // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
+                    const u64 a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
+                    const u32 sh = (o & 7) * 8;
+                    return sh ? (a >> sh) | (bb << (64 - sh)) : a;
+                };
+                if (len >= 8) {
+                    st64(d, v0);
+                    if (len > 8) st64(d + (len > 16 ? 8 : len - 8), ext(len > 16 ? 8 : len - 8));
+                    if (len > 16) st64(d + (len > 24 ? 16 : len - 8), ext(len > 24 ? 16 : len - 8));
+                    if (len > 24) st64(d + len - 8, ext(len - 8));
+                } else if (len >= 4) { st32(d, (u32)v0); st32(d + len - 4, (u32)(v0 >> (8 * (len - 4)))); }
+                else for (u32 i = 0; i < len; ++i) d[i] = (u8)(v0 >> (8 * i));
+            };
+            {   // literals: runs of up to 32 bytes one sequence per lane (four 8-byte loads, exact-length stores), longer runs by the wave
                 gbyte* gd = (gbyte*)dst; const gbyte* gl = (const gbyte*)litPtr;     // output and literal buffer are global memory
-                const bool shortl = ll <= 16 && (u64)myLit + 16 <= litSize + 0ull;   // the 16-byte read stays inside the literals
+                const bool shortl = ll <= 32 && (u64)myLit + 32 <= litSize + 0ull;   // the 32-byte read stays inside the literals
                 if (ll && shortl) {
-                    const u64 v0 = ld64(gl + myLit), v1 = ld64(gl + myLit + 8);
-                    gbyte* d = gd + myOut;
-                    if (ll >= 8) { st64(d, v0); if (ll > 8) { const u32 o2 = ll - 8; st64(d + o2, o2 == 8 ? v1 : (v0 >> (8 * o2)) | (v1 << (64 - 8 * o2))); } }
-                    else if (ll >= 4) { st32(d, (u32)v0); st32(d + ll - 4, (u32)(v0 >> (8 * (ll - 4)))); }
-                    else for (u32 i = 0; i < ll; ++i) d[i] = (u8)(v0 >> (8 * i));
+                    const u64 v0 = ld64(gl + myLit), v1 = ld64(gl + myLit + 8), v2 = ld64(gl + myLit + 16), v3 = ld64(gl + myLit + 24);
+                    put32(gd + myOut, ll, v0, v1, v2, v3);
                 }
                 for (u64 lm = ballot(ll && !shortl); lm; lm &= lm - 1) {
                     const int k = (int)__builtin_ctzll(lm);
@@ -2252,31 +2264,44 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             }
             wave_fence();
             DSTAGE(3);
-            {   // matches.  Those that copy from output produced before this tile (and are short) are independent of
-                // everything in the tile: all of them at once, one global round trip; the others in order, 64 lanes each.
+            {   // Matches, in dependency levels.  A match is READY when its source does not overlap the destination of a match of
+                // this tile that is still pending (literals are all in place by now; earlier tiles are complete).  All ready
+                // matches of a level go at once: the short ones that do not overlap themselves one per lane (one global round
+                // trip for all of them), the long or self-overlapping ones by the whole wave.  The lowest pending match is always
+                // ready, so every level makes progress; chains of matches that feed each other are two or three levels deep
+                // where an in-order loop pays a round trip per match.
                 gbyte* gd = (gbyte*)dst;
                 const u32 mo = myOut + ll, spos = mo - off;
-                const bool indep = (u32)lane < cnt && ml <= 32 && off >= ml && spos + ml <= out && (u64)spos + 32 <= cap;
-                if (indep) {
-                    const u64 v0 = ld64(gd + spos), v1 = ld64(gd + spos + 8), v2 = ld64(gd + spos + 16), v3 = ld64(gd + spos + 24);
-                    gbyte* d = gd + mo;
-                    auto ext = [&](u32 o) -> u64 {                                // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
-                        const u64 a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
-                        const u32 sh = (o & 7) * 8;
-                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
-                    };
-                    if (ml >= 8) {
-                        st64(d, v0);
-                        if (ml > 8) st64(d + (ml > 16 ? 8 : ml - 8), ext(ml > 16 ? 8 : ml - 8));
-                        if (ml > 16) st64(d + (ml > 24 ? 16 : ml - 8), ext(ml > 24 ? 16 : ml - 8));
-                        if (ml > 24) st64(d + ml - 8, ext(ml - 8));
-                    } else if (ml >= 4) { st32(d, (u32)v0); st32(d + ml - 4, (u32)(v0 >> (8 * (ml - 4)))); }
-                    else for (u32 i = 0; i < ml; ++i) d[i] = (u8)(v0 >> (8 * i));
-                }
-                wave_fence();
-                for (u64 dm = ballot((u32)lane < cnt && !indep); dm; dm &= dm - 1) {
-                    const int k = (int)__builtin_ctzll(dm);
-                    wave_match_copy(dst + lane_get(mo, k), lane_get(off, k), lane_get(ml, k), lane);
+                const bool mine = (u32)lane < cnt && ml != 0;
+                const bool small = mine && ml <= 32 && off >= ml && (u64)spos + 32 <= cap;
+                // level 0: every match whose source lies before this tile's output; only the others can be blocked, and only by
+                // one another (whatever blocks them among the level-0 matches is done by then)
+                const u64 inTile = ballot(mine && spos + ml > out);
+                u64 pend = ballot(mine);
+                bool first = true;
+                while (pend) {
+                    bool blocked = false;
+                    if (first) blocked = (inTile >> lane) & 1;
+                    else {
+                        for (u64 m = pend; m; m &= m - 1) {
+                            const int j = (int)__builtin_ctzll(m);
+                            const u32 mj = lane_get(mo, j), lj = lane_get(ml, j);
+                            blocked = blocked || (j < lane && spos < mj + lj && mj < spos + ml);
+                        }
+                    }
+                    first = false;
+                    const u64 ready = pend & ~ballot(blocked);
+                    const bool go = (ready >> lane) & 1;
+                    if (go && small) {
+                        const u64 v0 = ld64(gd + spos), v1 = ld64(gd + spos + 8), v2 = ld64(gd + spos + 16), v3 = ld64(gd + spos + 24);
+                        put32(gd + mo, ml, v0, v1, v2, v3);
+                    }
+                    for (u64 dm = ready & ballot(!small); dm; dm &= dm - 1) {
+                        const int k = (int)__builtin_ctzll(dm);
+                        wave_match_copy(dst + lane_get(mo, k), lane_get(off, k), lane_get(ml, k), lane);
+                    }
+                    wave_fence();
+                    pend &= ~ready;
                 }
             }
             litPos += totL; out += totO;
