@@ -236,8 +236,88 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             asm volatile("; chain begin" ::: "memory");
             // -------- resolve as many copies as this batch holds --------
             int start = 0;
-            bool done = false;
-            for (;;) {
+            bool done = false, leave = false;
+            auto request_next = [&]() {                   // the windows of the next batch (a search that starts at ip), requested early
+                const int32_t nj = (int32_t)lane - 1;
+                const uint32_t npos = nj < 0 ? ip : ip + 1 + sn_off((uint32_t)nj);
+                const bool nvalid = nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit;
+                pre.lo = 0; pre.hi = 0;
+                if (nvalid) pre = load_win(in, npos);
+                pre_fill = ld32(in + ip - 1);
+                have_pre = true;
+            };
+            // Fast-forward (the LZ4 kernel's mask-based resolve, lz4_kernels.hip): while the searches are the consecutive lanes
+            // of the batch - a search that follows a copy probes ip, ip+1, ... - every copy whose match fits the in-register
+            // windows is found by one readlane along precomputed `next match` links, and the table commit, the literal tags,
+            // the literal bytes and the copy elements of ALL of them are derived from lane masks and written at once.  What
+            // does not fit (a longer match, a search that leaves the consecutive lanes, the end of the fragment) is left to
+            // the one-copy-at-a-time loop below, which starts where the fast-forward stopped.
+            if (linlim == 34 && anchor == pos0) {
+                const int hi2 = lim < linlim ? lim : linlim;
+                const uint64_t okv = okmask & ((1ull << hi2) - 1);
+                const uint32_t endl = (uint32_t)lane + 4u + fw;                        // match end, in lanes
+                const uint64_t slowmask = ballot(mf);
+                uint32_t nxt;
+                {
+                    const uint64_t t = endl < 64 ? okv >> endl : 0;
+                    nxt = t ? endl + (uint32_t)__builtin_ctzll(t) : 64u;             // 64: no match in [endl, hi2)
+                    if (endl >= (uint32_t)hi2) nxt = 65;                              // 65: the next search leaves the consecutive lanes
+                    if (pos0 + endl >= ip_limit) nxt = 66;                            // 66: end of the fragment's searches (:1006-1008)
+                }
+                uint64_t marks = 0;
+                uint32_t mw = okv ? (uint32_t)__builtin_ctzll(okv) : 64u;
+                while (mw < 64) {
+                    if ((slowmask >> mw) & 1) break;                                  // needs the longer compare: the loop below
+                    marks |= 1ull << mw;
+                    mw = lane_get(nxt, (int)mw);
+                }
+                if (marks) {
+                    const int lastm = 63 - (int)__builtin_clzll(marks);
+                    const uint32_t cur = lane_get(endl, lastm);                       // first lane after the last copy (< 64)
+                    const bool marked = (marks >> lane) & 1;
+                    const uint64_t below = ~0ull >> (63 - lane) >> 1;
+                    const uint64_t mb_ = marks & below;
+                    const int q = 63 - (int)__builtin_clzll(mb_ | 1);                 // highest marked lane strictly below
+                    const uint32_t qend = (uint32_t)__shfl((int)endl, q);
+                    const bool covered = marked || (mb_ != 0 && (uint32_t)lane < qend);
+                    const uint64_t cover = ballot(covered);
+                    const bool cont = mw != 66 && cur < (uint32_t)hi2;               // the loop below goes on inside this batch
+                    {   // table writes the reference performs: every probed lane, and lane end-1 behind every copy (:1016-1017) - for
+                        // the last copy only if its successor search is resolved from this batch (else the next batch's back-fill)
+                        const uint64_t belowCur = ~(~0ull << cur);
+                        uint64_t ends = (cover << 1) & (~cover | marks);
+                        if (!cont) ends &= ~(1ull << cur);
+                        const uint64_t commit = (belowCur & ~(cover & ~marks)) | ((ends >> 1) & belowCur);
+                        if (((commit >> lane) & 1) && (later & commit) == 0) tput(h, pos, seq);
+                    }
+                    wave_fence();
+                    auto cntbelow = [&](uint64_t mk) -> uint32_t {
+                        return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    };
+                    const uint32_t lit = marked ? (uint32_t)lane - (mb_ ? qend : 0u) : 0u;       // literals in front of this copy (< 34)
+                    const uint32_t len = 4u + fw, offv = pos - cand;
+                    const bool three = !(len < 12 && offv < 2048);
+                    const uint64_t h1m = ballot(marked && lit > 0), c3m = ballot(marked && three);
+                    const uint64_t litmask = (~0ull >> (63 - lastm)) & ~cover;                    // lanes whose byte is a literal of some copy
+                    const uint32_t S = 2 * cntbelow(marks) + cntbelow(c3m) + cntbelow(h1m);       // tags + copy elements of the copies below
+                    const uint32_t Lb = cntbelow(litmask);
+                    const uint32_t cpos = op + S + Lb + (lit ? 1u : 0u);                          // marked lanes: where the copy element goes
+                    if (marked) {
+                        gbyte* o = out + cpos;
+                        if (lit) o[-(int)lit - 1] = (uint8_t)((lit - 1) << 2);
+                        if (three) { o[0] = (uint8_t)(2 | ((len - 1) << 2)); st16(o + 1, offv); }
+                        else st16(o, (1u | ((len - 4) << 2) | ((offv >> 8) << 5)) | ((offv & 0xFFu) << 8));
+                    }
+                    if ((litmask >> lane) & 1) out[op + S + 1 + Lb] = (uint8_t)litbyte;
+                    op = lane_get(cpos + (three ? 3u : 2u), lastm);
+                    ip = pos0 + cur; anchor = ip;
+                    extra = true; i0 = 0;
+                    if (mw == 66) done = true;
+                    else if (cont) start = (int)cur;
+                    else { request_next(); leave = true; }
+                }
+            }
+            if (!done && !leave) for (;;) {
                 const int hi = start == 0 ? lim : (lim < linlim ? lim : linlim);     // lanes usable by the search being resolved
                 const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
                 const int m = first_lane(rem);
@@ -300,15 +380,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     start = (int)Ln;
                     continue;
                 }
-                {   // otherwise request the windows of the next batch now
-                    const int32_t nj = (int32_t)lane - 1;
-                    const uint32_t npos = nj < 0 ? ip : ip + 1 + sn_off((uint32_t)nj);
-                    const bool nvalid = nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit;
-                    pre.lo = 0; pre.hi = 0;
-                    if (nvalid) pre = load_win(in, npos);
-                    pre_fill = ld32(in + ip - 1);
-                    have_pre = true;
-                }
+                request_next();                              // otherwise request the windows of the next batch now
                 break;
             }
             asm volatile("; chain end" ::: "memory");
