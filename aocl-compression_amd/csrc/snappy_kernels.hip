@@ -19,6 +19,11 @@ namespace {
 
 constexpr uint32_t kBlock = 65536, kMaxTable = 1u << 14, kMinTable = 1u << 8, kMargin = 15;
 constexpr uint32_t kSchedLen = 272;
+#ifndef SN_FIRST_WIDTH
+#define SN_FIRST_WIDTH 34        // lanes probed by the first batch of a search (>= 34: the consecutive steps); 64 = the whole schedule
+#endif
+static_assert(SN_FIRST_WIDTH >= 34 && SN_FIRST_WIDTH <= 64, "the first batch holds at least the schedule's consecutive steps");
+// measured (8 GiB, JSON/log records): 64 lanes 244.9 ms, 48 227.6, 40 223.0, 34 217.4
 
 // skip_j of the recurrence skip += skip >> 5 starting at 32 (snappy.cc:903-944); position offset = skip_j - 32.
 struct SkipTable {
@@ -152,9 +157,16 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
             const uint32_t pos = (j < 0) ? ip : base + sn_off((uint32_t)j);
             const bool valid = (j < 0) || (uint64_t)base + sn_off((uint32_t)(j + 1)) <= ip_limit;       // :946-950
+            // The first batch of a search only probes the schedule's consecutive steps (lanes [0, linlim)): a search in
+            // compressible data ends there, and the 30 lanes behind them (steps of 2-4 bytes) would each cost a window and a
+            // table slot - 64 bytes from the memory system for the HBM-table waves - that nobody looks at.  A search that
+            // does run past them continues with a full batch of the sparse steps.  `act` = probed in this batch.
+            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;        // lanes [0, linlim) probe consecutive positions
+            const int width = i0 == 0 ? SN_FIRST_WIDTH : 64;
+            const bool act = valid && lane < width;
             Win pw = {0, 0};
             if (i0 == 0 && have_pre) pw = pre;
-            else if (valid) pw = load_win(in, pos);
+            else if (act) pw = load_win(in, pos);
             if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
                 const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
                 const uint32_t h1 = sn_hash(fb, shift);
@@ -165,13 +177,12 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const uint32_t seq = (uint32_t)(pw.lo >> 32);
             const uint32_t h = sn_hash(seq, shift);
             uint32_t ent = 0;
-            if (valid) ent = tget(h);
+            if (act) ent = tget(h);
             const uint32_t cand = ent & 0xFFFFu;
-            const bool plausible = valid && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
+            const bool plausible = act && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
             Win cw = {~pw.lo, 0};
             if (plausible) cw = load_win(in, cand);
             // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
-            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;        // lanes [0, linlim) probe consecutive positions
             uint64_t c2 = 0, c3 = 0;
             const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
             const bool have2 = plausible && lane + 8 < linlim && v2 && cand + 20 <= n;
@@ -180,17 +191,17 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             if (have3) c3 = ld64(in + cand + 20);
             wave_fence();
             uint32_t w = (uint32_t)lane;
-            if (GT) w = lds_first_lane_per_slot((uint32_t)(uintptr_t)(scr + (h & (kScratch - 1))), (uint32_t)lane, valid);
+            if (GT) w = lds_first_lane_per_slot((uint32_t)(uintptr_t)(scr + (h & (kScratch - 1))), (uint32_t)lane, act);
             else {
-                bool pending = valid;
+                bool pending = act;
                 do {                                                      // exact per-slot minimum lane
                     if (pending) table[h] = (uint16_t)lane;
                     wave_fence();
-                    if (valid) w = table[h];
+                    if (act) w = table[h];
                     wave_fence();
-                    pending = valid && (uint32_t)lane < w;
+                    pending = act && (uint32_t)lane < w;
                 } while (ballot(pending) != 0);
-                if (valid) table[h] = (uint16_t)cand;                     // undo the lane ids
+                if (act) table[h] = (uint16_t)cand;                       // undo the lane ids
             }
             wave_fence();
             const int e = first_lane(ballot(!valid));
@@ -200,17 +211,17 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // The batch is cut at the first one that could match.  (With the 10-bit scratch of the HBM-table waves `w` also
             // flags lanes whose full hashes differ: those are ordinary lanes.)  `later` = this lane's slot is named again by
             // these later lanes; within one table commit the last of them owns the slot.
-            const uint64_t tabok = ballot(valid && (uint32_t)(cw.lo >> 32) == seq);
+            const uint64_t tabok = ballot(act && (uint32_t)(cw.lo >> 32) == seq);
             uint64_t later = 0;
             int f = 64;
-            for (uint64_t d = ballot(valid && w != (uint32_t)lane); d; d &= d - 1) {
+            for (uint64_t d = ballot(act && w != (uint32_t)lane); d; d &= d - 1) {
                 const int j = (int)__builtin_ctzll(d);
-                const uint64_t same = ballot(valid && h == lane_get(h, j)) & ((1ull << j) - 1);
+                const uint64_t same = ballot(act && h == lane_get(h, j)) & ((1ull << j) - 1);
                 if (!same) continue;
                 if (((tabok >> j) & 1) || (ballot(seq == lane_get(seq, j)) & same) != 0) { f = j; break; }
                 if ((same >> lane) & 1) later |= 1ull << j;
             }
-            const int lim = f < e ? f : e;
+            const int lim0 = f < e ? f : e, lim = lim0 < width ? lim0 : width;
             const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
             auto owns = [&](int a, int b) -> bool {       // lane in [a, b) and no later lane of [a, b) names its slot
                 const uint64_t r = (b >= 64 ? ~0ull : ((1ull << b) - 1)) & ~((1ull << a) - 1);
@@ -240,7 +251,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             auto request_next = [&]() {                   // the windows of the next batch (a search that starts at ip), requested early
                 const int32_t nj = (int32_t)lane - 1;
                 const uint32_t npos = nj < 0 ? ip : ip + 1 + sn_off((uint32_t)nj);
-                const bool nvalid = nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit;
+                const bool nvalid = (nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit) && lane < SN_FIRST_WIDTH;
                 pre.lo = 0; pre.hi = 0;
                 if (nvalid) pre = load_win(in, npos);
                 pre_fill = ld32(in + ip - 1);
@@ -326,7 +337,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     wave_fence();
                     // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
                     // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
-                    const bool at_end = start == 0 ? (hi == lim && e < 64 && e <= f)
+                    const bool at_end = start == 0 ? (hi == e && e < 64 && e <= f)
                                                    : ((uint64_t)pos0 + (uint32_t)hi + 1 > ip_limit);
                     if (at_end) { done = true; break; }
                     if (start == 0) i0 += (uint32_t)hi;
@@ -628,12 +639,15 @@ __global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b,
 // the CU's 128 LDS granules: 4 workgroups per CU = 4 LDS-table waves (the fast ones, no table traffic) + 12 HBM-table waves,
 // which is also what the registers allow (4 waves per SIMD).  Chunks are handed out through an atomic counter, so the faster
 // waves simply take more of them.
-__global__ void __launch_bounds__(256) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
+#ifndef SN_MIX_HBM
+#define SN_MIX_HBM 3
+#endif
+__global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
-    __shared__ __attribute__((aligned(16))) uint16_t scr[3][kScratch];
+    __shared__ __attribute__((aligned(16))) uint16_t scr[SN_MIX_HBM][kScratch];
     const uint32_t w = threadIdx.x >> 6;
-    uint32_t* gt = tables + ((size_t)blockIdx.x * 3 + (w ? w - 1 : 0)) * kMaxTable;
+    uint32_t* gt = tables + ((size_t)blockIdx.x * SN_MIX_HBM + (w ? w - 1 : 0)) * kMaxTable;
     for (;;) {
         uint32_t c = 0;
         if ((threadIdx.x & 63) == 0) c = atomicAdd(counter, 1u);
@@ -679,16 +693,16 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     if ((!forceLds && !forceHbm && b->nchunks > 16u * cus) || forceMix) {
         // large batches: the mixed kernel, 4 workgroups of 4 waves per CU (see snappy_compress_mix_kernel)
         uint32_t grid = 4u * cus;
-        if (grid > (b->nchunks + 3) / 4) grid = (b->nchunks + 3) / 4;
+        if (grid > (b->nchunks + SN_MIX_HBM) / (1 + SN_MIX_HBM)) grid = (b->nchunks + SN_MIX_HBM) / (1 + SN_MIX_HBM);
 #ifdef AOCLGPU_EXPERIMENTS
         if (const char* g = getenv("AOCLGPU_SNAPPY_MIX_PER_CU")) grid = (uint32_t)(atoi(g) > 0 ? atoi(g) : 4) * cus;   // tuning hook
 #endif
-        const size_t tbytes = (size_t)grid * 3 * aoclgpu::kMaxTable * sizeof(uint32_t);
+        const size_t tbytes = (size_t)grid * SN_MIX_HBM * aoclgpu::kMaxTable * sizeof(uint32_t);
         uint8_t* ws = (uint8_t*)aoclgpu::get_workspace(guard, tbytes + 256, stream);
         if (!ws) { aoclgpu::set_error_msg("snappy: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         uint32_t* counter = (uint32_t*)(ws + tbytes);
         if (hipMemsetAsync(counter, 0, 4, (hipStream_t)stream) != hipSuccess) { aoclgpu::set_error_msg("snappy: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
-        hipLaunchKernelGGL(aoclgpu::snappy_compress_mix_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *b, (uint32_t*)ws, counter);
+        hipLaunchKernelGGL(aoclgpu::snappy_compress_mix_kernel, dim3(grid), dim3(64 * (1 + SN_MIX_HBM)), 0, (hipStream_t)stream, *b, (uint32_t*)ws, counter);
         return aoclgpu::check_launch("snappy_compress_mix_kernel");
     }
     if (!forceLds && (b->nchunks > 5u * (uint32_t)prop.multiProcessorCount || forceHbm)) {
