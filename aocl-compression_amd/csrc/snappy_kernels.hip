@@ -20,10 +20,11 @@ namespace {
 constexpr uint32_t kBlock = 65536, kMaxTable = 1u << 14, kMinTable = 1u << 8, kMargin = 15;
 constexpr uint32_t kSchedLen = 272;
 #ifndef SN_FIRST_WIDTH
-#define SN_FIRST_WIDTH 34        // lanes probed by the first batch of a search (>= 34: the consecutive steps); 64 = the whole schedule
+#define SN_FIRST_WIDTH 64        // lanes of the batch that follows a copy: consecutive positions ip, ip+1, ... (34 = one search's own steps)
 #endif
 static_assert(SN_FIRST_WIDTH >= 34 && SN_FIRST_WIDTH <= 64, "the first batch holds at least the schedule's consecutive steps");
-// measured (8 GiB, JSON/log records): 64 lanes 244.9 ms, 48 227.6, 40 223.0, 34 217.4
+constexpr int kSearchLanes = 34;     // a search that follows a copy: the re-probe of ip and the 33 one-byte steps of the schedule
+// measured (8 GiB, JSON/log records), first batch = the schedule's own lanes: 64 lanes 244.9 ms, 48 227.6, 40 223.0, 34 217.4
 
 // skip_j of the recurrence skip += skip >> 5 starting at 32 (snappy.cc:903-944); position offset = skip_j - 32.
 struct SkipTable {
@@ -155,14 +156,20 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // -------- one batch of 64 speculative probes (snappy.cc:903-974, 1016-1032) --------
             const uint32_t base = ip + 1;
             const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-            const uint32_t pos = (j < 0) ? ip : base + sn_off((uint32_t)j);
-            const bool valid = (j < 0) || (uint64_t)base + sn_off((uint32_t)(j + 1)) <= ip_limit;       // :946-950
+            // A batch that follows a copy holds CONSECUTIVE positions ip + lane: lanes [0, 34) are the search's own steps, and
+            // the lanes behind them are there for the searches that follow the copies this batch resolves (each of them probes
+            // 34 consecutive positions of its own) - the mask-based fast-forward below runs through ~4 copies per batch that
+            // way.  Every other batch follows the schedule of the one search it belongs to.
+            const bool consb = extra && i0 == 0;
+            const uint32_t pos = consb ? ip + (uint32_t)lane : base + sn_off((uint32_t)j);
+            const bool valid = consb ? (lane == 0 || (uint64_t)ip + (uint32_t)lane + 1 <= ip_limit)
+                                     : (uint64_t)base + sn_off((uint32_t)(j + 1)) <= ip_limit;          // :946-950
             // The first batch of a search only probes the schedule's consecutive steps (lanes [0, linlim)): a search in
             // compressible data ends there, and the 30 lanes behind them (steps of 2-4 bytes) would each cost a window and a
             // table slot - 64 bytes from the memory system for the HBM-table waves - that nobody looks at.  A search that
             // does run past them continues with a full batch of the sparse steps.  `act` = probed in this batch.
-            const int linlim = (i0 == 0) ? (extra ? 34 : 33) : 0;        // lanes [0, linlim) probe consecutive positions
-            const int width = i0 == 0 ? SN_FIRST_WIDTH : 64;
+            const int linlim = (i0 == 0) ? (extra ? SN_FIRST_WIDTH : 33) : 0;   // lanes [0, linlim) probe consecutive positions
+            const int width = i0 == 0 ? (extra ? SN_FIRST_WIDTH : kSearchLanes) : 64;
             const bool act = valid && lane < width;
             Win pw = {0, 0};
             if (i0 == 0 && have_pre) pw = pre;
@@ -249,9 +256,8 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             int start = 0;
             bool done = false, leave = false;
             auto request_next = [&]() {                   // the windows of the next batch (a search that starts at ip), requested early
-                const int32_t nj = (int32_t)lane - 1;
-                const uint32_t npos = nj < 0 ? ip : ip + 1 + sn_off((uint32_t)nj);
-                const bool nvalid = (nj < 0 || (uint64_t)(ip + 1) + sn_off((uint32_t)(nj + 1)) <= ip_limit) && lane < SN_FIRST_WIDTH;
+                const uint32_t npos = ip + (uint32_t)lane;
+                const bool nvalid = (lane == 0 || (uint64_t)ip + (uint32_t)lane + 1 <= ip_limit) && lane < SN_FIRST_WIDTH;
                 pre.lo = 0; pre.hi = 0;
                 if (nvalid) pre = load_win(in, npos);
                 pre_fill = ld32(in + ip - 1);
@@ -263,20 +269,24 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // the literal bytes and the copy elements of ALL of them are derived from lane masks and written at once.  What
             // does not fit (a longer match, a search that leaves the consecutive lanes, the end of the fragment) is left to
             // the one-copy-at-a-time loop below, which starts where the fast-forward stopped.
-            if (linlim == 34 && anchor == pos0) {
+            if (consb) {
                 const int hi2 = lim < linlim ? lim : linlim;
-                const uint64_t okv = okmask & ((1ull << hi2) - 1);
+                const uint64_t okv = okmask & (hi2 >= 64 ? ~0ull : ((1ull << hi2) - 1));
                 const uint32_t endl = (uint32_t)lane + 4u + fw;                        // match end, in lanes
                 const uint64_t slowmask = ballot(mf);
+                // the 34th probe of a search is followed by a 2-byte step: it is only made if that step stays inside (:946-950)
+                auto own_lanes = [&](uint32_t s0) -> uint32_t { return (uint64_t)pos0 + s0 + 35 > ip_limit ? kSearchLanes - 1 : kSearchLanes; };
                 uint32_t nxt;
                 {
                     const uint64_t t = endl < 64 ? okv >> endl : 0;
-                    nxt = t ? endl + (uint32_t)__builtin_ctzll(t) : 64u;             // 64: no match in [endl, hi2)
+                    const uint32_t cz = t ? (uint32_t)__builtin_ctzll(t) : 64u;
+                    nxt = cz < own_lanes(endl) ? endl + cz : 64u;                     // 64: no match among the lanes of the search that starts at endl
                     if (endl >= (uint32_t)hi2) nxt = 65;                              // 65: the next search leaves the consecutive lanes
                     if (pos0 + endl >= ip_limit) nxt = 66;                            // 66: end of the fragment's searches (:1006-1008)
                 }
                 uint64_t marks = 0;
                 uint32_t mw = okv ? (uint32_t)__builtin_ctzll(okv) : 64u;
+                if (mw >= own_lanes(0)) mw = 64;
                 while (mw < 64) {
                     if ((slowmask >> mw) & 1) break;                                  // needs the longer compare: the loop below
                     marks |= 1ull << mw;
@@ -284,7 +294,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 }
                 if (marks) {
                     const int lastm = 63 - (int)__builtin_clzll(marks);
-                    const uint32_t cur = lane_get(endl, lastm);                       // first lane after the last copy (< 64)
+                    const uint32_t cur = lane_get(endl, lastm);                       // first lane after the last copy (may lie behind the batch)
                     const bool marked = (marks >> lane) & 1;
                     const uint64_t below = ~0ull >> (63 - lane) >> 1;
                     const uint64_t mb_ = marks & below;
@@ -295,9 +305,9 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     const bool cont = mw != 66 && cur < (uint32_t)hi2;               // the loop below goes on inside this batch
                     {   // table writes the reference performs: every probed lane, and lane end-1 behind every copy (:1016-1017) - for
                         // the last copy only if its successor search is resolved from this batch (else the next batch's back-fill)
-                        const uint64_t belowCur = ~(~0ull << cur);
+                        const uint64_t belowCur = cur >= 64 ? ~0ull : ~(~0ull << cur);
                         uint64_t ends = (cover << 1) & (~cover | marks);
-                        if (!cont) ends &= ~(1ull << cur);
+                        if (!cont && cur < 64) ends &= ~(1ull << cur);
                         const uint64_t commit = (belowCur & ~(cover & ~marks)) | ((ends >> 1) & belowCur);
                         if (((commit >> lane) & 1) && (later & commit) == 0) tput(h, pos, seq);
                     }
@@ -329,7 +339,11 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 }
             }
             if (!done && !leave) for (;;) {
-                const int hi = start == 0 ? lim : (lim < linlim ? lim : linlim);     // lanes usable by the search being resolved
+                // lanes usable by the search being resolved: its own steps, as far as the batch holds them
+                // (in a batch of consecutive positions the 34th probe of a search needs room for the 2-byte step behind it)
+                const bool trunc = consb && (uint64_t)pos0 + (uint32_t)start + 35 > ip_limit;
+                const int own = start + kSearchLanes - (trunc ? 1 : 0), cl = lim < linlim ? lim : linlim;
+                const int hi = start == 0 ? (i0 == 0 && lim > own ? own : lim) : (cl < own ? cl : own);
                 const uint64_t rem = okmask & (start ? (~0ull << start) : ~0ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1));
                 const int m = first_lane(rem);
                 if (m >= 64) {                                            // lanes [start, hi) were probed without a match
@@ -337,8 +351,8 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     wave_fence();
                     // next_ip > ip_limit: emit_remainder.  A chained search walks 1-byte steps whatever the batch's
                     // own schedule was, so its end test is on the position after lane hi-1, not on `e`.
-                    const bool at_end = start == 0 ? (hi == e && e < 64 && e <= f)
-                                                   : ((uint64_t)pos0 + (uint32_t)hi + 1 > ip_limit);
+                    const bool at_end = (trunc && hi == own) || (start == 0 ? (hi == e && e < 64 && e <= f)
+                                                                                   : ((uint64_t)pos0 + (uint32_t)hi + 1 > ip_limit));
                     if (at_end) { done = true; break; }
                     if (start == 0) i0 += (uint32_t)hi;
                     else i0 = (uint32_t)(hi - start);

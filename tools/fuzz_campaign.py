@@ -2,7 +2,7 @@
 """Random-seed parity campaign on the GPU box (TEST INFRASTRUCTURE: loads oracle/): LZ-grammar inputs as in
 tests/test_fuzz_gpu.py, but unbounded in number and covering what the fixed-seed test does not - LZ4 accelerations, all three
 LZ4 table modes (sizes around 64 KiB and 256 KiB), Zstd levels 1-4 with both level tables, ragged batches.  Every GPU output
-must equal the oracle's byte for byte and decode back.  usage: tools/fuzz_campaign.py <seconds> [seed]"""
+must equal the oracle's byte for byte and decode back.  usage: tools/fuzz_campaign.py <seconds> [seed] [lz4|snappy|zstd]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,7 @@ import oracle_lib as ol
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+only = sys.argv[3] if len(sys.argv) > 3 else None
 eng = a.engine(0); orc = ol.Oracle(); L = orc.L; lib = eng.lib
 L.orc_lz4_compress_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
 L.orc_zstd_compress_cparams.restype = C.c_size_t
@@ -89,10 +90,10 @@ n_ex = n_chunks = 0
 it = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + it); it += 1
-    codec = ["lz4", "snappy", "zstd"][it % 3]
+    codec = only or ["lz4", "snappy", "zstd"][it % 3]
     size = int(rng.choice([300, 5000, 40000, 65536 + 11, 70000, 140000, 262144, 300000, 400000]))
     raw = seq_shaped(rng, size) if rng.random() < 0.4 else build(rng, size)
-    chunk = int(rng.choice([0, 97, 1000, 4096, 65536, 65547, 131072, 262144]))
+    chunk = int(rng.choice([0, 97, 1000, 4096, 65536, 65547, 131072, 262144, int(rng.integers(16, 3000)), int(rng.integers(3000, 70000))]))
     upstream = False
     if codec == "lz4":
         acc = int(rng.choice([1, 1, 1, 2, 5, 64, 70, 3000])); flags = a.api.lz4_acceleration(acc); gc = a.LZ4
