@@ -252,6 +252,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
     }
 #ifdef ZSTD_PROF
     unsigned long long zacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zprev = __builtin_amdgcn_s_memtime(), zbatches = 0;
+    unsigned long long zcnt[6] = {0, 0, 0, 0, 0, 0};     // chain outcomes: restart, continue, event; one-match batches; immediate repcodes; refreshes
+#define ZCOUNT(k) (zcnt[k]++)
+#else
+#define ZCOUNT(k) ((void)0)
 #endif
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
@@ -281,6 +285,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
         auto rep_loop = [&](u32 ip0) -> u32 {
             bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
             while (hit) {
+                ZCOUNT(4);
                 const u32 rLength = wave_count(src, ip0 + 4, ip0 + 4 - rep2, n, lane) + 4;
                 const u32 t = rep2; rep2 = rep1; rep1 = t;
                 const u64 vc = ld64(src + ip0);
@@ -379,6 +384,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                                 [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
                                 [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0);
                         if (wo.outcome != zchain::ZC_REFRESH) break;
+                        ZCOUNT(5);
                         // the map of the current rep1 came from a match's window and ends too early: one load round for full-width
                         // maps of both repcodes instead of a whole new batch (lanes below the repcode's reach are not needed)
                         u32 nb1 = 0x100, nb2 = 0x100;
@@ -400,6 +406,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
 #endif
                 anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
                 ZSTAGE(3);
+                ZCOUNT(wo.outcome == zchain::ZC_RESTART ? 0 : (wo.outcome == zchain::ZC_CONTINUE ? 1 : 2));
                 if (wo.outcome == zchain::ZC_RESTART) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {                       // the chain's last table writes, one by one
@@ -424,6 +431,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
                 }
             }
             if (!ev) for (;;) {
+                ZCOUNT(3);
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
                 u32 am, sg, st;
                 if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
@@ -554,7 +562,8 @@ __device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 
         }
     }
 #ifdef ZSTD_PROF
-    if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq); }
+    if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq);
+                     for (int k = 0; k < 6; ++k) atomicAdd(&g_zstd_prof[10 + k], zcnt[k]); }
 #endif
     if constexpr (FRAME) {
         saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;           // :614-630

@@ -19,6 +19,7 @@ tot = sum(buf[:8]); nseq = buf[9]
 for n, v in zip(names, buf[:8]):
     print(f"{n:44s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq")
 print("total cyc/seq", tot / nseq, "batches", buf[8], "seqs", nseq, "batches/seq", buf[8] / nseq)
+print("chain outcomes: restart %d continue %d event %d | one-match batches %d | immediate repcodes %d | map refreshes %d" % tuple(buf[10:16]))
 dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, src.numel(), 131072)
 torch.cuda.synchronize()
 eng.lib.aoclgpu_debug_zstd_dprof(buf)
