@@ -101,7 +101,7 @@ ZC_FN WalkOut walk(const uint64_t okmask, const int lim, const uint32_t pos0, in
     bool fin = false, post = false;                      // the chain ended with a sequence whose table writes / rep2 test are pending
     while (S < lim) {                                    // (S <= 63 in the body)
         const uint64_t okS = okmask >> S;
-        const uint64_t t = ((q1 >> 1) >> (S + 1)) & 0x5555555555555555ull;           // R events of this search, relative to S
+        const uint64_t t = ((q1 >> 2) >> S) & 0x5555555555555555ull;                 // R events of this search, relative to S (S + 2 may be 65: two shifts)
         const int jm = S + ctz64(okS);                                                // first M event, >= 64: none
         const int kr = S + ctz64(t);                                                  // first R event
         if (t != 0 && kr <= jm) {

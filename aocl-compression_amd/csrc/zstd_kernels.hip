@@ -41,6 +41,13 @@ constexpr u32 kRingBlk = 240;                   // source ring of the chain batc
 }
 constexpr uint32_t kSrcRingBytes = 512;
 constexpr uint32_t kDfScratchBytes = 4096;
+#ifndef DF_WAVES
+#define DF_WAVES 2          // double-fast: independent wavefronts per workgroup (they share the entropy stage's LDS, one at a time)
+#endif
+constexpr uint32_t kDfWaves = DF_WAVES;
+// (3 wavefronts per workgroup change nothing: the kernel's 135 VGPRs allow 12 per CU.  A register budget of 4 waves per SIMD
+//  is not reached: with the entropy stage inlined under amdgpu_waves_per_eu(4,4) / amdgpu_num_vgpr(128) the allocator
+//  stops at 132 VGPRs with 47 spills.)
 namespace {
 
 // ---- pair schedule of the fast match finder (zstd_fast.c:491-631): offset of pair m from the search
@@ -607,6 +614,9 @@ struct DfSched {
 };
 __device__ const DfSched g_dfs{};
 constexpr u32 kDfScratch = 1024;                // u16 slots per hash for the slot-reuse rounds
+#ifndef DF_FIRST_WIDTH
+#define DF_FIRST_WIDTH 16                       // lanes probed by the first batch of a search
+#endif
 
 __device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }   // ZSTD_hash8
 
@@ -677,35 +687,41 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         else { am = 0x40000000u; am1 = 0x40000000u; }
         const bool valid = (int64_t)s + (int64_t)am1 <= ilimit;             // the loop reaches probe m (:405, :473)
         const u32 pos = s + am;
+        // A search's first batch probes DF_FIRST_WIDTH lanes only: both tables live in HBM (0.75 MB per chunk), every probe is
+        // two scattered table reads and up to three candidate reads, and the kernel runs at the memory system's rate for such
+        // reads (~52 G/s, bench `fetch_calibration`) - while most searches end within a few probes (the literal run in front of
+        // a match is short).  A search that gets further continues with full batches.  `act` = probed in this batch.
+        const int width = i0 == 0 ? DF_FIRST_WIDTH : 64;
+        const bool act = valid && lane < width;
         u64 v8 = 0;
-        if (valid) v8 = ld64(src + pos);
+        if (act) v8 = ld64(src + pos);
         const u32 hl = z_hash8(v8, hlogL), hs = z_hash<MLS>(v8, hlogS);
         u32 idxl = 0, idxs = 0;
-        if (valid) { idxl = tget(L, hl); idxs = tget(S, hs); }
+        if (act) { idxl = tget(L, hl); idxs = tget(S, hs); }
         u64 cl = ~v8; u32 cs = ~(u32)v8, r4 = ~(u32)(v8 >> 8);
-        if (valid && idxl > prefixIdx) cl = ld64(src + idxl - 2);
-        if (valid && idxs > prefixIdx) cs = ld32(src + idxs - 2);
-        if (valid && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
+        if (act && idxl > prefixIdx) cl = ld64(src + idxl - 2);
+        if (act && idxs > prefixIdx) cs = ld32(src + idxs - 2);
+        if (act && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
         const bool repHit = r4 == (u32)(v8 >> 8), longHit = cl == v8, shortHit = cs == (u32)v8;
         wave_fence();
-        const u32 wl = lds_first_lane_per_slot((u32)(uintptr_t)(scrL + (hl & (kDfScratch - 1))), (u32)lane, valid);
+        const u32 wl = lds_first_lane_per_slot((u32)(uintptr_t)(scrL + (hl & (kDfScratch - 1))), (u32)lane, act);
         wave_fence();
-        const u32 wsm = lds_first_lane_per_slot((u32)(uintptr_t)(scrS + (hs & (kDfScratch - 1))), (u32)lane, valid);
+        const u32 wsm = lds_first_lane_per_slot((u32)(uintptr_t)(scrS + (hs & (kDfScratch - 1))), (u32)lane, act);
         wave_fence();
         int f = 64;                                          // first lane whose long or short slot an earlier lane names
-        for (u64 d = ballot(valid && (wl != (u32)lane || wsm != (u32)lane)); d; d &= d - 1) {
+        for (u64 d = ballot(act && (wl != (u32)lane || wsm != (u32)lane)); d; d &= d - 1) {
             const int j = (int)__builtin_ctzll(d);
             const u64 before = (1ull << j) - 1;
-            if (((ballot(valid && hl == lane_get(hl, j)) | ballot(valid && hs == lane_get(hs, j))) & before) != 0) { f = j; break; }
+            if (((ballot(act && hl == lane_get(hl, j)) | ballot(act && hs == lane_get(hs, j))) & before) != 0) { f = j; break; }
         }
         const int e = first_lane(ballot(!valid));
-        const int lim = f < e ? f : e;
+        const int lim0 = f < e ? f : e, lim = lim0 < width ? lim0 : width;
         const int el = first_lane(ballot(lane < lim && (repHit || longHit || shortHit)));
         const int ncommit = el < 64 ? el + 1 : lim;
         if (lane < ncommit) { tput(L, hl, pos + 2); tput(S, hs, pos + 2); }   // hashLong[hl0] = hashSmall[hs0] = curr (:423)
         wave_fence();
         if (el >= 64) {
-            if (e < 64 && e <= f) break;                     // the next probe's successor would pass ilimit: _cleanup
+            if (e < 64 && e <= f && e <= width) break;       // the next probe's successor would pass ilimit: _cleanup
             i0 += (u32)lim;
             continue;
         }
@@ -1187,8 +1203,8 @@ __device__ __forceinline__ u32 flags_level(u32 flags)
 // 181 -> 8 per CU and level 1 lost 10 %).
 template <bool DF>
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
-                                  void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf)
-{
+                                  void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf, void* entLds = nullptr, u32* lock = nullptr)
+{   // entLds / lock (double-fast kernel): the entropy stage's LDS is shared by the workgroup's wavefronts, taken one at a time
     // (the block is staged in the workspace and only copied out when it fits: a slot smaller than ZSTD_compressBound works
     //  whenever the frame itself fits, as with the reference's ZSTD_compress)
     if (n > kBlockMax || cap < 5u + ((n < 256) ? 1u : (n < 65536 + 256 ? 2u : 4u)) + 3u) return 0;
@@ -1227,7 +1243,17 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         if (expf & 16) cSize = 0;      // experiment build (timing only): match finder alone, block emitted raw
         else
 #endif
-        cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(lds), lane, zp.strategy);
+        {
+            if (lock) {
+                if (lane == 0) while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            cSize = entropy_compress(ws->tmp, ws, litSize, nbSeq, reinterpret_cast<EntropyLds*>(entLds ? entLds : lds), lane, zp.strategy);
+            if (lock) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicExch(lock, 0u);
+            }
+        }
         if (cSize >= n - ((n >> 6) + 2)) cSize = 0;                      // ZSTD_minGain, zstd_compress.c:3055-3057
     }
     if ((u64)op + 3 + (cSize ? cSize : n) > cap) return 0;               // dstSize_tooSmall
@@ -2399,14 +2425,27 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
 
 }  // namespace
 
+// Double-fast (DF): a workgroup is kDfWaves INDEPENDENT wavefronts (own chunk, own tables and workspace, own 4 KB of slot-reuse
+// scratch; no barrier after the first instruction).  The finder needs almost no LDS and waits on HBM most of the time, the
+// entropy stage needs 17.5 KB for a few percent of a chunk's time: the waves of a workgroup share ONE entropy area behind a
+// lock word, so that LDS no longer bounds the resident chunks (9 -> 12 per CU, the register bound).
 template <bool DF>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DF ? 4 : 1, DF ? 4 : 8))) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
+__global__ void __launch_bounds__(DF ? 64 * DF_WAVES : 64) __attribute__((amdgpu_waves_per_eu(DF ? 3 : 1, DF ? 4 : 8))) zstd_compress_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes,
                                                            uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes, uint32_t* counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
-    u32* tabs = tabBase ? reinterpret_cast<u32*>(tabBase + (size_t)blockIdx.x * tabBytes) : nullptr;   // double-fast: this workgroup's two tables
+    const uint32_t wv = DF ? threadIdx.x >> 6 : 0u, unit = DF ? blockIdx.x * kDfWaves + wv : blockIdx.x;
+    Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + unit;
+    u32* tabs = tabBase ? reinterpret_cast<u32*>(tabBase + (size_t)unit * tabBytes) : nullptr;          // double-fast: this wave's two tables
     const int lane = lane_id();
+    uint8_t* mine = lds; void* entLds = nullptr; u32* lock = nullptr;
+    if constexpr (DF) {
+        const uint32_t ent = (uint32_t)((sizeof(EntropyLds) + 255) & ~(size_t)255);
+        entLds = lds; mine = lds + ent + wv * kDfScratchBytes; lock = reinterpret_cast<u32*>(lds + ent + kDfWaves * kDfScratchBytes);
+        if (threadIdx.x == 0) *lock = 0;
+        __syncthreads();
+        ldsBytes = kDfScratchBytes;
+    }
     // chunks are handed out through a counter (zeroed by the launcher): a chunk's duration varies by a factor of several with
     // its content, and a static stride leaves the workgroups that drew the short ones idle at the end of the launch
     for (;;) {
@@ -2416,7 +2455,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DF ? 4 
         if (c >= count) break;
         c += first;
         const ChunkView v = compress_view(b, c);
-        const int r = zstd_compress_wave<DF>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, ws, tabs, lane, b.reserved);
+        const int r = zstd_compress_wave<DF>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, mine, ldsBytes, ws, tabs, lane, b.reserved, entLds, lock);
         if (lane == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -2485,7 +2524,10 @@ using aoclgpu::get_workspace;
 uint32_t lds_for_chunk(uint64_t n, int level = 1)
 {   // hash table bytes of the level's parameters for an n-byte chunk, never less than the entropy-stage LDS
     uint32_t need;
-    if (level >= 3) need = aoclgpu::kDfScratchBytes;     // double-fast: tables in HBM, LDS only holds the slot-reuse scratch
+    if (level >= 3) {                                    // double-fast: tables in HBM; LDS = one entropy area + the waves' slot-reuse scratch + lock word
+        const uint32_t ent = ((uint32_t)aoclgpu::zstd_entropy_lds_bytes() + 255u) & ~255u;
+        return ent + aoclgpu::kDfWaves * aoclgpu::kDfScratchBytes + 256u;
+    }
     else if (n <= 16384) {
         uint32_t srcLog = 6; if (n >= 64) { srcLog = 0; uint64_t t = n - 1; while (t) { srcLog++; t >>= 1; } }
         const uint32_t w = srcLog < 14 ? srcLog : 14, hl = (15 < w + 1) ? 15 : w + 1;
@@ -2625,13 +2667,14 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
         } else L[nl++] = { 0, b->nchunks, lds_for_chunk(b->nchunks > 1 ? b->chunk_bytes : tail, level) };
     }
     const void* kfn = level >= 3 ? (const void*)aoclgpu::zstd_compress_kernel<true> : (const void*)aoclgpu::zstd_compress_kernel<false>;
+    const uint32_t wpb = level >= 3 ? aoclgpu::kDfWaves : 1u;   // wavefronts (= chunks in flight) per workgroup
     aoclgpu::WsGuard guard;                               // held until the kernels that use the scratch are enqueued
     for (int i = 0; i < nl; ++i) {
         // persistent blocks: exactly as many as are resident at once for this LDS size (gfx950 allocates LDS in 1280-byte
         // granules, the occupancy query counts bytes: the smaller of the two, see aoclgpu_zstd_decompress_chunks)
         int perCU = 0, dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, 64, L[i].lds) != hipSuccess || perCU < 1) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, (int)(64u * wpb), L[i].lds) != hipSuccess || perCU < 1) {
             aoclgpu::set_error_msg("zstd: occupancy query failed"); return AOCLGPU_ERR_HIP;
         }
         {
@@ -2639,10 +2682,11 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
             if (byLds >= 1 && byLds < perCU) perCU = byLds;
         }
         uint32_t grid = (uint32_t)(perCU * prop.multiProcessorCount);
-        if (grid > L[i].count) grid = L[i].count;
-        const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
+        if (grid > (L[i].count + wpb - 1) / wpb) grid = (L[i].count + wpb - 1) / wpb;
+        const size_t units = (size_t)grid * wpb;           // resident chunks: one workspace and (double-fast) one pair of tables each
+        const size_t seqBytes = (units * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
         // (one hand-out counter per launch of this call, behind the scratch: the launches of a call run back to back on the stream)
-        const size_t ctrOff = (seqBytes + (size_t)grid * tabBytes + 255) & ~(size_t)255;
+        const size_t ctrOff = (seqBytes + units * tabBytes + 255) & ~(size_t)255;
         void* ws = get_workspace(guard, ctrOff + 256, stream);
         if (!ws) { aoclgpu::set_error_msg("zstd: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
         uint8_t* tabBase = tabBytes ? (uint8_t*)ws + seqBytes : nullptr;
@@ -2652,7 +2696,7 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
             hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L[i].lds);
             if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
         }
-        if (level >= 3) hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<true>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
+        if (level >= 3) hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<true>, dim3(grid), dim3(64 * wpb), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
                                            tabBase, (uint32_t)tabBytes, counter);
         else hipLaunchKernelGGL(aoclgpu::zstd_compress_kernel<false>, dim3(grid), dim3(64), L[i].lds, s, *b, (uint8_t*)ws, L[i].lds, L[i].first, L[i].count,
                                 tabBase, (uint32_t)tabBytes, counter);

@@ -96,6 +96,13 @@ def lz_grammar(rng, nbytes, alphabet):
     return bytes(out[:nbytes])
 
 
+def test_search_that_starts_at_the_last_lane(model, orc):
+    """tests/golden/zstd_walk_search_at_lane63.bin (found by tools/fuzz_campaign.py, seed 9903): a repcode match ends at lane 62
+    of a batch, so the next search starts at lane 63 - its repcode test needs bytes behind the batch and the walk has to stop
+    there instead of taking lane 63's table match (the shift that builds the repcode events of the search was by 64)."""
+    check(model, orc, open(os.path.join(HERE, "golden", "zstd_walk_search_at_lane63.bin"), "rb").read())
+
+
 @pytest.mark.parametrize("alphabet", [2, 4, 16, 256])
 def test_grammar_inputs(model, orc, alphabet):
     rng = np.random.default_rng(1234 + alphabet)

@@ -254,3 +254,14 @@ def test_huffman_sort_bucket_of_count_164(eng, oracle):
         slots, lens, slot = eng.compress_chunks(a.ZSTD, src, len(data))
         got = slots[:int(lens[0])].cpu().numpy().tobytes()
         assert got == oracle.compress(ol.ZSTD, data), seed
+
+
+def test_search_that_starts_at_the_last_lane(eng, oracle):
+    """tests/golden/zstd_walk_search_at_lane63.bin (tools/fuzz_campaign.py seed 9903; CPU twin in tests/test_zstd_chain_model.py):
+    the search that follows a repcode match ending at lane 62 starts at the batch's last lane"""
+    import os
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_walk_search_at_lane63.bin"), "rb").read()
+    t = eng.torch
+    src = t.frombuffer(bytearray(data), dtype=t.uint8).to(eng.device)
+    slots, lens, slot = eng.compress_chunks(a.ZSTD, src, len(data))
+    assert slots[:int(lens[0])].cpu().numpy().tobytes() == oracle.compress(ol.ZSTD, data)
