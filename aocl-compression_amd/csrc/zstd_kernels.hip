@@ -678,8 +678,18 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
     }
     const int64_t ilimit = (int64_t)n - 8 - 19;
     u32 i0 = 0;                                              // probes of the current search already examined
+#ifdef ZSTD_PROF
+    unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0}, dprev = __builtin_amdgcn_s_memtime(), dcnt[4] = {0, 0, 0, 0};
+#define DFSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dacc[k] += t_ - dprev; dprev = t_; } while (0)
+#define DFCOUNT(k) (dcnt[k]++)
+#else
+#define DFSTAGE(k) do { } while (0)
+#define DFCOUNT(k) ((void)0)
+#endif
     for (;;) {
         // ---------------- one batch of 64 speculative probes ----------------
+        DFCOUNT(i0 == 0 ? 0 : 1);
         const u32 m = i0 + (u32)lane;
         u32 am, am1;
         if (m < 256) { am = m; am1 = m + 1; }                // (the schedule is the identity for the first 256 bytes)
@@ -695,15 +705,18 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         const bool act = valid && lane < width;
         u64 v8 = 0;
         if (act) v8 = ld64(src + pos);
+        DFSTAGE(0);
         const u32 hl = z_hash8(v8, hlogL), hs = z_hash<MLS>(v8, hlogS);
         u32 idxl = 0, idxs = 0;
         if (act) { idxl = tget(L, hl); idxs = tget(S, hs); }
+        DFSTAGE(1);
         u64 cl = ~v8; u32 cs = ~(u32)v8, r4 = ~(u32)(v8 >> 8);
         if (act && idxl > prefixIdx) cl = ld64(src + idxl - 2);
         if (act && idxs > prefixIdx) cs = ld32(src + idxs - 2);
         if (act && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
         const bool repHit = r4 == (u32)(v8 >> 8), longHit = cl == v8, shortHit = cs == (u32)v8;
         wave_fence();
+        DFSTAGE(2);
         const u32 wl = lds_first_lane_per_slot((u32)(uintptr_t)(scrL + (hl & (kDfScratch - 1))), (u32)lane, act);
         wave_fence();
         const u32 wsm = lds_first_lane_per_slot((u32)(uintptr_t)(scrS + (hs & (kDfScratch - 1))), (u32)lane, act);
@@ -718,6 +731,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         const int lim0 = f < e ? f : e, lim = lim0 < width ? lim0 : width;
         const int el = first_lane(ballot(lane < lim && (repHit || longHit || shortHit)));
         const int ncommit = el < 64 ? el + 1 : lim;
+        DFSTAGE(3);
         if (lane < ncommit) { tput(L, hl, pos + 2); tput(S, hs, pos + 2); }   // hashLong[hl0] = hashSmall[hs0] = curr (:423)
         wave_fence();
         if (el >= 64) {
@@ -785,6 +799,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
                 rep2 = rep1; rep1 = offset; offBase = offset + 3u;
             }
         }
+        DFSTAGE(4);
         if (insert1) { if (lane == 0) tput(L, hl1, ip1 + 2); }               // :516-526
         put_seq(nbSeq, ip - anchor, offBase, mLength, anchor);
         litSize += ip - anchor; nbSeq++;
@@ -816,7 +831,12 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
             }
         }
         s = ip; i0 = 0;
+        DFSTAGE(5);
     }
+#ifdef ZSTD_PROF
+    if (lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_zstd_prof[k], dacc[k]); atomicAdd(&g_zstd_prof[8], dcnt[0] + dcnt[1]); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq);
+                     atomicAdd(&g_zstd_prof[10], dcnt[0]); atomicAdd(&g_zstd_prof[11], dcnt[1]); }
+#endif
     if constexpr (FRAME) {
         saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;           // :478-486
         *rep1io = rep1 ? rep1 : saved1;
