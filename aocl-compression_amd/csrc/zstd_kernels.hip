@@ -197,12 +197,17 @@ __device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
 // the catch-up stops there, the repeat offsets come in and go out (zstd_fast.c:481-489, :614-634); the source ring counts its
 // 240-byte blocks from bs.
 template <int MLS, typename T, bool HI, bool FRAME = false>
-__device__ u32 fast_block(const gbyte* __restrict__ src, const u32 n, const u32 hlog, lbyte* lds, Workspace* ws,
-                          u32* litSizeOut, int lane, const u32 expf, const u32 bs_ = 0, const FrameWindow* win = nullptr,
+__device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u32 hlog_, lbyte* lds_, Workspace* ws_,
+                          u32* litSizeOut, int lane, const u32 expf_, const u32 bs_ = 0, const FrameWindow* win = nullptr,
                           u32* rep1io = nullptr, u32* rep2io = nullptr)
 {
     static_assert(FRAME ? (sizeof(T) == 4 && !HI) : sizeof(T) == 2, "u16 slots for chunks, u32 slots for frames");
-    const u32 bs = FRAME ? bs_ : 0u;                                    // (a compile-time zero for chunks)
+    // (arguments of a non-inlined function arrive in VGPRs and count as divergent: everything the control flow hangs on is
+    //  made wave-uniform here, or the scalar walk below is compiled as exec-masked vector code - common.hip.h)
+    const gbyte* __restrict__ src = uni_ptr(src_);
+    lbyte* lds = uni_ptr(lds_); Workspace* ws = uni_ptr(ws_);
+    const u32 n = uni(n_), hlog = uni(hlog_), expf = uni(expf_);
+    const u32 bs = FRAME ? uni(bs_) : 0u;                               // (a compile-time zero for chunks)
     typedef __attribute__((address_space(3))) T LT;
     typedef __attribute__((address_space(3))) u32 L32;
     constexpr bool kHi = HI;                                            // positions need 17 bits (chunks above 16 KiB)
