@@ -22,6 +22,7 @@
 // forward match extension compare 64 / 256 bytes per step with ballot; token, length bytes and
 // literals are written cooperatively.
 #include "common.hip.h"
+#include "host_util.h"
 
 namespace aoclgpu {
 namespace {
@@ -887,10 +888,17 @@ __device__ uint32_t lz4_wave_count(const gbyte* __restrict__ src, uint32_t a, ui
     }
 }
 
-// one block [b0, iend) of the frame at src; returns its compressed size, 0 when it does not fit olimit bytes
+// one block [b0, iend) of the frame at src; returns its compressed size, 0 when it does not fit olimit bytes.
+// The last four arguments describe the block of a STREAM (LZ4_compress_fast_continue, lz4.c:3179-3254, as LZ4F_compressUpdate
+// drives it): src is a window of the stream whose byte 0 has stream index idxBase (the table holds stream indices),
+// candidates below lowCand are outside the dictionary (dictSmall, :1000, :1137), the catch-up stops at lowPos - the start
+// of the dictionary - or, with ext (usingExtDict: the block does not follow its dictionary in memory), at the block's start
+// for a match inside the block (:1112-1119, :1149).  A one-shot frame is the stream whose dictionary is the frame so far.
 __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32_t b0, const uint32_t iend, uint32_t* table, const uint32_t accel,
-                                     gbyte* __restrict__ d, const uint32_t olimit, int lane)
+                                     gbyte* __restrict__ d, const uint32_t olimit, int lane,
+                                     const uint32_t idxBase = 0, const uint32_t lowCand = 0, const uint32_t lowPos = 0, const bool ext = false)
 {
+    const uint32_t lowIdx = lowCand > idxBase ? lowCand : idxBase;      // (what lies below the window is further than 64 KB away)
     typedef __attribute__((address_space(3))) uint32_t L32;
     L32* T = (L32*)table;
     const uint32_t bn = iend - b0;
@@ -898,7 +906,7 @@ __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32
     uint32_t ip = b0, anchor = b0;
     uint64_t op = 0;
     if (bn >= 13) {                                                      // LZ4_minLength (:1039)
-        if (lane == 0) T[lz4_hash<false>(ld64(src + ip))] = ip;          // first byte (:1042)
+        if (lane == 0) T[lz4_hash<false>(ld64(src + ip))] = ip + idxBase;   // first byte (:1042)
         wave_fence();
         uint32_t s = ip + 1, i0 = 0;
         for (;;) {
@@ -910,7 +918,7 @@ __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32
             uint64_t seq = 0; uint32_t h = 0, cand = 0;
             if (valid) { seq = ld64(src + pos); h = lz4_hash<false>(seq); cand = T[h]; }
             uint32_t m4 = ~(uint32_t)seq;
-            if (valid && (uint64_t)cand + 65535u >= pos) m4 = ld32(src + cand);       // not "too far" (:1124-1127)
+            if (valid && cand >= lowIdx && (uint64_t)cand + 65535u >= (uint64_t)pos + idxBase) m4 = ld32(src + (cand - idxBase));   // not "too far" (:1124-1127)
             wave_fence();
             const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&T[h], (uint32_t)lane, valid);
             wave_fence();
@@ -921,7 +929,7 @@ __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32
             const int lim = f < e ? f : e;
             const int el = first_lane(ballot(lane < lim && m4 == (uint32_t)seq));
             const int ncommit = el < 64 ? el + 1 : lim;
-            if (lane < ncommit) T[h] = pos;                              // LZ4_putIndexOnHash (:1121)
+            if (lane < ncommit) T[h] = pos + idxBase;                    // LZ4_putIndexOnHash (:1121)
             wave_fence();
             if (el == 64) {
                 if (e < 64 && e <= f) break;                             // _last_literals
@@ -929,9 +937,10 @@ __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32
                 continue;
             }
             ip = lane_get(pos, el);
-            uint32_t match = lane_get(cand, el);
-            {   // catch up (:1139-1140): lowLimit is the frame's start
-                const uint32_t a = ip - anchor, maxback = a < match ? a : match;
+            uint32_t match = lane_get(cand, el) - idxBase;
+            {   // catch up (:1139-1140): lowLimit is the dictionary's start (a one-shot frame: the frame's)
+                const uint32_t lowM = (ext && match >= b0) ? b0 : lowPos;
+                const uint32_t a = ip - anchor, bq = match - lowM, maxback = a < bq ? a : bq;
                 uint32_t back = 0;
                 while (back < maxback) {
                     const uint32_t k = back + (uint32_t)lane;
@@ -969,14 +978,14 @@ __device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32
                 {   // fill the table (:1277), test the next position (:1279-1330)
                     const uint64_t s2 = ld64(src + ip - 2), s0 = ld64(src + ip);
                     const uint32_t h2 = lz4_hash<false>(s2), h0 = lz4_hash<false>(s0);
-                    if (lane == 0) T[h2] = ip - 2;
+                    if (lane == 0) T[h2] = ip - 2 + idxBase;
                     wave_fence();
                     const uint32_t c0 = T[h0];
                     wave_fence();
-                    if (lane == 0) T[h0] = ip;
+                    if (lane == 0) T[h0] = ip + idxBase;
                     wave_fence();
-                    if ((uint64_t)c0 + 65535u >= ip && uni(ld32(src + c0) == (uint32_t)s0 ? 1u : 0u)) {
-                        token_pos = op++; token = 0; match = c0; again = true;
+                    if (c0 >= lowIdx && (uint64_t)c0 + 65535u >= (uint64_t)ip + idxBase && uni(ld32(src + (c0 - idxBase)) == (uint32_t)s0 ? 1u : 0u)) {
+                        token_pos = op++; token = 0; match = c0 - idxBase; again = true;
                     }
                 }
             } while (again);
@@ -1015,6 +1024,30 @@ __global__ void __launch_bounds__(64) lz4_compress_linked_kernel(aoclgpu_batch b
         wave_fence();
         if (lane == 0) b.out_len[c] = (int32_t)r;
     }
+}
+
+// The blocks one LZ4F_compressUpdate / LZ4F_flush call completes in a frame with linked blocks (csrc/lz4frame_api.cpp): one
+// wavefront, block after block, on a window of the stream (the 64 KB before the call's first block + the call's blocks).  The
+// stream's hash table lives in gtable between calls.
+__global__ void __launch_bounds__(64) lz4_compress_stream_kernel(const uint8_t* src, uint32_t idxBase, const aoclgpu::Lz4StreamJob* jobs, uint32_t njobs,
+                                                                 uint32_t* gtable, uint8_t* dst, uint32_t slot, int32_t* out_len, uint32_t accel)
+{
+    __shared__ uint32_t table[4096];
+    const int lane = lane_id();
+    for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) table[i] = gtable[i];
+    wave_fence();
+    for (uint32_t j = 0; j < njobs; ++j) {
+        const uint32_t off = uni(jobs[j].off), len = uni(jobs[j].len), lowCand = uni(jobs[j].lowCand), lowPos = uni(jobs[j].lowPos), ext = uni(jobs[j].ext);
+        uint32_t r = 0;
+        if (len >= 1) {
+            const uint32_t room = slot < len - 1 ? slot : len - 1;
+            r = lz4_linked_block((const gbyte*)src, off, off + len, table, accel, (gbyte*)dst + (uint64_t)j * slot, room, lane, idxBase, lowCand, lowPos, ext != 0);
+        }
+        wave_fence();
+        if (lane == 0) out_len[j] = (int32_t)r;
+    }
+    wave_fence();
+    for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) gtable[i] = table[i];
 }
 
 template <bool RAP>
@@ -1107,6 +1140,16 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
     }
     return AOCLGPU_OK;
 }
+
+namespace aoclgpu {
+int lz4_stream_blocks(const uint8_t* d_src, uint32_t idxBase, const Lz4StreamJob* d_jobs, uint32_t njobs, uint32_t* d_table, uint8_t* d_dst, uint32_t slot,
+                      int32_t* d_len, uint32_t accel, void* stream)
+{
+    if (!njobs) return AOCLGPU_OK;
+    hipLaunchKernelGGL(lz4_compress_stream_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_src, idxBase, d_jobs, njobs, d_table, d_dst, slot, d_len, accel);
+    return check_launch("lz4_compress_stream_kernel");
+}
+}  // namespace aoclgpu
 
 extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream)
 {

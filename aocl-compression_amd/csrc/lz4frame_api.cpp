@@ -23,6 +23,7 @@
 #include "../../include/aocl_native_api.h"
 #include "../../include/aocl_gpu_codec.h"
 #include <hip/hip_runtime.h>
+#include "host_util.h"
 #include <atomic>
 #include <stdlib.h>
 #include <string.h>
@@ -588,10 +589,54 @@ static size_t LZ4F_decompress_impl(LZ4F_dctx* dctx, void* dstBuffer, size_t* dst
 // ---- streaming compressor (lz4frame.c:570-1030): same buffering rules as the reference (a block is cut when blockSize bytes
 //      are there, or at every call with autoFlush), so for LZ4F_blockIndependent the bytes equal the reference's for the same
 //      sequence of calls; every LZ4F_compressUpdate compresses the blocks it completes in one launch ----
+// State of the LZ4_stream_t a reference cctx owns, as far as it decides bytes (lz4.c:3179-3254, :972-1046, LZ4_prepareTable
+// :810-853, LZ4_saveDict :3283-3311): the index of the next byte (currentOffset), the table's type, and WHERE the dictionary
+// is - the reference picks prefix or external-dictionary mode by comparing addresses, so the emulation keeps addresses too:
+// the caller's own for blocks compressed in place, offsets into an imaginary tmpBuff (kTmpSpace) for buffered data.
+struct Lz4StreamState {
+    uint32_t cur = 0; int type = 0;                          // type: 0 clearedTable, 2 byU32, 3 byU16 (lz4.h tableType_t)
+    uint64_t dict = 0; uint32_t dictSize = 0;                // dictionary = [dict, dict + dictSize); 0 / 0 = none
+};
+constexpr uint64_t kTmpSpace = 0xA0C1ull << 48;              // tmpBuff + x (no user buffer lives there)
+
 struct LZ4F_cctx_s {
     unsigned version; LZ4F_preferences_t prefs; int stage; size_t bs;
     std::vector<uint8_t> tmp; size_t tmpSize; unsigned long long total; Xxh32Stream xxh;
+    // linked blocks (LZ4F_blockLinked): the stream the blocks of the frame continue
+    bool linked = false; Lz4StreamState lz; uint32_t* d_table = nullptr; bool tableZero = false;
+    std::vector<uint8_t> hist;                               // the last <= 64 KB of the stream
+    size_t tmpInOff = 0, maxBufferSize = 0;                  // cctx->tmpIn - cctx->tmpBuff, cctx->maxBufferSize (lz4frame.c:640-655)
+    ~LZ4F_cctx_s() { if (d_table) (void)hipFree(d_table); }
 };
+
+namespace {
+// LZ4_prepareTable (lz4.c:810-853)
+void lz_prepare(Lz4StreamState& z, bool& clearTable, uint32_t inputSize, int want)
+{
+    if (z.type != 0) {
+        if (z.type != want || (want == 3 && z.cur + inputSize >= 0xFFFFu) || (want == 2 && z.cur > (1u << 30)) || inputSize >= 4096) {
+            clearTable = true; z.cur = 0; z.type = 0;
+        }
+    }
+    if (z.cur != 0 && want == 2) z.cur += 65536;
+    z.dict = 0; z.dictSize = 0;
+}
+// what an independent block leaves in the stream state (LZ4_compress_fast_extState_fastReset, lz4.c:1408-1445, limited output)
+void lz_after_independent_block(Lz4StreamState& z, bool& clearTable, uint32_t n)
+{
+    const int want = n < 65547 ? 3 : 2;
+    lz_prepare(z, clearTable, n, want);
+    z.cur += n; z.type = want; z.dictSize = n;               // (dictSize += inputSize, :1037; nobody reads it before the next reset)
+}
+// LZ4_saveDict(stream, tmpBuff, 64 KB) (lz4.c:3283-3311)
+uint32_t lz_save_dict(Lz4StreamState& z)
+{
+    const uint32_t ds = z.dictSize < 65536 ? z.dictSize : 65536;
+    z.dict = kTmpSpace; z.dictSize = ds;
+    return ds;
+}
+struct StreamBlock { const uint8_t* p; uint32_t len; uint64_t addr; };   // addr: where the reference sees the block (user pointer or tmpBuff offset)
+}  // namespace
 
 extern "C" {
 
@@ -616,14 +661,129 @@ static size_t LZ4F_compressBegin_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t d
     if (!cctx || !dstBuffer) return err(E_GENERIC);
     if (dstCapacity < kMaxHeader) return err(E_dstMaxSize_tooSmall);
     if (prefsPtr) cctx->prefs = *prefsPtr; else memset(&cctx->prefs, 0, sizeof(cctx->prefs));
-    if (cctx->prefs.compressionLevel < 0 || cctx->prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);
+    if (cctx->prefs.compressionLevel >= 3) return err(E_compressionLevel_invalid);                            // only the fast compressor (negative: acceleration)
     if (cctx->prefs.frameInfo.blockSizeID == 0) cctx->prefs.frameInfo.blockSizeID = LZ4F_max64KB;
     cctx->bs = block_size((int)cctx->prefs.frameInfo.blockSizeID);
     if (!cctx->bs) return err(E_maxBlockSize_invalid);
     cctx->tmp.resize(cctx->bs); cctx->tmpSize = 0; cctx->total = 0; cctx->xxh.reset();
+    cctx->linked = cctx->prefs.frameInfo.blockMode == LZ4F_blockLinked && block_linking();
+    {   // buffer management (lz4frame.c:640-655): the size of tmpBuff decides when the buffered data wraps around
+        const size_t need = cctx->prefs.autoFlush ? (cctx->prefs.frameInfo.blockMode == LZ4F_blockLinked ? 65536u : 0u)
+                                                  : cctx->bs + (cctx->prefs.frameInfo.blockMode == LZ4F_blockLinked ? 131072u : 0u);
+        if (cctx->maxBufferSize < need) cctx->maxBufferSize = need;
+    }
+    cctx->tmpInOff = 0;
+    if (cctx->linked) {                                                   // LZ4F_initStream -> LZ4_resetStream_fast (lz4frame.c:570-590, :661-664)
+        if (!cctx->d_table) {
+            if (hipMalloc((void**)&cctx->d_table, 16384) != hipSuccess) { cctx->d_table = nullptr; return err(E_allocation_failed); }
+            cctx->tableZero = false; cctx->lz = Lz4StreamState();
+        }
+        bool clear = false;
+        lz_prepare(cctx->lz, clear, 0, 2);
+        if ((clear || cctx->lz.cur == 0) && !cctx->tableZero) {          // (a table that starts at index 0 is a zeroed table)
+            if (hipMemset(cctx->d_table, 0, 16384) != hipSuccess) return err(E_GENERIC);
+            cctx->tableZero = true;
+        }
+        cctx->hist.clear();                                              // (whatever an earlier frame left is more than 64 KB of indices away)
+    }
     cctx->stage = 1;
-    return write_header((uint8_t*)dstBuffer, cctx->prefs);
+    return write_header((uint8_t*)dstBuffer, cctx->prefs, !cctx->linked);
 }
+
+namespace {
+// LZ4_compress_fast_continue on every block of `blks` in order (lz4.c:3179-3254): mode and limits of each block from the
+// stream state and the addresses, the blocks themselves on the GPU in one launch (lz4_compress_stream_kernel), output as
+// LZ4F_makeBlock writes it.  Returns the bytes written or an error code.
+size_t make_stream_blocks(LZ4F_cctx* c, const std::vector<StreamBlock>& blks, uint8_t* op)
+{
+    const size_t nb = blks.size();
+    if (!nb) return 0;
+    uint8_t* const op0 = op;
+    Lz4StreamState& z = c->lz;
+    const int level = c->prefs.compressionLevel;
+    const uint32_t accel = level < 0 ? (uint32_t)(-level + 1) : 1u;
+    size_t total = c->hist.size();
+    for (const StreamBlock& b : blks) total += b.len;
+    {   // LZ4_renormDictT (lz4.c:3127-3146): indices are rebased before they pass 2 GB
+        size_t fresh = total - c->hist.size();
+        if ((uint64_t)z.cur + fresh > 0x7FFF0000ull) {
+            std::vector<uint32_t> t(4096);
+            if (hipMemcpy(t.data(), c->d_table, 16384, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+            const uint32_t delta = z.cur - 65536;
+            for (uint32_t& v : t) v = v < delta ? 0 : v - delta;
+            if (hipMemcpy(c->d_table, t.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) return err(E_GENERIC);
+            z.cur = 65536;
+            if (z.dictSize > 65536) { z.dict += z.dictSize - 65536; z.dictSize = 65536; }
+        }
+    }
+    const uint32_t idxBase = z.cur - (uint32_t)c->hist.size();
+    std::vector<aoclgpu::Lz4StreamJob> jobs(nb);
+    uint32_t off = (uint32_t)c->hist.size();
+    for (size_t i = 0; i < nb; ++i) {
+        const uint64_t src = blks[i].addr; const uint32_t n = blks[i].len;
+        uint64_t dictEnd = z.dict + z.dictSize;
+        if (z.dictSize - 1 < 3 && dictEnd != src) { z.dictSize = 0; z.dict = src; dictEnd = src; }         // tiny dictionaries (:3198-3205)
+        {   const uint64_t srcEnd = src + n;                                                                 // overlapping input / dictionary (:3207-3215)
+            if (srcEnd > z.dict && srcEnd < dictEnd) {
+                uint64_t ds = dictEnd - srcEnd;
+                if (ds > 65536) ds = 65536;
+                if (ds < 4) ds = 0;
+                z.dictSize = (uint32_t)ds; z.dict = dictEnd - ds;
+            }
+        }
+        const bool prefix = dictEnd == src;
+        const bool dictSmall = z.dictSize < 65536 && z.dictSize < z.cur;
+        aoclgpu::Lz4StreamJob& j = jobs[i];
+        memset(&j, 0, sizeof(j));
+        j.off = off; j.len = n; j.ext = prefix ? 0u : 1u;
+        j.lowCand = dictSmall ? z.cur - z.dictSize : 0u;
+        {   // start of the dictionary as a position of the window (never below the window: 64 KB of history are there, a catch-up
+            // cannot pass them - the match it extends is at most 65535 bytes behind a position of the block)
+            const uint32_t dictIdx = z.cur - z.dictSize;
+            j.lowPos = dictIdx > idxBase ? dictIdx - idxBase : 0u;
+        }
+        if (prefix) z.dictSize += n; else { z.dict = src; z.dictSize = n; }                                  // (:1037, :3251-3252)
+        z.cur += n; z.type = 2;
+        off += n;
+    }
+    aoclgpu::DeviceScope scope(aoclgpu_host_device());
+    DevBuf D;
+    const size_t slot = (c->bs + 15) & ~(size_t)15;
+    uint8_t* d_src = (uint8_t*)D.get(total); uint8_t* d_dst = (uint8_t*)D.get(nb * slot); int32_t* d_len = (int32_t*)D.get(nb * 4);
+    aoclgpu::Lz4StreamJob* d_jobs = (aoclgpu::Lz4StreamJob*)D.get(nb * sizeof(aoclgpu::Lz4StreamJob));
+    if (!d_src || !d_dst || !d_len || !d_jobs) return err(E_allocation_failed);
+    if (!c->hist.empty() && hipMemcpy(d_src, c->hist.data(), c->hist.size(), hipMemcpyHostToDevice) != hipSuccess) return err(E_GENERIC);
+    for (size_t i = 0; i < nb; ++i)
+        if (hipMemcpy(d_src + jobs[i].off, blks[i].p, blks[i].len, hipMemcpyHostToDevice) != hipSuccess) return err(E_GENERIC);
+    if (hipMemcpy(d_jobs, jobs.data(), nb * sizeof(aoclgpu::Lz4StreamJob), hipMemcpyHostToDevice) != hipSuccess) return err(E_GENERIC);
+    c->tableZero = false;
+    if (aoclgpu::lz4_stream_blocks(d_src, idxBase, d_jobs, (uint32_t)nb, c->d_table, d_dst, (uint32_t)slot, d_len, accel, nullptr) != AOCLGPU_OK) return err(E_GENERIC);
+    std::vector<int32_t> ol(nb);
+    std::vector<uint8_t> slots(nb * slot);
+    if (hipMemcpy(ol.data(), d_len, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(slots.data(), d_dst, nb * slot, hipMemcpyDeviceToHost) != hipSuccess) return err(E_GENERIC);
+    const bool blockCrc = c->prefs.frameInfo.blockChecksumFlag != 0;
+    for (size_t i = 0; i < nb; ++i) {
+        uint32_t cs = ol[i] > 0 ? (uint32_t)ol[i] : 0;
+        if (cs == 0) { cs = blks[i].len; wr32(op, cs | kStored); memcpy(op + kBH, blks[i].p, cs); }      // stored block
+        else { wr32(op, cs); memcpy(op + kBH, slots.data() + i * slot, cs); }
+        if (blockCrc) wr32(op + kBH + cs, xxh32(op + kBH, cs, 0));
+        op += kBH + cs + (blockCrc ? kBF : 0);
+    }
+    // the last 64 KB of the stream for the next call
+    for (size_t i = 0; i < nb; ++i) c->hist.insert(c->hist.end(), blks[i].p, blks[i].p + blks[i].len);
+    if (c->hist.size() > 65536) c->hist.erase(c->hist.begin(), c->hist.end() - 65536);
+    return (size_t)(op - op0);
+}
+// Independent blocks do not use the stream's table here, but a reference cctx compresses them with the same LZ4_stream_t: what
+// they leave behind (index, table type) decides how a later frame with linked blocks on the same cctx starts.
+void track_independent_blocks(LZ4F_cctx* c, const std::vector<BlockRef>& blks)
+{
+    bool clr = false;
+    for (const BlockRef& b : blks) lz_after_independent_block(c->lz, clr, b.len);
+    if (clr && c->d_table && !c->tableZero) { if (hipMemset(c->d_table, 0, 16384) == hipSuccess) c->tableZero = true; }
+}
+}  // namespace
 
 static size_t LZ4F_compressUpdate_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const void* srcBuffer, size_t srcSize,
                                         const LZ4F_compressOptions_t* opts)
@@ -633,6 +793,36 @@ static size_t LZ4F_compressUpdate_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t 
     if (dstCapacity < bound_internal(srcSize, &cctx->prefs, cctx->tmpSize)) return err(E_dstMaxSize_tooSmall);
     const size_t bs = cctx->bs;
     const uint8_t* sp = (const uint8_t*)srcBuffer; const uint8_t* const se = sp + srcSize;
+    if (cctx->linked) {
+        // lz4frame.c:849-923 with the stream behind it: which block is compressed where (in the caller's buffer or in tmpBuff,
+        // behind the saved dictionary) decides prefix / external-dictionary mode and with it the bytes
+        std::vector<StreamBlock> sb;
+        std::vector<uint8_t> hold;                                        // the buffered block, completed (kept until the launch is done)
+        int last = 0;                                                     // 1 fromTmpBuffer, 2 fromSrcBuffer
+        if (cctx->tmpSize > 0) {
+            const size_t toCopy = bs - cctx->tmpSize;
+            if (toCopy > srcSize) { memcpy(cctx->tmp.data() + cctx->tmpSize, sp, srcSize); sp = se; cctx->tmpSize += srcSize; }
+            else {
+                memcpy(cctx->tmp.data() + cctx->tmpSize, sp, toCopy); sp += toCopy;
+                hold.assign(cctx->tmp.begin(), cctx->tmp.begin() + bs);
+                sb.push_back(StreamBlock{hold.data(), (uint32_t)bs, kTmpSpace + cctx->tmpInOff});
+                last = 1; cctx->tmpInOff += bs; cctx->tmpSize = 0;
+            }
+        }
+        while ((size_t)(se - sp) >= bs) { sb.push_back(StreamBlock{sp, (uint32_t)bs, (uint64_t)(uintptr_t)sp}); sp += bs; last = 2; }
+        if (cctx->prefs.autoFlush && sp < se) { sb.push_back(StreamBlock{sp, (uint32_t)(se - sp), (uint64_t)(uintptr_t)sp}); sp = se; last = 2; }
+        const size_t w = make_stream_blocks(cctx, sb, (uint8_t*)dstBuffer);
+        if (LZ4F_isError(w)) return w;
+        if (last == 2) {                                                  // preserve the dictionary (:895-904)
+            if (opts && opts->stableSrc) cctx->tmpInOff = 0;
+            else { const uint32_t ds = lz_save_dict(cctx->lz); if (!ds) return err(E_GENERIC); cctx->tmpInOff = ds; }
+        }
+        if (cctx->tmpInOff + bs > cctx->maxBufferSize && !cctx->prefs.autoFlush) cctx->tmpInOff = lz_save_dict(cctx->lz);   // keep tmpIn within limits (:906-912)
+        if (sp < se) { memcpy(cctx->tmp.data(), sp, (size_t)(se - sp)); cctx->tmpSize = (size_t)(se - sp); }
+        if (cctx->prefs.frameInfo.contentChecksumFlag) cctx->xxh.update(srcBuffer, srcSize);
+        cctx->total += srcSize;
+        return w;
+    }
     std::vector<BlockRef> blks;
     if (cctx->tmpSize > 0) {                                              // complete the buffered block first
         const size_t toCopy = bs - cctx->tmpSize;
@@ -645,8 +835,10 @@ static size_t LZ4F_compressUpdate_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t 
     }
     while ((size_t)(se - sp) >= bs) { blks.push_back(BlockRef{sp, (uint32_t)bs}); sp += bs; }
     if (cctx->prefs.autoFlush && sp < se) { blks.push_back(BlockRef{sp, (uint32_t)(se - sp)}); sp = se; }
-    const size_t w = make_blocks(blks, bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer);
+    const size_t w = make_blocks(blks, bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer,
+                                 cctx->prefs.compressionLevel < 0 ? -cctx->prefs.compressionLevel + 1 : 1);
     if (LZ4F_isError(w)) return w;
+    track_independent_blocks(cctx, blks);
     if (sp < se) { memcpy(cctx->tmp.data(), sp, (size_t)(se - sp)); cctx->tmpSize = (size_t)(se - sp); }   // < blockSize: buffered
     if (cctx->prefs.frameInfo.contentChecksumFlag) cctx->xxh.update(srcBuffer, srcSize);
     cctx->total += srcSize;
@@ -660,9 +852,19 @@ static size_t LZ4F_flush_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapaci
     if (cctx->tmpSize == 0) return 0;
     if (cctx->stage != 1 || !dstBuffer) return err(E_GENERIC);
     if (dstCapacity < cctx->tmpSize + kBH + kBF) return err(E_dstMaxSize_tooSmall);
+    if (cctx->linked) {                                                   // lz4frame.c:956-973
+        std::vector<StreamBlock> sb(1, StreamBlock{cctx->tmp.data(), (uint32_t)cctx->tmpSize, kTmpSpace + cctx->tmpInOff});
+        const size_t w = make_stream_blocks(cctx, sb, (uint8_t*)dstBuffer);
+        if (LZ4F_isError(w)) return w;
+        cctx->tmpInOff += cctx->tmpSize; cctx->tmpSize = 0;
+        if (cctx->tmpInOff + cctx->bs > cctx->maxBufferSize) cctx->tmpInOff = lz_save_dict(cctx->lz);
+        return w;
+    }
     std::vector<BlockRef> blks(1, BlockRef{cctx->tmp.data(), (uint32_t)cctx->tmpSize});
-    const size_t w = make_blocks(blks, cctx->bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer);
+    const size_t w = make_blocks(blks, cctx->bs, cctx->prefs.frameInfo.blockChecksumFlag != 0, (uint8_t*)dstBuffer,
+                                 cctx->prefs.compressionLevel < 0 ? -cctx->prefs.compressionLevel + 1 : 1);
     if (LZ4F_isError(w)) return w;
+    track_independent_blocks(cctx, blks);
     cctx->tmpSize = 0;
     return w;
 }

@@ -250,8 +250,8 @@ def test_compress_bound_matches_reference(G, R):
 @pytest.mark.gpu
 @pytest.mark.parametrize("auto_flush", [False, True])
 def test_streaming_compress(eng, G, R, auto_flush):
-    """LZ4F_compressBegin / Update / flush / End with the reference's buffering rules: for independent blocks the frame equals the
-    reference's for the same sequence of calls; linked-mode requests give an independent-block frame that the reference decodes"""
+    """LZ4F_compressBegin / Update / flush / End with the reference's buffering rules: the frame equals the reference's for the same
+    sequence of calls, with independent and with linked blocks (more of the latter in tests/test_lz4frame_stream_linked.py)"""
     rng = np.random.default_rng(23)
     base = a.corpus.make("jsonlog", 3 << 20).tobytes()
     for n in [0, 1, 70000, 300000, (2 << 20) + 11]:
@@ -266,5 +266,4 @@ def test_streaming_compress(eng, G, R, auto_flush):
             got = lf.compress_stream(G, data, p, pieces, flush_at)
             assert isinstance(got, bytes), got
             assert lf.decompress(R, got, n) == (data, len(got)), (n, o)
-            if o.get("independent"):
-                assert got == lf.compress_stream(R, data, p, pieces, flush_at), (n, o, auto_flush)
+            assert got == lf.compress_stream(R, data, p, pieces, flush_at), (n, o, auto_flush)

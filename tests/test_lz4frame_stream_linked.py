@@ -1,0 +1,138 @@
+"""LZ4F_compressBegin / Update / flush / End with LZ4F_blockLinked (the default block mode) against the reference's lz4frame.c +
+lz4.c (oracle/_ref): the frame must equal the reference's BYTE FOR BYTE for the same sequence of calls.  What decides the bytes
+there is the LZ4 stream behind the frame (lz4.c:3179-3254): every block is compressed in prefix mode or in external-dictionary
+mode depending on where it lies in memory relative to its dictionary (the caller's buffer or tmpBuff behind the saved 64 KB),
+with a dictionary that is cut to the last block after every external-dictionary block - csrc/lz4frame_api.cpp keeps that state
+and the kernel takes the limits that follow from it (csrc/lz4_kernels.hip lz4_linked_block)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import aocl_compression_amd as a
+from aocl_compression_amd import api
+import oracle_lib as ol
+import lz4f_lib as lf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    return lf.bind(api.load_library())
+
+
+@pytest.fixture(scope="module")
+def R():
+    if not os.path.exists(ol.REF_SO):
+        pytest.skip("reference build not present")
+    L = C.CDLL(ol.REF_SO)
+    if not hasattr(L, "LZ4F_compressFrame"):
+        pytest.skip("reference build without lz4frame.c")
+    return lf.bind(L)
+
+
+class Opts(C.Structure):
+    _fields_ = [("stableSrc", C.c_uint), ("reserved", C.c_uint * 3)]
+
+
+def frames(L, ctx, buf, jobs):
+    """jobs: list of (prefs, start, pieces, flush_at, stable, copies) - one frame each on the SAME cctx; pieces are handed over
+    as pointers into buf (contiguous in memory) or, with copies, as separately allocated buffers"""
+    out = []
+    for p, start, pieces, flush_at, stable, copies in jobs:
+        fr = bytearray()
+        hb = C.create_string_buffer(64)
+        r = L.LZ4F_compressBegin(ctx, hb, 64, C.byref(p))
+        assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+        fr += hb.raw[:r]
+        pos = start
+        opts = Opts(); opts.stableSrc = 1 if stable else 0
+        keep = []
+        for k, n in enumerate(pieces):
+            cap = L.LZ4F_compressBound(n, C.byref(p))
+            ob = C.create_string_buffer(cap + 1)
+            if copies:
+                piece = C.create_string_buffer(bytes(buf[pos:pos + n]), max(n, 1)); keep.append(piece)
+                src = C.cast(piece, C.c_void_p)
+            else:
+                src = C.c_void_p(C.addressof(buf) + pos)
+            r = L.LZ4F_compressUpdate(ctx, ob, cap, src, n, C.byref(opts))
+            assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+            fr += ob.raw[:r]; pos += n
+            if k in flush_at:
+                r = L.LZ4F_flush(ctx, ob, cap, None)
+                assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+                fr += ob.raw[:r]
+        cap = L.LZ4F_compressBound(0, C.byref(p))
+        ob = C.create_string_buffer(cap + 1)
+        r = L.LZ4F_compressEnd(ctx, ob, cap, None)
+        assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+        fr += ob.raw[:r]
+        out.append(bytes(fr))
+    return out
+
+
+def run(L, buf, jobs):
+    ctx = C.c_void_p()
+    assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
+    try:
+        return frames(L, ctx, buf, jobs)
+    finally:
+        L.LZ4F_freeCompressionContext(ctx)
+
+
+def cut(rng, n, lo, hi):
+    pieces = []
+    while n:
+        k = int(min(n, rng.integers(lo, hi))); pieces.append(k); n -= k
+    return pieces
+
+
+@pytest.mark.parametrize("kind", ["text", "jsonlog", "binary", "database"])
+def test_linked_stream_equals_reference(eng, G, R, kind):
+    rng = np.random.default_rng(hash(kind) % 1000)
+    n = 1_500_000
+    raw = a.corpus.make(kind, n, seed=11).tobytes()
+    buf = (C.c_char * n).from_buffer_copy(raw)
+    for trial in range(14):
+        bsid = int(rng.choice([0, 4, 4, 5, 6]))
+        total = int(rng.integers(1, n))
+        if bsid >= 6:
+            total = n - 1
+        start = int(rng.integers(0, n - total))
+        lo, hi = [(1, 3000), (1, 150000), (60000, 70000), (1, 400000)][trial % 4]
+        p = lf.prefs(bsid=bsid, auto_flush=bool(trial & 1), level=int(rng.choice([0, 0, -4])), block_checksum=bool(trial % 5 == 0), content_checksum=bool(trial % 3 == 0))
+        pieces = cut(rng, total, lo, hi)
+        flush_at = set(int(x) for x in rng.integers(0, len(pieces), 3)) if trial % 3 == 1 else set()
+        stable = trial % 7 == 3
+        copies = trial % 2 == 0 and not stable
+        job = [(p, start, pieces, flush_at, stable, copies)]
+        want = run(R, buf, job)[0]
+        got = run(G, buf, job)[0]
+        assert got == want, (kind, trial, bsid, total, len(pieces), sorted(flush_at), stable, copies, len(got), len(want))
+        assert lf.decompress(R, got, total) == (raw[start:start + total], len(got))
+
+
+def test_cctx_reuse_across_frames(eng, G, R):
+    """a second and third frame on the same cctx: the stream's index goes on (plus the 64 KB gap of LZ4_resetStream_fast) or
+    restarts, depending on what the frame before left in the LZ4 stream"""
+    rng = np.random.default_rng(5)
+    n = 900_000
+    raw = a.corpus.make("jsonlog", n, seed=3).tobytes()
+    buf = (C.c_char * n).from_buffer_copy(raw)
+    for trial in range(6):
+        jobs = []
+        for f in range(3):
+            independent = bool((trial >> f) & 1)
+            total = int(rng.integers(1000, 400000))
+            if trial == 5 and f == 0:
+                total = 3000                                  # a short independent frame leaves a byU16 table behind
+            start = int(rng.integers(0, n - total))
+            p = lf.prefs(bsid=int(rng.choice([4, 5])), independent=independent, auto_flush=bool(rng.integers(0, 2)))
+            jobs.append((p, start, cut(rng, total, 1, 120000), set(), False, bool(rng.integers(0, 2))))
+        want = run(R, buf, jobs)
+        got = run(G, buf, jobs)
+        for f in range(3):
+            assert got[f] == want[f], (trial, f, len(got[f]), len(want[f]))
