@@ -359,12 +359,23 @@ bool host_grow(uint8_t** p, size_t* cap, size_t need)
 // Frees the device buffers of every idle host context (aocl_llc_destroy calls it); contexts in use keep theirs.
 extern "C" void aoclgpu_host_trim(void)
 {
-    std::lock_guard<std::mutex> lk(g_host_mu);
-    for (HostCtx* c : g_host_ctx) {
-        if (c->busy) continue;
-        DeviceScope ds(c->dev);
-        if (c->dsrc) { (void)hipFree(c->dsrc); c->dsrc = nullptr; c->srcCap = 0; }
-        if (c->ddst) { (void)hipFree(c->ddst); c->ddst = nullptr; c->dstCap = 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (HostCtx* c : g_host_ctx) {
+            if (c->busy) continue;
+            DeviceScope ds(c->dev);
+            if (c->dsrc) { (void)hipFree(c->dsrc); c->dsrc = nullptr; c->srcCap = 0; }
+            if (c->ddst) { (void)hipFree(c->ddst); c->ddst = nullptr; c->dstCap = 0; }
+        }
+    }
+    // the launchers' scratch pool too (hash tables, per-chunk workspaces - up to 32 GiB after a large Zstd level-3 batch);
+    // hipFree waits for the work that still uses an entry
+    WsGuard held;
+    for (WsPool& q : g_pool) {
+        if (!q.p) continue;
+        DeviceScope ds(q.dev);
+        (void)hipFree(q.p);
+        q.p = nullptr; q.bytes = 0;
     }
 }
 

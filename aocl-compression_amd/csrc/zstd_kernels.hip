@@ -28,6 +28,7 @@
 #include "host_util.h"
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 
 namespace aoclgpu {
 namespace {
@@ -1226,15 +1227,29 @@ __device__ __forceinline__ u32 flags_level(u32 flags)
 // DF = the double-fast launches (levels 3-4).  Two kernels on purpose: the register budget of the level 1-2 kernel decides how
 // many chunks are resident per CU (136 VGPRs -> 9 by LDS; with the double-fast finder compiled into the same kernel it needed
 // 181 -> 8 per CU and level 1 lost 10 %).
-template <bool DF>
+template <bool DF, int PHASE = 0>
 __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* __restrict__ dst, const u32 cap,
-                                  void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf, void* entLds = nullptr, u32* lock = nullptr)
+                                  void* lds, u32 ldsBytes, Workspace* ws, u32* tabs, int lane, u32 expf, void* entLds = nullptr, u32* lock = nullptr,
+                                  u32* meta = nullptr)
 {   // entLds / lock (double-fast kernel): the entropy stage's LDS is shared by the workgroup's wavefronts, taken one at a time
+    // PHASE (double-fast as two kernels): 1 = the match finder alone, its sequence count and literal size go to meta[0..1];
+    // 2 = everything else, from the sequences and literals phase 1 left in the workspace
     // (the block is staged in the workspace and only copied out when it fits: a slot smaller than ZSTD_compressBound works
     //  whenever the frame itself fits, as with the reference's ZSTD_compress)
     if (n > kBlockMax || cap < 5u + ((n < 256) ? 1u : (n < 65536 + 256 ? 2u : 4u)) + 3u) return 0;
     const ZParams zp = level_cparams(flags_level(expf), (expf & AOCLGPU_FLAG_ZSTD_UPSTREAM_TABLE) != 0, n);
-    if (zp.strategy == 0 || (zp.strategy == 2) != DF || (DF && !tabs)) return 0;   // no GPU parse for these parameters / wrong launch class
+    if (zp.strategy == 0 || (zp.strategy == 2) != DF || (DF && PHASE != 2 && !tabs)) return 0;   // no GPU parse for these parameters / wrong launch class
+    if constexpr (PHASE == 1) {
+        static_assert(DF || PHASE != 1, "only the double-fast finder runs as a kernel of its own");
+        if (n >= 7) {
+            u32 litSize = 0, nbSeq = 0;
+            if (2u * 2u * kDfScratch > ldsBytes) return 0;
+            if (zp.mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+            else nbSeq = dfast_block<5>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+            if (lane == 0) { meta[0] = nbSeq; meta[1] = litSize; }
+        }
+        return 0;
+    }
     u32 op = 0;
     const u32 fcs = (n >= 256) + (n >= 65536 + 256);
     if (lane == 0) {                                                     // ZSTD_writeFrameHeader :4586-4632
@@ -1250,7 +1265,8 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 litSize = 0, nbSeq;
         const u32 hlog = zp.hlog, mls = zp.mls;
-        if constexpr (DF) {
+        if constexpr (PHASE == 2) { nbSeq = uni(meta[0]); litSize = uni(meta[1]); (void)hlog; (void)mls; }
+        else if constexpr (DF) {
             if (2u * 2u * kDfScratch > ldsBytes) return 0;
             if (mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
             else nbSeq = dfast_block<5>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
@@ -2486,6 +2502,46 @@ __global__ void __launch_bounds__(DF ? 64 * DF_WAVES : 64) __attribute__((amdgpu
     }
 }
 
+// Double-fast as two kernels (large batches).  The finder needs 36 VGPRs and 4 KB of LDS - the hardware's 32 wavefronts per CU
+// fit - and spends its life waiting for tables in HBM; fused with the entropy stage (135 VGPRs) only 12 chunks per CU are in
+// flight.  So: zstd_df_find_kernel parses a slab of chunks into per-chunk workspaces, zstd_df_entropy_kernel turns every
+// workspace into its frame.
+__global__ void __launch_bounds__(64) zstd_df_find_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t first, uint32_t count, uint8_t* tabBase, uint32_t tabBytes,
+                                                          uint32_t* counter, uint32_t* meta)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kDfScratchBytes];
+    u32* tabs = reinterpret_cast<u32*>(tabBase + (size_t)blockIdx.x * tabBytes);
+    const int lane = lane_id();
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        c = uni(c);
+        if (c >= count) break;
+        const ChunkView v = compress_view(b, first + c);
+        (void)zstd_compress_wave<true, 1>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, kDfScratchBytes, reinterpret_cast<Workspace*>(wsBase) + c,
+                                          tabs, lane, b.reserved, nullptr, nullptr, meta + 2 * (size_t)c);
+        wave_fence();
+    }
+}
+
+__global__ void __launch_bounds__(64) zstd_df_entropy_kernel(aoclgpu_batch b, uint8_t* wsBase, uint32_t ldsBytes, uint32_t first, uint32_t count,
+                                                             uint32_t* counter, uint32_t* meta)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        c = uni(c);
+        if (c >= count) break;
+        const ChunkView v = compress_view(b, first + c);
+        const int r = zstd_compress_wave<true, 2>((const uint8_t*)v.src, v.src_len, (uint8_t*)v.dst, v.dst_cap, lds, ldsBytes, reinterpret_cast<Workspace*>(wsBase) + c,
+                                                  nullptr, lane, b.reserved, nullptr, nullptr, meta + 2 * (size_t)c);
+        if (lane == 0) b.out_len[first + c] = r;
+        wave_fence();
+    }
+}
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase, uint32_t* counter)
 {
     __shared__ DecLds L;
@@ -2669,6 +2725,57 @@ extern "C" int aoclgpu_debug_zstd_prof(unsigned long long* host16)
     return 0;
 }
 #endif
+namespace {
+// Double-fast on a large batch: finder kernel + entropy kernel per slab of chunks (see zstd_df_find_kernel).  A chunk's
+// sequences and literals wait in a workspace of its own between the two kernels (1 MB per chunk), so the batch goes through in
+// slabs of at most AOCLGPU_ZSTD_DF_SLAB_MB (default: 32 GiB or a quarter of the device's memory, whichever is smaller).
+// Returns AOCLGPU_OK when enqueued, 1 when the caller should use the fused kernel (batch too small to gain, scratch not
+// available), an error code otherwise.
+int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size_t tabBytes, const aoclgpu::WsGuard& guard, hipStream_t s)
+{
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    if (const char* e = getenv("AOCLGPU_ZSTD_DF_SPLIT")) { if (!strcmp(e, "0")) return 1; }
+    if (count <= 16u * cus) return 1;                     // every chunk gets its own wavefront at once anyway
+    int perA = 0, perB = 0;
+    const uint32_t ldsB = ((uint32_t)aoclgpu::zstd_entropy_lds_bytes() + 255u) & ~255u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perA, (const void*)aoclgpu::zstd_df_find_kernel, 64, 0) != hipSuccess || perA < 1 ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&perB, (const void*)aoclgpu::zstd_df_entropy_kernel, 64, ldsB) != hipSuccess || perB < 1) return 1;
+    {
+        const int byLds = (int)((160u << 10) / (((ldsB + 1279u) / 1280u) * 1280u));
+        if (byLds >= 1 && byLds < perB) perB = byLds;
+        if (perA > 32) perA = 32;
+    }
+    size_t budget = (size_t)32 << 30;
+    if (prop.totalGlobalMem / 4 < budget) budget = prop.totalGlobalMem / 4;
+    if (const char* e = getenv("AOCLGPU_ZSTD_DF_SLAB_MB")) { const long long mb = atoll(e); if (mb > 0) budget = (size_t)mb << 20; }
+    const size_t wsz = aoclgpu::zstd_workspace_bytes();
+    uint32_t slab = (uint32_t)(budget / wsz < count ? budget / wsz : count);
+    if (slab < 8u * cus) return 1;                       // too few chunks in flight to beat the fused kernel
+    // equal slabs (the last one is not a remainder of a few chunks)
+    const uint32_t nslab = (count + slab - 1) / slab;
+    slab = (count + nslab - 1) / nslab;
+    uint32_t gridA = (uint32_t)perA * cus; if (gridA > slab) gridA = slab;
+    uint32_t gridB = (uint32_t)perB * cus; if (gridB > slab) gridB = slab;
+    const size_t seqBytes = ((size_t)slab * wsz + 255) & ~(size_t)255;
+    const size_t tabOff = seqBytes, metaOff = (tabOff + (size_t)gridA * tabBytes + 255) & ~(size_t)255;
+    const size_t ctrOff = (metaOff + (size_t)slab * 8 + 255) & ~(size_t)255;
+    uint8_t* ws = (uint8_t*)get_workspace(guard, ctrOff + (size_t)nslab * 256, s);
+    if (!ws) return 1;
+    if (hipMemsetAsync(ws + ctrOff, 0, (size_t)nslab * 256, s) != hipSuccess) { aoclgpu::set_error_msg("zstd: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
+    for (uint32_t k = 0; k < nslab; ++k) {
+        const uint32_t f0 = first + k * slab, m = (k + 1) * slab <= count ? slab : count - k * slab;
+        uint32_t* ctr = (uint32_t*)(ws + ctrOff + (size_t)k * 256);
+        hipLaunchKernelGGL(aoclgpu::zstd_df_find_kernel, dim3(gridA < m ? gridA : m), dim3(64), 0, s, *b, ws, f0, m, ws + tabOff, (uint32_t)tabBytes, ctr, (uint32_t*)(ws + metaOff));
+        if (int rc = aoclgpu::check_launch("zstd_df_find_kernel")) return rc;
+        hipLaunchKernelGGL(aoclgpu::zstd_df_entropy_kernel, dim3(gridB < m ? gridB : m), dim3(64), ldsB, s, *b, ws, ldsB, f0, m, ctr + 1, (uint32_t*)(ws + metaOff));
+        if (int rc = aoclgpu::check_launch("zstd_df_entropy_kernel")) return rc;
+    }
+    return AOCLGPU_OK;
+}
+}  // namespace
+
 extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream)
 {
     if (int rc = aoclgpu::check_batch(b, false)) return rc;
@@ -2695,6 +2802,10 @@ extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream
     const uint32_t wpb = level >= 3 ? aoclgpu::kDfWaves : 1u;   // wavefronts (= chunks in flight) per workgroup
     aoclgpu::WsGuard guard;                               // held until the kernels that use the scratch are enqueued
     for (int i = 0; i < nl; ++i) {
+        if (level >= 3) {
+            const int rc = df_split_launch(b, L[i].first, L[i].count, tabBytes, guard, s);
+            if (rc != 1) { if (rc != AOCLGPU_OK) return rc; continue; }   // 1: not worth it / no memory - the fused kernel below
+        }
         // persistent blocks: exactly as many as are resident at once for this LDS size (gfx950 allocates LDS in 1280-byte
         // granules, the occupancy query counts bytes: the smaller of the two, see aoclgpu_zstd_decompress_chunks)
         int perCU = 0, dev = 0; hipDeviceProp_t prop;

@@ -307,7 +307,10 @@ int64_t aoclgpu_zstd_decompress_host_frames(const void* host_src, size_t n, void
 int aoclgpu_set_host_device(int device);
 int aoclgpu_host_device(void);
 /* The host-buffer entry points keep their device staging buffers between calls (up to 256 MiB each; larger ones are freed when
- * the call returns).  aoclgpu_host_trim frees those of every idle context; aocl_llc_destroy calls it. */
+ * the call returns), and the launchers keep one scratch allocation per (device, stream) - hash tables and sequence stores of
+ * the resident chunks; after a Zstd level 3-4 batch of thousands of chunks up to AOCLGPU_ZSTD_DF_SLAB_MB (default 32 GiB) of
+ * per-chunk workspaces.  aoclgpu_host_trim frees the staging buffers of every idle context and all launcher scratch (it waits
+ * for the work that still uses it); aocl_llc_destroy calls it. */
 void aoclgpu_host_trim(void);
 
 int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);

@@ -265,3 +265,46 @@ def test_search_that_starts_at_the_last_lane(eng, oracle):
     src = t.frombuffer(bytearray(data), dtype=t.uint8).to(eng.device)
     slots, lens, slot = eng.compress_chunks(a.ZSTD, src, len(data))
     assert slots[:int(lens[0])].cpu().numpy().tobytes() == oracle.compress(ol.ZSTD, data)
+
+
+@pytest.mark.parametrize("slab_mb", [None, "2500"])
+def test_double_fast_large_batch_two_kernels(eng, oracle, slab_mb):
+    """more chunks than the fused kernel holds at once: the finder and the entropy stage run as two kernels over slabs of
+    per-chunk workspaces (zstd_df_find_kernel / zstd_df_entropy_kernel); one slab, and two slabs with a small slab budget"""
+    import os
+    import ctypes as C
+    level = 3
+    lib = eng.lib
+    lib.ZSTD_getCParams.restype = _CP
+    lib.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    lib.aocl_setup_zstd_encode.restype = C.c_void_p
+    lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
+    oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    chunk, nchunks = 8192, 4600
+    data = a.corpus.silesia_mix(chunk * nchunks - 777, seed=level).tobytes()
+    lib.aocl_destroy_zstd_encode()
+    lib.aocl_setup_zstd_encode(0, 0, 0, level, 0)
+    old = os.environ.get("AOCLGPU_ZSTD_DF_SLAB_MB")
+    try:
+        if slab_mb:
+            os.environ["AOCLGPU_ZSTD_DF_SLAB_MB"] = slab_mb
+        src = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(eng.device)
+        slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.zstd_level(level, False))
+        lens = out_len.cpu().tolist(); host = slots.cpu().numpy()
+        assert all(l > 0 for l in lens)
+        for k in list(range(0, len(lens), 37)) + [len(lens) - 1]:
+            part = data[k * chunk:(k + 1) * chunk]
+            cp = lib.ZSTD_getCParams(level, len(part), 0)
+            cap = max(ol.bound(ol.ZSTD, len(part)), 16); w = C.create_string_buffer(cap)
+            r = oracle.L.orc_zstd_compress_cparams(part, len(part), w, cap, cp.strategy, cp.hashLog, cp.chainLog, cp.minMatch)
+            assert host[k * slot:k * slot + lens[k]].tobytes() == w.raw[:r], k
+        dst, dl = eng.decompress_chunks(a.ZSTD, slots, out_len, slot, len(data), chunk)
+        assert torch.equal(dst, src)
+    finally:
+        if old is None:
+            os.environ.pop("AOCLGPU_ZSTD_DF_SLAB_MB", None)
+        else:
+            os.environ["AOCLGPU_ZSTD_DF_SLAB_MB"] = old
+        lib.aocl_destroy_zstd_encode()
+        lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
