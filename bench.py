@@ -629,6 +629,14 @@ class Run:
         fam = "zstd" if self.name == "zstd3" else self.name
         kernel = ("snappy_compress_mix_kernel" if (self.name, dom) == ("snappy", "compress") and self.nchunks > 16 * 256
                   else f"{fam}_{dom}_kernel" + ("<double-fast>" if (self.name, dom) == ("zstd3", "compress") else ""))
+        launches = None
+        if (self.name, dom) == ("zstd3", "compress") and self.nchunks > 16 * 256:
+            # large level-3 batches: finder kernel + entropy kernel per slab of <= 32 Ki chunks (csrc/zstd_kernels.hip df_split_launch);
+            # avg_launch_ms below is the whole compress call = the sum of its launches (profiles/r03_zstd3_*_kernel_trace_and_pmc.txt)
+            nslab = -(-self.nchunks // 32768)
+            kernel = "zstd_df_find_kernel"
+            launches = {"per_compress_call": {"zstd_df_find_kernel": nslab, "zstd_df_entropy_kernel": nslab},
+                        "note": "avg_launch_ms = one compress call = all of these launches back to back"}
         out = {
             "value": round(unc_total / GIB / (elapsed / args.steps), 3), "unit": "GiB/s", "ms_per_step": round(ms_step, 3),
             "config": {
@@ -650,6 +658,8 @@ class Run:
                 "other_kernel_frac": round(alg_bytes / ((ms_d if dom == "compress" else ms_c) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
             },
         }
+        if launches:
+            out["roofline"]["launches"] = launches
         # HBM-side traffic of the dominant kernel: not measurable from inside this process; taken from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/traffic.json), raw counter
         # bytes per launch, only when this run has the profiled shape.
