@@ -113,7 +113,7 @@ typedef __attribute__((address_space(3))) uint16_t lu16;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 constexpr uint32_t kScratch = 1024;
 
-template <bool GT, int TAG = 0>
+template <bool GT, bool INL = false>
 __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in, const uint32_t n,
                                                                    gbyte* __restrict__ out, uint16_t* table_, lu16* scr, int lane)
 {
@@ -416,7 +416,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
     return op;
 }
 
-template <bool GT, int TAG = 0>
+template <bool GT>
 __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* __restrict__ dst,
                                 const uint32_t cap, uint16_t* table, lu16* scr)
 {
@@ -428,7 +428,7 @@ __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n,
     op++;
     for (uint32_t pos = 0; pos < n; pos += kBlock) {                      // snappy.cc:1761-1816
         const uint32_t frag = n - pos < kBlock ? n - pos : kBlock;
-        op += sn_compress_fragment<GT, TAG>(src + pos, frag, dst + op, table, scr, lane);
+        op += sn_compress_fragment<GT>(src + pos, frag, dst + op, table, scr, lane);
         wave_fence();
     }
     return (int)op;
@@ -656,13 +656,7 @@ __global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b,
 #ifndef SN_MIX_HBM
 #define SN_MIX_HBM 3
 #endif
-#ifndef SN_MIX_WAVES_PER_SIMD
-#define SN_MIX_WAVES_PER_SIMD 4
-#endif
-// (the register budget of 4 waves per SIMD reaches the two non-inlined fragments only because they are instantiations of
-//  their own - TAG 1 - that nobody else calls: the backend hands a callee the loosest budget among its callers, and shared with
-//  the single-wave kernels the HBM-table fragment took 132 VGPRs, i.e. 3 workgroups per CU instead of 4)
-__global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_waves_per_eu(SN_MIX_WAVES_PER_SIMD, SN_MIX_WAVES_PER_SIMD))) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
+__global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint16_t scr[SN_MIX_HBM][kScratch];
@@ -675,8 +669,8 @@ __global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_w
         if (c >= b.nchunks) break;
         const ChunkView v = compress_view(b, c);
         int r;
-        if (w == 0) r = sn_compress_wave<false, 1>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
-        else r = sn_compress_wave<true, 1>(v.src, v.src_len, v.dst, v.dst_cap, (uint16_t*)gt, (lu16*)scr[w - 1]);
+        if (w == 0) r = sn_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
+        else r = sn_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, (uint16_t*)gt, (lu16*)scr[w - 1]);
         if ((threadIdx.x & 63) == 0) b.out_len[c] = r;
         wave_fence();
     }
