@@ -674,9 +674,10 @@ static size_t LZ4F_compressBegin_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t d
     }
     cctx->tmpInOff = 0;
     if (cctx->linked) {                                                   // LZ4F_initStream -> LZ4_resetStream_fast (lz4frame.c:570-590, :661-664)
-        if (!cctx->d_table) {
+        if (!cctx->d_table) {                                            // (the stream state may already have a history: independent frames)
             if (hipMalloc((void**)&cctx->d_table, 16384) != hipSuccess) { cctx->d_table = nullptr; return err(E_allocation_failed); }
-            cctx->tableZero = false; cctx->lz = Lz4StreamState();
+            if (hipMemset(cctx->d_table, 0, 16384) != hipSuccess) return err(E_GENERIC);
+            cctx->tableZero = true;
         }
         bool clear = false;
         lz_prepare(cctx->lz, clear, 0, 2);

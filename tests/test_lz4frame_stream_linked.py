@@ -136,3 +136,16 @@ def test_cctx_reuse_across_frames(eng, G, R):
         got = run(G, buf, jobs)
         for f in range(3):
             assert got[f] == want[f], (trial, f, len(got[f]), len(want[f]))
+
+
+def test_linked_frame_after_an_independent_block_that_keeps_the_table(eng, G, R):
+    """found by tools/fuzz_lz4f_campaign.py (seed 426756): an independent frame of ONE block of 65 547 bytes or more leaves the
+    cctx's LZ4 stream at a non-zero index with a byU32 table, so the linked frame that follows starts 64 KB further on with every
+    old entry out of reach (dictSmall) - not at index 0, where empty slots are candidates"""
+    n = 400_000
+    raw = a.corpus.make("jsonlog", n, seed=9).tobytes()
+    buf = (C.c_char * n).from_buffer_copy(raw)
+    rng = np.random.default_rng(1)
+    jobs = [(lf.prefs(bsid=5, independent=True), 1000, [65556, 65364, 65691, 24447], set(), False, True),
+            (lf.prefs(bsid=0, auto_flush=True, block_checksum=True), 230000, cut(rng, 46926, 100, 3000), set(), False, False)]
+    assert run(G, buf, jobs) == run(R, buf, jobs)
