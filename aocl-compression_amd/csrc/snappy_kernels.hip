@@ -636,13 +636,13 @@ __global__ void __launch_bounds__(64) snappy_compress_kernel(aoclgpu_batch b)
 }
 
 // persistent grid, hash tables in a global workspace (tables + blockIdx.x * kMaxTable)
-__global__ void __launch_bounds__(64) snappy_compress_gt_kernel(aoclgpu_batch b, uint16_t* tables)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) snappy_compress_gt_kernel(aoclgpu_batch b, uint16_t* tables)
 {
     __shared__ __attribute__((aligned(16))) uint16_t scr[kScratch];
     uint16_t* table = tables + (size_t)blockIdx.x * kMaxTable * 2;       // u32[kMaxTable] per workgroup
     for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = sn_compress_wave<true>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr);
+        const int r = sn_compress_wave<true, 2>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr);   // (TAG 2: this kernel's register budget, see the mixed kernel)
         if (threadIdx.x == 0) b.out_len[c] = r;
         wave_fence();
     }

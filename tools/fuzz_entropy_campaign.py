@@ -71,6 +71,12 @@ def seq_shaped(rng, n):
     return bytes(out[:n])
 
 
+# the level table ZSTD_getCParams answers from must be the one the batch flags select (AOCL's): as in the reference, the library
+# starts with the upstream table until the dispatcher has run (csrc/zstd_api.cpp)
+eng.lib.aocl_setup_zstd_encode.restype = C.c_void_p
+eng.lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+eng.lib.aocl_destroy_zstd_encode()
+eng.lib.aocl_setup_zstd_encode(0, 0, 0, 3, 0)
 t0 = time.time(); it = 0; chunks = 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed0 + it); it += 1
