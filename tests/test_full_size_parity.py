@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 SILESIA_BYTES = 211_938_580
 TOTAL = 8 << 30
 CASES = [("lz4", a.LZ4, ol.LZ4, 262144, "LZ4_compress_default"), ("snappy", a.SNAPPY, ol.SNAPPY, 65536, "snappy_compress"),
-         ("zstd", a.ZSTD, ol.ZSTD, 131072, "ZSTD_compress")]
+         ("zstd", a.ZSTD, ol.ZSTD, 131072, "ZSTD_compress"), ("zstd3", a.ZSTD, ol.ZSTD, 131072, "ZSTD_compress")]
 
 
 @pytest.mark.parametrize("name,gc,oc,chunk,ref_fn", CASES)
@@ -29,15 +29,25 @@ def test_whole_bench_stream_equals_the_checker(eng, oracle, name, gc, oc, chunk,
     base = torch.from_numpy(base_np).to(eng.device)
     src = base.repeat(-(-TOTAL // base.numel()))[:TOTAL].contiguous()          # bench.py Run.shard_of(0)
     del base
-    slots, out_len, slot = eng.compress_chunks(gc, src, chunk)                 # ONE launch, as in the bench
+    level = 3 if name == "zstd3" else 1                                        # zstd3: level 3 (double-fast), the bench's `codecs.zstd3`
+    if level != 1 and not os.path.exists(ol.REF_SO):
+        pytest.skip("level 3 is checked against the real reference only")
+    slots, out_len, slot = eng.compress_chunks(gc, src, chunk, flags=a.api.zstd_level(level) if level != 1 else 0)   # ONE call, as in the bench
     torch.cuda.synchronize()
     nchunks = TOTAL // chunk
     glen = out_len.cpu().numpy().astype(np.int32)
     assert (glen > 0).all()
     fn = None
     if os.path.exists(ol.REF_SO):
-        fn = C.cast(getattr(C.CDLL(ol.REF_SO), ref_fn), C.c_void_p)
+        ref = C.CDLL(ol.REF_SO)
+        fn = C.cast(getattr(ref, ref_fn), C.c_void_p)
+        if level != 1:                                                         # the reference's own (AOCL) level table, whatever ran before
+            ref.aocl_setup_zstd_encode.restype = C.c_void_p
+            ref.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+            ref.aocl_destroy_zstd_encode()
+            ref.aocl_setup_zstd_encode(0, 0, 0, 0, 0)
     L = oracle.L
+    L.orc_set_zstd_level(level)
     L.orc_compress_chunks_fn.restype = C.c_int
     L.orc_compress_chunks_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     slab_chunks = (1 << 30) // chunk
@@ -64,4 +74,5 @@ def test_whole_bench_stream_equals_the_checker(eng, oracle, name, gc, oc, chunk,
             used = col < wlen[c0:c0 + 512, None].astype(np.uint32)
             bad = np.nonzero((got[c0:c0 + 512] != w2[c0:c0 + 512]) & used)
             assert bad[0].size == 0, f"{name}: first differing byte in chunk {s0 + c0 + bad[0][0]} at {bad[1][0]}"
+    L.orc_set_zstd_level(1)
     assert torch.equal(src[:chunk], torch.from_numpy(base_np[:chunk]).to(eng.device))
