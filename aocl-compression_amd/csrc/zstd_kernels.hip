@@ -2738,6 +2738,7 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
     if (const char* e = getenv("AOCLGPU_ZSTD_DF_SPLIT")) { if (!strcmp(e, "0")) return 1; }
     if (count <= 16u * cus) return 1;                     // every chunk gets its own wavefront at once anyway
+    if (b->src_off || b->chunk_bytes < (64u << 10)) return 1;   // a workspace is 1 MB whatever the chunk's size: not for batches of small chunks
     int perA = 0, perB = 0;
     const uint32_t ldsB = ((uint32_t)aoclgpu::zstd_entropy_lds_bytes() + 255u) & ~255u;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perA, (const void*)aoclgpu::zstd_df_find_kernel, 64, 0) != hipSuccess || perA < 1 ||

@@ -281,7 +281,7 @@ def test_double_fast_large_batch_two_kernels(eng, oracle, slab_mb):
     lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
     oracle.L.orc_zstd_compress_cparams.restype = C.c_size_t
     oracle.L.orc_zstd_compress_cparams.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint]
-    chunk, nchunks = 8192, 4600
+    chunk, nchunks = 65536, 4300                        # (the two-kernel path is for chunks of 64 KiB and more)
     data = a.corpus.silesia_mix(chunk * nchunks - 777, seed=level).tobytes()
     lib.aocl_destroy_zstd_encode()
     lib.aocl_setup_zstd_encode(0, 0, 0, level, 0)
@@ -293,7 +293,7 @@ def test_double_fast_large_batch_two_kernels(eng, oracle, slab_mb):
         slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.zstd_level(level, False))
         lens = out_len.cpu().tolist(); host = slots.cpu().numpy()
         assert all(l > 0 for l in lens)
-        for k in list(range(0, len(lens), 37)) + [len(lens) - 1]:
+        for k in list(range(0, len(lens), 61)) + [len(lens) - 1]:
             part = data[k * chunk:(k + 1) * chunk]
             cp = lib.ZSTD_getCParams(level, len(part), 0)
             cap = max(ol.bound(ol.ZSTD, len(part)), 16); w = C.create_string_buffer(cap)
