@@ -651,6 +651,14 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
     const u32 prefixPos = prefixIdx - 2;
     auto tget = [&](gu32* t, u32 h) -> u32 { return __hip_atomic_load((u32*)(t + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto tput = [&](gu32* t, u32 h, u32 v) { __hip_atomic_store((u32*)(t + h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // Chunks: an entry is index (18 bits) | 14 check bits of the bytes at that position (the 8 bytes the long table compares, the
+    // 4 bytes the short one does).  The check bits never change a decision - a candidate whose check bits differ cannot pass the
+    // compare - they spare the probing lanes the scattered candidate load, which is what this kernel is made of.  Frames need
+    // all 32 bits for the index.
+    constexpr bool kChk = !FRAME;
+    constexpr u32 kIdxMask = kChk ? 0x3FFFFu : 0xFFFFFFFFu;
+    auto chkL = [&](u64 v) -> u32 { return kChk ? ((u32)((v * 0x9E3779B97F4A7C15ull) >> 50) << 18) : 0u; };
+    auto chkS = [&](u64 v) -> u32 { return kChk ? (((u32)v * 2246822519u) & ~kIdxMask) : 0u; };
     lu16* scrL = (lu16*)lds; lu16* scrS = scrL + kDfScratch;
     u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;           // sequence records parked one per lane, written 64 at a time
     auto flush_seq = [&](u32 first, u32 count) {
@@ -713,12 +721,16 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         if (act) v8 = ld64(src + pos);
         DFSTAGE(0);
         const u32 hl = z_hash8(v8, hlogL), hs = z_hash<MLS>(v8, hlogS);
-        u32 idxl = 0, idxs = 0;
-        if (act) { idxl = tget(L, hl); idxs = tget(S, hs); }
+        u32 idxl = 0, idxs = 0; bool plausL = true, plausS = true;
+        if (act) {
+            const u32 eL = tget(L, hl), eS = tget(S, hs);
+            idxl = eL & kIdxMask; idxs = eS & kIdxMask;
+            plausL = (eL & ~kIdxMask) == chkL(v8); plausS = (eS & ~kIdxMask) == chkS(v8);
+        }
         DFSTAGE(1);
         u64 cl = ~v8; u32 cs = ~(u32)v8, r4 = ~(u32)(v8 >> 8);
-        if (act && idxl > prefixIdx) cl = ld64(src + idxl - 2);
-        if (act && idxs > prefixIdx) cs = ld32(src + idxs - 2);
+        if (act && idxl > prefixIdx && plausL) cl = ld64(src + idxl - 2);
+        if (act && idxs > prefixIdx && plausS) cs = ld32(src + idxs - 2);
         if (act && rep1 > 0) r4 = ld32(src + pos + 1 - rep1);
         const bool repHit = r4 == (u32)(v8 >> 8), longHit = cl == v8, shortHit = cs == (u32)v8;
         wave_fence();
@@ -738,7 +750,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         const int el = first_lane(ballot(lane < lim && (repHit || longHit || shortHit)));
         const int ncommit = el < 64 ? el + 1 : lim;
         DFSTAGE(3);
-        if (lane < ncommit) { tput(L, hl, pos + 2); tput(S, hs, pos + 2); }   // hashLong[hl0] = hashSmall[hs0] = curr (:423)
+        if (lane < ncommit) { tput(L, hl, (pos + 2) | chkL(v8)); tput(S, hs, (pos + 2) | chkS(v8)); }   // hashLong[hl0] = hashSmall[hs0] = curr (:423)
         wave_fence();
         if (el >= 64) {
             if (e < 64 && e <= f && e <= width) break;       // the next probe's successor would pass ilimit: _cleanup
@@ -754,19 +766,20 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
         const bool nextOk = el + 1 < lim;                    // lane el+1 probed ip1 and no earlier lane of the batch names its slots
         const int eln = (el + 1) & 63;
         u32 ip = curr, mLength, mpos = 0, base = 4, offBase = 1;
-        u32 hl1 = 0; bool insert1 = false;
+        u32 hl1 = 0, ck1 = 0; bool insert1 = false;
         if (kind == 2) ip = curr + 1;                        // repcode at ip+1 (:425-431)
         else {
             u64 v1;
             if (nextOk) { v1 = ((u64)lane_get((u32)(v8 >> 32), eln) << 32) | lane_get((u32)v8, eln); hl1 = lane_get(hl, eln); }
             else { v1 = ld64(src + ip1); hl1 = uni(z_hash8(v1, hlogL)); }
+            ck1 = chkL(v1);
             bool isLong = kind == 1;
             if (kind == 1) mpos = lane_get(idxl, el) - 2;    // long match at ip (:436-449)
             else {                                           // short match: a long match at ip1 wins (:495-504)
                 u32 idxl1; u64 c1;
                 if (nextOk) { idxl1 = lane_get(idxl, eln); c1 = ((u64)lane_get((u32)(cl >> 32), eln) << 32) | lane_get((u32)cl, eln); }
                 else {
-                    idxl1 = uni(tget(L, hl1));
+                    idxl1 = uni(tget(L, hl1)) & kIdxMask;
                     c1 = ~v1;
                     if (idxl1 > prefixIdx) c1 = ld64(src + idxl1 - 2);
                 }
@@ -806,7 +819,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
             }
         }
         DFSTAGE(4);
-        if (insert1) { if (lane == 0) tput(L, hl1, ip1 + 2); }               // :516-526
+        if (insert1) { if (lane == 0) tput(L, hl1, (ip1 + 2) | ck1); }       // :516-526
         put_seq(nbSeq, ip - anchor, offBase, mLength, anchor);
         litSize += ip - anchor; nbSeq++;
         ip += mLength; anchor = ip;                          // _match_stored
@@ -817,10 +830,10 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
             u32 r0 = 0, r1 = 1;
             if (chk) { r0 = ld32(src + ip); r1 = ld32(src + ip - rep2); }   // the immediate rep2 test's bytes ride along
             if (lane == 0) {
-                tput(L, z_hash8(va, hlogL), ins + 2);
-                tput(L, z_hash8(vb, hlogL), ip - 2 + 2);
-                tput(S, z_hash<MLS>(va, hlogS), ins + 2);
-                tput(S, z_hash<MLS>(vc, hlogS), ip - 1 + 2);
+                tput(L, z_hash8(va, hlogL), (ins + 2) | chkL(va));
+                tput(L, z_hash8(vb, hlogL), (ip - 2 + 2) | chkL(vb));
+                tput(S, z_hash<MLS>(va, hlogS), (ins + 2) | chkS(va));
+                tput(S, z_hash<MLS>(vc, hlogS), (ip - 1 + 2) | chkS(vc));
             }
             wave_fence();
             bool hit = chk && uni(r0 == r1 ? 1u : 0u) != 0;
@@ -828,7 +841,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
                 const u32 rLength = wave_count(src, ip + 4, ip + 4 - rep2, n, lane) + 4;
                 const u32 t = rep2; rep2 = rep1; rep1 = t;
                 const u64 vi = ld64(src + ip);
-                if (lane == 0) { tput(S, z_hash<MLS>(vi, hlogS), ip + 2); tput(L, z_hash8(vi, hlogL), ip + 2); }
+                if (lane == 0) { tput(S, z_hash<MLS>(vi, hlogS), (ip + 2) | chkS(vi)); tput(L, z_hash8(vi, hlogL), (ip + 2) | chkL(vi)); }
                 put_seq(nbSeq, 0, 1u, rLength, ip);
                 wave_fence();
                 nbSeq++;
