@@ -100,6 +100,20 @@ __device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint3
     return w;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP adds: four row shifts settle each row of 16 lanes, row_bcast15 /
+// row_bcast31 carry the row totals into rows 1, 3 and 2-3.  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+    int t = (int)x;
+    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xF, 0xF, true);      // row_shr:1
+    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xF, 0xF, true);      // row_shr:2
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xF, 0xF, true);      // row_shr:4
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xF, 0xF, true);      // row_shr:8
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return (uint32_t)t;
+}
+
 // Chunk geometry of a batch (see aoclgpu_batch in include/aocl_gpu_codec.h)
 struct ChunkView {
     const gbyte* src; uint32_t src_len;

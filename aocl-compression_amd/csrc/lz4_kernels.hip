@@ -31,6 +31,13 @@ constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMfLimit = 12, kMinLength =
 constexpr uint32_t kDistMax = 65535, k64KLimit = 65536 + 11, kMaxInput = 0x7E000000u;
 constexpr uint32_t kTableBytes = 16384;   // LZ4_MEMORY_USAGE 14 (lz4.h:163)
 constexpr uint32_t kSrcRing = 544;        // compressor's source ring: 2 x 256 B + 32 B mirror
+// Sequence records: the parser does not write the block itself.  Every sequence it decides becomes a record (literal
+// length, match length - 4, offset) in a small LDS buffer behind the source ring - the bytes that were left of the chunk's
+// LDS granules - and when the buffer may overflow in the next batch the wave formats all buffered sequences at once, ONE
+// SEQUENCE PER LANE (prefix sums give every sequence its literal source and its output position).  A batch adds at most 16
+// sequences (64 consecutive positions, a sequence covers at least 4) plus one from the one-at-a-time path.
+constexpr uint32_t kRecCap = 60, kRecFlush = kRecCap - 17;
+constexpr uint32_t rec_bytes(int mode) { return mode == 1 ? 8u : 16u; }   // byU32 tables above 256 KiB: 32-bit fields
 #ifndef LZ4_LDS_PAD
 #define LZ4_LDS_PAD 0
 #endif
@@ -150,15 +157,75 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     wave_fence();
 
     const bool limited = cap < lz4_bound(n);              // lz4.c:2522
-#ifdef AOCLGPU_EXPERIMENTS
-    const bool do_st = !(expf & 1);                       // experiment build only: suppress per-sequence stores (timing)
-#else
-    constexpr bool do_st = true; (void)expf;
-#endif
     const uint32_t mfl1 = n - kMfLimit + 1;               // mflimitPlusOne
     const uint32_t matchlimit = n - kLastLiterals;
-    uint32_t ip = 1, anchor = 0, op = 0;
+    uint32_t ip = 1, anchor = 0;
     bool extra = false;                                   // next batch starts with the post-match probe
+    // buffered sequence records [0, nrec): they describe src[f_anchor, anchor) and go to dst + f_op
+    lbyte* recs = lds + (MODE == 1 ? 9216u : kTableBytes) + kSrcRing;
+    uint32_t nrec = 0, f_op = 0, f_anchor = 0;
+    typedef __attribute__((address_space(3))) uint64_t L64;
+    typedef __attribute__((address_space(3))) u32x4 L128;
+    auto rec_put = [&](uint32_t idx, uint32_t lit, uint32_t mcode, uint32_t off) {
+        if (MODE == 1) *(L64*)(recs + 8u * idx) = (uint64_t)lit | ((uint64_t)mcode << 24) | ((uint64_t)off << 48);
+        else *(L128*)(recs + 16u * idx) = u32x4{lit, mcode, off, 0u};
+    };
+    // Format the buffered sequences (lz4.c:1611-1740: token, literal length, literals, offset, match length), one per
+    // lane; false = the output does not fit (limitedOutput, :1660-1668 and :1711-1716 - the parse never depends on the
+    // output position, so checking a whole buffer at once returns 0 for exactly the inputs the reference returns 0 for).
+    auto flush = [&]() -> bool {
+        const uint32_t L = (uint32_t)lane;
+        const bool act = L < nrec;
+        uint32_t lit = 0, mc = 0, off = 0;
+        if (act) {
+            if (MODE == 1) { const uint64_t r = *(L64*)(recs + 8u * L); lit = (uint32_t)r & 0xFFFFFFu; mc = (uint32_t)(r >> 24) & 0xFFFFFFu; off = (uint32_t)(r >> 48); }
+            else { const u32x4 r = *(L128*)(recs + 16u * L); lit = r.x; mc = r.y; off = r.z; }
+        }
+        const uint32_t lb = lit >= 15 ? (lit - 15) / 255 + 1 : 0u, mb = mc >= 15 ? (mc - 15) / 255 + 1 : 0u;
+        const uint32_t osz = act ? 3 + lb + lit + mb : 0u, isz = act ? lit + kMinMatch + mc : 0u;
+        const uint32_t oinc = wave_scan_incl(osz), iinc = wave_scan_incl(isz);
+        const uint32_t tp = f_op + oinc - osz;            // where this sequence's token goes
+        const uint32_t sp = f_anchor + iinc - isz;        // where its literals are
+        if (limited) {
+            const bool bad = act && ((uint64_t)tp + 1 + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap ||
+                                     (uint64_t)tp + 1 + lb + lit + 2 + (1 + kLastLiterals) + (mc + 240) / 255 > cap);
+            if (ballot(bad)) return false;
+        }
+        const uint32_t lp = tp + 1 + lb;                  // literals, then the offset at lp + lit
+        typedef u32x4 __attribute__((aligned(1))) U128;
+        typedef __attribute__((address_space(1))) U128 G128;
+        if (act) {
+            dst[tp] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mc < 15 ? mc : 15));
+            if (lit >= 15) dst[tp + lb] = (uint8_t)(lit - 15 - (lb - 1) * 255);
+            st16(dst + lp + lit, off);
+            if (mc >= 15) dst[lp + lit + 1 + mb] = (uint8_t)(mc - 15 - (mb - 1) * 255);
+            // literals of up to 32 bytes: two loads (first k bytes, last k bytes), two overlapping stores per size class
+            const gbyte* s = src + sp; gbyte* d = dst + lp;
+            if (lit > 32) {}
+            else if (lit >= 16) { const u32x4 a = *(const G128*)s, b = *(const G128*)(s + lit - 16); *(G128*)d = a; *(G128*)(d + lit - 16) = b; }
+            else if (lit >= 8) { const uint64_t a = ld64(s), b = ld64(s + lit - 8); st64(d, a); st64(d + lit - 8, b); }
+            else if (lit >= 4) { const uint32_t a = ld32(s), b = ld32(s + lit - 4); st32(d, a); st32(d + lit - 4, b); }
+            else if (lit) { const uint8_t a = s[0], b = s[lit >> 1], c = s[lit - 1]; d[0] = a; d[lit >> 1] = b; d[lit - 1] = c; }
+        }
+        // the rare long fields, sequence after sequence by the whole wave: runs of 255 of a length, literals beyond 32 bytes
+        for (uint64_t m = ballot(act && lb > 1); m; m &= m - 1) {
+            const int k = (int)__builtin_ctzll(m);
+            const uint32_t o = lane_get(tp, k) + 1, c = lane_get(lb, k) - 1;
+            for (uint32_t i = L; i < c; i += kWave) dst[o + i] = 255;
+        }
+        for (uint64_t m = ballot(act && mb > 1); m; m &= m - 1) {
+            const int k = (int)__builtin_ctzll(m);
+            const uint32_t o = lane_get(lp + lit, k) + 2, c = lane_get(mb, k) - 1;
+            for (uint32_t i = L; i < c; i += kWave) dst[o + i] = 255;
+        }
+        for (uint64_t m = ballot(act && lit > 32); m; m &= m - 1) {
+            const int k = (int)__builtin_ctzll(m);
+            wave_copy(dst + lane_get(lp, k), src + lane_get(sp, k), lane_get(lit, k), lane);
+        }
+        f_op += lane_get(oinc, 63); f_anchor = anchor; nrec = 0;
+        wave_fence();
+        return true;
+    };
     // software pipeline: the probe windows of the NEXT search's first batch (and the ip-2 back-fill bytes) are
     // requested as soon as the current match length is known, ahead of the table commit and the emission
     // Source ring: the bytes around the parse position are staged in LDS as two 256-byte blocks (block b of the
@@ -297,7 +364,6 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             }
             const uint32_t yb = (uint32_t)pw.lo ^ (uint32_t)cw.lo;
             const uint32_t bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
-            const uint32_t litbyte = (uint32_t)(pw.lo >> 32) & 0xFF;
 
             if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
             asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
@@ -309,7 +375,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             // is derived from 64-bit lane masks and done once per batch.  Sequences that need a loop (longer catch-up /
             // extension than the windows hold), every sequence of a non-linear batch and of limitedOutput mode are
             // "special": they end the walk and take the one-at-a-time path below.
-            const uint64_t slowmask = limited ? ~0ull : ballot(!linear || mf);
+            const uint64_t slowmask = ballot(!linear || mf);
             const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes
             uint32_t nxt;                                 // next matching lane, or 64 + stop code
             {
@@ -359,47 +425,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t back = bk4 < maxback ? bk4 : maxback;
                 const uint32_t lit = room - back;
                 const uint32_t mcode = back + fw;                                         // <= 28: one length byte at most
-                const uint32_t lb = lit < 15 ? 0u : 1u + (lit - 15) / 255;
-                const uint64_t lbmask = ballot(marked && lit >= 15), mbmask = ballot(marked && mcode >= 15);
-                const uint64_t backcover = (ballot(marked && back >= 1) >> 1) | (ballot(marked && back >= 2) >> 2) | (ballot(marked && back >= 3) >> 3) | (ballot(marked && back >= 4) >> 4);
-                const uint64_t litmask = (~0ull >> (63 - lastm)) & ~cover & ~backcover;   // lanes whose byte is a literal of some sequence
-                const int firstm = (int)__builtin_ctzll(marks);
-                // bytes that precede lane L's contribution: 3 per earlier sequence (token + offset), their length bytes,
-                // all earlier literal lanes, and (after the first sequence) its carried-in literals / extra length bytes
-                uint32_t adj = 0, lb1 = 0;
-                const uint32_t carry = (uint32_t)(-arel0);
-                if (arel0 < 0) {
-                    const uint32_t lit1 = lane_get(lit, firstm);
-                    lb1 = lit1 < 15 ? 0u : 1u + (lit1 - 15) / 255;
-                    adj = carry + lb1 - (lit1 >= 15 ? 1u : 0u);
-                }
-                auto cntbelow = [&](uint64_t mk) -> uint32_t {
-                    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                };
-                const uint32_t H = 3 * cntbelow(marks) + cntbelow(lbmask) + cntbelow(mbmask) + cntbelow(litmask) + (lane > firstm ? adj : 0u);
-                const uint32_t ownlit = lit - (lane == firstm ? carry : 0u);              // this sequence's literal lanes
-                const uint32_t outv = op + H - ownlit;                                    // marked lanes: where the token goes
                 if (PROF) cnt[1] += (uint32_t)__builtin_popcountll(marks);
-                if (do_st) {
-                    if (marked) {
-                        gbyte* o = dst + outv;
-                        o[0] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
-                        if (lit >= 15 && la >= 0) o[1] = (uint8_t)(lit - 15);            // in-batch literal runs are < 64 bytes
-                        st16(o + 1 + lb + lit, pos - cand);
-                        if (mcode >= 15) o[1 + lb + lit + 2] = (uint8_t)(mcode - 15);
-                    }
-                    if ((litmask >> lane) & 1) {          // literals: lane L holds src[pos0+L]; its sequence is the first marked lane after it
-                        const uint64_t up = marks >> lane;
-                        const uint64_t iso = up & (0 - up);
-                        const uint32_t lbo = lane < firstm && arel0 < 0 ? lb1 : (((lbmask >> lane) & iso) ? 1u : 0u);
-                        dst[op + H + 1 + lbo + (lane < firstm ? carry : 0u)] = (uint8_t)litbyte;
-                    }
-                    if (arel0 < 0) {                      // the carried-in part of the first literal run
-                        if (lb1) put_len_bytes(dst + op + 1, lane_get(lit, firstm) - 15, lane);
-                        wave_copy(dst + op + 1 + lb1, src + anchor, carry, lane);
-                    }
-                }
-                op = lane_get(outv + 1 + lb + lit + 2 + (mcode >= 15 ? 1u : 0u), lastm);
+                // one record per sequence, in sequence order behind the buffered ones
+                const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
+                if (marked) rec_put(idx, lit, mcode, pos - cand);
+                nrec += (uint32_t)__builtin_popcountll(marks);
                 ip = pos0 + (uint32_t)cur;
                 anchor = ip;
                 extra = true; i0 = 0;
@@ -464,21 +494,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t mstart = m_pos - back;
                 const uint32_t lit = mstart - anchor;
                 const uint32_t mcode = back + fwd;
-                const uint32_t token_pos = op++;
-                if (limited && (uint64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
-                if (lit >= 15) { if (do_st) put_len_bytes(dst + op, lit - 15, lane); op += (lit - 15) / 255 + 1; }
-                if (do_st) {
-                    if (linear && anchor >= pos0) {       // the literals are this batch's own bytes: lane L holds src[pos0+L]
-                        const uint32_t aL = anchor - pos0;
-                        if ((uint32_t)lane >= aL && (uint32_t)lane < aL + lit) dst[op + lane - aL] = (uint8_t)litbyte;
-                    } else wave_copy(dst + op, src + anchor, lit, lane);
-                }
-                op += lit;
-                if (do_st && lane == 0) st16(dst + op, m_pos - m_cand);
-                op += 2;
-                if (limited && (uint64_t)op + (1 + kLastLiterals) + (mcode + 240) / 255 > cap) return 0;
-                if (mcode >= 15) { if (do_st) put_len_bytes(dst + op, mcode - 15, lane); op += (mcode - 15) / 255 + 1; }
-                if (do_st && lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
+                if (lane == 0) rec_put(nrec, lit, mcode, m_pos - m_cand);
+                nrec++;
                 if (PROF) { cnt[1]++; cnt[4]++; }
                 ip = mstart + kMinMatch + mcode;
                 anchor = ip;
@@ -487,10 +504,12 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             }
             STAGE(5);
             asm volatile("; resolve end" ::: "memory");
+            if (nrec > kRecFlush || done) { wave_fence(); if (!flush()) return 0; }
             if (done) break;
         }
     }
     // ---------------- last literals (lz4.c:1808-1834) ----------------
+    uint32_t op = f_op;
     {
         const uint32_t lastRun = n - anchor;
         *last_run = lastRun;
@@ -801,7 +820,7 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
 template <int MODE, bool PROF>
 __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint32_t first)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 + LZ4_LDS_PAD : kTableBytes) + kSrcRing];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(MODE == 1 ? 9216 + LZ4_LDS_PAD : kTableBytes) + kSrcRing + kRecCap * rec_bytes(MODE)];
     const uint32_t c = first + blockIdx.x;
     if (c >= b.nchunks) return;
 #ifdef AOCLGPU_EXPERIMENTS
