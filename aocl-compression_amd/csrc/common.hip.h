@@ -114,6 +114,22 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
     return (uint32_t)t;
 }
 
+// Inclusive prefix maximum over the 64 lanes (same DPP pattern; 0 is the identity).
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
+{
+    auto mx = [](uint32_t a, int b) -> uint32_t { return a > (uint32_t)b ? a : (uint32_t)b; };
+    uint32_t t = x;
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xF, 0xF, true));
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xF, 0xF, true));
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, true));
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, true));
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, false));
+    t = mx(t, __builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, false));
+    return t;
+}
+// lane L gets lane L-1's value, lane 0 gets 0 (DPP wave_shr:1)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true); }
+
 // Chunk geometry of a batch (see aoclgpu_batch in include/aocl_gpu_codec.h)
 struct ChunkView {
     const gbyte* src; uint32_t src_len;

@@ -66,6 +66,17 @@ __device__ __forceinline__ uint32_t lz4_hash(uint64_t seq)
     return (uint32_t)(((seq << 24) * 889523592379ull) >> (64 - 12));
 }
 
+// the same hash of the 8 bytes lo | hi << 32 in 32-bit arithmetic: (seq << 24) * P = seq * (P << 24) mod 2^64, and only the
+// product's upper half is looked at
+template <bool U16>
+__device__ __forceinline__ uint32_t lz4_hash2(uint32_t lo, uint32_t hi)
+{
+    if (U16) return (lo * 2654435761u) >> (32 - 13);
+    constexpr uint64_t K = 889523592379ull << 24;
+    constexpr uint32_t Klo = (uint32_t)K, Khi = (uint32_t)(K >> 32);
+    return (__umulhi(lo, Klo) + lo * Khi + hi * Klo) >> 20;
+}
+
 // write the LZ4 "length - 15" continuation bytes (255,255,...,rem); returns bytes written
 __device__ __forceinline__ uint32_t put_len_bytes(gbyte* d, uint32_t rem, int lane)
 {
@@ -126,7 +137,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     };
     auto tput_blind = [&](uint32_t h, uint32_t v) {
         table[h] = (T)v;
-        if (MODE == 1) { const uint32_t sh = (h & 15) * 2; __hip_atomic_fetch_and(&hib[h >> 4], ~(3u << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_or(&hib[h >> 4], ((v >> 16) & 3u) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        if (MODE == 1) {                                              // one masked-or instead of an AND and an OR: word = (word & ~mask) | bits
+            const uint32_t sh = (h & 15) * 2;
+            asm volatile("ds_mskor_b32 %0, %1, %2" :: "v"((uint32_t)(uintptr_t)&hib[h >> 4]), "v"(3u << sh), "v"(((v >> 16) & 3u) << sh) : "memory");
+        }
     };
     const int lane = lane_id();
     uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -226,55 +240,51 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         wave_fence();
         return true;
     };
-    // software pipeline: the probe windows of the NEXT search's first batch (and the ip-2 back-fill bytes) are
-    // requested as soon as the current match length is known, ahead of the table commit and the emission
     // Source ring: the bytes around the parse position are staged in LDS as two 256-byte blocks (block b of the
     // chunk sits at ring offset (b & 1) * 256, the first 32 ring bytes are mirrored behind the end so that a 32-byte
-    // read never wraps).  The block after the newest one is always in flight in a register, requested ~256 bytes of
-    // parsing ahead of its use, so the 64 probe windows of a batch are LDS reads instead of a global round trip.
+    // read never wraps; block -1 is zeros: bytes before the chunk read as 0).  The block after the newest one is always
+    // in flight in a register, requested ~256 bytes of parsing ahead of its use, so the 64 probe windows of a batch
+    // are LDS reads instead of a global round trip.
     lbyte* ring = lds + (MODE == 1 ? 9216u : kTableBytes);
     int32_t rb = -4;                                      // newest block in the ring (blocks rb-1 and rb are valid)
     uint32_t pend = 0; bool have_pend = false;            // block rb+1, in flight
     auto blk_load = [&](int32_t b) -> uint32_t {
-        const uint32_t a = 256u * (uint32_t)b + 4u * (uint32_t)lane;
         uint32_t v = 0;
-        if (a + 4 <= n) v = ld32(src + a);
-        else if (a < n) for (uint32_t t = 0; t < n - a; ++t) v |= (uint32_t)src[a + t] << (8 * t);
+        if (b >= 0) {
+            const uint32_t a = 256u * (uint32_t)b + 4u * (uint32_t)lane;
+            if (a + 4 <= n) v = ld32(src + a);
+            else if (a < n) for (uint32_t t = 0; t < n - a; ++t) v |= (uint32_t)src[a + t] << (8 * t);
+        }
         return v;
     };
     auto blk_store = [&](int32_t b, uint32_t v) {
         *(L32*)(ring + (((uint32_t)b & 1u) << 8) + 4u * (uint32_t)lane) = v;
         if (!(b & 1) && lane < 8) *(L32*)(ring + 512u + 4u * (uint32_t)lane) = v;
     };
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
 
     if (n >= kMinLength) {
         uint32_t i0 = 0;                                  // probes of the current search already examined
         for (;;) {
             asm volatile("; batch begin" ::: "memory");
-            // ---------------- one batch of 64 speculative probes (lz4.c:1483-1608, 1746-1804) ----------------
-            uint32_t pos, posmax; bool valid;
-            if (i0 == 0 && accel == 1) {                  // first 64 probes of a search: consecutive positions
-                pos = ip + (uint32_t)lane; posmax = ip + 63;
-                valid = pos + 1 <= mfl1;                                        // lz4.c:1513
-            } else {                                      // probe j of the schedule (j = -1: the post-match probe at ip)
-                const uint32_t base = extra ? ip + 1 : ip;
-                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (extra ? 1 : 0);
-                const uint64_t p64 = j < 0 ? (uint64_t)base - 1 : (uint64_t)base + sched((uint32_t)j, accel);
-                const uint64_t pm64 = (uint64_t)base + sched(i0 + 63u - (extra ? 1u : 0u), accel);
-                pos = p64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)p64;
-                posmax = pm64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)pm64;
-                valid = (uint64_t)base + sched((uint32_t)(j + 1), accel) <= mfl1;
-            }
-            // 16-byte windows [p-4, p+12) around the probe and around its candidate: the 4 bytes of the match
-            // test, 4 bytes of catch-up and 8 bytes of forward extension arrive in one round trip
-            const uint32_t pos0 = lane_get(pos, 0);
-            // probe windows [p-4, p+28): from the source ring when the whole batch fits two blocks, else 16 bytes from memory
-            const bool use_ring = posmax + 28 - (pos0 < 4 ? 0 : pos0 - 4) <= 256;
-            Win pw = {0, 0}; uint64_t p2 = 0, p3 = 0;
-            uint64_t fb = 0;                              // the 8 bytes at ip-2 (back-fill)
-            if (use_ring) {
-                const int32_t bl = pos0 < 4 ? 0 : (int32_t)((pos0 - 4) >> 8), bh = (int32_t)((posmax + 27) >> 8);
-                if (!(bh <= rb && rb <= bl + 1)) {
+            const uint32_t ex = extra ? 1u : 0u;
+            const uint32_t s0 = uni(ip + i0);             // position of lane 0 while the schedule's steps are 1 byte
+            bool done = false;
+            int special = -1;                             // lane whose sequence takes the one-at-a-time path below
+            uint32_t pos, cand, fw, bk4; bool mf;         // per lane, read by that path
+            if (accel == 1 && i0 <= 65 + ex && s0 + 92 <= mfl1) {
+                // ---------------- 64 CONSECUTIVE positions s0 + lane (lz4.c:1483-1608, 1746-1804) ----------------
+                // Probe j of a search sits at its start + j for j <= 65 (step = searchMatchNb++ >> 6), so the first `own`
+                // lanes are probes of the current search and EVERY lane is a probe of any search that starts behind a match
+                // of this batch: the batch resolves sequence after sequence.  Far from the chunk's end (s0 + 92 <=
+                // mflimitPlusOne) every lane is a valid probe, every window is inside the chunk and no match reaches
+                // matchlimit; the chunk's last hundred bytes take the general path.
+                const uint32_t own = 66 + ex - i0 < 64 ? 66 + ex - i0 : 64;
+                pos = s0 + (uint32_t)lane;
+                const int32_t w0 = (int32_t)s0 - 4;       // the ring must hold [w0, w0 + 96)
+                if ((uint32_t)(w0 - 256 * (rb - 1)) > 512u - 96u) {
+                    const int32_t bl = w0 >> 8, bh = (w0 + 95) >> 8;
                     if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
                     else {
                         const uint32_t v0 = blk_load(bl), v1 = blk_load(bh);
@@ -285,163 +295,208 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     pend = blk_load(rb + 1); have_pend = true;
                     wave_fence();
                 }
-                const uint32_t off = (pos - 4) & 511u;
-                const u32x4 a = lds_ld128(ring + off), b = lds_ld128(ring + off + 16);
-                pw.lo = a.x | ((uint64_t)a.y << 32); pw.hi = a.z | ((uint64_t)a.w << 32);
-                p2 = b.x | ((uint64_t)b.y << 32); p3 = b.z | ((uint64_t)b.w << 32);
-                if (pos0 < 4 && pos < 4) pw.lo &= ~0ull << (8 * (4 - pos));              // bytes before the chunk read as 0
-                if (extra && i0 == 0) fb = lds_ld64(ring + ((ip - 2) & 511u));
-            } else {
-                if (valid) pw = load_win(src, pos);
-                if (extra && i0 == 0) fb = ld64(src + ip - 2);
-            }
-            if (extra && i0 == 0) {                       // back-fill ip-2 (lz4.c:1750) before the batch reads the table
-                const uint32_t h2 = lz4_hash<MODE == 0>(fb);
-                if (lane == 0) tput_blind(h2, (ip - 2) | chk((uint32_t)fb));
+                // 32-byte probe windows [p-4, p+28): a = {p-4, p, p+4, p+8}, b = {p+12, p+16, p+20, p+24}
+                const uint32_t roff = (uint32_t)(w0 + lane) & 511u;
+                const u32x4 a = lds_ld128(ring + roff), b = lds_ld128(ring + roff + 16);
+                if (extra && i0 == 0) {                   // back-fill ip-2 (lz4.c:1750) before the batch reads the table: lane 0's window holds its bytes
+                    const uint32_t f_lo = __builtin_amdgcn_alignbit(a.y, a.x, 16), f_hi = a.y >> 16;
+                    const uint32_t h2 = lz4_hash2<U16>(f_lo, f_hi);
+                    if (lane == 0) tput_blind(h2, (ip - 2) | chk(f_lo));
+                    wave_fence();
+                }
+                STAGE(0);
+                const uint32_t my4 = a.y;
+                const uint32_t h = lz4_hash2<U16>(a.y, a.z);
+                const uint32_t ent = tget(h);
+                cand = ent & posMask;
+                const uint32_t mychk = chk(my4);
+                // only lanes that can still pass the test fetch their candidate window
+                const bool plausible = (MODE != 2 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
+                STAGE(1);
+                // candidate windows [c-4, c+28) (cand < pos, so they end inside the chunk): 4 bytes of catch-up, the 4 bytes of
+                // the match test and 24 bytes of forward extension arrive in one round trip
+                u32x4 A = {~a.x, ~a.y, 0u, 0u}, B = {0u, 0u, 0u, 0u};
+                if (plausible) {
+                    const uint32_t cq = cand >= 4 ? cand - 4 : 0u;
+                    A = *(const G128*)(src + cq); B = *(const G128*)(src + cq + 16);
+                }
+                // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
                 wave_fence();
-            }
-            STAGE(0);
-            const uint64_t seq = (pw.lo >> 32) | (pw.hi << 32);
-            const uint32_t h = lz4_hash<MODE == 0>(seq);
-            uint32_t ent = 0;
-            if (valid) ent = tget(h);
-            const uint32_t cand = ent & posMask;
-            const uint32_t mychk = chk((uint32_t)(pw.lo >> 32));
-            // only lanes that can still pass the test fetch their candidate window
-            const bool plausible = valid && (MODE != 2 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
-            STAGE(1);
-            Win cw = {~pw.lo, 0};
-            if (plausible) cw = load_win(src, cand);
-            // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
-            uint64_t c2 = 0, c3 = 0;
-            const bool have2 = plausible && use_ring && cand + 20 <= n;
-            const bool have3 = have2 && cand + 28 <= n;
-            if (have3) {                                  // one 16-byte load
-                typedef u32x4 __attribute__((aligned(1))) U;
-                const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + cand + 12);
-                c2 = v.x | ((uint64_t)v.y << 32); c3 = v.z | ((uint64_t)v.w << 32);
-            } else if (have2) c2 = ld64(src + cand + 12);
-            // exact first in-batch slot reuse: per-slot minimum lane by write / read-back rounds
-            wave_fence();
-            const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane, valid);
-            wave_fence();
-            if (valid) table[h] = (T)ent;                 // undo the lane ids (the low halves; extra bits were not touched)
-            wave_fence();
-            STAGE(2);
-            const int e = first_lane(ballot(!valid));
-            // Lanes whose slot an earlier lane of the batch also names ("duplicates") have a candidate that depends on the
-            // parse: the earlier lane's position if that lane's table write happens, else the table entry.  Such a lane is
-            // still decided when NEITHER can match - its table candidate fails the 4-byte test and no earlier lane on its slot
-            // holds the same 4 bytes: it is a probe that finds nothing, whoever its candidate is.  The batch is cut at the
-            // first duplicate that could match.  `later` = this lane's slot is named again by these later lanes (the last
-            // one whose write happens owns the slot when the batch commits).
-            const uint32_t my4 = (uint32_t)(pw.lo >> 32);
-            const uint64_t tabok = ballot(plausible && (uint32_t)(cw.lo >> 32) == my4);
-            uint64_t later = 0;
-            int f = 64;
-            for (uint64_t d = ballot(valid && w != (uint32_t)lane); d; d &= d - 1) {
-                const int j = (int)__builtin_ctzll(d);
-                const uint64_t before = (1ull << j) - 1;
-                const uint64_t same = ballot(valid && h == lane_get(h, j)) & before;
-                if (((tabok >> j) & 1) || (ballot(my4 == lane_get(my4, j)) & same) != 0) { f = j; break; }
-                if ((same >> lane) & 1) later |= 1ull << j;
-            }
-            const int lim = f < e ? f : e;                // lanes < lim are decided exactly as the sequential parse decides them
-            const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
-            const bool linear = (i0 == 0) && accel == 1;  // lane L probes pos0 + L (the default schedule is the identity below 66)
-            // in-lane forward extension (<= 24 bytes), LZ4_count lz4.c:656-679: the probe-side bytes beyond +12 sit in
-            // the windows of lanes +8 and +16 (linear batches), the candidate side is fetched by plausible lanes only
-            uint32_t fw; bool mf;
-            {
-                const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
-                uint32_t avail = 8;                       // bytes of forward data compared in registers
-                fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
-                if (fw == 8 && have2) { avail = 16; fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8; }
-                if (fw == 16 && have3) { avail = 24; fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8; }
-                const uint32_t maxfwd = matchlimit - (pos + kMinMatch);
-                mf = fw == avail && maxfwd > avail;
-                fw = fw < maxfwd ? fw : maxfwd;
-            }
-            const uint32_t yb = (uint32_t)pw.lo ^ (uint32_t)cw.lo;
-            const uint32_t bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
-
-            if (PROF) { cnt[0]++; cnt[6] += (uint32_t)lim; }
-            asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
-            // ---------------- resolve every sequence this batch holds ----------------
-            // The next search after a match (back-fill ip-2, probe ip, ip+1, ...) can be resolved from THIS batch because
-            // its probes are lanes of the batch whose table slots nobody before them touched (lanes < lim).  Every
-            // matching lane precomputes where the chain continues after its match (`nxt`), so the scalar walk is one
-            // readlane per sequence; everything else (table commit, token/length/offset/literal bytes of ALL sequences)
-            // is derived from 64-bit lane masks and done once per batch.  Sequences that need a loop (longer catch-up /
-            // extension than the windows hold), every sequence of a non-linear batch and of limitedOutput mode are
-            // "special": they end the walk and take the one-at-a-time path below.
-            const uint64_t slowmask = ballot(!linear || mf);
-            const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes
-            uint32_t nxt;                                 // next matching lane, or 64 + stop code
-            {
-                const uint64_t t = endl < 64 ? okmask >> endl : 0;
-                nxt = t ? endl + (uint32_t)__builtin_ctzll(t) : 64u;                      // 64: no match in [endl, lim)
-                if (endl >= (uint32_t)lim) nxt = 65;                                      // 65: next search starts beyond lim
-                if (pos0 + endl >= mfl1) nxt = 66;                                        // 66: end of input (lz4.c:1747)
-            }
-            uint64_t marks = 0;                           // lanes that start a sequence
-            int special = -1;
-            uint32_t mw = okmask ? (uint32_t)__builtin_ctzll(okmask) : 64u;
-            while (mw < 64) {
-                if ((slowmask >> mw) & 1) { special = (int)mw; break; }
-                marks |= 1ull << mw;
-                mw = lane_get(nxt, (int)mw);
-            }
-            int stop = special >= 0 ? 3 : (int)mw - 64;   // 0 no match in [cur, lim), 1 beyond lim, 2 end of input, 3 special
-            const int32_t arel0 = (int32_t)(anchor - pos0);      // <= 0; negative: literals carried in from earlier batches
-            // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it
-            const uint64_t beloweq = ~0ull >> (63 - lane), below = beloweq >> 1;
-            const uint64_t mb_ = marks & below;
-            const int q = 63 - (int)__builtin_clzll(mb_ | 1);                             // highest marked lane strictly below
-            const uint32_t qend = (uint32_t)__shfl((int)endl, q);
-            const int32_t la = mb_ ? (int32_t)qend : arel0;
-            const uint32_t room = (uint32_t)((int32_t)lane - la);                        // m_pos - anchor
-            const uint32_t maxback = room < cand ? room : cand;
-            {   // a catch-up that runs past the 4 bytes of the window needs the loop: cut the chain in front of it
-                const uint64_t need = ballot(((marks >> lane) & 1) && bk4 == 4 && maxback > 4);
-                if (need) { special = (int)__builtin_ctzll(need); stop = 3; marks &= ~(~0ull << special); }
-            }
-            const int lastm = 63 - (int)__builtin_clzll(marks | 1);
-            const int cur = marks ? (int)lane_get(endl, lastm) : 0;                       // first lane of the unfinished search
-            const bool marked = (marks >> lane) & 1;
-            const bool covered = marked || (mb_ != 0 && (uint32_t)lane < qend);           // lanes inside a match [m, endl)
-            const uint64_t cover = ballot(covered);
-            {   // table writes the reference performs: every probed lane of every search, plus the ip-2 back-fills
-                const int R = stop == 0 ? lim : (stop == 3 ? special + 1 : cur);
-                const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
-                const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
-                const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
-                if (((commit >> lane) & 1) && (later & commit) == 0) tput(h, pos | mychk, ent);
-            }
-            wave_fence();
-            STAGE(3);
-            if (marks) {
-                // per-sequence quantities, in the lane that found the match (lz4.c:1611-1740)
-                const uint32_t back = bk4 < maxback ? bk4 : maxback;
-                const uint32_t lit = room - back;
-                const uint32_t mcode = back + fw;                                         // <= 28: one length byte at most
-                if (PROF) cnt[1] += (uint32_t)__builtin_popcountll(marks);
-                // one record per sequence, in sequence order behind the buffered ones
-                const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
-                if (marked) rec_put(idx, lit, mcode, pos - cand);
-                nrec += (uint32_t)__builtin_popcountll(marks);
-                ip = pos0 + (uint32_t)cur;
-                anchor = ip;
-                extra = true; i0 = 0;
-            }
-            STAGE(4);
-            bool done = false;
-            if (stop == 2) done = true;
-            else if (stop == 1) { /* next batch starts at ip */ }
-            else if (stop == 0) {
-                if (e < 64 && e <= f) done = true;                                        // next probe would pass mflimitPlusOne
-                else i0 += (uint32_t)(lim - cur);                                         // probes of the current search already examined
+                const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane);
+                wave_fence();
+                table[h] = (T)ent;                        // undo the lane ids (the low halves; extra bits were not touched)
+                wave_fence();
+                if (ballot(plausible && cand < 4)) {      // window that starts before the chunk: loaded from byte 0, moved up 4 - cand bytes
+                    if (plausible && cand < 4) {
+                        const uint32_t k = 8u * cand;     // alignbit(W[i], W[i-1], 32 - 8 * (4 - cand))
+                        B.w = __builtin_amdgcn_alignbit(B.w, B.z, k); B.z = __builtin_amdgcn_alignbit(B.z, B.y, k); B.y = __builtin_amdgcn_alignbit(B.y, B.x, k); B.x = __builtin_amdgcn_alignbit(B.x, A.w, k);
+                        A.w = __builtin_amdgcn_alignbit(A.w, A.z, k); A.z = __builtin_amdgcn_alignbit(A.z, A.y, k); A.y = __builtin_amdgcn_alignbit(A.y, A.x, k);
+                        A.x = __builtin_amdgcn_alignbit(A.x, 0u, k);
+                    }
+                }
+                STAGE(2);
+                // Lanes whose slot an earlier lane of the batch also names ("duplicates") have a candidate that depends on the
+                // parse: the earlier lane's position if that lane's table write happens, else the table entry.  Such a lane is
+                // still decided when NEITHER can match - its table candidate fails the 4-byte test and no earlier lane on its slot
+                // holds the same 4 bytes: it is a probe that finds nothing, whoever its candidate is.  The batch is cut at the
+                // first duplicate that could match.  `later` = this lane's slot is named again by these later lanes (the last
+                // one whose write happens owns the slot when the batch commits).
+                const uint64_t tabok = ballot(plausible && A.y == my4);
+                uint64_t later = 0;
+                uint32_t lim = 64;
+                const uint64_t dups = ballot(w != (uint32_t)lane);
+                for (uint64_t d = dups; d; d &= d - 1) {
+                    const int j = (int)__builtin_ctzll(d);
+                    const uint64_t before = (1ull << j) - 1;
+                    const uint64_t same = ballot(h == lane_get(h, j)) & before;
+                    if (((tabok >> j) & 1) || (ballot(my4 == lane_get(my4, j)) & same) != 0) { lim = (uint32_t)j; break; }
+                    if ((same >> lane) & 1) later |= 1ull << j;
+                }
+                const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));   // lanes < lim are decided exactly as the sequential parse decides them
+                // forward extension (<= 24 bytes, LZ4_count lz4.c:656-679) and catch-up (<= 4 bytes), in registers
+                {
+                    const uint64_t x1 = (uint64_t)(a.z ^ A.z) | ((uint64_t)(a.w ^ A.w) << 32);
+                    const uint64_t x2 = (uint64_t)(b.x ^ B.x) | ((uint64_t)(b.y ^ B.y) << 32);
+                    const uint64_t x3 = (uint64_t)(b.z ^ B.z) | ((uint64_t)(b.w ^ B.w) << 32);
+                    fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                    if (fw == 8) fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
+                    if (fw == 16) fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
+                    mf = fw == 24;
+                    const uint32_t yb = a.x ^ A.x;
+                    bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
+                }
+                if (PROF) { cnt[0]++; cnt[6] += lim; if (i0) cnt[3]++; }
+                asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
+                // ---------------- resolve every sequence this batch holds ----------------
+                // Every matching lane precomputes where the chain continues after its match (`nxt` = first matching lane at or
+                // after the match's end, >= 64: none), so the scalar walk is one readlane per sequence; everything else (the
+                // anchor of every sequence, the table commit, the records) is derived from 64-bit lane masks once per batch.
+                // Sequences that need a loop (longer extension / catch-up than the windows hold) are "special": they end
+                // the walk and take the one-at-a-time path below.
+                const uint64_t slowmask = ballot(mf);
+                const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes (<= 91)
+                uint32_t nxt;
+                {
+                    const uint64_t t = (okmask >> (endl < 63 ? endl : 63)) | (1ull << 63);   // (endl >= 4: the shift clears bit 63)
+                    nxt = endl + (uint32_t)__builtin_ctzll(t);
+                }
+                uint64_t marks = 0;                           // lanes that start a sequence
+                {
+                    const uint64_t first = okmask & (own >= 64 ? ~0ull : ((1ull << own) - 1));
+                    uint32_t mw = first ? (uint32_t)__builtin_ctzll(first) : 64u;
+                    while (mw < 64) {
+                        if ((slowmask >> mw) & 1) { special = (int)mw; break; }
+                        marks |= 1ull << mw;
+                        mw = lane_get(nxt, (int)mw);
+                    }
+                }
+                // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it
+                const int32_t arel0 = (int32_t)(anchor - s0);       // <= 0; negative: literals carried in from earlier batches
+                bool marked = __builtin_amdgcn_inverse_ballot_w64(marks);
+                const uint32_t qend = wave_shr1(wave_scan_max(marked ? endl : 0u));          // 0: no match starts below this lane
+                const int32_t la = qend ? (int32_t)qend : arel0;
+                const uint32_t room = (uint32_t)((int32_t)lane - la);                        // m_pos - anchor
+                const uint32_t maxback = room < cand ? room : cand;
+                {   // a catch-up that runs past the 4 bytes of the window needs the loop: cut the chain in front of it
+                    const uint64_t need = ballot(marked && bk4 == 4 && maxback > 4);
+                    if (need) { special = (int)__builtin_ctzll(need); marks &= ~(~0ull << special); marked = __builtin_amdgcn_inverse_ballot_w64(marks); }
+                }
+                const uint64_t cover = ballot(marked || (uint32_t)lane < qend);               // lanes inside a match [m, endl) (below `special`: of the sequences kept)
+                uint32_t cur = 0;                             // first lane of the unfinished search
+                if (marks) cur = lane_get(endl, 63 - (int)__builtin_clzll(marks));
+                {   // table writes the reference performs: every probed lane of every search, plus the ip-2 back-fills
+                    const uint32_t R = special >= 0 ? (uint32_t)special + 1 : (marks == 0 ? (own < lim ? own : lim) : (cur >= lim ? cur : lim));
+                    const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
+                    const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
+                    const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
+                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos | mychk, ent); }
+                    else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, pos | mychk, ent);
+                }
+                wave_fence();
+                STAGE(3);
+                if (marks) {
+                    // per-sequence quantities, in the lane that found the match (lz4.c:1611-1740); one record per sequence, in
+                    // sequence order behind the buffered ones
+                    const uint32_t back = bk4 < maxback ? bk4 : maxback;
+                    const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
+                    if (marked) rec_put(idx, room - back, back + fw, pos - cand);
+                    const uint32_t ns = (uint32_t)__builtin_popcountll(marks);
+                    nrec += ns;
+                    if (PROF) cnt[1] += ns;
+                    ip = s0 + cur; anchor = ip; extra = true; i0 = 0;
+                }
+                STAGE(4);
+                if (special < 0) {
+                    if (marks == 0) i0 += own < lim ? own : lim;       // the search goes on
+                    else if (cur < lim) i0 = lim - cur;                // lanes [cur, lim) of the next search found nothing
+                }
             } else {
+                // ---------------- general batch: probe i0 + lane of the schedule (any acceleration, long searches, the chunk's
+                // end); lane k evaluates probe k speculatively, the first hit below the first in-batch slot reuse is the match
+                // (lz4.c:1483-1608), resolved one at a time ----------------
+                const uint32_t base = extra ? ip + 1 : ip;
+                const int32_t j = (int32_t)(i0 + (uint32_t)lane) - (int32_t)ex;             // j = -1: the post-match probe at ip
+                const uint64_t p64 = j < 0 ? (uint64_t)base - 1 : (uint64_t)base + sched((uint32_t)j, accel);
+                pos = p64 > 0x7FFFFF00ull ? 0x7FFFFF00u : (uint32_t)p64;
+                const bool valid = (uint64_t)base + sched((uint32_t)(j + 1), accel) <= mfl1;   // lz4.c:1513
+                Win pw = {0, 0};
+                if (valid) pw = load_win(src, pos);
+                if (extra && i0 == 0) {                   // back-fill ip-2 (lz4.c:1750) before the batch reads the table
+                    const uint64_t fb = ld64(src + ip - 2);
+                    const uint32_t h2 = lz4_hash2<U16>((uint32_t)fb, (uint32_t)(fb >> 32));
+                    if (lane == 0) tput_blind(h2, (ip - 2) | chk((uint32_t)fb));
+                    wave_fence();
+                }
+                const uint32_t my4 = (uint32_t)(pw.lo >> 32);
+                const uint32_t h = lz4_hash2<U16>(my4, (uint32_t)pw.hi);
+                uint32_t ent = 0;
+                if (valid) ent = tget(h);
+                cand = ent & posMask;
+                const uint32_t mychk = chk(my4);
+                const bool plausible = valid && (MODE != 2 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
+                Win cw = {~pw.lo, 0};
+                if (plausible) cw = load_win(src, cand);
+                wave_fence();
+                const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane, valid);
+                wave_fence();
+                if (valid) table[h] = (T)ent;
+                wave_fence();
+                const uint32_t e = (uint32_t)first_lane(ballot(!valid));
+                const uint64_t tabok = ballot(plausible && (uint32_t)(cw.lo >> 32) == my4);
+                uint64_t later = 0;
+                uint32_t f = 64;
+                for (uint64_t d = ballot(valid && w != (uint32_t)lane); d; d &= d - 1) {
+                    const int k = (int)__builtin_ctzll(d);
+                    const uint64_t before = (1ull << k) - 1;
+                    const uint64_t same = ballot(valid && h == lane_get(h, k)) & before;
+                    if (((tabok >> k) & 1) || (ballot(my4 == lane_get(my4, k)) & same) != 0) { f = (uint32_t)k; break; }
+                    if ((same >> lane) & 1) later |= 1ull << k;
+                }
+                const uint32_t lim = f < e ? f : e;
+                const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
+                {
+                    const uint64_t x1 = pw.hi ^ cw.hi;
+                    fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                    const uint32_t maxfwd = matchlimit - (pos + kMinMatch);
+                    mf = fw == 8 && maxfwd > 8;
+                    fw = fw < maxfwd ? fw : maxfwd;
+                    const uint32_t yb = (uint32_t)pw.lo ^ (uint32_t)cw.lo;
+                    bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
+                }
+                if (PROF) { cnt[0]++; cnt[2]++; cnt[6] += lim; }
+                if (okmask) special = (int)__builtin_ctzll(okmask);
+                {
+                    const uint32_t R = special >= 0 ? (uint32_t)special + 1 : lim;
+                    const uint64_t commit = R >= 64 ? ~0ull : ~(~0ull << R);
+                    if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos | mychk, ent);
+                }
+                wave_fence();
+                if (special < 0) {
+                    if (e < 64 && e <= f) done = true;                                        // next probe would pass mflimitPlusOne
+                    else i0 += lim;
+                }
+            }
+            if (special >= 0) {
                 // ---------------- one special sequence, lane `special` (lz4.c:1611-1740) ----------------
                 const int m = special;
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
@@ -492,9 +547,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     }
                 }
                 const uint32_t mstart = m_pos - back;
-                const uint32_t lit = mstart - anchor;
                 const uint32_t mcode = back + fwd;
-                if (lane == 0) rec_put(nrec, lit, mcode, m_pos - m_cand);
+                if (lane == 0) rec_put(nrec, mstart - anchor, mcode, m_pos - m_cand);
                 nrec++;
                 if (PROF) { cnt[1]++; cnt[4]++; }
                 ip = mstart + kMinMatch + mcode;
@@ -504,7 +558,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             }
             STAGE(5);
             asm volatile("; resolve end" ::: "memory");
-            if (nrec > kRecFlush || done) { wave_fence(); if (!flush()) return 0; }
+            if (nrec > kRecFlush || done) { wave_fence(); if (PROF) cnt[5]++; if (!flush()) return 0; }
             if (done) break;
         }
     }
