@@ -285,12 +285,12 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const int32_t w0 = (int32_t)s0 - 4;       // the ring must hold [w0, w0 + 96)
                 if ((uint32_t)(w0 - 256 * (rb - 1)) > 512u - 96u) {
                     const int32_t bl = w0 >> 8, bh = (w0 + 95) >> 8;
-                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
+                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb = (int32_t)uni((uint32_t)(rb + 1)); }
                     else {
                         const uint32_t v0 = blk_load(bl), v1 = blk_load(bh);
                         blk_store(bl, v0);
                         if (bh != bl) blk_store(bh, v1);
-                        rb = bh;
+                        rb = (int32_t)uni((uint32_t)bh);
                     }
                     pend = blk_load(rb + 1); have_pend = true;
                     wave_fence();
@@ -556,9 +556,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 if (ip >= mfl1) done = true;              // lz4.c:1747
                 else { extra = true; i0 = 0; }
             }
-            STAGE(5);
             asm volatile("; resolve end" ::: "memory");
             if (nrec > kRecFlush || done) { wave_fence(); if (PROF) cnt[5]++; if (!flush()) return 0; }
+            STAGE(5);
             if (done) break;
         }
     }
