@@ -143,7 +143,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         }
     };
     const int lane = lane_id();
-    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PROF: batches, sequences, stop: beyond-batch, lim, more_fwd, nomatch, sum(lim), -
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #ifdef LZ4_PROF_NOWAIT   /* stamps without draining the global loads: a stage is charged the waits the compiler placed in it */
@@ -180,6 +180,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     uint32_t nrec = 0, f_op = 0, f_anchor = 0;
     typedef __attribute__((address_space(3))) uint64_t L64;
     typedef __attribute__((address_space(3))) u32x4 L128;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
     auto rec_put = [&](uint32_t idx, uint32_t lit, uint32_t mcode, uint32_t off) {
         if (MODE == 1) *(L64*)(recs + 8u * idx) = (uint64_t)lit | ((uint64_t)mcode << 24) | ((uint64_t)off << 48);
         else *(L128*)(recs + 16u * idx) = u32x4{lit, mcode, off, 0u};
@@ -206,22 +208,30 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             if (ballot(bad)) return false;
         }
         const uint32_t lp = tp + 1 + lb;                  // literals, then the offset at lp + lit
-        typedef u32x4 __attribute__((aligned(1))) U128;
-        typedef __attribute__((address_space(1))) U128 G128;
+        // Literals of up to 64 bytes, one sequence per lane: four pieces per size class (16-byte pieces for 16 .. 64 bytes, 4-byte
+        // pieces for 4 .. 15, single bytes below) at offsets 0, k, 2k clamped to lit - k and at lit - k: overlapping pieces carry the
+        // same bytes, every access stays inside the run.  All loads of all classes are requested before the first store.
+        const gbyte* s = src + sp; gbyte* d = dst + lp;
+        const bool c16 = act && lit >= 16 && lit <= 64, c4 = act && lit >= 4 && lit < 16, c1 = act && lit >= 1 && lit < 4;
+        const uint32_t e16 = lit - 16, p16a = e16 < 16 ? e16 : 16u, p16b = e16 < 32 ? e16 : 32u;
+        const uint32_t e4 = lit - 4, p4a = e4 < 4 ? e4 : 4u, p4b = e4 < 8 ? e4 : 8u;
+        u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        uint8_t b0 = 0, b1 = 0, b2 = 0;
+        if (c16) { q0 = *(const G128*)s; q1 = *(const G128*)(s + p16a); q2 = *(const G128*)(s + p16b); q3 = *(const G128*)(s + e16); }
+        if (c4) { r0 = ld32(s); r1 = ld32(s + p4a); r2 = ld32(s + p4b); r3 = ld32(s + e4); }
+        if (c1) { b0 = s[0]; b1 = s[lit >> 1]; b2 = s[lit - 1]; }
         if (act) {
             dst[tp] = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mc < 15 ? mc : 15));
             if (lit >= 15) dst[tp + lb] = (uint8_t)(lit - 15 - (lb - 1) * 255);
             st16(dst + lp + lit, off);
             if (mc >= 15) dst[lp + lit + 1 + mb] = (uint8_t)(mc - 15 - (mb - 1) * 255);
-            // literals of up to 32 bytes: two loads (first k bytes, last k bytes), two overlapping stores per size class
-            const gbyte* s = src + sp; gbyte* d = dst + lp;
-            if (lit > 32) {}
-            else if (lit >= 16) { const u32x4 a = *(const G128*)s, b = *(const G128*)(s + lit - 16); *(G128*)d = a; *(G128*)(d + lit - 16) = b; }
-            else if (lit >= 8) { const uint64_t a = ld64(s), b = ld64(s + lit - 8); st64(d, a); st64(d + lit - 8, b); }
-            else if (lit >= 4) { const uint32_t a = ld32(s), b = ld32(s + lit - 4); st32(d, a); st32(d + lit - 4, b); }
-            else if (lit) { const uint8_t a = s[0], b = s[lit >> 1], c = s[lit - 1]; d[0] = a; d[lit >> 1] = b; d[lit - 1] = c; }
         }
-        // the rare long fields, sequence after sequence by the whole wave: runs of 255 of a length, literals beyond 32 bytes
+        asm volatile("" ::: "memory");                    // (the loads above stay above)
+        if (c16) { *(G128*)d = q0; *(G128*)(d + p16a) = q1; *(G128*)(d + p16b) = q2; *(G128*)(d + e16) = q3; }
+        if (c4) { st32(d, r0); st32(d + p4a, r1); st32(d + p4b, r2); st32(d + e4, r3); }
+        if (c1) { d[0] = b0; d[lit >> 1] = b1; d[lit - 1] = b2; }
+        // the rare long fields, sequence after sequence by the whole wave: runs of 255 of a length, literals beyond 64 bytes
         for (uint64_t m = ballot(act && lb > 1); m; m &= m - 1) {
             const int k = (int)__builtin_ctzll(m);
             const uint32_t o = lane_get(tp, k) + 1, c = lane_get(lb, k) - 1;
@@ -232,7 +242,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             const uint32_t o = lane_get(lp + lit, k) + 2, c = lane_get(mb, k) - 1;
             for (uint32_t i = L; i < c; i += kWave) dst[o + i] = 255;
         }
-        for (uint64_t m = ballot(act && lit > 32); m; m &= m - 1) {
+        for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
             const int k = (int)__builtin_ctzll(m);
             wave_copy(dst + lane_get(lp, k), src + lane_get(sp, k), lane_get(lit, k), lane);
         }
@@ -261,8 +271,6 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         *(L32*)(ring + (((uint32_t)b & 1u) << 8) + 4u * (uint32_t)lane) = v;
         if (!(b & 1) && lane < 8) *(L32*)(ring + 512u + 4u * (uint32_t)lane) = v;
     };
-    typedef u32x4 __attribute__((aligned(1))) U128;
-    typedef __attribute__((address_space(1))) U128 G128;
 
     if (n >= kMinLength) {
         uint32_t i0 = 0;                                  // probes of the current search already examined
@@ -366,6 +374,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
                 }
                 if (PROF) { cnt[0]++; cnt[6] += lim; if (i0) cnt[3]++; }
+                STAGE(3);
                 asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
                 // ---------------- resolve every sequence this batch holds ----------------
                 // Every matching lane precomputes where the chain continues after its match (`nxt` = first matching lane at or
@@ -413,7 +422,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, pos | mychk, ent);
                 }
                 wave_fence();
-                STAGE(3);
+                STAGE(4);
                 if (marks) {
                     // per-sequence quantities, in the lane that found the match (lz4.c:1611-1740); one record per sequence, in
                     // sequence order behind the buffered ones
@@ -425,7 +434,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     if (PROF) cnt[1] += ns;
                     ip = s0 + cur; anchor = ip; extra = true; i0 = 0;
                 }
-                STAGE(4);
+                STAGE(5);
                 if (special < 0) {
                     if (marks == 0) i0 += own < lim ? own : lim;       // the search goes on
                     else if (cur < lim) i0 = lim - cur;                // lanes [cur, lim) of the next search found nothing
@@ -497,6 +506,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 }
             }
             if (special >= 0) {
+                STAGE(7);                                 // (a general batch)
                 // ---------------- one special sequence, lane `special` (lz4.c:1611-1740) ----------------
                 const int m = special;
                 const uint32_t m_pos = lane_get(pos, m), m_cand = lane_get(cand, m);
@@ -555,10 +565,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 anchor = ip;
                 if (ip >= mfl1) done = true;              // lz4.c:1747
                 else { extra = true; i0 = 0; }
+                STAGE(6);
             }
             asm volatile("; resolve end" ::: "memory");
             if (nrec > kRecFlush || done) { wave_fence(); if (PROF) cnt[5]++; if (!flush()) return 0; }
-            STAGE(5);
+            STAGE(7);
             if (done) break;
         }
     }
@@ -575,7 +586,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         op += lastRun;
     }
 #ifdef AOCLGPU_EXPERIMENTS
-    if (PROF && lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
+    if (PROF && lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
 #endif
 #undef STAGE
     return (int)op;
@@ -1183,7 +1194,7 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
 #else
     const bool prof = false;
 #endif
-    const bool forceU32 = prof || (b->reserved & AOCLGPU_FLAG_LZ4_TABLE_U32) != 0;
+    const bool forceU32 = (b->reserved & AOCLGPU_FLAG_LZ4_TABLE_U32) != 0;
     auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !forceU32) ? 1 : 2); };
     struct Launch { uint32_t first, count; int mode; } L[2]; int nl = 0;
     if (b->src_off) L[nl++] = { 0, b->nchunks, 3 };
@@ -1200,7 +1211,11 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
         const dim3 g(L[i].count), t(64);
         switch (L[i].mode) {
         case 0: hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<0, false>), g, t, 0, s, *b, L[i].first); break;
-        case 1: hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<1, false>), g, t, 0, s, *b, L[i].first); break;
+        case 1:
+#ifdef AOCLGPU_EXPERIMENTS
+            if (prof) { hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<1, true>), g, t, 0, s, *b, L[i].first); break; }
+#endif
+            hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<1, false>), g, t, 0, s, *b, L[i].first); break;
         case 2:
 #ifdef AOCLGPU_EXPERIMENTS
             if (prof) { hipLaunchKernelGGL((aoclgpu::lz4_compress_kernel<2, true>), g, t, 0, s, *b, L[i].first); break; }

@@ -13,9 +13,10 @@ slots, out_len, slot = eng.compress_chunks(a.LZ4, src, chunk, flags=8)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_lz4_prof(buf)
-names = ["ring + probe windows + backfill", "hash + table lookup", "cand loads + slot-reuse", "fw/bk + walk + commit", "records", "one-at-a-time path + general batches + flush"]
-tot = sum(buf[:6]); c = list(buf[8:16]); nseq = max(c[1], 1)
-for n, v in zip(names, buf[:6]):
+names = ["ring + probe windows + backfill", "hash + table lookup", "cand loads + slot-reuse", "cand<4 fix-up + dups + fw/bk", "walk + anchors + commit", "records + state",
+         "one-at-a-time path", "general batches + flush"]
+tot = sum(buf[:8]); c = list(buf[8:16]); nseq = max(c[1], 1)
+for n, v in zip(names, buf[:8]):
     print(f"{n:46s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq  {v/max(c[0],1):8.1f} cyc/batch")
 print("total cyc/seq", tot / nseq, " cyc/batch", tot / max(c[0], 1))
 print("batches", c[0], "(general", c[2], ", consecutive batches of a continuing search", c[3], ") sequences", c[1], "seq/batch", c[1] / max(c[0], 1),
