@@ -128,9 +128,20 @@ void* get_workspace(const WsGuard&, size_t bytes, void* stream)
         if (e->dev != dev) (void)hipSetDevice(cur);
         e->p = nullptr; e->bytes = 0;
     }
-    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; return nullptr; }
+    if (hipMalloc(&e->p, bytes) != hipSuccess) {
+        (void)hipGetLastError();                          // the failure must not surface as the next launch's error (callers fall back)
+        e->p = nullptr; return nullptr;
+    }
     e->bytes = bytes; e->dev = dev; e->stream = stream;
     return e->p;
+}
+
+size_t workspace_held(const WsGuard&, void* stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    for (WsPool& q : g_pool) if (q.p && q.dev == dev && q.stream == stream) return q.bytes;
+    return 0;
 }
 
 }  // namespace aoclgpu
@@ -193,16 +204,25 @@ extern "C" int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, 
 // buffer (the codecs' candidate-window pattern); run under rocprofv3 --pmc FETCH_SIZE it calibrates that counter for
 // scattered loads (bytes fetched per load).
 __global__ void __launch_bounds__(256) probe_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16)
-{
+{   // four 16-byte loads in flight per lane (a single load per lane and trip leaves the memory pipeline a third empty)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
-__global__ void __launch_bounds__(256) probe_scatter8_kernel(const uint64_t* __restrict__ src, size_t n8, uint32_t loads_per_lane, uint64_t* __restrict__ sink)
-{
+template <int UNROLL>
+__global__ void __launch_bounds__(256) probe_scatter8_kernel(const uint64_t* __restrict__ src, size_t mask8, uint32_t loads_per_lane, uint64_t* __restrict__ sink)
+{   // UNROLL independent loads per trip: twice the loads in flight must not change the rate if the memory system is the limit
     uint64_t x = 0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1), acc = 0;
-    for (uint32_t k = 0; k < loads_per_lane; ++k) {
-        x ^= x << 13; x ^= x >> 7; x ^= x << 17;                   // xorshift64: addresses do not depend on loaded data
-        acc += src[x % n8];
+    for (uint32_t k = 0; k < loads_per_lane; k += UNROLL) {
+        uint64_t a[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; a[u] = x & mask8; }   // xorshift64: addresses do not depend on loaded data
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += src[a[u]];
     }
     if (acc == 0x1234567887654321ull) *sink = acc;                 // (keeps the loads alive)
 }
@@ -211,10 +231,11 @@ extern "C" double aoclgpu_probe_copy(void* dst, const void* src, size_t bytes, i
 {
     if (!dst || !src || bytes < 16 || iters <= 0) { set_error_msg("probe_copy: bad arguments"); return -1.0; }
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { set_error_msg("hipEventCreate failed"); return -1.0; }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error_msg("probe_copy: device query failed"); return -1.0; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) { set_error_msg("hipEventCreate failed"); return -1.0; }
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); set_error_msg("hipEventCreate failed"); return -1.0; }
     const dim3 g((unsigned)prop.multiProcessorCount * 8), t(256);
     hipLaunchKernelGGL(probe_copy_kernel, g, t, 0, s, (uint4*)dst, (const uint4*)src, bytes / 16);       // warm-up
     hipEventRecord(e0, s);
@@ -238,10 +259,18 @@ extern "C" double aoclgpu_probe_scatter8(const void* src, size_t bytes, uint32_t
     uint64_t* sink = nullptr;
     if (hipMalloc((void**)&sink, 8) != hipSuccess) { set_error_msg("probe_scatter8: hipMalloc failed"); return -1.0; }
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); set_error_msg("hipEventCreate failed"); return -1.0; }
+    if (hipEventCreate(&e0) != hipSuccess) { (void)hipFree(sink); set_error_msg("hipEventCreate failed"); return -1.0; }
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); (void)hipFree(sink); set_error_msg("hipEventCreate failed"); return -1.0; }
     const dim3 g((unsigned)prop.multiProcessorCount * 8), t(256);
+    // addresses: a power-of-two part of the buffer (no division in the address chain); bit 31 of loads_per_lane asks for eight
+    // independent loads per trip instead of four
+    size_t n8 = 1; while (n8 * 2 <= bytes / 8) n8 *= 2;
+    const bool wide = (loads_per_lane >> 31) != 0;
+    loads_per_lane = (loads_per_lane & 0x7FFFFFFFu) / 8 * 8;
+    if (!loads_per_lane) loads_per_lane = 8;
     hipEventRecord(e0, s);
-    hipLaunchKernelGGL(probe_scatter8_kernel, g, t, 0, s, (const uint64_t*)src, bytes / 8, loads_per_lane, sink);
+    if (wide) hipLaunchKernelGGL(probe_scatter8_kernel<8>, g, t, 0, s, (const uint64_t*)src, n8 - 1, loads_per_lane, sink);
+    else hipLaunchKernelGGL(probe_scatter8_kernel<4>, g, t, 0, s, (const uint64_t*)src, n8 - 1, loads_per_lane, sink);
     hipEventRecord(e1, s);
     double ms = -1.0;
     if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) {

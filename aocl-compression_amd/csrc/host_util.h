@@ -12,6 +12,7 @@ int check_launch(const char* kernel);
 // The caller holds a WsGuard from before this call until its kernel is enqueued (see capi.hip).
 struct WsGuard { WsGuard(); ~WsGuard(); WsGuard(const WsGuard&) = delete; WsGuard& operator=(const WsGuard&) = delete; };
 void* get_workspace(const WsGuard& held, size_t bytes, void* stream);
+size_t workspace_held(const WsGuard& held, void* stream);   // bytes the pool already holds for this (device, stream)
 // The host-buffer entry points work on aoclgpu_host_device(); the calling thread's current device is put back when they
 // return (a caller that drives another GPU with its own HIP code must not find it changed under its feet).
 struct DeviceScope {

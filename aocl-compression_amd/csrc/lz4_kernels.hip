@@ -741,140 +741,269 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // return value is the end position op0 + decoded size.
 // (HIST is a template parameter and the function is inlined into each kernel: a shared, non-inlined copy receives its
 //  arguments in VGPRs, loses its scalar control flow, and the plain decoder drops from 250 to 156 GiB/s.)
+//
+// Group path (round 4).  The tokens of a block are a chain (where the next token starts is only known once this one is
+// parsed), everything else is not.  So the wave SCANS - lane k parses "a token starts at ip + k" from the staged input, a
+// scalar walk over the lanes picks the real starts - and only RECORDS what it finds (literal source, literal length, match
+// length, offset: 8 bytes per sequence in LDS).  When 64 sequences are buffered, or their output reaches 2 KB, or a token
+// comes up that the scan does not take (a length of 255 or more in one field, more than 64 literal or match bytes, the
+// buffer ends), the group is EXECUTED with one sequence per lane: a prefix sum gives every sequence its place in a 2 KB
+// output block kept in LDS; all literals and all matches whose source lies before the block are fetched in one round of
+// loads (four pieces per size class, every access inside its run) and written into the block; matches that read the block
+// itself - or the 64 bytes in front of it, kept as history in front of the block - follow in sequence order as LDS-to-LDS
+// copies (130 cycles each instead of a trip to memory); the block then leaves with 16-byte stores.  Whatever the scan does
+// not take goes through the sequential one-sequence path, which implements every check of the reference.
+constexpr uint32_t kDecRecs = 64, kDecBlock = 2048, kDecHist = 64;
+constexpr uint32_t kDecLds = kRing + 16 + kDecRecs * 4 + kDecHist + kDecBlock + 16;
+
 template <bool RAP, bool HIST = false>
-__device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src, const int32_t n, gbyte* dst, const int32_t cap,
-                                                   uint8_t* ring, const bool rap, const int32_t op0_ = 0)
+__device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src_, const int32_t n_, gbyte* dst_, const int32_t cap_,
+                                                   lbyte* lds_, const bool rap, const int32_t op0_ = 0)
 {
-    const int32_t op0 = HIST ? op0_ : 0;
+    const gbyte* __restrict__ src = uni_ptr(src_);
+    gbyte* dst = uni_ptr(dst_);
+    lbyte* ring = uni_ptr(lds_);
+    const int32_t n = (int32_t)uni((uint32_t)n_), cap = (int32_t)uni((uint32_t)cap_);
+    const int32_t op0 = HIST ? (int32_t)uni((uint32_t)op0_) : 0;
     const int lane = lane_id();
+    const uint32_t L = (uint32_t)lane;
     if (cap == 0) return (n == 1 && src[0] == 0) ? op0 : -1;  // lz4.c:3412-3416
     if (n <= 0) return -1;                                    // lz4.c:3418
+    typedef __attribute__((address_space(3))) uint32_t L32;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
+    typedef __attribute__((address_space(3))) U128 S128;
+    typedef uint32_t __attribute__((aligned(1))) U32;
+    typedef __attribute__((address_space(3))) U32 S32;
+    typedef uint16_t __attribute__((aligned(1))) U16;
+    typedef __attribute__((address_space(3))) U16 S16;
+    lbyte* recs = ring + kRing + 16;                          // 64 records of 4 bytes: offset | literal length << 16 | (match length - 4) << 24
+    lbyte* cb = recs + kDecRecs * 4;                          // 64 bytes of history | the output block
     const int32_t iend = n, oend = op0 + cap;
     int32_t ip = 0, op = op0, rend = 0;                       // ring holds compressed bytes [.., rend)
-    uint4 pend = make_uint4(0, 0, 0, 0); bool have_pend = false;
+    uint32_t nrec = 0, gbase = 0;                             // buffered sequences; where the first one's token is
+    bool hist_ok = false;                                     // cb[0, 64) holds dst[op - 64, op)
+    u32x4 pend = {0u, 0u, 0u, 0u}; bool have_pend = false;
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4D_PROF)
+    uint64_t dt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = __builtin_amdgcn_s_memtime(); uint32_t dc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DSTAGE(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dt[k] += t_ - dprev; dprev = t_; } while (0)
+#define DCOUNT(k, v) do { dc[k] += (v); } while (0)
+#else
+#define DSTAGE(k) do { } while (0)
+#define DCOUNT(k, v) do { } while (0)
+#endif
     for (;;) {
         // ---- keep >= 160 staged bytes ahead of ip (requested one iteration early) ----
         if (ip > rend) { rend = ip & ~15; have_pend = false; }
         if (have_pend) {
-            *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
-            if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *reinterpret_cast<uint4*>(ring + kRing) = pend;   // mirror: 16-byte reads never wrap
+            *(__attribute__((address_space(3))) u32x4*)(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
+            if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *(__attribute__((address_space(3))) u32x4*)(ring + kRing) = pend;   // mirror: 16-byte reads never wrap
             wave_fence();
             rend += 1024; have_pend = false;
         }
         if (rend - ip < 640 && rend + 1024 <= iend) {
-            { typedef u32x4 __attribute__((aligned(1))) U; const u32x4 t_ = *(const __attribute__((address_space(1))) U*)(src + rend + 16 * lane); pend = make_uint4(t_.x, t_.y, t_.z, t_.w); }
+            pend = *(const G128*)(src + rend + 16 * lane);
             have_pend = true;
             if (rend - ip < 160) {
-                *reinterpret_cast<uint4*>(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
-                if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *reinterpret_cast<uint4*>(ring + kRing) = pend;
+                *(__attribute__((address_space(3))) u32x4*)(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
+                if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *(__attribute__((address_space(3))) u32x4*)(ring + kRing) = pend;
                 wave_fence();
                 rend += 1024; have_pend = false;
             }
         }
-        bool window = rend - ip >= 352;
-        uint64_t mask = 0; int cur = 0;
-        uint32_t lit = 0, mlen = 0, off = 0, litsrc = 0;
-        const uint32_t p = (uint32_t)ip + (uint32_t)lane;
-        if (window) {
-            // lane k parses "a sequence starts at ip+k"; at most one length-extension byte (< 255) per field
-            const uint32_t t = ring[p & kRingMask];
-            uint32_t q = p + 1;
-            bool simple = true;
-            lit = t >> 4;
-            if (lit == 15) { const uint32_t e1 = ring[q & kRingMask]; q++; lit += e1; simple = e1 != 255; }
-            litsrc = q; q += lit;
-            off = (uint32_t)ring[q & kRingMask] | ((uint32_t)ring[(q + 1) & kRingMask] << 8);
-            q += 2;
-            mlen = (t & 15) + kMinMatch;
-            if ((t & 15) == 15) { const uint32_t e2 = ring[q & kRingMask]; q++; mlen += e2; simple = simple && e2 != 255; }
-            const uint32_t nx = simple ? q - (uint32_t)ip : 0xFFFFu;     // lane index of the next token
-            while (cur < 64) {                                // walk the real token starts
-                const uint32_t v = lane_get(nx, cur);
-                if (v == 0xFFFFu) break;
-                mask |= 1ull << cur; cur = (int)v;
+        // ---- scan: 64 bytes of tokens per round, at most one length-extension byte per field ----
+        DSTAGE(0);
+        int why = 3;                                          // 0 ran through its bytes, 2 a token the scan does not take, 3 input not staged
+        while (rend - ip >= 352) {
+            const uint32_t p = (uint32_t)ip + L;
+            const uint32_t w1 = *(const S16*)(ring + (p & kRingMask));
+            const uint32_t t = w1 & 0xFFu, e1 = w1 >> 8;
+            uint32_t lit = t >> 4;
+            const bool x1 = lit == 15;
+            bool hard = x1 && e1 > 240;                       // 255: more bytes follow; above 240: the record's 8 bits do not hold the length
+            if (x1) lit += e1;
+            const uint32_t q = p + 1 + (x1 ? 1u : 0u) + lit;
+            const uint32_t w2 = *(const S32*)(ring + (q & kRingMask));
+            const uint32_t off = w2 & 0xFFFFu, e2 = (w2 >> 16) & 0xFFu;
+            const bool x2 = (t & 15) == 15;
+            const uint32_t mcode = (t & 15) + (x2 ? e2 : 0u);                 // match length - 4
+            hard = hard || (x2 && e2 > 240);
+#ifdef LZ4D_SHORT
+            hard = hard || lit > 64 || mcode > 60;
+#endif
+            const uint32_t nx = hard ? 0x80000000u : q + 2 + (x2 ? 1u : 0u) - (uint32_t)ip;   // the next token's lane
+            DSTAGE(1); DCOUNT(0, 1);
+            // walk the real token starts: mask |= 1 << cur; cur = nx[cur] until cur >= 64 or a token the scan does not take
+            uint64_t mask; uint32_t cur, stop, tmp;
+#ifdef LZ4D_NOASM
+            mask = 0; cur = 0; stop = 0; tmp = 0;
+            while (cur < 64) { const uint32_t v = lane_get(nx, (int)cur); if ((int32_t)v < 0) { stop = 2; break; } mask |= 1ull << cur; cur = v; }
+#else
+            asm volatile("s_mov_b64 %0, 0\n\t"
+                         "s_mov_b32 %1, 0\n\t"
+                         "s_mov_b32 %2, 0\n"
+                         "1:\n\t"
+                         "v_readlane_b32 %3, %4, %1\n\t"
+                         "s_cmp_lt_i32 %3, 0\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_bitset1_b64 %0, %1\n\t"
+                         "s_mov_b32 %1, %3\n\t"
+                         "s_cmp_lt_u32 %1, 64\n\t"
+                         "s_cbranch_scc1 1b\n\t"
+                         "s_branch 3f\n"
+                         "2:\n\t"
+                         "s_mov_b32 %2, 2\n"
+                         "3:"
+                         : "=&s"(mask), "=&s"(cur), "=&s"(stop), "=&s"(tmp) : "v"(nx) : "scc");
+#endif
+            why = (int)stop;
+            if (mask) {                                       // (a round adds at most 64 / 3 records)
+                if (nrec == 0) gbase = (uint32_t)ip;
+                const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (__builtin_amdgcn_inverse_ballot_w64(mask)) *(L32*)(recs + 4u * idx) = off | (lit << 16) | (mcode << 24);
+                nrec += (uint32_t)__builtin_popcountll(mask); ip += (int32_t)cur;
+                wave_fence();
             }
-            if (mask == 0) window = false;
+            DSTAGE(2); DCOUNT(1, (uint32_t)__builtin_popcountll(mask));
+            if (why != 0 || nrec > kDecRecs - 22 || rend - ip < 640) break;
         }
-        if (window) {
-            const bool marked = (mask >> lane) & 1;
-            const uint32_t olen = marked ? lit + mlen : 0;
-            uint32_t inc = olen;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
-            const uint32_t opos = (uint32_t)op + inc - olen;  // output position of this sequence's literals
-            const uint32_t mstart = opos + lit;
-            // stop in front of the first sequence the window path must not handle
-            const bool bad = marked && (off == 0 || off > mstart);
-            const int fb = first_lane(ballot(bad));
-            uint32_t total = lane_get(inc, 63);
-            if (fb < 64) { mask &= (1ull << fb) - 1; cur = fb; total = lane_get(inc - olen, fb); }
-            if (mask == 0 || (int64_t)op + total + 32 > oend) window = false;
-            else {
-                const bool act = (mask >> lane) & 1;
-                // short literal runs: straight from the ring, one sequence per lane
-                if (act && lit && lit < 15) {             // one 16-byte LDS read, exact-length overlapping stores
-                    uint4 q4; __builtin_memcpy(&q4, ring + (litsrc & kRingMask), 16);
-                    const uint64_t v0 = q4.x | ((uint64_t)q4.y << 32), v1 = q4.z | ((uint64_t)q4.w << 32);
-                    gbyte* d = dst + opos;
-                    if (lit >= 8) { st64(d, v0); if (lit > 8) { const uint32_t o2 = lit - 8; st64(d + o2, (v0 >> (8 * o2)) | (v1 << (64 - 8 * o2))); } }
-                    else if (lit >= 4) { st32(d, (uint32_t)v0); st32(d + lit - 4, (uint32_t)(v0 >> (8 * (lit - 4)))); }
-                    else for (uint32_t i = 0; i < lit; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
+        if (why == 0 && nrec <= kDecRecs - 22) continue;
+        // ---- execute buffered sequences, one per lane, until the buffer has room again (all of them in front of a sequential step) ----
+        bool forced = false;
+        while (nrec && !forced) {
+            bool act = L < nrec;
+            uint32_t lit = 0, mlen = 0, off = 0;
+            if (act) { const uint32_t r = *(const L32*)(recs + 4u * L); off = r & 0xFFFFu; lit = (r >> 16) & 0xFFu; mlen = (r >> 24) + kMinMatch; }
+            // where each sequence's token is (prefix sum of the compressed sizes) and where its output goes
+            const uint32_t csz = act ? 3 + lit + (lit >= 15 ? 1u : 0u) + (mlen >= 19 ? 1u : 0u) : 0u;
+            const uint32_t cinc = wave_scan_incl(csz);
+            const uint32_t tokpos = gbase + cinc - csz, litsrc = tokpos + 1 + (lit >= 15 ? 1u : 0u);
+            const uint32_t olen = lit + mlen;
+            const uint32_t oinc = wave_scan_incl(olen);
+            const uint32_t lpos = oinc - olen, mst = lpos + lit;          // block-relative: literals, match
+            // what fits the block and the output buffer (with the reference's margin for its fast loop, lz4.c:3654); the
+            // first sequence whose offset is 0 or reaches before the start of the output ends the group in front of it and
+            // the sequential path decides what the reference decides (lz4.c:3745-3753, :3710)
+            const int32_t room_o = oend - 32 - op;
+            const uint32_t capo = room_o <= 0 ? 0u : ((uint32_t)room_o < kDecBlock ? (uint32_t)room_o : kDecBlock);
+            uint32_t ng = (uint32_t)__builtin_popcountll(ballot(act && oinc <= capo));
+            {
+                // (also: a long match that starts further in front of the block than the history kept there)
+                const int32_t srel_ = (int32_t)mst - (int32_t)off;
+                const uint64_t badm = ballot(act && (off == 0 || off > (uint32_t)op + mst || (srel_ + (int32_t)mlen > 0 && srel_ < -(int32_t)kDecHist)));
+                const uint32_t fb = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;
+                if (fb < ng) { ng = fb; forced = true; }
+                else if (ng == 0) forced = true;              // the output buffer ends: the sequential path takes the next sequence
+                if (forced) {
+                    ip = (int32_t)lane_get(tokpos, (int)ng);             // back to that sequence's token; later records are dropped
+                    if (rend - ip > (int32_t)kRing) { rend = ip & ~15; have_pend = false; }   // further back than the ring holds: stage again from there
                 }
-                // long literal runs: whole wave, from the compressed stream
-                for (uint64_t lm = ballot(act && lit >= 15); lm; lm &= lm - 1) {
-                    const int k = (int)__builtin_ctzll(lm);
-                    wave_copy(dst + lane_get(opos, k), src + lane_get(litsrc, k), lane_get(lit, k), lane);
+                act = L < ng;
+            }
+            const uint32_t total = ng ? lane_get(oinc, (int)ng - 1) : 0u;
+            if (ng) {
+                if (!hist_ok) {                               // the 64 bytes in front of the block (after a sequential step, at the start)
+                    uint8_t b = 0;
+                    if ((uint32_t)op + L >= kDecHist) b = dst[(uint32_t)op + L - kDecHist];
+                    cb[L] = b;
                 }
-                // short matches whose source was produced before this window: one round of loads for all of them
-                const uint32_t spos = mstart - off;
-                const bool indep = act && mlen <= 32 && spos + mlen <= (uint32_t)op;
-                if (indep) {
-                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16), v3 = ld64(dst + spos + 24);
-                    gbyte* d = dst + mstart;
-                    auto ext = [&](uint32_t o) -> uint64_t {          // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
-                        const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
-                        const uint32_t sh = (o & 7) * 8;
-                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
-                    };
-                    if (mlen >= 8) {
-                        st64(d, v0);
-                        if (mlen > 8) st64(d + (mlen > 16 ? 8 : mlen - 8), ext(mlen > 16 ? 8 : mlen - 8));
-                        if (mlen > 16) st64(d + (mlen > 24 ? 16 : mlen - 8), ext(mlen > 24 ? 16 : mlen - 8));
-                        if (mlen > 24) st64(d + mlen - 8, ext(mlen - 8));
-                    } else {
-                        const uint32_t lo = (uint32_t)v0; st32(d, lo);
-                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); st32(d + mlen - 4, hi);
-                    }
+                lbyte* blk = cb + kDecHist;
+                // literals (input -> block) and matches whose source ends in front of the block (output -> block): every
+                // load is requested before the first write; four pieces per size class at 0, k, 2k and len - k (clamped)
+                const int32_t srel = (int32_t)mst - (int32_t)off;                  // source start, block-relative
+                const bool far = act && srel + (int32_t)mlen <= 0;
+                const bool near = act && !far;
+                const uint32_t mo = (uint32_t)(op + srel);                         // far matches: source start in dst
+                const bool l16 = act && lit >= 16 && lit <= 64, l4 = act && lit >= 4 && lit < 16, l1 = act && lit >= 1 && lit < 4;
+                const bool m16 = far && mlen >= 16 && mlen <= 64, m4 = far && mlen < 16;
+                const uint32_t le16 = lit - 16, lp16a = le16 < 16 ? le16 : 16u, lp16b = le16 < 32 ? le16 : 32u;
+                const uint32_t le4 = lit - 4, lp4a = le4 < 4 ? le4 : 4u, lp4b = le4 < 8 ? le4 : 8u;
+                const uint32_t me16 = mlen - 16, mp16a = me16 < 16 ? me16 : 16u, mp16b = me16 < 32 ? me16 : 32u;
+                const uint32_t me4 = mlen - 4, mp4a = me4 < 4 ? me4 : 4u, mp4b = me4 < 8 ? me4 : 8u;
+                u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
+                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+                uint8_t b0 = 0, b1 = 0, b2 = 0;
+                if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
+                if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
+                if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
+                if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
+                if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
+                asm volatile("" ::: "memory");
+                DSTAGE(3); DCOUNT(2, 1); DCOUNT(3, ng); DCOUNT(4, (uint32_t)__builtin_popcountll(ballot(near)));
+                lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
+                if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
+                if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
+                if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
+                if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
+                if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
+                // runs of 65 .. 255 bytes (rare): the whole wave, 4 bytes per lane, one after the other
+                for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
+                    const int k = (int)__builtin_ctzll(m);
+                    const uint32_t n_ = lane_get(lit, k), so = lane_get(litsrc, k), o4 = 4u * L < n_ - 4 ? 4u * L : n_ - 4;
+                    if (4u * L < n_) *(S32*)(blk + lane_get(lpos, k) + o4) = ld32(src + (so + o4));
+                }
+                for (uint64_t m = ballot(far && mlen > 64); m; m &= m - 1) {
+                    const int k = (int)__builtin_ctzll(m);
+                    const uint32_t n_ = lane_get(mlen, k), so = lane_get(mo, k), o4 = 4u * L < n_ - 4 ? 4u * L : n_ - 4;
+                    if (4u * L < n_) *(S32*)(blk + lane_get(mst, k) + o4) = ld32(dst + (so + o4));
                 }
                 wave_fence();
-                // the other matches (long, or reading this window's own output, or overlapping themselves):
-                // in order, whole wave, 64 bytes per round
-                for (uint64_t dm = ballot(act && !indep); dm; dm &= dm - 1) {
-                    const int k = (int)__builtin_ctzll(dm);
-                    const uint32_t ms = lane_get(mstart, k), ml = lane_get(mlen, k), of = lane_get(off, k);
-                    gbyte* d = dst + ms; const gbyte* sp = d - of;
-                    if (of >= kWave) {
-                        for (uint32_t r = 0; r < ml; r += kWave) {
-                            const uint32_t i = r + (uint32_t)lane;
-                            uint8_t v = 0;
-                            if (i < ml) v = sp[i];
-                            if (i < ml) d[i] = v;
-                            wave_fence();
-                        }
-                    } else {
-                        uint32_t kk = (uint32_t)lane % of; const uint32_t adv = kWave % of;
-                        for (uint32_t i = (uint32_t)lane; i < ml; i += kWave) { d[i] = sp[kk]; kk += adv; if (kk >= of) kk -= of; }
-                        wave_fence();
+                DSTAGE(4);
+                // matches that read the block (or the history in front of it): in sequence order, the whole wave a byte per lane
+                for (uint64_t m = ballot(near); m; m &= m - 1) {
+                    const int k = (int)__builtin_ctzll(m);
+                    const uint32_t ml = lane_get(mlen, k), of = lane_get(off, k);
+                    lbyte* sp = blk + (int32_t)lane_get((uint32_t)srel, k); lbyte* dp = blk + lane_get(mst, k);
+                    if (of >= 64 || of >= ml) {                  // no lane reads what another lane of the same pass writes
+                        for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i]; dp[i] = b; wave_fence(); }   // (a pass reads what the pass before wrote)
+                    } else {                                      // offset < length: the pattern repeats (lz4.c:3745-3790)
+                        for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i % of]; dp[i] = b; }
                     }
+                    wave_fence();
                 }
-                ip += cur; op += (int32_t)total;
+                DSTAGE(5);
+                // the block leaves: 16 bytes per lane, then the odd bytes
+                const uint32_t full = total & ~15u;
+                for (uint32_t o = 16u * L; o < full; o += 16u * kWave) *(G128*)(dst + ((uint32_t)op + o)) = *(const S128*)(blk + o);
+                if (L < (total & 15u)) dst[(uint32_t)op + full + L] = blk[full + L];
+                // the last 64 bytes become the next block's history
+                {
+                    uint32_t hv = 0;
+                    if (L < 16) hv = *(const S32*)(cb + total + 4u * L);
+                    wave_fence();
+                    if (L < 16) *(L32*)(cb + 4u * L) = hv;
+                }
+                op += (int32_t)total; hist_ok = true;
+                wave_fence();
+                DSTAGE(6);
+            }
+            if (forced) nrec = 0;
+            else {                                            // records that did not fit the block move to the front
+                const uint32_t left = nrec - ng;
+                uint32_t r = 0;
+                if (L < left) r = *(const L32*)(recs + 4u * (ng + L));
+                wave_fence();
+                if (L < left) *(L32*)(recs + 4u * L) = r;
+                wave_fence();
+                gbase += lane_get(cinc, (int)ng - 1);
+                nrec = left;
+                if (why == 0) break;                          // the buffer has room again: scan on
             }
         }
-        if (!window) {
+        if (why == 0 && !forced) continue;
+        {
             const int r = (RAP && rap) ? lz4_decode_one_rap(src, iend, dst, oend, ip, op, lane) : lz4_decode_one(src, iend, dst, oend, ip, op, lane);
             if (r < 0) return r;
             if (r == 1) break;
+            hist_ok = false;
+            DSTAGE(7); DCOUNT(5, 1);
         }
     }
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4D_PROF)
+    if (lane == 0) { for (int k = 0; k < 8; ++k) { atomicAdd(&g_lz4_prof[k], (unsigned long long)dt[k]); atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)dc[k]); } }
+#endif
+#undef DSTAGE
+#undef DCOUNT
     return op;
 }
 
@@ -922,7 +1051,7 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
 // of block i or < 0 (then every later block is < 0 as well); dst_cap[i] bounds block i, dst_off is ignored.
 __global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch b, uint64_t dst_total)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kDecLds];
     const int lane = lane_id();
     int32_t op = 0; bool bad = false;
     for (uint32_t c = 0; c < b.nchunks; ++c) {
@@ -934,7 +1063,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch
             if ((uint64_t)op + cap > dst_total) cap = (uint32_t)(dst_total - (uint64_t)op);
             if (sl >> 31) {
                 if (n <= cap) { wave_copy((gbyte*)b.dst + op, src, n, lane); r = op + (int32_t)n; }
-            } else r = lz4_decompress_wave<false, true>(src, (int32_t)n, (gbyte*)b.dst, (int32_t)cap, ring, false, op);
+            } else r = lz4_decompress_wave<false, true>(src, (int32_t)n, (gbyte*)b.dst, (int32_t)cap, (lbyte*)ring, false, op);
             wave_fence();
         }
         if (r < 0) { bad = true; if (lane == 0) b.out_len[c] = -1; }
@@ -1134,10 +1263,13 @@ __global__ void __launch_bounds__(64) lz4_compress_stream_kernel(const uint8_t* 
     for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) gtable[i] = table[i];
 }
 
+#ifndef LZ4D_WAVES
+#define LZ4D_WAVES 6
+#endif
 template <bool RAP>
-__global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4D_WAVES, LZ4D_WAVES))) lz4_decompress_kernel(aoclgpu_batch b)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kDecLds];
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
 #ifdef AOCLGPU_EXPERIMENTS
@@ -1146,7 +1278,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_kernel(aoclgpu_batch b)
     const ChunkView v = decompress_view(b, c);
     int r;
     if (v.src_len > 0x7FFFFFFFu || v.dst_cap > 0x7FFFFFFFu) r = -1;
-    else r = lz4_decompress_wave<RAP>(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, ring, RAP && c + 1 < b.nchunks);
+    else r = lz4_decompress_wave<RAP>(v.src, (int32_t)v.src_len, v.dst, (int32_t)v.dst_cap, (lbyte*)ring, RAP && c + 1 < b.nchunks);
     if (threadIdx.x == 0) b.out_len[c] = r;
 #ifdef AOCLGPU_EXPERIMENTS
     if ((b.reserved & 2u) && b.aux) {                      // experiment build: per-chunk duration (s_memtime ticks / 64)
@@ -1192,7 +1324,7 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
 #ifdef AOCLGPU_EXPERIMENTS
     const bool prof = (b->reserved & 8u) != 0;
 #else
-    const bool prof = false;
+    const bool prof = false; (void)prof;
 #endif
     const bool forceU32 = (b->reserved & AOCLGPU_FLAG_LZ4_TABLE_U32) != 0;
     auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !forceU32) ? 1 : 2); };

@@ -2763,6 +2763,15 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     }
     size_t budget = (size_t)32 << 30;
     if (prop.totalGlobalMem / 4 < budget) budget = prop.totalGlobalMem / 4;
+    {   // what the device can actually give (another allocator, e.g. torch's caching allocator, may hold most of it): the scratch
+        // this stream already owns plus the free memory, less a margin
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t margin = (size_t)512 << 20, have = aoclgpu::workspace_held(guard, s);
+            const size_t avail = have + (freeB > margin ? freeB - margin : 0);
+            if (avail < budget) budget = avail;
+        } else (void)hipGetLastError();
+    }
     if (const char* e = getenv("AOCLGPU_ZSTD_DF_SLAB_MB")) { const long long mb = atoll(e); if (mb > 0) budget = (size_t)mb << 20; }
     const size_t wsz = aoclgpu::zstd_workspace_bytes();
     uint32_t slab = (uint32_t)(budget / wsz < count ? budget / wsz : count);
