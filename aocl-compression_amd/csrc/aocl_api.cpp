@@ -74,7 +74,11 @@ int64_t wrap_compress(int t, const aocl_compression_desc* h)
             if (rap_geometry() == 1) {
                 // the reference's own geometry: min(numThreads, partitions of window size) frames (threads/threads.c:46-118)
                 ZSTD_parameters zp = ZSTD_getParams((int)h->level, h->inSize, 0);
-                if (h->optVar && zp.cParams.windowLog > h->optVar) zp.cParams.windowLog = (unsigned)h->optVar;
+                if (h->optVar && zp.cParams.windowLog > h->optVar) {        // api/codec.cpp:402-408: the window AND the chain table follow optVar
+                    zp.cParams.windowLog = (unsigned)h->optVar;
+                    zp.cParams.chainLog = (unsigned)h->optVar + ((zp.cParams.strategy == ZSTD_btlazy2) || (zp.cParams.strategy == ZSTD_btopt) ||
+                                                                  (zp.cParams.strategy == ZSTD_btultra));
+                }
                 const uint64_t wf = h->inSize < (100ull << 20) ? 1 : (h->inSize > (400ull << 20) ? 4 : h->inSize / (100ull << 20));
                 const uint64_t chunk = ((uint64_t)1 << zp.cParams.windowLog) * wf;
                 uint64_t parts = 1;

@@ -22,6 +22,7 @@
 // forward match extension compare 64 / 256 bytes per step with ballot; token, length bytes and
 // literals are written cooperatively.
 #include "common.hip.h"
+#include "lz_group.hip.h"
 #include "host_util.h"
 
 namespace aoclgpu {
@@ -753,8 +754,8 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // itself - or the 64 bytes in front of it, kept as history in front of the block - follow in sequence order as LDS-to-LDS
 // copies (130 cycles each instead of a trip to memory); the block then leaves with 16-byte stores.  Whatever the scan does
 // not take goes through the sequential one-sequence path, which implements every check of the reference.
-constexpr uint32_t kDecRecs = 64, kDecBlock = 2048, kDecHist = 64;
-constexpr uint32_t kDecLds = kRing + 16 + kDecRecs * 4 + kDecHist + kDecBlock + 16;
+constexpr uint32_t kDecRecs = 64, kDecBlock = kGrpBlock, kDecHist = kGrpHist;
+constexpr uint32_t kDecLds = kRing + 16 + kDecRecs * 4 + kGrpLds;
 
 template <bool RAP, bool HIST = false>
 __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src_, const int32_t n_, gbyte* dst_, const int32_t cap_,
@@ -772,7 +773,6 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
     typedef __attribute__((address_space(3))) uint32_t L32;
     typedef u32x4 __attribute__((aligned(1))) U128;
     typedef __attribute__((address_space(1))) U128 G128;
-    typedef __attribute__((address_space(3))) U128 S128;
     typedef uint32_t __attribute__((aligned(1))) U32;
     typedef __attribute__((address_space(3))) U32 S32;
     typedef uint16_t __attribute__((aligned(1))) U16;
@@ -813,8 +813,9 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
         }
         // ---- scan: 64 bytes of tokens per round, at most one length-extension byte per field ----
         DSTAGE(0);
-        int why = 3;                                          // 0 ran through its bytes, 2 a token the scan does not take, 3 input not staged
-        while (rend - ip >= 352) {
+        int why = nrec > kDecRecs - 22 ? 0 : 3;               // 0 ran through its bytes (or the buffer has no room for another round: records
+                                                              // that did not fit the last block), 2 a token the scan does not take, 3 input not staged
+        while (nrec <= kDecRecs - 22 && rend - ip >= 352) {
             const uint32_t p = (uint32_t)ip + L;
             const uint32_t w1 = *(const S16*)(ring + (p & kRingMask));
             const uint32_t t = w1 & 0xFFu, e1 = w1 >> 8;
@@ -834,28 +835,8 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             const uint32_t nx = hard ? 0x80000000u : q + 2 + (x2 ? 1u : 0u) - (uint32_t)ip;   // the next token's lane
             DSTAGE(1); DCOUNT(0, 1);
             // walk the real token starts: mask |= 1 << cur; cur = nx[cur] until cur >= 64 or a token the scan does not take
-            uint64_t mask; uint32_t cur, stop, tmp;
-#ifdef LZ4D_NOASM
-            mask = 0; cur = 0; stop = 0; tmp = 0;
-            while (cur < 64) { const uint32_t v = lane_get(nx, (int)cur); if ((int32_t)v < 0) { stop = 2; break; } mask |= 1ull << cur; cur = v; }
-#else
-            asm volatile("s_mov_b64 %0, 0\n\t"
-                         "s_mov_b32 %1, 0\n\t"
-                         "s_mov_b32 %2, 0\n"
-                         "1:\n\t"
-                         "v_readlane_b32 %3, %4, %1\n\t"
-                         "s_cmp_lt_i32 %3, 0\n\t"
-                         "s_cbranch_scc1 2f\n\t"
-                         "s_bitset1_b64 %0, %1\n\t"
-                         "s_mov_b32 %1, %3\n\t"
-                         "s_cmp_lt_u32 %1, 64\n\t"
-                         "s_cbranch_scc1 1b\n\t"
-                         "s_branch 3f\n"
-                         "2:\n\t"
-                         "s_mov_b32 %2, 2\n"
-                         "3:"
-                         : "=&s"(mask), "=&s"(cur), "=&s"(stop), "=&s"(tmp) : "v"(nx) : "scc");
-#endif
+            uint64_t mask; uint32_t cur, stop;
+            lz_walk_tokens(nx, mask, cur, stop);
             why = (int)stop;
             if (mask) {                                       // (a round adds at most 64 / 3 records)
                 if (nrec == 0) gbase = (uint32_t)ip;
@@ -865,7 +846,7 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
                 wave_fence();
             }
             DSTAGE(2); DCOUNT(1, (uint32_t)__builtin_popcountll(mask));
-            if (why != 0 || nrec > kDecRecs - 22 || rend - ip < 640) break;
+            if (why != 0 || rend - ip < 640) break;
         }
         if (why == 0 && nrec <= kDecRecs - 22) continue;
         // ---- execute buffered sequences, one per lane, until the buffer has room again (all of them in front of a sequential step) ----
@@ -890,91 +871,36 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             {
                 // (also: a long match that starts further in front of the block than the history kept there)
                 const int32_t srel_ = (int32_t)mst - (int32_t)off;
-                const uint64_t badm = ballot(act && (off == 0 || off > (uint32_t)op + mst || (srel_ + (int32_t)mlen > 0 && srel_ < -(int32_t)kDecHist)));
+#if defined(LZ4D_DBG_A)
+                const bool dbg_ = mlen > 64;
+#elif defined(LZ4D_DBG_B)
+                const bool dbg_ = lit > 64;
+#elif defined(LZ4D_DBG_C)
+                const bool dbg_ = mlen > 64 && srel_ + (int32_t)mlen > 0;      // long in-block matches
+#elif defined(LZ4D_DBG_D)
+                const bool dbg_ = mlen > 64 && srel_ + (int32_t)mlen <= 0;     // long far matches
+#else
+                const bool dbg_ = false;
+#endif
+                const uint64_t badm = ballot(act && (dbg_ || off == 0 || off > (uint32_t)op + mst || (srel_ + (int32_t)mlen > 0 && srel_ < -(int32_t)kDecHist)));
                 const uint32_t fb = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;
                 if (fb < ng) { ng = fb; forced = true; }
                 else if (ng == 0) forced = true;              // the output buffer ends: the sequential path takes the next sequence
                 if (forced) {
                     ip = (int32_t)lane_get(tokpos, (int)ng);             // back to that sequence's token; later records are dropped
-                    if (rend - ip > (int32_t)kRing) { rend = ip & ~15; have_pend = false; }   // further back than the ring holds: stage again from there
+                    // the scan had run ahead: a refill in flight would overwrite the oldest KiB of the ring, which holds ip again
+                    if (rend - ip > 1024) have_pend = false;
+                    if (rend - ip > (int32_t)kRing) rend = ip & ~15;     // further back than the ring holds: stage again from there
                 }
                 act = L < ng;
             }
             const uint32_t total = ng ? lane_get(oinc, (int)ng - 1) : 0u;
             if (ng) {
-                if (!hist_ok) {                               // the 64 bytes in front of the block (after a sequential step, at the start)
-                    uint8_t b = 0;
-                    if ((uint32_t)op + L >= kDecHist) b = dst[(uint32_t)op + L - kDecHist];
-                    cb[L] = b;
-                }
-                lbyte* blk = cb + kDecHist;
-                // literals (input -> block) and matches whose source ends in front of the block (output -> block): every
-                // load is requested before the first write; four pieces per size class at 0, k, 2k and len - k (clamped)
-                const int32_t srel = (int32_t)mst - (int32_t)off;                  // source start, block-relative
-                const bool far = act && srel + (int32_t)mlen <= 0;
-                const bool near = act && !far;
-                const uint32_t mo = (uint32_t)(op + srel);                         // far matches: source start in dst
-                const bool l16 = act && lit >= 16 && lit <= 64, l4 = act && lit >= 4 && lit < 16, l1 = act && lit >= 1 && lit < 4;
-                const bool m16 = far && mlen >= 16 && mlen <= 64, m4 = far && mlen < 16;
-                const uint32_t le16 = lit - 16, lp16a = le16 < 16 ? le16 : 16u, lp16b = le16 < 32 ? le16 : 32u;
-                const uint32_t le4 = lit - 4, lp4a = le4 < 4 ? le4 : 4u, lp4b = le4 < 8 ? le4 : 8u;
-                const uint32_t me16 = mlen - 16, mp16a = me16 < 16 ? me16 : 16u, mp16b = me16 < 32 ? me16 : 32u;
-                const uint32_t me4 = mlen - 4, mp4a = me4 < 4 ? me4 : 4u, mp4b = me4 < 8 ? me4 : 8u;
-                u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
-                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-                uint8_t b0 = 0, b1 = 0, b2 = 0;
-                if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
-                if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
-                if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
-                if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
-                if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
-                asm volatile("" ::: "memory");
-                DSTAGE(3); DCOUNT(2, 1); DCOUNT(3, ng); DCOUNT(4, (uint32_t)__builtin_popcountll(ballot(near)));
-                lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
-                if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
-                if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
-                if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
-                if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
-                if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
-                // runs of 65 .. 255 bytes (rare): the whole wave, 4 bytes per lane, one after the other
-                for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
-                    const int k = (int)__builtin_ctzll(m);
-                    const uint32_t n_ = lane_get(lit, k), so = lane_get(litsrc, k), o4 = 4u * L < n_ - 4 ? 4u * L : n_ - 4;
-                    if (4u * L < n_) *(S32*)(blk + lane_get(lpos, k) + o4) = ld32(src + (so + o4));
-                }
-                for (uint64_t m = ballot(far && mlen > 64); m; m &= m - 1) {
-                    const int k = (int)__builtin_ctzll(m);
-                    const uint32_t n_ = lane_get(mlen, k), so = lane_get(mo, k), o4 = 4u * L < n_ - 4 ? 4u * L : n_ - 4;
-                    if (4u * L < n_) *(S32*)(blk + lane_get(mst, k) + o4) = ld32(dst + (so + o4));
-                }
-                wave_fence();
-                DSTAGE(4);
-                // matches that read the block (or the history in front of it): in sequence order, the whole wave a byte per lane
-                for (uint64_t m = ballot(near); m; m &= m - 1) {
-                    const int k = (int)__builtin_ctzll(m);
-                    const uint32_t ml = lane_get(mlen, k), of = lane_get(off, k);
-                    lbyte* sp = blk + (int32_t)lane_get((uint32_t)srel, k); lbyte* dp = blk + lane_get(mst, k);
-                    if (of >= 64 || of >= ml) {                  // no lane reads what another lane of the same pass writes
-                        for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i]; dp[i] = b; wave_fence(); }   // (a pass reads what the pass before wrote)
-                    } else {                                      // offset < length: the pattern repeats (lz4.c:3745-3790)
-                        for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i % of]; dp[i] = b; }
-                    }
-                    wave_fence();
-                }
-                DSTAGE(5);
-                // the block leaves: 16 bytes per lane, then the odd bytes
-                const uint32_t full = total & ~15u;
-                for (uint32_t o = 16u * L; o < full; o += 16u * kWave) *(G128*)(dst + ((uint32_t)op + o)) = *(const S128*)(blk + o);
-                if (L < (total & 15u)) dst[(uint32_t)op + full + L] = blk[full + L];
-                // the last 64 bytes become the next block's history
-                {
-                    uint32_t hv = 0;
-                    if (L < 16) hv = *(const S32*)(cb + total + 4u * L);
-                    wave_fence();
-                    if (L < 16) *(L32*)(cb + 4u * L) = hv;
-                }
-                op += (int32_t)total; hist_ok = true;
-                wave_fence();
+                DSTAGE(3); DCOUNT(2, 1); DCOUNT(3, ng);
+#ifdef LZ4D_NOHIST
+                hist_ok = false;
+#endif
+                op += (int32_t)lz_group_execute<false>(src, dst, cb, hist_ok, (uint32_t)op, ng, act, lit, mlen, off, litsrc, lpos, mst, total);
                 DSTAGE(6);
             }
             if (forced) nrec = 0;

@@ -606,7 +606,7 @@ struct LZ4F_cctx_s {
     bool linked = false; Lz4StreamState lz; uint32_t* d_table = nullptr; bool tableZero = false;
     std::vector<uint8_t> hist;                               // the last <= 64 KB of the stream
     size_t tmpInOff = 0, maxBufferSize = 0;                  // cctx->tmpIn - cctx->tmpBuff, cctx->maxBufferSize (lz4frame.c:640-655)
-    ~LZ4F_cctx_s() { if (d_table) (void)hipFree(d_table); }
+    ~LZ4F_cctx_s() { if (d_table) { aoclgpu::DeviceScope scope(aoclgpu_host_device()); (void)hipFree(d_table); } }
 };
 
 namespace {
@@ -674,6 +674,7 @@ static size_t LZ4F_compressBegin_impl(LZ4F_cctx* cctx, void* dstBuffer, size_t d
     }
     cctx->tmpInOff = 0;
     if (cctx->linked) {                                                   // LZ4F_initStream -> LZ4_resetStream_fast (lz4frame.c:570-590, :661-664)
+        aoclgpu::DeviceScope scope(aoclgpu_host_device());                // the stream's table lives on the device its kernels run on
         if (!cctx->d_table) {                                            // (the stream state may already have a history: independent frames)
             if (hipMalloc((void**)&cctx->d_table, 16384) != hipSuccess) { cctx->d_table = nullptr; return err(E_allocation_failed); }
             if (hipMemset(cctx->d_table, 0, 16384) != hipSuccess) return err(E_GENERIC);
@@ -706,6 +707,7 @@ size_t make_stream_blocks(LZ4F_cctx* c, const std::vector<StreamBlock>& blks, ui
     size_t total = c->hist.size();
     for (const StreamBlock& b : blks) total += b.len;
     {   // LZ4_renormDictT (lz4.c:3127-3146): indices are rebased before they pass 2 GB
+        aoclgpu::DeviceScope scope(aoclgpu_host_device());
         size_t fresh = total - c->hist.size();
         if ((uint64_t)z.cur + fresh > 0x7FFF0000ull) {
             std::vector<uint32_t> t(4096);
@@ -782,7 +784,10 @@ void track_independent_blocks(LZ4F_cctx* c, const std::vector<BlockRef>& blks)
 {
     bool clr = false;
     for (const BlockRef& b : blks) lz_after_independent_block(c->lz, clr, b.len);
-    if (clr && c->d_table && !c->tableZero) { if (hipMemset(c->d_table, 0, 16384) == hipSuccess) c->tableZero = true; }
+    if (clr && c->d_table && !c->tableZero) {
+        aoclgpu::DeviceScope scope(aoclgpu_host_device());
+        if (hipMemset(c->d_table, 0, 16384) == hipSuccess) c->tableZero = true;
+    }
 }
 }  // namespace
 

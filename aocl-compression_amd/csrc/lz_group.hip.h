@@ -1,0 +1,133 @@
+// csrc/lz_group.hip.h -- the decoders' group execution (LZ4 blocks, Snappy elements).
+//
+// A decoder scans its token chain into small records and then executes up to 64 of them at once, one per lane: lane i
+// holds a literal run (lit bytes at src + litsrc) followed by a copy of earlier output (mlen bytes, `off` back); prefix
+// sums have given it its place (lpos, mst = lpos + lit) in a 2 KB output block that lives in LDS behind 64 bytes of
+// history (the output just in front of the block).  lz_group_execute does the rest:
+//   1. literals (input -> block) and copies whose source ends in front of the block (output -> block): four pieces per size
+//      class at 0, k, 2k and len - k (clamped) - overlapping pieces carry the same bytes, every access stays inside its
+//      run - with every load requested before the first write: one trip to memory for the whole group; runs of 65 .. 255
+//      bytes (rare) follow by the whole wave, 4 bytes per lane;
+//   2. copies that read the block itself (or the history): in record order as LDS-to-LDS copies, a byte per lane;
+//   3. the block leaves with 16-byte stores and its last 64 bytes become the next block's history.
+// The caller has checked offsets and capacities: act lanes are [0, ng), every copy source starts at or after the start of
+// the output and - when it reaches into the block - not further in front of it than the history.
+#pragma once
+#include "common.hip.h"
+
+namespace aoclgpu {
+
+constexpr uint32_t kGrpBlock = 2048, kGrpHist = 64;
+constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | block | slack for the history read behind a full block
+
+// TINY: copies shorter than 4 bytes exist (Snappy).  Returns the group's output bytes (= what `op` advances by).
+template <bool TINY>
+__device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ src, gbyte* dst, lbyte* cb, bool& hist_ok, const uint32_t op,
+                                                     const uint32_t ng, const bool act, const uint32_t lit, const uint32_t mlen, const uint32_t off,
+                                                     const uint32_t litsrc, const uint32_t lpos, const uint32_t mst, const uint32_t total)
+{
+    typedef __attribute__((address_space(3))) uint32_t L32;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
+    typedef __attribute__((address_space(3))) U128 S128;
+    typedef uint32_t __attribute__((aligned(1))) U32;
+    typedef __attribute__((address_space(3))) U32 S32;
+    const uint32_t L = (uint32_t)lane_id();
+    if (!hist_ok) {                                           // the 64 bytes in front of the block (after a sequential step, at the start)
+        uint8_t b = 0;
+        if (op + L >= kGrpHist) b = dst[op + L - kGrpHist];
+        cb[L] = b;
+    }
+    lbyte* blk = cb + kGrpHist;
+    const int32_t srel = (int32_t)mst - (int32_t)off;                          // source start, block-relative
+    const bool far = act && mlen && srel + (int32_t)mlen <= 0;
+    const bool near = act && mlen && !far;
+    const uint32_t mo = (uint32_t)((int32_t)op + srel);                        // far copies: source start in dst
+    const bool l16 = act && lit >= 16 && lit <= 64, l4 = act && lit >= 4 && lit < 16, l1 = act && lit >= 1 && lit < 4;
+    const bool m16 = far && mlen >= 16 && mlen <= 64, m4 = far && mlen >= 4 && mlen < 16, m1 = TINY && far && mlen < 4;
+    const uint32_t le16 = lit - 16, lp16a = le16 < 16 ? le16 : 16u, lp16b = le16 < 32 ? le16 : 32u;
+    const uint32_t le4 = lit - 4, lp4a = le4 < 4 ? le4 : 4u, lp4b = le4 < 8 ? le4 : 8u;
+    const uint32_t me16 = mlen - 16, mp16a = me16 < 16 ? me16 : 16u, mp16b = me16 < 32 ? me16 : 32u;
+    const uint32_t me4 = mlen - 4, mp4a = me4 < 4 ? me4 : 4u, mp4b = me4 < 8 ? me4 : 8u;
+    u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    uint8_t b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
+    if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
+    if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
+    if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
+    if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
+    if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
+    if (m1) { c0 = dst[mo]; c1 = dst[mo + (mlen >> 1)]; c2 = dst[mo + mlen - 1]; }
+    asm volatile("" ::: "memory");
+    lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
+    if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
+    if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
+    if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
+    if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
+    if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
+    if (m1) { md_[0] = c0; md_[mlen >> 1] = c1; md_[mlen - 1] = c2; }
+    // runs of 65 .. 259 bytes (rare): the whole wave, 4 bytes per lane, one after the other
+    for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
+        const int k = (int)__builtin_ctzll(m);
+        const uint32_t n_ = lane_get(lit, k), so = lane_get(litsrc, k), d_ = lane_get(lpos, k);
+        for (uint32_t o = 4u * L; o < n_; o += 4u * kWave) { const uint32_t o4 = o < n_ - 4 ? o : n_ - 4; *(S32*)(blk + d_ + o4) = ld32(src + (so + o4)); }
+    }
+    for (uint64_t m = ballot(far && mlen > 64); m; m &= m - 1) {
+        const int k = (int)__builtin_ctzll(m);
+        const uint32_t n_ = lane_get(mlen, k), so = lane_get(mo, k), d_ = lane_get(mst, k);
+        for (uint32_t o = 4u * L; o < n_; o += 4u * kWave) { const uint32_t o4 = o < n_ - 4 ? o : n_ - 4; *(S32*)(blk + d_ + o4) = ld32(dst + (so + o4)); }   // (a match may be 259 bytes: one lane comes round again)
+    }
+    wave_fence();
+    // copies that read the block (or the history in front of it): in record order, the whole wave a byte per lane
+    for (uint64_t m = ballot(near); m; m &= m - 1) {
+        const int k = (int)__builtin_ctzll(m);
+        const uint32_t ml = lane_get(mlen, k), of = lane_get(off, k);
+        lbyte* sp = blk + (int32_t)lane_get((uint32_t)srel, k); lbyte* dp = blk + lane_get(mst, k);
+        if (of >= 64 || of >= ml) {                          // no lane reads what another lane of the same pass writes
+            for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i]; dp[i] = b; wave_fence(); }   // (a pass reads what the pass before wrote)
+        } else {                                              // offset < length: the pattern repeats
+            for (uint32_t i = L; i < ml; i += kWave) { const uint8_t b = sp[i % of]; dp[i] = b; }
+        }
+        wave_fence();
+    }
+    // the block leaves: 16 bytes per lane, then the odd bytes
+    const uint32_t full = total & ~15u;
+    for (uint32_t o = 16u * L; o < full; o += 16u * kWave) *(G128*)(dst + (op + o)) = *(const S128*)(blk + o);
+    if (L < (total & 15u)) dst[op + full + L] = blk[full + L];
+    // the last 64 bytes become the next block's history
+    {
+        uint32_t hv = 0;
+        if (L < 16) hv = *(const S32*)(cb + total + 4u * L);
+        wave_fence();
+        if (L < 16) *(L32*)(cb + 4u * L) = hv;
+    }
+    hist_ok = true;
+    wave_fence();
+    return total;
+}
+
+// The scan's walk over the token starts of a round of 64 byte positions: nx[k] = lane of the token that follows a token at
+// lane k, or negative when the scan does not take that token.  mask |= 1 << cur; cur = nx[cur] until cur >= 64 (stop = 0)
+// or a token that is not taken (stop = 2, cur stays on it).  Seven scalar instructions per token.
+__device__ __forceinline__ void lz_walk_tokens(const uint32_t nx, uint64_t& mask, uint32_t& cur, uint32_t& stop)
+{
+    uint32_t tmp;
+    asm volatile("s_mov_b64 %0, 0\n\t"
+                 "s_mov_b32 %1, 0\n\t"
+                 "s_mov_b32 %2, 0\n"
+                 "1:\n\t"
+                 "v_readlane_b32 %3, %4, %1\n\t"
+                 "s_cmp_lt_i32 %3, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitset1_b64 %0, %1\n\t"
+                 "s_mov_b32 %1, %3\n\t"
+                 "s_cmp_lt_u32 %1, 64\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "s_branch 3f\n"
+                 "2:\n\t"
+                 "s_mov_b32 %2, 2\n"
+                 "3:"
+                 : "=&s"(mask), "=&s"(cur), "=&s"(stop), "=&s"(tmp) : "v"(nx) : "scc");
+}
+
+}  // namespace aoclgpu

@@ -11,6 +11,7 @@
 // first 16 steps), the u16 table of 256..16384 entries (32 KB of LDS), the ip-1 back-fill + immediate
 // re-probe after every copy (:1016-1021), and the tag-byte output format.
 #include "common.hip.h"
+#include "lz_group.hip.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -476,22 +477,32 @@ __device__ int sn_decode_one(const gbyte* __restrict__ src, const uint32_t n, gb
     return 0;
 }
 
-// bytes [o, o+8) of the 24-byte little-endian string v0|v1|v2 (o <= 16)
-__device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2, uint32_t o)
-{
-    const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : v2), b = o < 8 ? v1 : v2;
-    const uint32_t sh = (o & 7) * 8;
-    return sh ? (a >> sh) | (b << (64 - sh)) : a;
-}
+// RawUncompress: decoded length, or -1 for any malformed stream (the reference returns false).  Same structure as the LZ4
+// decoder (csrc/lz_group.hip.h): elements far from the end of the input are SCANNED 64 byte positions at a time from an LDS
+// ring (lane k = "an element starts at ip + k", a scalar walk over the real starts) into 8-byte records - one per element,
+// a literal run or a copy - and up to 64 buffered elements are EXECUTED at once, one per lane, through a 2 KB output block
+// in LDS; everything else (literals with 2 - 4 length bytes, the end of the input, every rule that is broken) goes through
+// the one-element path, which implements all checks of DecompressAllTags / SnappyArrayWriter.
+constexpr uint32_t kSnRecs = 64;
+constexpr uint32_t kSnDecLds = kRing + 32 + kSnRecs * 8 + kGrpLds;
 
-// RawUncompress: decoded length, or -1 for any malformed stream (the reference returns false).  Same two-path
-// structure as the LZ4 decoder: elements far from the end of the input are parsed 64 byte positions at a time from an
-// LDS ring (lane k = "an element starts at ip+k", scalar walk over the real starts, prefix sum for the output
-// positions, all short literals and all short copies of earlier output at once); everything else one at a time.
-__device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* dst, const uint32_t cap,
-                                  uint8_t* ring, const bool rap)
+__device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_, const uint32_t n_, gbyte* dst_, const uint32_t cap_,
+                                                  lbyte* lds_, const bool rap)
 {
+    const gbyte* __restrict__ src = uni_ptr(src_);
+    gbyte* dst = uni_ptr(dst_);
+    lbyte* ring = uni_ptr(lds_);
+    const uint32_t n = uni(n_), cap = uni(cap_);
     const int lane = lane_id();
+    const uint32_t L = (uint32_t)lane;
+    typedef __attribute__((address_space(3))) uint64_t L64;
+    typedef uint64_t __attribute__((aligned(1))) U64;
+    typedef __attribute__((address_space(3))) U64 S64;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
+    typedef __attribute__((address_space(3))) u32x4 LV;
+    lbyte* recs = ring + kRing + 32;                          // 64 records: offset | (length | type << 16) << 32
+    lbyte* cb = recs + kSnRecs * 8;                           // 64 bytes of history | the output block
     uint32_t ulen = 0, shift = 0, ip = 0;
     if (rap) ulen = cap;                                                  // RAP partition: no prefix, exact size known (snappy.cc:2567-2654)
     else for (;;) {                                                       // ReadUncompressedLength :1202-1223
@@ -505,119 +516,110 @@ __device__ int sn_decompress_wave(const gbyte* __restrict__ src, const uint32_t 
     }
     if (ulen > cap) return -1;                                            // api/codec.cpp:296-303
     uint32_t op = 0, rend = 0;
-    uint4 pend = make_uint4(0, 0, 0, 0); bool have_pend = false;
-    while (ip < n) {                                                      // DecompressAllTags :1466-1570
-        if (ip > rend) { rend = ip & ~15u; have_pend = false; }
-        if (have_pend) {
-            *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
-            if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
-            wave_fence();
-            rend += 1024; have_pend = false;
-        }
-        if ((int32_t)(rend - ip) < 640 && (uint64_t)rend + 1024 <= n) {
-            __builtin_memcpy(&pend, src + rend + 16 * lane, 16);
-            have_pend = true;
-            if ((int32_t)(rend - ip) < 352) {
-                *reinterpret_cast<uint4*>(ring + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;
-                if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
-            if (((rend + 16u * (uint32_t)lane) & kRingMask) < 32) *reinterpret_cast<uint4*>(ring + kRing + ((rend + 16u * (uint32_t)lane) & kRingMask)) = pend;   // mirror: 32-byte reads never wrap
-                wave_fence();
-                rend += 1024; have_pend = false;
+    uint32_t nrec = 0, gbase = 0;                             // buffered elements; where the first one's tag is
+    bool hist_ok = false;
+    u32x4 pend = {0u, 0u, 0u, 0u}; bool have_pend = false;
+    auto ring_put = [&]() {
+        const uint32_t o = (rend + 16u * L) & kRingMask;
+        *(LV*)(ring + o) = pend;
+        if (o < 32) *(LV*)(ring + kRing + o) = pend;          // mirror: 32-byte reads never wrap
+        wave_fence();
+        rend += 1024; have_pend = false;
+    };
+    for (;;) {                                                            // DecompressAllTags :1466-1570
+        int why = nrec > kSnRecs - 32 ? 0 : 3;                // 0 ran through its bytes (or no room for another round), 2 an element the scan does not take, 3 input not staged
+        if (ip < n && why == 3) {
+            if (ip > rend) { rend = ip & ~15u; have_pend = false; }
+            if (have_pend) ring_put();
+            if ((int32_t)(rend - ip) < 640 && (uint64_t)rend + 1024 <= n) {
+                pend = *(const G128*)(src + (rend + 16u * L));
+                have_pend = true;
+                if ((int32_t)(rend - ip) < 352) ring_put();
             }
-        }
-        bool window = (int32_t)(rend - ip) >= 352;
-        uint64_t mask = 0; uint32_t cur = 0;
-        uint32_t lit = 0, mlen = 0, off = 0, litsrc = 0;
-        const uint32_t p = ip + (uint32_t)lane;
-        if (window) {
-            const uint32_t t = ring[p & kRingMask], type = t & 3, b1 = ring[(p + 1) & kRingMask], b2 = ring[(p + 2) & kRingMask];
-            uint32_t nx = 0xFFFFu;
-            if (type == 0) {
-                const uint32_t l6 = t >> 2;
-                if (l6 < 60) { lit = l6 + 1; litsrc = p + 1; nx = (uint32_t)lane + 1 + lit; }
-                else if (l6 == 60) { lit = b1 + 1; litsrc = p + 2; nx = (uint32_t)lane + 2 + lit; }
-                // longer literals: sequential path
-            } else if (type == 1) { mlen = 4 + ((t >> 2) & 7); off = ((t >> 5) << 8) | b1; nx = (uint32_t)lane + 2; }
-            else if (type == 2) { mlen = (t >> 2) + 1; off = b1 | (b2 << 8); nx = (uint32_t)lane + 3; }
-            else {
-                mlen = (t >> 2) + 1;
-                off = b1 | (b2 << 8) | ((uint32_t)ring[(p + 3) & kRingMask] << 16) | ((uint32_t)ring[(p + 4) & kRingMask] << 24);
-                nx = (uint32_t)lane + 5;
-            }
-            while (cur < 64) {                                            // walk the real element starts
-                const uint32_t v = lane_get(nx, (int)cur);
-                if (v == 0xFFFFu) break;
-                mask |= 1ull << cur; cur = v;
-            }
-            if (mask == 0) window = false;
-        }
-        if (window) {
-            const bool marked = (mask >> lane) & 1;
-            const uint32_t olen = marked ? lit + mlen : 0;
-            uint32_t inc = olen;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
-            const uint32_t opos = op + inc - olen;
-            // stop in front of the first element that breaks a rule (the sequential path reports it)
-            const bool bad = marked && ((mlen && (off == 0 || off > opos)) || (uint64_t)opos + olen > ulen);
-            const int fb = first_lane(ballot(bad));
-            uint32_t total = lane_get(inc, 63);
-            if (fb < 64) { mask &= (1ull << fb) - 1; cur = (uint32_t)fb; total = lane_get(inc - olen, fb); }
-            if (mask == 0) window = false;
-            else {
-                const bool act = (mask >> lane) & 1;
-                // short literals from the ring, long ones by the whole wave from the compressed stream
-                if (act && lit && lit <= 32) {            // two 16-byte LDS reads, exact-length overlapping stores
-                    uint4 qa, qb; __builtin_memcpy(&qa, ring + (litsrc & kRingMask), 16); __builtin_memcpy(&qb, ring + (litsrc & kRingMask) + 16, 16);
-                    const uint64_t v0 = qa.x | ((uint64_t)qa.y << 32), v1 = qa.z | ((uint64_t)qa.w << 32);
-                    const uint64_t v2 = qb.x | ((uint64_t)qb.y << 32), v3 = qb.z | ((uint64_t)qb.w << 32);
-                    auto ext = [&](uint32_t o) -> uint64_t {  // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
-                        const uint64_t a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
-                        const uint32_t sh = (o & 7) * 8;
-                        return sh ? (a >> sh) | (bb << (64 - sh)) : a;
-                    };
-                    gbyte* d = dst + opos;
-                    if (lit >= 8) {
-                        st64(d, v0);
-                        if (lit > 8) st64(d + (lit > 16 ? 8 : lit - 8), ext(lit > 16 ? 8 : lit - 8));
-                        if (lit > 16) st64(d + (lit > 24 ? 16 : lit - 8), ext(lit > 24 ? 16 : lit - 8));
-                        if (lit > 24) st64(d + lit - 8, ext(lit - 8));
-                    } else if (lit >= 4) { st32(d, (uint32_t)v0); st32(d + lit - 4, (uint32_t)(v0 >> (8 * (lit - 4)))); }
-                    else for (uint32_t i = 0; i < lit; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
-                }
-                for (uint64_t lm = ballot(act && lit > 32); lm; lm &= lm - 1) {
-                    const int k = (int)__builtin_ctzll(lm);
-                    wave_copy(dst + lane_get(opos, k), src + lane_get(litsrc, k), lane_get(lit, k), lane);
-                }
-                // short copies of output produced before this window: one round of loads for all of them
-                const uint32_t spos = opos - off;
-                const bool indep = act && mlen && mlen <= 24 && spos + mlen <= op && (uint64_t)spos + 24 <= ulen;
-                if (indep) {
-                    const uint64_t v0 = ld64(dst + spos), v1 = ld64(dst + spos + 8), v2 = ld64(dst + spos + 16);
-                    gbyte* d = dst + opos;
-                    if (mlen >= 8) {
-                        __builtin_memcpy(d, &v0, 8);
-                        if (mlen > 8) { const uint32_t o2 = mlen > 16 ? 8 : mlen - 8; const uint64_t x = ext64(v0, v1, v2, o2); __builtin_memcpy(d + o2, &x, 8); }
-                        if (mlen > 16) { const uint64_t x = ext64(v0, v1, v2, mlen - 8); __builtin_memcpy(d + mlen - 8, &x, 8); }
-                    } else if (mlen >= 4) {
-                        const uint32_t lo = (uint32_t)v0; __builtin_memcpy(d, &lo, 4);
-                        const uint32_t hi = (uint32_t)(v0 >> (8 * (mlen - 4))); __builtin_memcpy(d + mlen - 4, &hi, 4);
-                    } else for (uint32_t i = 0; i < mlen; ++i) d[i] = (uint8_t)(v0 >> (8 * i));
-                }
-                wave_fence();
-                // the other copies: in order, whole wave (elements are <= 64 bytes)
-                for (uint64_t dm = ballot(act && mlen && !indep); dm; dm &= dm - 1) {
-                    const int k = (int)__builtin_ctzll(dm);
-                    const uint32_t ms = lane_get(opos, k), ml = lane_get(mlen, k), of = lane_get(off, k);
-                    gbyte* d = dst + ms; const gbyte* sp = d - of;
-                    if ((uint32_t)lane < ml) { const uint8_t v = sp[of >= kWave ? (uint32_t)lane : (uint32_t)lane % of]; d[lane] = v; }
+            // ---- scan: 64 byte positions per round ----
+            while ((int32_t)(rend - ip) >= 352) {
+                const uint32_t p = ip + L;
+                const uint64_t w = *(const S64*)(ring + (p & kRingMask));
+                const uint32_t t = (uint32_t)w & 0xFFu, type = t & 3u, b1 = ((uint32_t)w >> 8) & 0xFFu;
+                uint32_t len, off = 0, adv;
+                bool hard = false;
+                if (type == 0) {
+                    const uint32_t l6 = t >> 2;
+                    len = l6 < 60 ? l6 + 1 : b1 + 1;
+                    hard = l6 > 60;                           // 2 - 4 length bytes: the one-element path
+                    adv = (l6 < 60 ? 1u : 2u) + len;
+                } else if (type == 1) { len = 4 + ((t >> 2) & 7); off = ((t >> 5) << 8) | b1; adv = 2; }
+                else if (type == 2) { len = (t >> 2) + 1; off = ((uint32_t)w >> 8) & 0xFFFFu; adv = 3; }
+                else { len = (t >> 2) + 1; off = (uint32_t)(w >> 8); adv = 5; }
+                const uint32_t nx = hard ? 0x80000000u : L + adv;
+                uint64_t mask; uint32_t cur, stop;
+                lz_walk_tokens(nx, mask, cur, stop);
+                why = (int)stop;
+                if (mask) {                                   // (a round adds at most 64 / 2 records)
+                    if (nrec == 0) gbase = ip;
+                    const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (__builtin_amdgcn_inverse_ballot_w64(mask)) *(L64*)(recs + 8u * idx) = (uint64_t)off | ((uint64_t)(len | (type << 16)) << 32);
+                    nrec += (uint32_t)__builtin_popcountll(mask); ip += cur;
                     wave_fence();
                 }
-                ip += cur; op += total;
+                if (why != 0 || nrec > kSnRecs - 32 || (int32_t)(rend - ip) < 640) break;   // (nrec <= 32 on entry: at most 64 after a round)
+            }
+            if (why == 0 && nrec <= kSnRecs - 32) continue;
+        }
+        // ---- execute buffered elements, one per lane, until the buffer has room again (all of them in front of a one-element step) ----
+        bool forced = false;
+        while (nrec && !forced) {
+            bool act = L < nrec;
+            uint32_t off = 0, len = 0, type = 0;
+            if (act) { const uint64_t r = *(const L64*)(recs + 8u * L); off = (uint32_t)r; const uint32_t h = (uint32_t)(r >> 32); len = h & 0xFFFFu; type = h >> 16; }
+            const uint32_t taglen = type == 0 ? (len <= 60 ? 1u : 2u) : (type == 1 ? 2u : (type == 2 ? 3u : 5u));
+            const uint32_t lit = type == 0 ? len : 0u, mlen = type == 0 ? 0u : len;
+            const uint32_t csz = act ? taglen + lit : 0u;
+            const uint32_t cinc = wave_scan_incl(csz);
+            const uint32_t tokpos = gbase + cinc - csz, litsrc = tokpos + taglen;
+            const uint32_t oinc = wave_scan_incl(act ? len : 0u);
+            const uint32_t lpos = oinc - (act ? len : 0u), mst = lpos;      // block-relative (an element is a literal run OR a copy)
+            // what fits the block and the output (len > ulen - op is an error the one-element path reports, :2149-2158, :2189-2207);
+            // the first copy whose offset is 0 or reaches before the start of the output ends the group in front of it
+            const uint32_t room_o = ulen - op;
+            const uint32_t capo = room_o < kGrpBlock ? room_o : kGrpBlock;
+            uint32_t ng = (uint32_t)__builtin_popcountll(ballot(act && oinc <= capo));
+            {
+                const uint64_t badm = ballot(act && mlen && (off == 0 || off > op + mst));
+                const uint32_t fb = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;
+                if (fb < ng) { ng = fb; forced = true; }
+                else if (ng == 0) forced = true;              // the output ends: the one-element path decides
+                if (forced) {
+                    ip = lane_get(tokpos, (int)ng);           // back to that element's tag; later records are dropped
+                    // the scan had run ahead: a refill in flight would overwrite the oldest KiB of the ring, which holds ip again
+                    if ((int32_t)(rend - ip) > 1024) have_pend = false;
+                    if ((int32_t)(rend - ip) > (int32_t)kRing) rend = ip & ~15u;   // further back than the ring holds: stage again from there
+                }
+                act = L < ng;
+            }
+            if (ng) {
+                const uint32_t total = lane_get(oinc, (int)ng - 1);
+                op += lz_group_execute<true>(src, dst, cb, hist_ok, op, ng, act, lit, mlen, off, litsrc, lpos, mst, total);
+            }
+            if (forced) nrec = 0;
+            else {                                            // records that did not fit the block move to the front
+                const uint32_t left = nrec - ng;
+                uint64_t r = 0;
+                if (L < left) r = *(const L64*)(recs + 8u * (ng + L));
+                wave_fence();
+                if (L < left) *(L64*)(recs + 8u * L) = r;
+                wave_fence();
+                gbase += lane_get(cinc, (int)ng - 1);
+                nrec = left;
+                if (why == 0) break;                          // the buffer has room again: scan on
             }
         }
-        if (!window) {
+        if (why == 0 && !forced) continue;
+        if (ip >= n) break;
+        {
             const int r = sn_decode_one(src, n, dst, ulen, ip, op, lane);
             if (r < 0) return r;
+            hist_ok = false;
         }
     }
     return op == ulen ? (int)op : -1;                                     // CheckLength :2146
@@ -682,13 +684,16 @@ __global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_w
     }
 }
 
-__global__ void __launch_bounds__(64) snappy_decompress_kernel(aoclgpu_batch b)
+#ifndef SND_WAVES
+#define SND_WAVES 6
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SND_WAVES, SND_WAVES))) snappy_decompress_kernel(aoclgpu_batch b)
 {
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kSnDecLds];
     const ChunkView v = decompress_view(b, c);
-    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, ring, (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) != 0);
+    const int r = sn_decompress_wave(v.src, v.src_len, v.dst, v.dst_cap, (lbyte*)ring, (b.reserved & AOCLGPU_FLAG_RAP_PARTITIONS) != 0);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 

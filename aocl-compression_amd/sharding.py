@@ -29,14 +29,24 @@ class CExchange:
         import torch
         self.torch, self.eng, self.rank, self.world = torch, eng, rank, world
         lib = eng.lib
+        # every step that can fail on one rank only is followed by an agreement step, so that all ranks raise together and
+        # nobody is left waiting in a collective (the caller then falls back to torch.distributed on every rank)
         ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            eng._check(lib.aoclgpu_comm_unique_id(ident), "comm_unique_id")
-        obj = [bytes(ident)]
+        rc = lib.aoclgpu_comm_unique_id(ident) if rank == 0 else 0
+        obj = [(int(rc), bytes(ident))]
         dist.broadcast_object_list(obj, src=0)
-        ident = (C.c_uint8 * 128).from_buffer_copy(obj[0])
+        rc, raw = obj[0]
+        if rc != 0:
+            raise RuntimeError("aoclgpu_comm_unique_id failed on rank 0 (is librccl.so.1 loadable?)")
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         comm = C.c_void_p()
-        eng._check(lib.aoclgpu_comm_create(ident, world, rank, C.byref(comm)), "comm_create")
+        rc = int(lib.aoclgpu_comm_create(ident, world, rank, C.byref(comm)))
+        rcs = [None] * world
+        dist.all_gather_object(rcs, rc)
+        if any(rcs):
+            if rc == 0 and comm:
+                lib.aoclgpu_comm_destroy(comm)
+            raise RuntimeError(f"aoclgpu_comm_create failed on ranks {[r for r, v in enumerate(rcs) if v]}")
         self.comm = comm
         self.side = torch.cuda.Stream(device=eng.device)
 
@@ -49,9 +59,13 @@ class CExchange:
         return [_StreamWait(self.torch, self.side)]
 
     def allgather_words(self, out, mine):
-        """out[r * n ..] = rank r's `mine` (int32 / uint32 device tensors)"""
+        """out[r * n ..] = rank r's `mine` (int32 / uint32 device tensors).  Enqueued on the SAME side stream as the segment
+        exchange: one communicator never has operations in flight on two streams."""
+        cur = self.torch.cuda.current_stream()
+        self.side.wait_stream(cur)
         self.eng._check(self.eng.lib.aoclgpu_allgather_words(self.comm, mine.data_ptr(), out.data_ptr(), int(mine.numel()), self.world, self.rank,
-                                                             self.torch.cuda.current_stream().cuda_stream), "allgather_words")
+                                                             self.side.cuda_stream), "allgather_words")
+        cur.wait_stream(self.side)
 
     def close(self):
         if self.comm:

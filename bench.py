@@ -460,11 +460,27 @@ class Run:
             self.packed = self.gather_buf[self.seg_off[self.rank]:self.seg_off[self.rank] + self.seg[self.rank]]
             # one untimed exchange: if this RCCL build cannot run the grouped send/recv, every rank sees the same exception and
             # all of them fall back to the padded all-gather together (the JSON line says which exchange ran)
+            # ... and one that never returns (two communicators on one device, a link that does not come up) must not take the
+            # whole run with it: a watchdog ends this process with a JSON error line after 60 s - no retry, no re-exec
+            import threading
+
+            def _expired():
+                print(json.dumps({"error": "exchange timeout", "exchange": self.args.exchange, "rank": self.rank, "n_gpus": self.world,
+                                  "note": "the first (untimed) exchange of compressed segments did not complete within 60 s"}), flush=True)
+                os._exit(3)
+            dog = threading.Timer(60.0, _expired)
+            dog.daemon = True
+            dog.start()
             try:
                 for w in self.exchange():
                     w.wait()
-                torch.cuda.synchronize()
+                done = torch.cuda.Event()
+                done.record()
+                while not done.query():
+                    time.sleep(0.005)
+                dog.cancel()
             except Exception as e:  # noqa: BLE001
+                dog.cancel()
                 nxt = "sendrecv" if self.args.exchange == "c" else "allgather"
                 if self.rank == 0:
                     print(f"bench: {self.args.exchange} exchange failed ({e!r}); using {nxt}", file=sys.stderr)

@@ -1,4 +1,6 @@
 """GPU parity: HIP LZ4 kernels (through the C-ABI) vs the CPU oracle -- bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -101,6 +103,20 @@ def test_decode_foreign_and_malformed(eng, oracle):
         assert got == want
         n_checked += 1
     assert n_checked == 200
+
+
+def test_decode_group_path_regressions(eng, oracle):
+    """Inputs that drive the decoder's group path through its rare steps (round 4): long literal runs and matches between
+    groups, groups that overflow the 2 KB block, and the fuzz input on which a refill in flight overwrote the part of the
+    input ring the token chain had been rewound to (tools/fuzz_campaign.py seed 13759)."""
+    import test_lz4_group_model as tm
+    cases = [open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lz4_decode_rewind_seed13759_chunk2.bin"), "rb").read(),
+             tm._lz_text(np.random.default_rng(5), 1500, 600, 4, 600)[:200000],
+             tm._lz_text(np.random.default_rng(6), 3000, 20, 40, 200)[:250000]]
+    for raw in cases:
+        comp = oracle.compress(ol.LZ4, raw)
+        assert eng.decompress_host(a.LZ4, comp, len(raw)) == raw
+        assert eng.compress_host(a.LZ4, raw) == comp
 
 
 def test_explicit_batch_ragged(eng, oracle):

@@ -128,6 +128,9 @@ while time.time() < t_end:
             n_chunks += 1
         if ok:
             dst, dl = eng.decompress_chunks(gc, slots, out_len, slot, len(raw), chunk)
+            if not torch.equal(dst, src):                       # keep the input for tools/debug/lz4_dec_diff.py
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.bin"), "wb").write(raw)
             assert torch.equal(dst, src), tag
     n_ex += 1
 lib.aocl_destroy_zstd_encode()
