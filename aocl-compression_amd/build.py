@@ -137,8 +137,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def clean_variants(verbose: bool = False) -> None:
+    """Development builds (build_variant: kernel experiments, profiling instantiations) are scratch: the product build removes
+    their libraries and object trees so that they do not ship with every GPU run or pile up in the package directory.
+    Kept: the product, the core library and the sanitised host build.  AOCLGPU_KEEP_VARIANTS=1 (or --keep-variants) keeps them."""
+    import shutil
+    keep = {os.path.basename(LIB), os.path.basename(CORE_LIB), "libaocl_compression_gpu_asan.so"}
+    for f in os.listdir(HERE):
+        if f.startswith("libaocl_compression_gpu_") and f.endswith(".so") and f not in keep:
+            os.unlink(os.path.join(HERE, f))
+            if verbose:
+                print("removed", f)
+    if os.path.isdir(OBJDIR):
+        for d in os.listdir(OBJDIR):
+            full = os.path.join(OBJDIR, d)
+            if os.path.isdir(full) and d not in ("stub", "asan"):
+                shutil.rmtree(full, ignore_errors=True)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--variant" not in sys.argv and "--keep-variants" not in sys.argv and os.environ.get("AOCLGPU_KEEP_VARIANTS") != "1":
+        clean_variants(verbose=True)
     if "--sanitize" in sys.argv or os.environ.get("AOCLGPU_SANITIZE") == "1":
         build_sanitized(verbose=True)
     # python build.py --variant prof -DAOCLGPU_EXPERIMENTS -DZSTD_PROF

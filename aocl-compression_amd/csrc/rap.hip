@@ -14,7 +14,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <chrono>
+#include <mutex>
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.hip.h"
 #include "host_util.h"
 
@@ -390,48 +394,154 @@ extern "C" int64_t aoclgpu_rap_compress_host(aoclgpu_codec codec, const void* hs
 {
     return aoclgpu_rap_compress_host_ex(codec, hsrc, n, hdst, cap, chunk_bytes, 0);
 }
-// flags: the codec's AOCLGPU_FLAG_* / AOCLGPU_ZSTD_LEVEL(l) / AOCLGPU_LZ4_ACCELERATION(a) for every partition
+namespace {
+// Device buffers and streams of the host-buffer calls, kept between calls (one set per process, for whichever device the
+// host entry points use; a second caller at the same time works on buffers of its own).  hipMalloc / hipFree of gigabyte
+// buffers cost more than the kernels they feed, and hipFree synchronises the device.
+// A slab's kernel lasts as long as its slowest chunk (~10 ms for 256 KiB of LZ4) whatever the slab's size, and the runtime
+// runs four kernels side by side (its default number of hardware queues; tools/stream_overlap_probe.cpp): a call is cut into
+// at most FOUR slabs, one stream each - sixteen slabs took four rounds of that time, 41 ms behind the last copy of 1 GiB.
+constexpr int kHostStreams = 4;
+struct HostPathCache {
+    std::mutex mu;
+    int dev = -1;
+    void* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t cap[5] = {0, 0, 0, 0, 0};
+    hipStream_t work[kHostStreams] = {}, copy = nullptr;
+};
+HostPathCache* g_hp = new HostPathCache;                       // (never destroyed: the HIP runtime may be gone before static destructors run)
+
+struct HostBufs {                                             // the five buffers of one call: the cache's when it is free, else the call's own
+    void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t work[kHostStreams] = {}, copy = nullptr;
+    bool cached = false;
+    ~HostBufs()
+    {
+        if (cached) { g_hp->mu.unlock(); return; }
+        for (void* q : p) if (q) (void)hipFree(q);
+        for (hipStream_t q : work) if (q) (void)hipStreamDestroy(q);
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+    bool get(const size_t need[5])
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (g_hp->mu.try_lock()) {
+            cached = true;
+            HostPathCache& c = *g_hp;
+            if (c.dev != dev) {                                // another device than last time: start over (rare: the host device is a process-wide setting)
+                for (int i = 0; i < 5; ++i) { c.buf[i] = nullptr; c.cap[i] = 0; }
+                for (hipStream_t& q : c.work) q = nullptr;
+                c.copy = nullptr; c.dev = dev;
+            }
+            for (int i = 0; i < 5; ++i) {
+                if (c.cap[i] < need[i]) {
+                    if (c.buf[i]) (void)hipFree(c.buf[i]);
+                    c.buf[i] = nullptr; c.cap[i] = 0;
+                    const size_t want = need[i] + need[i] / 8 + 4096;             // a little room to grow
+                    if (hipMalloc(&c.buf[i], want) != hipSuccess) { (void)hipGetLastError(); if (hipMalloc(&c.buf[i], need[i] ? need[i] : 1) != hipSuccess) return false; c.cap[i] = need[i]; }
+                    else c.cap[i] = want;
+                }
+                p[i] = c.buf[i];
+            }
+            for (int i = 0; i < kHostStreams; ++i) { if (!c.work[i] && hipStreamCreateWithFlags(&c.work[i], hipStreamNonBlocking) != hipSuccess) return false; work[i] = c.work[i]; }
+            if (!c.copy && hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking) != hipSuccess) return false;
+            copy = c.copy;
+            return true;
+        }
+        for (int i = 0; i < 5; ++i) if (hipMalloc(&p[i], need[i] ? need[i] : 1) != hipSuccess) return false;
+        for (int i = 0; i < kHostStreams; ++i) if (hipStreamCreateWithFlags(&work[i], hipStreamNonBlocking) != hipSuccess) return false;
+        return hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess;
+    }
+};
+}  // namespace
+
+// flags: the codec's AOCLGPU_FLAG_* / AOCLGPU_ZSTD_LEVEL(l) / AOCLGPU_LZ4_ACCELERATION(a) for every partition.
+// The input goes to the device in up to four slabs (whole chunks) and every slab's chunks are compressed as soon as they have
+// arrived - each slab on a stream of its own, so the kernels overlap each other and the copies behind them; the
+// partitions are then joined on the device (rap_pack) and the stream comes back in one copy.  (Pageable host memory moves at
+// ~55 GB/s on this platform, pinned staging would not be faster - tools/host_copy_probe.cpp - so the copies are plain.)
 extern "C" int64_t aoclgpu_rap_compress_host_ex(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap,
                                                 uint64_t chunk_bytes, uint32_t flags)
 {
     if ((!hsrc && n) || !hdst || n > 0x7FFFFFFFull) { set_error_msg("rap_compress_host: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
-    if (chunk_bytes == 0) chunk_bytes = aoclgpu_rap_default_chunk(codec);
+    if (chunk_bytes == 0) {
+        chunk_bytes = aoclgpu_rap_default_chunk(codec);
+        // The caller left the partition size to the library.  A slab's kernel lasts as long as its slowest chunk, which for LZ4 is
+        // proportional to the chunk size: with 128 KiB partitions the kernels finish 8 ms behind the last copy of a 1 GiB input
+        // instead of 15 ms (26.7 instead of 22.4 GiB/s end to end) and the stream grows by 0.8 %.
+        if (codec == AOCLGPU_LZ4 && n >= ((size_t)64 << 20)) chunk_bytes = 128u << 10;
+        if (const char* e = getenv("AOCLGPU_RAP_HOST_CHUNK_KB")) { const long kb = atol(e); if (kb >= 4) chunk_bytes = (uint64_t)kb << 10; }
+    }
     if (codec == AOCLGPU_ZSTD && chunk_bytes > (128u << 10)) chunk_bytes = 128u << 10;
     uint64_t K = n ? (n + chunk_bytes - 1) / chunk_bytes : 1;
     while (K > 65535) { chunk_bytes *= 2; K = (n + chunk_bytes - 1) / chunk_bytes; }   // 16-bit partition count
     if (codec == AOCLGPU_ZSTD && chunk_bytes > (128u << 10)) { set_error_msg("rap_compress_host: zstd input needs more than 65535 partitions"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
     const uint64_t slot = (aoclgpu_compress_bound(codec, chunk_bytes) + 15) & ~(uint64_t)15;
     const uint64_t scap = aoclgpu_rap_frame_bytes(codec, (uint32_t)K) + K * slot + 16;
-    DevBuf dsrc, dslots, dlen, daux, dout;
-    if (!dsrc.alloc(n) || !dslots.alloc(K * slot) || !dlen.alloc(K * 4) || !daux.alloc(K * 4) || !dout.alloc(scap)) {
-        set_error_msg("rap_compress_host: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP;
-    }
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("rap_compress_host: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    const bool trace = getenv("AOCLGPU_HOST_TRACE") != nullptr;   // stage times of this call on stderr (development aid)
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    HostBufs hb;
+    const size_t need[5] = {n, (size_t)(K * slot), (size_t)(K * 4), (size_t)(K * 4), (size_t)scap};
+    if (!hb.get(need)) { (void)hipGetLastError(); set_error_msg("rap_compress_host: hipMalloc / hipStreamCreate"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    uint8_t* dsrc = (uint8_t*)hb.p[0]; uint8_t* dslots = (uint8_t*)hb.p[1]; int32_t* dlen = (int32_t*)hb.p[2]; uint32_t* daux = (uint32_t*)hb.p[3]; uint8_t* dout = (uint8_t*)hb.p[4];
 #define HCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error(#call, e_); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; } } while (0)
-    if (n) HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    const double t1 = now();
+    uint64_t nslab = n / ((size_t)32 << 20);                                        // slabs of at least 32 MiB, at most one per stream
+    if (nslab < 1) nslab = 1;
+    if (nslab > (uint64_t)kHostStreams) nslab = kHostStreams;
+    const uint64_t per = (K + nslab - 1) / nslab;                                   // chunks per slab
+    int si = 0;
+    for (uint64_t c0 = 0; c0 < K; c0 += per, ++si) {
+        const uint64_t cn = K - c0 < per ? K - c0 : per;
+        const uint64_t o = c0 * chunk_bytes, bytes = (o + cn * chunk_bytes <= n ? cn * chunk_bytes : n - o);
+        if (bytes) {
+            HCK(hipMemcpyAsync(dsrc + o, (const uint8_t*)hsrc + o, bytes, hipMemcpyHostToDevice, hb.copy));
+            HCK(hipStreamSynchronize(hb.copy));
+        }
+        aoclgpu_batch b; memset(&b, 0, sizeof(b));
+        b.src = dsrc + o; b.dst = dslots + c0 * slot; b.out_len = dlen + c0; b.aux = daux + c0;
+        b.nchunks = (uint32_t)cn; b.total_bytes = n ? bytes : 0; b.chunk_bytes = chunk_bytes; b.slot_bytes = slot; b.reserved = flags;
+        void* st = hb.work[si % kHostStreams];
+        const int rc = codec == AOCLGPU_LZ4 ? aoclgpu_lz4_compress_chunks(&b, st)
+                     : codec == AOCLGPU_SNAPPY ? aoclgpu_snappy_compress_chunks(&b, st) : aoclgpu_zstd_compress_chunks(&b, st);
+        if (rc) { for (hipStream_t q : hb.work) (void)hipStreamSynchronize(q); return AOCLGPU_HOST_FAIL + rc; }
+    }
+    const double t2 = now();
+    for (hipStream_t q : hb.work) HCK(hipStreamSynchronize(q));
+    const double t3 = now();
     aoclgpu_batch b; memset(&b, 0, sizeof(b));
-    b.src = (const uint8_t*)dsrc.p; b.dst = (uint8_t*)dslots.p; b.out_len = (int32_t*)dlen.p; b.aux = (uint32_t*)daux.p;
+    b.src = dsrc; b.dst = dslots; b.out_len = dlen; b.aux = daux;
     b.nchunks = (uint32_t)K; b.total_bytes = n; b.chunk_bytes = chunk_bytes; b.slot_bytes = slot; b.reserved = flags;
-    int rc = codec == AOCLGPU_LZ4 ? aoclgpu_lz4_compress_chunks(&b, nullptr)
-           : codec == AOCLGPU_SNAPPY ? aoclgpu_snappy_compress_chunks(&b, nullptr) : aoclgpu_zstd_compress_chunks(&b, nullptr);
-    if (rc) return AOCLGPU_HOST_FAIL + rc;
     uint64_t bytes = 0;
-    rc = aoclgpu_rap_pack(codec, &b, (uint8_t*)dout.p, scap, &bytes, nullptr);
+    const int rc = aoclgpu_rap_pack(codec, &b, dout, scap, &bytes, hb.work[0]);
     if (rc) return AOCLGPU_HOST_FAIL + rc;
     if (bytes > cap) return 0;                                   // does not fit the caller's buffer
-    HCK(hipMemcpy(hdst, dout.p, bytes, hipMemcpyDeviceToHost));
+    HCK(hipStreamSynchronize(hb.work[0]));
+    const double t4 = now();
+    HCK(hipMemcpyAsync(hdst, dout, bytes, hipMemcpyDeviceToHost, hb.copy));
+    HCK(hipStreamSynchronize(hb.copy));
+    if (trace) fprintf(stderr, "rap_compress_host: buffers %.1f ms, slabs in + launches %.1f, kernels' tail %.1f, join %.1f, out %.1f (n %zu, %llu partitions)\n",
+                       t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4, n, (unsigned long long)K);
     return (int64_t)bytes;
 }
 
 extern "C" int64_t aoclgpu_rap_decompress_host(aoclgpu_codec codec, const void* hsrc, size_t n, void* hdst, size_t cap)
 {
     if (!hsrc || !hdst || n == 0) { set_error_msg("rap_decompress_host: bad arguments"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_ARG; }
-    DevBuf dsrc, ddst;
-    if (!dsrc.alloc(n) || !ddst.alloc(cap)) { set_error_msg("rap_decompress_host: hipMalloc"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
-    HCK(hipMemcpy(dsrc.p, hsrc, n, hipMemcpyHostToDevice));
+    aoclgpu::DeviceScope devScope(aoclgpu_host_device());
+    if (!devScope.ok) { set_error_msg("rap_decompress_host: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
+    HostBufs hb;
+    const size_t need[5] = {n, cap, 0, 0, 0};
+    if (!hb.get(need)) { (void)hipGetLastError(); set_error_msg("rap_decompress_host: hipMalloc / hipStreamCreate"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_HIP; }
+    HCK(hipMemcpyAsync(hb.p[0], hsrc, n, hipMemcpyHostToDevice, hb.copy));
+    HCK(hipStreamSynchronize(hb.copy));
     int64_t r = -1;
-    const int rc = aoclgpu_rap_unpack(codec, (const uint8_t*)dsrc.p, n, (uint8_t*)ddst.p, cap, &r, nullptr);
+    const int rc = aoclgpu_rap_unpack(codec, (const uint8_t*)hb.p[0], n, (uint8_t*)hb.p[1], cap, &r, hb.work[0]);
     if (rc) return AOCLGPU_HOST_FAIL + rc;
-    if (r > 0) HCK(hipMemcpy(hdst, ddst.p, (size_t)r, hipMemcpyDeviceToHost));
+    if (r > 0) { HCK(hipMemcpyAsync(hdst, hb.p[1], (size_t)r, hipMemcpyDeviceToHost, hb.copy)); HCK(hipStreamSynchronize(hb.copy)); }
 #undef HCK
     return r;
 }

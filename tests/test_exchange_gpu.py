@@ -186,7 +186,9 @@ def test_llc_zstd_threads_reference_geometry(eng, level):
         assert r > 0, eng.lib.aoclgpu_last_error()
         L = tza._bind(eng.lib)
         p = L.ZSTD_getParams(level, len(data), 0).cParams      # what the wrapper asked for (the dispatcher has run by now)
-        cp = zfc.CParams(17, p.chainLog, p.hashLog, p.searchLog, p.minMatch, p.targetLength, p.strategy)
+        # api/codec.cpp:402-408: a window clamped to optVar takes the chain table's log with it (+1 for the binary-tree finders)
+        chain = 17 + (1 if p.strategy in (6, 7, 8) else 0) if p.windowLog > 17 else p.chainLog
+        cp = zfc.CParams(17, chain, p.hashLog, p.searchLog, p.minMatch, p.targetLength, p.strategy)
         mt.set_threads(T)
         want = zfc.ref_frame(mt, data, cp, extra=4096)
         assert blob == want, (level, len(blob), len(want))
