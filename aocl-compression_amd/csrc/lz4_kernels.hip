@@ -382,8 +382,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 // after the match's end, >= 64: none), so the scalar walk is one readlane per sequence; everything else (the
                 // anchor of every sequence, the table commit, the records) is derived from 64-bit lane masks once per batch.
                 // Sequences that need a loop (longer extension / catch-up than the windows hold) are "special": they end
-                // the walk and take the one-at-a-time path below.
-                const uint64_t slowmask = ballot(mf);
+                // the walk (their `nxt` is negative) and take the one-at-a-time path below.
                 const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes (<= 91)
                 uint32_t nxt;
                 {
@@ -393,11 +392,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 uint64_t marks = 0;                           // lanes that start a sequence
                 {
                     const uint64_t first = okmask & (own >= 64 ? ~0ull : ((1ull << own) - 1));
-                    uint32_t mw = first ? (uint32_t)__builtin_ctzll(first) : 64u;
-                    while (mw < 64) {
-                        if ((slowmask >> mw) & 1) { special = (int)mw; break; }
-                        marks |= 1ull << mw;
-                        mw = lane_get(nxt, (int)mw);
+                    if (first) {                              // marks |= 1 << mw; mw = nxt[mw] until mw >= 64 or a lane of slowmask (lz_group.hip.h)
+                        uint32_t mw, stop;
+                        lz_walk_tokens(mf ? 0x80000000u : nxt, marks, mw, stop, (uint32_t)__builtin_ctzll(first));
+                        if (stop) special = (int)mw;
                     }
                 }
                 // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it

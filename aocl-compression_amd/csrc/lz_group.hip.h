@@ -109,11 +109,11 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
 // The scan's walk over the token starts of a round of 64 byte positions: nx[k] = lane of the token that follows a token at
 // lane k, or negative when the scan does not take that token.  mask |= 1 << cur; cur = nx[cur] until cur >= 64 (stop = 0)
 // or a token that is not taken (stop = 2, cur stays on it).  Seven scalar instructions per token.
-__device__ __forceinline__ void lz_walk_tokens(const uint32_t nx, uint64_t& mask, uint32_t& cur, uint32_t& stop)
-{
+__device__ __forceinline__ void lz_walk_tokens(const uint32_t nx, uint64_t& mask, uint32_t& cur, uint32_t& stop, const uint32_t first = 0)
+{   // first: the lane the walk starts at (< 64)
     uint32_t tmp;
     asm volatile("s_mov_b64 %0, 0\n\t"
-                 "s_mov_b32 %1, 0\n\t"
+                 "s_mov_b32 %1, %5\n\t"
                  "s_mov_b32 %2, 0\n"
                  "1:\n\t"
                  "v_readlane_b32 %3, %4, %1\n\t"
@@ -127,7 +127,7 @@ __device__ __forceinline__ void lz_walk_tokens(const uint32_t nx, uint64_t& mask
                  "2:\n\t"
                  "s_mov_b32 %2, 2\n"
                  "3:"
-                 : "=&s"(mask), "=&s"(cur), "=&s"(stop), "=&s"(tmp) : "v"(nx) : "scc");
+                 : "=&s"(mask), "=&s"(cur), "=&s"(stop), "=&s"(tmp) : "v"(nx), "s"(first) : "scc");
 }
 
 }  // namespace aoclgpu
