@@ -293,6 +293,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 pos = s0 + (uint32_t)lane;
                 const int32_t w0 = (int32_t)s0 - 4;       // the ring must hold [w0, w0 + 96)
                 if ((uint32_t)(w0 - 256 * (rb - 1)) > 512u - 96u) {
+                asm volatile("; ring refill begin");
                     const int32_t bl = w0 >> 8, bh = (w0 + 95) >> 8;
                     if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb = (int32_t)uni((uint32_t)(rb + 1)); }
                     else {
@@ -304,6 +305,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     pend = blk_load(rb + 1); have_pend = true;
                     wave_fence();
                 }
+                asm volatile("; ring refill end");
                 // 32-byte probe windows [p-4, p+28): a = {p-4, p, p+4, p+8}, b = {p+12, p+16, p+20, p+24}
                 const uint32_t roff = (uint32_t)(w0 + lane) & 511u;
                 const u32x4 a = lds_ld128(ring + roff), b = lds_ld128(ring + roff + 16);
@@ -439,6 +441,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     else if (cur < lim) i0 = lim - cur;                // lanes [cur, lim) of the next search found nothing
                 }
             } else {
+                asm volatile("; general batch begin");
                 // ---------------- general batch: probe i0 + lane of the schedule (any acceleration, long searches, the chunk's
                 // end); lane k evaluates probe k speculatively, the first hit below the first in-batch slot reuse is the match
                 // (lz4.c:1483-1608), resolved one at a time ----------------
@@ -504,7 +507,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     else i0 += lim;
                 }
             }
+            asm volatile("; general batch end");
             if (special >= 0) {
+                asm volatile("; special begin");
                 STAGE(7);                                 // (a general batch)
                 // ---------------- one special sequence, lane `special` (lz4.c:1611-1740) ----------------
                 const int m = special;
@@ -565,9 +570,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 if (ip >= mfl1) done = true;              // lz4.c:1747
                 else { extra = true; i0 = 0; }
                 STAGE(6);
+                asm volatile("; special end");
             }
             asm volatile("; resolve end" ::: "memory");
-            if (nrec > kRecFlush || done) { wave_fence(); if (PROF) cnt[5]++; if (!flush()) return 0; }
+            if (nrec > kRecFlush || done) { asm volatile("; flush begin"); wave_fence(); if (PROF) cnt[5]++; if (!flush()) return 0; asm volatile("; flush end"); }
             STAGE(7);
             if (done) break;
         }
