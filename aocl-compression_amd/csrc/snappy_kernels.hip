@@ -114,10 +114,21 @@ typedef __attribute__((address_space(3))) uint16_t lu16;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 constexpr uint32_t kScratch = 1024;
 
+// Round 4: the parser does not write the block itself.  Every copy it decides becomes an 8-byte record in LDS (literal length in
+// front of it | copy length << 17 | offset << 34) and when the buffer may overflow in the next batch the wave formats all buffered
+// copies at once, ONE PER LANE: prefix sums give each its literal source and its output position, the literal tag, the literals
+// (four pieces per size class, lz_group.hip.h), and the copy elements (EmitCopy's 64-byte elements, the 60-byte one, the last one
+// of 2 or 3 bytes) are computed per lane.  A batch adds at most 17 copies (64 consecutive positions, a copy covers at least 4).
+constexpr uint32_t kSnRecCap = 60, kSnRecFlush = kSnRecCap - 17, kSnRecBytes = kSnRecCap * 8;
+
 template <bool GT, int TAG = 0>
-__device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in, const uint32_t n,
-                                                                   gbyte* __restrict__ out, uint16_t* table_, lu16* scr, int lane)
+__device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in_, const uint32_t n_,
+                                                                   gbyte* __restrict__ out_, uint16_t* table_, lu16* scr, lbyte* recs_, int lane)
 {
+    const gbyte* __restrict__ in = uni_ptr(in_);
+    gbyte* __restrict__ out = uni_ptr(out_);
+    lbyte* recs = uni_ptr(recs_);
+    const uint32_t n = uni(n_);
     // GT: a slot is a u32 = position | check bits of the 4 bytes at that position << 16.  The check bits never change a
     // decision (a probe whose check bits differ cannot pass the 4-byte test); they spare the speculative lanes the fetch
     // of a candidate window that cannot match - most of the kernel's memory traffic.  An empty slot aliases position 0
@@ -148,6 +159,70 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
     wave_fence();
 
     uint32_t ip = 0, op = 0, anchor = 0;                                  // anchor = next_emit
+    // buffered copies [0, nrec): they describe in[f_anchor, anchor) and go to out + op
+    uint32_t nrec = 0, f_anchor = 0;
+    typedef __attribute__((address_space(3))) uint64_t L64;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef __attribute__((address_space(1))) U128 G128;
+    auto rec_put = [&](uint32_t idx, uint32_t lit, uint32_t len, uint32_t off) {
+        *(L64*)(recs + 8u * idx) = (uint64_t)lit | ((uint64_t)len << 17) | ((uint64_t)off << 34);
+    };
+    auto flush = [&]() {                                   // EmitLiteral :435-476 + EmitCopy :478-568 for every buffered copy
+        const uint32_t L = (uint32_t)lane;
+        const bool act = L < nrec;
+        uint32_t lit = 0, len = 0, off = 0;
+        if (act) { const uint64_t r = *(const L64*)(recs + 8u * L); lit = (uint32_t)r & 0x1FFFFu; len = (uint32_t)(r >> 17) & 0x1FFFFu; off = (uint32_t)(r >> 34); }
+        const uint32_t hdr = lit == 0 ? 0u : (lit <= 60 ? 1u : (lit <= 256 ? 2u : 3u));
+        const uint32_t n64 = len >= 68 ? (len - 4) / 64 : 0u;
+        uint32_t rem = len - 64 * n64;
+        const bool big60 = rem > 64;
+        if (big60) rem -= 60;
+        const bool two = rem < 12 && off < 2048;
+        const uint32_t csz = 3 * n64 + (big60 ? 3u : 0u) + (two ? 2u : 3u);
+        const uint32_t osz = act ? hdr + lit + csz : 0u, isz = act ? lit + len : 0u;
+        const uint32_t oinc = wave_scan_incl(osz), iinc = wave_scan_incl(isz);
+        const uint32_t tp = op + oinc - osz;              // the literal's tag (or the first copy element)
+        const uint32_t sp = f_anchor + iinc - isz;        // the literal's bytes
+        const uint32_t lp = tp + hdr, cp = lp + lit;      // literal bytes, copy elements
+        const gbyte* sl = in + sp; gbyte* d = out + lp;
+        const bool c16 = act && lit >= 16 && lit <= 64, c4 = act && lit >= 4 && lit < 16, c1 = act && lit >= 1 && lit < 4;
+        const uint32_t e16 = lit - 16, p16a = e16 < 16 ? e16 : 16u, p16b = e16 < 32 ? e16 : 32u;
+        const uint32_t e4 = lit - 4, p4a = e4 < 4 ? e4 : 4u, p4b = e4 < 8 ? e4 : 8u;
+        u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        uint8_t b0 = 0, b1 = 0, b2 = 0;
+        if (c16) { q0 = *(const G128*)sl; q1 = *(const G128*)(sl + p16a); q2 = *(const G128*)(sl + p16b); q3 = *(const G128*)(sl + e16); }
+        if (c4) { r0 = ld32(sl); r1 = ld32(sl + p4a); r2 = ld32(sl + p4b); r3 = ld32(sl + e4); }
+        if (c1) { b0 = sl[0]; b1 = sl[lit >> 1]; b2 = sl[lit - 1]; }
+        if (act) {
+            if (lit) {
+                const uint32_t nl = lit - 1;
+                out[tp] = (uint8_t)(nl < 60 ? (nl << 2) : ((nl < 256 ? 60u : 61u) << 2));
+                if (nl >= 60) out[tp + 1] = (uint8_t)nl;
+                if (nl >= 256) out[tp + 2] = (uint8_t)(nl >> 8);
+            }
+            gbyte* c = out + cp + 3 * n64;
+            if (big60) { c[0] = (uint8_t)(2 | (59 << 2)); st16(c + 1, off); c += 3; }
+            if (two) st16(c, (1u | ((rem - 4) << 2) | ((off >> 8) << 5)) | ((off & 0xFFu) << 8));
+            else { c[0] = (uint8_t)(2 | ((rem - 1) << 2)); st16(c + 1, off); }
+        }
+        asm volatile("" ::: "memory");                    // (the loads above stay above)
+        if (c16) { *(G128*)d = q0; *(G128*)(d + p16a) = q1; *(G128*)(d + p16b) = q2; *(G128*)(d + e16) = q3; }
+        if (c4) { st32(d, r0); st32(d + p4a, r1); st32(d + p4b, r2); st32(d + e4, r3); }
+        if (c1) { d[0] = b0; d[lit >> 1] = b1; d[lit - 1] = b2; }
+        // rare: copies of 68 bytes and more (their 64-byte elements), literal runs beyond 64 bytes - one after the other, whole wave
+        for (uint64_t m = ballot(act && n64 > 0); m; m &= m - 1) {
+            const int k = (int)__builtin_ctzll(m);
+            const uint32_t o = lane_get(cp, k), c = lane_get(n64, k), of = lane_get(off, k);
+            for (uint32_t e = L; e < c; e += kWave) { gbyte* q = out + o + 3 * e; q[0] = (uint8_t)(2 | (63 << 2)); q[1] = (uint8_t)of; q[2] = (uint8_t)(of >> 8); }
+        }
+        for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
+            const int k = (int)__builtin_ctzll(m);
+            wave_copy(out + lane_get(lp, k), in + lane_get(sp, k), lane_get(lit, k), lane);
+        }
+        op += lane_get(oinc, 63); f_anchor = anchor; nrec = 0;
+        wave_fence();
+    };
     if (n >= kMargin) {
         const uint32_t ip_limit = n - kMargin;
         bool extra = false, have_pre = false; Win pre = {0, 0}; uint32_t pre_fill = 0;
@@ -250,7 +325,6 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 mf = fw == avail && maxfwd > avail;
                 fw = fw < maxfwd ? fw : maxfwd;
             }
-            const uint32_t litbyte = seq & 0xFF;
 
             asm volatile("; chain begin" ::: "memory");
             // -------- resolve as many copies as this batch holds --------
@@ -296,12 +370,11 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 if (marks) {
                     const int lastm = 63 - (int)__builtin_clzll(marks);
                     const uint32_t cur = lane_get(endl, lastm);                       // first lane after the last copy (may lie behind the batch)
-                    const bool marked = (marks >> lane) & 1;
-                    const uint64_t below = ~0ull >> (63 - lane) >> 1;
-                    const uint64_t mb_ = marks & below;
-                    const int q = 63 - (int)__builtin_clzll(mb_ | 1);                 // highest marked lane strictly below
-                    const uint32_t qend = (uint32_t)__shfl((int)endl, q);
-                    const bool covered = marked || (mb_ != 0 && (uint32_t)lane < qend);
+                    const bool marked = __builtin_amdgcn_inverse_ballot_w64(marks);
+                    // end of the last copy that starts below this lane (0: none): a DPP prefix maximum over the copies' ends
+                    const uint32_t qend = wave_shr1(wave_scan_max(marked ? endl : 0u));
+                    const bool mb_ = qend != 0;
+                    const bool covered = marked || (uint32_t)lane < qend;
                     const uint64_t cover = ballot(covered);
                     const bool cont = mw != 66 && cur < (uint32_t)hi2;               // the loop below goes on inside this batch
                     {   // table writes the reference performs: every probed lane, and lane end-1 behind every copy (:1016-1017) - for
@@ -310,28 +383,15 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                         uint64_t ends = (cover << 1) & (~cover | marks);
                         if (!cont && cur < 64) ends &= ~(1ull << cur);
                         const uint64_t commit = (belowCur & ~(cover & ~marks)) | ((ends >> 1) & belowCur);
-                        if (((commit >> lane) & 1) && (later & commit) == 0) tput(h, pos, seq);
+                        if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos, seq);
                     }
                     wave_fence();
-                    auto cntbelow = [&](uint64_t mk) -> uint32_t {
-                        return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                    };
+                    // one record per copy, in order behind the buffered ones (a batch of consecutive positions starts at the
+                    // end of a copy: no literals are carried in)
                     const uint32_t lit = marked ? (uint32_t)lane - (mb_ ? qend : 0u) : 0u;       // literals in front of this copy (< 34)
-                    const uint32_t len = 4u + fw, offv = pos - cand;
-                    const bool three = !(len < 12 && offv < 2048);
-                    const uint64_t h1m = ballot(marked && lit > 0), c3m = ballot(marked && three);
-                    const uint64_t litmask = (~0ull >> (63 - lastm)) & ~cover;                    // lanes whose byte is a literal of some copy
-                    const uint32_t S = 2 * cntbelow(marks) + cntbelow(c3m) + cntbelow(h1m);       // tags + copy elements of the copies below
-                    const uint32_t Lb = cntbelow(litmask);
-                    const uint32_t cpos = op + S + Lb + (lit ? 1u : 0u);                          // marked lanes: where the copy element goes
-                    if (marked) {
-                        gbyte* o = out + cpos;
-                        if (lit) o[-(int)lit - 1] = (uint8_t)((lit - 1) << 2);
-                        if (three) { o[0] = (uint8_t)(2 | ((len - 1) << 2)); st16(o + 1, offv); }
-                        else st16(o, (1u | ((len - 4) << 2) | ((offv >> 8) << 5)) | ((offv & 0xFFu) << 8));
-                    }
-                    if ((litmask >> lane) & 1) out[op + S + 1 + Lb] = (uint8_t)litbyte;
-                    op = lane_get(cpos + (three ? 3u : 2u), lastm);
+                    const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
+                    if (marked) rec_put(idx, lit, 4u + fw, pos - cand);
+                    nrec += (uint32_t)__builtin_popcountll(marks);
                     ip = pos0 + cur; anchor = ip;
                     extra = true; i0 = 0;
                     if (mw == 66) done = true;
@@ -381,17 +441,9 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                         break;
                     }
                 }
-                // -------- literal [anchor, m_pos) (:979); none after an immediate re-probe hit --------
-                const uint32_t lit = m_pos - anchor;
-                if (lit) {
-                    if (linlim && anchor >= pos0 && m < linlim) {         // the literal is this batch's own bytes
-                        const uint32_t nl = lit - 1, hdr = nl < 60 ? 1u : 2u, aL = anchor - pos0;
-                        if (lane == 0) { out[op] = (uint8_t)(nl < 60 ? (nl << 2) : (60u << 2)); if (nl >= 60) out[op + 1] = (uint8_t)nl; }
-                        if ((uint32_t)lane >= aL && (uint32_t)lane < aL + lit) out[op + hdr + lane - aL] = (uint8_t)litbyte;
-                        op += hdr + lit;
-                    } else op += emit_literal(out + op, in + anchor, lit, lane);
-                }
-                op += emit_copy(out + op, m_pos - m_cand, matched, lane);
+                // -------- literal [anchor, m_pos) (:979; none after an immediate re-probe hit) + copy: one record --------
+                if (lane == 0) rec_put(nrec, m_pos - anchor, matched, m_pos - m_cand);
+                nrec++;
                 ip = m_pos + matched;
                 anchor = ip;
                 if (ip >= ip_limit) { done = true; break; }               // :1006-1008
@@ -410,16 +462,18 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 break;
             }
             asm volatile("; chain end" ::: "memory");
+            if (nrec > kSnRecFlush || done) { wave_fence(); flush(); }
             if (done) break;
         }
     }
+    if (nrec) { wave_fence(); flush(); }
     if (anchor < n) op += emit_literal(out + op, in + anchor, n - anchor, lane);     // emit_remainder (:1039-1043)
     return op;
 }
 
 template <bool GT, int TAG = 0>
 __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n, gbyte* __restrict__ dst,
-                                const uint32_t cap, uint16_t* table, lu16* scr)
+                                const uint32_t cap, uint16_t* table, lu16* scr, lbyte* recs)
 {
     const int lane = lane_id();
     if ((uint64_t)cap < 32ull + n + n / 6) return 0;                      // api/codec.cpp:271-274
@@ -429,7 +483,7 @@ __device__ int sn_compress_wave(const gbyte* __restrict__ src, const uint32_t n,
     op++;
     for (uint32_t pos = 0; pos < n; pos += kBlock) {                      // snappy.cc:1761-1816
         const uint32_t frag = n - pos < kBlock ? n - pos : kBlock;
-        op += sn_compress_fragment<GT, TAG>(src + pos, frag, dst + op, table, scr, lane);
+        op += sn_compress_fragment<GT, TAG>(src + pos, frag, dst + op, table, scr, recs, lane);
         wave_fence();
     }
     return (int)op;
@@ -630,10 +684,11 @@ __device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_
 __global__ void __launch_bounds__(64) snappy_compress_kernel(aoclgpu_batch b)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
+    __shared__ __attribute__((aligned(16))) uint8_t recs[kSnRecBytes];
     const uint32_t c = blockIdx.x;
     if (c >= b.nchunks) return;
     const ChunkView v = compress_view(b, c);
-    const int r = sn_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
+    const int r = sn_compress_wave<false>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr, (lbyte*)recs);
     if (threadIdx.x == 0) b.out_len[c] = r;
 }
 
@@ -641,10 +696,11 @@ __global__ void __launch_bounds__(64) snappy_compress_kernel(aoclgpu_batch b)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) snappy_compress_gt_kernel(aoclgpu_batch b, uint16_t* tables)
 {
     __shared__ __attribute__((aligned(16))) uint16_t scr[kScratch];
+    __shared__ __attribute__((aligned(16))) uint8_t recs[kSnRecBytes];
     uint16_t* table = tables + (size_t)blockIdx.x * kMaxTable * 2;       // u32[kMaxTable] per workgroup
     for (uint32_t c = blockIdx.x; c < b.nchunks; c += gridDim.x) {
         const ChunkView v = compress_view(b, c);
-        const int r = sn_compress_wave<true, 2>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr);   // (TAG 2: this kernel's register budget, see the mixed kernel)
+        const int r = sn_compress_wave<true, 2>(v.src, v.src_len, v.dst, v.dst_cap, table, (lu16*)scr, (lbyte*)recs);   // (TAG 2: this kernel's register budget, see the mixed kernel)
         if (threadIdx.x == 0) b.out_len[c] = r;
         wave_fence();
     }
@@ -668,6 +724,7 @@ __global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_w
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint16_t scr[SN_MIX_HBM][kScratch];
+    __shared__ __attribute__((aligned(16))) uint8_t recs[1 + SN_MIX_HBM][kSnRecBytes];   // (32 KB + 3 x 2 KB + 4 x 480 B = 31.9 of the CU's 128 granules)
     const uint32_t w = threadIdx.x >> 6;
     uint32_t* gt = tables + ((size_t)blockIdx.x * SN_MIX_HBM + (w ? w - 1 : 0)) * kMaxTable;
     for (;;) {
@@ -677,8 +734,8 @@ __global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_w
         if (c >= b.nchunks) break;
         const ChunkView v = compress_view(b, c);
         int r;
-        if (w == 0) r = sn_compress_wave<false, 1>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr);
-        else r = sn_compress_wave<true, 1>(v.src, v.src_len, v.dst, v.dst_cap, (uint16_t*)gt, (lu16*)scr[w - 1]);
+        if (w == 0) r = sn_compress_wave<false, 1>(v.src, v.src_len, v.dst, v.dst_cap, table, nullptr, (lbyte*)recs[0]);
+        else r = sn_compress_wave<true, 1>(v.src, v.src_len, v.dst, v.dst_cap, (uint16_t*)gt, (lu16*)scr[w - 1], (lbyte*)recs[w]);
         if ((threadIdx.x & 63) == 0) b.out_len[c] = r;
         wave_fence();
     }
