@@ -91,13 +91,18 @@ __device__ __forceinline__ uint32_t emit_copy(gbyte* op, uint32_t offset, uint32
 }
 
 // One <=64 KiB fragment (AOCL_CompressFragment).  Returns bytes written.
-// 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the fragment start read as 0)
-struct Win { uint64_t lo, hi; };
-__device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t p)
+struct Win { u32x4 a, b; };                              // bytes [p, p+16) and [p+16, p+32)
+// 32-byte window [p, p+32): the 4 bytes of the test and 24 (of 28) bytes of forward extension in the lane's own registers - two
+// 16-byte loads instead of two 8-byte loads plus the neighbours' registers by `ds_bpermute` (round 3 took bytes +12 .. +27 from
+// lanes +8 and +16, which only consecutive lanes could do).  far = the second half lies inside the fragment (p + 32 <= n).
+__device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t p, bool far)
 {
+    typedef u32x4 __attribute__((aligned(1))) U;
+    typedef const __attribute__((address_space(1))) U* GP;
     Win w;
-    w.lo = p >= 4 ? ld64(src + p - 4) : ld64(src) << (8 * (4 - p));
-    w.hi = ld64(src + p + 4);
+    w.a = *(GP)(src + p);
+    w.b = u32x4{0u, 0u, 0u, 0u};
+    if (far) w.b = *(GP)(src + p + 16);
     return w;
 }
 
@@ -225,7 +230,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
     };
     if (n >= kMargin) {
         const uint32_t ip_limit = n - kMargin;
-        bool extra = false, have_pre = false; Win pre = {0, 0}; uint32_t pre_fill = 0;
+        bool extra = false, have_pre = false; Win pre = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}; uint32_t pre_fill = 0;
         uint32_t i0 = 0;
         for (;;) {
             asm volatile("; batch begin" ::: "memory");
@@ -247,9 +252,10 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const int linlim = (i0 == 0) ? (extra ? SN_FIRST_WIDTH : 33) : 0;   // lanes [0, linlim) probe consecutive positions
             const int width = i0 == 0 ? (extra ? SN_FIRST_WIDTH : kSearchLanes) : 64;
             const bool act = valid && lane < width;
-            Win pw = {0, 0};
+            const bool far = (uint64_t)pos + 32 <= n;                     // (a candidate lies below its probe: its second half is inside too)
+            Win pw = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
             if (i0 == 0 && have_pre) pw = pre;
-            else if (act) pw = load_win(in, pos);
+            else if (act) pw = load_win(in, pos, far);
             if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
                 const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
                 const uint32_t h1 = sn_hash(fb, shift);
@@ -257,21 +263,14 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 wave_fence();
             }
             have_pre = false;
-            const uint32_t seq = (uint32_t)(pw.lo >> 32);
+            const uint32_t seq = pw.a.x;
             const uint32_t h = sn_hash(seq, shift);
             uint32_t ent = 0;
             if (act) ent = tget(h);
             const uint32_t cand = ent & 0xFFFFu;
             const bool plausible = act && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
-            Win cw = {~pw.lo, 0};
-            if (plausible) cw = load_win(in, cand);
-            // the next 16 candidate bytes (forward extension beyond +12) travel in the same round of loads
-            uint64_t c2 = 0, c3 = 0;
-            const int v2 = __shfl_down((int)valid, 8), v3 = __shfl_down((int)valid, 16);   // all lanes take part
-            const bool have2 = plausible && lane + 8 < linlim && v2 && cand + 20 <= n;
-            const bool have3 = have2 && lane + 16 < linlim && v3 && cand + 28 <= n;
-            if (have2) c2 = ld64(in + cand + 12);
-            if (have3) c3 = ld64(in + cand + 20);
+            Win cw = {{~seq, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (plausible) cw = load_win(in, cand, far);                  // the whole candidate window travels in one round of loads
             wave_fence();
             uint32_t w = (uint32_t)lane;
             if (GT) w = lds_first_lane_per_slot((uint32_t)(uintptr_t)(scr + (h & (kScratch - 1))), (uint32_t)lane, act);
@@ -294,7 +293,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // The batch is cut at the first one that could match.  (With the 10-bit scratch of the HBM-table waves `w` also
             // flags lanes whose full hashes differ: those are ordinary lanes.)  `later` = this lane's slot is named again by
             // these later lanes; within one table commit the last of them owns the slot.
-            const uint64_t tabok = ballot(act && (uint32_t)(cw.lo >> 32) == seq);
+            const uint64_t tabok = ballot(act && cw.a.x == seq);
             uint64_t later = 0;
             int f = 64;
             for (uint64_t d = ballot(act && w != (uint32_t)lane); d; d &= d - 1) {
@@ -315,12 +314,15 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // in-lane forward extension (<= 24 bytes beyond the 4 tested), FindMatchLength snappy-internal.h:228-352
             uint32_t fw; bool mf;
             {
-                const uint64_t p2 = __shfl_down(pw.hi, 8), p3 = __shfl_down(pw.hi, 16);
-                const uint64_t x1 = pw.hi ^ cw.hi, x2 = p2 ^ c2, x3 = p3 ^ c3;
-                uint32_t avail = 8;
+                const uint64_t x1 = (uint64_t)(pw.a.y ^ cw.a.y) | ((uint64_t)(pw.a.z ^ cw.a.z) << 32);
+                const uint64_t x2 = (uint64_t)(pw.a.w ^ cw.a.w) | ((uint64_t)(pw.b.x ^ cw.b.x) << 32);
+                const uint64_t x3 = (uint64_t)(pw.b.y ^ cw.b.y) | ((uint64_t)(pw.b.z ^ cw.b.z) << 32);
+                const uint32_t x4 = pw.b.w ^ cw.b.w;
+                const uint32_t avail = far ? 28u : 8u;
                 fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
-                if (fw == 8 && have2) { avail = 16; fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8; }
-                if (fw == 16 && have3) { avail = 24; fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8; }
+                if (fw == 8 && far) fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
+                if (fw == 16 && far) fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
+                if (fw == 24 && far) fw += x4 ? ((uint32_t)__builtin_ctz(x4) >> 3) : 4;
                 const uint32_t maxfwd = n - (pos + 4);
                 mf = fw == avail && maxfwd > avail;
                 fw = fw < maxfwd ? fw : maxfwd;
@@ -333,8 +335,8 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             auto request_next = [&]() {                   // the windows of the next batch (a search that starts at ip), requested early
                 const uint32_t npos = ip + (uint32_t)lane;
                 const bool nvalid = (lane == 0 || (uint64_t)ip + (uint32_t)lane + 1 <= ip_limit) && lane < SN_FIRST_WIDTH;
-                pre.lo = 0; pre.hi = 0;
-                if (nvalid) pre = load_win(in, npos);
+                pre.a = u32x4{0u, 0u, 0u, 0u}; pre.b = pre.a;
+                if (nvalid) pre = load_win(in, npos, (uint64_t)npos + 32 <= n);
                 pre_fill = ld32(in + ip - 1);
                 have_pre = true;
             };
