@@ -124,7 +124,7 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 // Literal buffer of a block: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the search
 // loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal lengths, short runs one per
 // lane, long runs by the whole wave.  Returns the size of the last literal run (the others were counted by the parse).
-__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws, const u32 nbSeq, const u32 anchor, int lane)
+__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
 {
     u32 lpos = 0;
     for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
@@ -161,6 +161,7 @@ __device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Works
     }
     wave_copy(ws->lits + lpos, src + anchor, n - anchor, lane);
     wave_fence();
+    if (seqLits) *seqLits = lpos;                                       // literals of the sequences (the parse need not count them)
     return n - anchor;
 }
 
@@ -186,6 +187,205 @@ __device__ unsigned long long g_zstd_prof[16];
 #else
 #define ZSTAGE(k) do { } while (0)
 #endif
+// ---- the chain walk of zstd_chain.h as scalar assembly (same inputs, same result; the C++ text stays the specification: the CPU
+//      lane model runs it, -DZSTD_WALK_CXX puts it back into the kernel).  The compiler turns the C++ loop into ~140 scalar
+//      instructions per sequence - conditions kept as 64-bit lane masks, converted through v_cndmask / v_readfirstlane, two dozen
+//      phi copies per iteration; written by hand a table match takes 75 and a repcode 62.  Temporaries are fixed registers
+//      s[83:101] (the operand list of an asm statement ends at 30).  FRAME: the match offset travels in its own VGPR.
+//      Exit word: how (0 ran out of lanes, 1 search continues at lim, 3 special, 4 chain ends with the sequence, 5 no event)
+//      | table match << 3 | post << 4 | event lane << 8 | E << 16 | search start << 24.
+#define ZW_TA  "s[84:85]"
+#define ZW_TB  "s[86:87]"
+#define ZW_OFF_CHUNK "s_and_b32 s98, s88, 0x1ffff\n\t"
+#define ZW_OFF_FRAME "v_readlane_b32 s98, %[offv], s93\n\t"
+#define ZSTD_WALK_ASM(OFFLINE) \
+    "1:\n\t"                                            /* ---- loop top ---- */ \
+    "s_cmp_ge_u32 %[S], %[lim]\n\t" \
+    "s_cbranch_scc1 90f\n\t" \
+    "s_lshr_b64 " ZW_TA ", %[q1], 2\n\t" \
+    "s_lshr_b64 " ZW_TA ", " ZW_TA ", %[S]\n\t" \
+    "s_and_b32 s84, s84, 0x55555555\n\t" \
+    "s_and_b32 s85, s85, 0x55555555\n\t" \
+    "s_lshr_b64 " ZW_TB ", %[ok], %[S]\n\t" \
+    "s_ff1_i32_b64 s91, " ZW_TA "\n\t"                  /* dr, -1: none */ \
+    "s_ff1_i32_b64 s92, " ZW_TB "\n\t"                  /* dm, -1: none */ \
+    "s_mov_b32 s83, %[S]\n\t"                           /* Sev */ \
+    "s_cmp_lt_u32 s92, s91\n\t" \
+    "s_cbranch_scc1 20f\n\t"                            /* table match in front of the first repcode event */ \
+    "s_cmp_eq_u32 s91, -1\n\t" \
+    "s_cbranch_scc1 95f\n\t"                            /* neither */ \
+    /* ---- repcode found by even probe k at k + 2 ---- */ \
+    "s_add_i32 s93, %[S], s91\n\t"                      /* k */ \
+    "s_cmp_ge_u32 s93, %[lim]\n\t" \
+    "s_cbranch_scc1 91f\n\t" \
+    "s_add_i32 s88, s93, 1\n\t" \
+    "s_lshr_b64 " ZW_TA ", %[eq1], s88\n\t"             /* e1k */ \
+    "s_and_b32 s96, s84, 1\n\t"                         /* back1 */ \
+    "s_lshr_b64 " ZW_TA ", " ZW_TA ", 5\n\t" \
+    "s_not_b64 " ZW_TA ", " ZW_TA "\n\t" \
+    "s_ff1_i32_b64 s95, " ZW_TA "\n\t"                  /* f */ \
+    "s_add_i32 s94, s93, s95\n\t" \
+    "s_add_i32 s94, s94, 6\n\t"                         /* E */ \
+    "s_add_i32 s88, s94, 4\n\t" \
+    "s_bfe_u32 s89, %[ends], 0x80008\n\t"               /* end2 */ \
+    "s_min_u32 s90, %[rep2], 1\n\t"                     /* rep2 != 0 */ \
+    "s_cmp_le_u32 s88, s89\n\t" \
+    "s_cselect_b32 s100, s90, 0\n\t"                    /* imm */ \
+    "s_lshr_b64 " ZW_TA ", %[q2], s94\n\t" \
+    "s_and_b32 s88, s84, s100\n\t"                      /* immediate rep2 match */ \
+    "s_and_b32 s89, %[ends], 0xff\n\t"                  /* end1 */ \
+    "s_xor_b32 s101, s100, s90\n\t"                     /* post = rep2 != 0 && !imm */ \
+    "s_sub_i32 s97, s93, s96\n\t" \
+    "s_sub_i32 s97, s97, %[arel]\n\t" \
+    "s_add_i32 s97, s97, 2\n\t"                         /* ll */ \
+    "s_mov_b32 s98, 1\n\t"                              /* offBase */ \
+    "s_add_i32 s99, s96, s95\n\t" \
+    "s_add_i32 s99, s99, 4\n\t"                         /* ml */ \
+    "s_cmp_ge_u32 s94, s89\n\t" \
+    "s_cbranch_scc1 92f\n\t"                            /* the run leaves the known part of the map */ \
+    "s_cmp_lg_u32 s88, 0\n\t" \
+    "s_cbranch_scc1 92f\n\t" \
+    "s_branch 50f\n" \
+    /* ---- table match at lane j ---- */ \
+    "20:\n\t" \
+    "s_add_i32 s93, %[S], s92\n\t"                      /* j */ \
+    "s_and_b32 s89, %[ends], 0xff\n\t"                  /* end1 */ \
+    "s_cmp_lg_u32 s91, -1\n\t" \
+    "s_cbranch_scc1 21f\n\t" \
+    "s_add_i32 s88, s93, 5\n\t"                         /* no repcode event at all: the tests are known below end1 - 5 only */ \
+    "s_cmp_ge_u32 s88, s89\n\t" \
+    "s_cbranch_scc1 95f\n" \
+    "21:\n\t" \
+    "v_readlane_b32 s88, %[info], s93\n\t" \
+    "s_bfe_u32 s95, s88, 0x50011\n\t"                   /* fw */ \
+    "s_bfe_u32 s96, s88, 0x30016\n\t"                   /* catch-up code */ \
+    OFFLINE                                             /* s98 = offset */ \
+    "s_sub_i32 s90, s93, %[arel]\n\t"                   /* room */ \
+    "s_min_u32 s96, s96, s90\n\t"                       /* back */ \
+    "s_add_i32 s94, s93, s95\n\t" \
+    "s_add_i32 s94, s94, 4\n\t"                         /* E */ \
+    "s_add_i32 s88, s94, 4\n\t" \
+    "s_cmp_le_u32 s88, s89\n\t" \
+    "s_cselect_b32 s100, 1, 0\n\t"                      /* imm */ \
+    "s_lshr_b64 " ZW_TA ", %[q1], s94\n\t" \
+    "s_and_b32 s88, s84, s100\n\t"                      /* immediate rep2 match (rep2 = the old rep1) */ \
+    "s_lshr_b64 " ZW_TA ", %[hard], s93\n\t" \
+    "s_and_b32 s84, s84, 1\n\t" \
+    "s_or_b32 s88, s88, s84\n\t" \
+    "s_xor_b32 s101, s100, 1\n\t"                       /* post */ \
+    "s_sub_i32 s97, s93, s96\n\t" \
+    "s_sub_i32 s97, s97, %[arel]\n\t"                   /* ll */ \
+    "s_add_i32 s99, s96, s95\n\t" \
+    "s_add_i32 s99, s99, 4\n\t"                         /* ml */ \
+    "s_cmp_eq_u32 s96, 5\n\t" \
+    "s_cbranch_scc1 93f\n\t"                            /* more than four bytes of catch-up possible */ \
+    "s_cmp_lg_u32 s88, 0\n\t" \
+    "s_cbranch_scc1 93f\n\t" \
+    "s_mov_b32 %[rep2], %[rep1]\n\t" \
+    "s_mov_b32 %[rep1], s98\n\t" \
+    "s_add_i32 s98, s98, 3\n\t"                         /* offBase */ \
+    "s_mov_b64 %[q2], %[q1]\n\t" \
+    "v_readlane_b32 s84, %[eqb], s93\n\t" \
+    "s_lshr_b32 s84, s84, 4\n\t" \
+    "s_mov_b32 s85, 0\n\t" \
+    "s_lshl_b64 %[eq1], " ZW_TA ", s93\n\t" \
+    "s_lshr_b64 " ZW_TA ", %[eq1], 1\n\t" \
+    "s_and_b64 " ZW_TA ", " ZW_TA ", %[eq1]\n\t" \
+    "s_lshr_b64 %[q1], " ZW_TA ", 2\n\t" \
+    "s_and_b64 %[q1], %[q1], " ZW_TA "\n\t" \
+    "s_min_u32 s88, s93, 36\n\t" \
+    "s_add_i32 s88, s88, 28\n\t" \
+    "s_lshl_b32 s89, s89, 8\n\t" \
+    "s_or_b32 %[ends], s89, s88\n" \
+    /* ---- one sequence: park the record, move on ---- */ \
+    "50:\n\t" \
+    "s_mov_b32 m0, %[rl]\n\t" \
+    "v_writelane_b32 %[qll], s97, m0\n\t" \
+    "v_writelane_b32 %[qoff], s98, m0\n\t" \
+    "v_writelane_b32 %[qml], s99, m0\n\t" \
+    "s_add_i32 %[rl], %[rl], 1\n\t" \
+    "s_mov_b32 %[arel], s94\n\t" \
+    "s_mov_b32 %[S], s94\n\t" \
+    "s_sub_i32 s88, s94, 2\n\t" \
+    "s_cmp_ge_u32 s88, %[lim]\n\t" \
+    "s_cbranch_scc1 94f\n\t"                            /* table writes behind the trustworthy lanes */ \
+    "s_cmp_lg_u32 s101, 0\n\t" \
+    "s_cbranch_scc1 94f\n\t"                            /* immediate rep2 test not decidable from the maps */ \
+    "s_lshl_b64 " ZW_TA ", -1, s83\n\t" \
+    "s_add_i32 s89, s93, 2\n\t" \
+    "s_lshl_b64 " ZW_TB ", -2, s89\n\t" \
+    "s_andn2_b64 " ZW_TA ", " ZW_TA ", " ZW_TB "\n\t" \
+    "s_or_b64 %[commit], %[commit], " ZW_TA "\n\t" \
+    "s_bitset1_b64 %[commit], s88\n\t" \
+    "s_branch 1b\n" \
+    /* ---- exits ---- */ \
+    "90:\n\t" "s_mov_b32 %[xw], 0\n\t" "s_branch 99f\n" \
+    "91:\n\t" "s_mov_b32 %[xw], 1\n\t" "s_branch 99f\n" \
+    "95:\n\t" "s_mov_b32 %[xw], 5\n\t" "s_branch 99f\n" \
+    "92:\n\t" "s_mov_b32 %[xw], 3\n\t" "s_branch 96f\n" \
+    "93:\n\t" "s_mov_b32 %[xw], 11\n\t" "s_branch 96f\n" \
+    "94:\n\t" "s_mov_b32 %[xw], 4\n" \
+    "96:\n\t" \
+    "s_lshl_b32 s101, s101, 4\n\t" \
+    "s_lshl_b32 s93, s93, 8\n\t" \
+    "s_lshl_b32 s94, s94, 16\n\t" \
+    "s_lshl_b32 s83, s83, 24\n\t" \
+    "s_or_b32 %[xw], %[xw], s101\n\t" \
+    "s_or_b32 s93, s93, s94\n\t" \
+    "s_or_b32 %[xw], %[xw], s83\n\t" \
+    "s_or_b32 %[xw], %[xw], s93\n" \
+    "99:"
+
+template <bool FRAME>
+__device__ __forceinline__ zchain::WalkOut walk_scalar(const u64 okmask, const u64 hard, const int lim_, int32_t arel_, u32 rep1, u32 rep2, u64 eq1, const u64 eq2,
+                                                       const u32 infoV, const u32 eqbV, const u32 offV, u32& q_ll, u32& q_off, u32& q_ml, u32& nbSeq,
+                                                       const u32 qbase, const int S0, const u64 commit0)
+{
+    auto uni64 = [](u64 v) -> u64 { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); };
+    eq1 = uni64(eq1); rep1 = uni(rep1); rep2 = uni(rep2);
+    const u64 okm = uni64(okmask), hardm = uni64(hard);
+    u64 q1 = zchain::quad(eq1), q2 = zchain::quad(uni64(eq2)), commit = uni64(commit0);
+    u32 S = uni((u32)S0), arel = uni((u32)arel_), ends = 64u | (64u << 8), rl = uni(nbSeq - qbase), xw;
+    const u32 lim = uni((u32)lim_);
+    if constexpr (FRAME)
+        asm volatile(ZSTD_WALK_ASM(ZW_OFF_FRAME)
+            : [S] "+s"(S), [arel] "+s"(arel), [rep1] "+s"(rep1), [rep2] "+s"(rep2), [eq1] "+s"(eq1), [q1] "+s"(q1), [q2] "+s"(q2), [ends] "+s"(ends),
+              [commit] "+s"(commit), [rl] "+s"(rl), [qll] "+v"(q_ll), [qoff] "+v"(q_off), [qml] "+v"(q_ml), [xw] "=&s"(xw)
+            : [ok] "s"(okm), [hard] "s"(hardm), [lim] "s"(lim), [info] "v"(infoV), [eqb] "v"(eqbV), [offv] "v"(offV)
+            : "scc", "m0", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+    else
+        asm volatile(ZSTD_WALK_ASM(ZW_OFF_CHUNK)
+            : [S] "+s"(S), [arel] "+s"(arel), [rep1] "+s"(rep1), [rep2] "+s"(rep2), [eq1] "+s"(eq1), [q1] "+s"(q1), [q2] "+s"(q2), [ends] "+s"(ends),
+              [commit] "+s"(commit), [rl] "+s"(rl), [qll] "+v"(q_ll), [qoff] "+v"(q_off), [qml] "+v"(q_ml), [xw] "=&s"(xw)
+            : [ok] "s"(okm), [hard] "s"(hardm), [lim] "s"(lim), [info] "v"(infoV), [eqb] "v"(eqbV)
+            : "scc", "m0", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+    nbSeq = qbase + rl;
+    // how the chain ended (zstd_chain.h, behind the loop)
+    const u32 how = xw & 7u, el = (xw >> 8) & 0xFFu, E = (xw >> 16) & 0xFFu, Sev = xw >> 24, end1 = ends & 0xFFu;
+    zchain::WalkOut o;
+    o.outcome = zchain::ZC_RESTART; o.S = (int)S; o.R = 0; o.ev = 0; o.el = 0; o.why = 0; o.arel = (int32_t)arel; o.rep1 = rep1; o.rep2 = rep2;
+    o.ntail = 0; o.tail[0] = o.tail[1] = o.tail[2] = 0; o.post = false;
+    if (how == 1) { o.R = (int)lim; commit |= zchain::span(S, lim); o.outcome = zchain::ZC_CONTINUE; }
+    else if (how == 5) {
+        const u32 R = end1 - 5 < lim ? end1 - 5 : lim;
+        if (R < lim && S > 0) o.outcome = end1 < 64 ? zchain::ZC_REFRESH : zchain::ZC_RESTART;
+        else { o.R = (int)R; commit |= zchain::span(S, R); o.outcome = zchain::ZC_CONTINUE; }
+    }
+    else if (how == 3) { commit |= zchain::span(S, el + 1); o.outcome = zchain::ZC_SPECIAL; o.ev = (xw & 8u) ? 1 : 2; o.el = (int)el; }
+    else if (how == 4) {
+        const int w1 = (int)el + 1, w2 = (int)el + 2, w3 = (int)E - 2, l = (int)lim;
+        commit |= zchain::span(Sev, el + 1);
+        o.tail[0] = w1; o.tail[1] = w2; o.tail[2] = w3;
+        o.ntail = (w1 >= l) + (w2 >= l) + (w3 >= l);
+        if (w1 < l) commit |= zchain::lane_bit(w1);
+        if (w2 < l) commit |= zchain::lane_bit(w2);
+        if (w3 < l) commit |= zchain::lane_bit(w3);
+        o.post = (xw & 16u) != 0;
+    }
+    o.commit = commit;
+    return o;
+}
+
 // window of a frame (ZSTD_window_t): indices are position + 2
 struct FrameWindow { u32 dictLimit, lowLimit, maxDist; };
 __device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
@@ -240,19 +440,31 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
     constexpr bool kChk = false;
     constexpr u32 kPosMask = 0x3FFFFu;
     auto chk = [&](u32 v4) -> u32 { return kChk ? ((v4 * 2654435761u) & ~kPosMask) : 0u; };
-    // Sequence records are parked one per lane and written 64 at a time (four coalesced stores): a store in the search
-    // loop would sit in front of every following load in vmcnt order.
-    u32 q_ll = 0, q_off = 0, q_ml = 0, q_src = 0;
-    auto flush_seq = [&](u32 first, u32 count) {
-        if ((u32)lane < count) { ws->seqLL[first + lane] = q_ll; ws->seqOff[first + lane] = q_off; ws->seqML[first + lane] = q_ml; ws->seqSrc[first + lane] = q_src; }
+    // Sequence records are parked one per lane and written 64 at a time (coalesced stores): a store in the search loop
+    // would sit in front of every following load in vmcnt order.  Three fields per record; where a sequence's literals
+    // start (seqSrc, for gather_literals) follows from the sequences before it - they leave no gaps - and is a prefix
+    // sum at flush time.  The chain walk parks up to 16 records per call without looking: room is made in front of it.
+    u32 q_ll = 0, q_off = 0, q_ml = 0;
+    u32 nbSeq = 0, qbase = 0, srcNext = bs;                              // record qbase sits in lane 0; its literals start at srcNext
+    auto flush_seq = [&](u32 count) {
+        const u32 adv = (u32)lane < count ? q_ll + q_ml : 0u;
+        const u32 inc = wave_scan_incl(adv);
+        if ((u32)lane < count) {
+            ws->seqLL[qbase + lane] = q_ll; ws->seqOff[qbase + lane] = q_off; ws->seqML[qbase + lane] = q_ml; ws->seqSrc[qbase + lane] = srcNext + inc - adv;
+        }
+        srcNext += lane_get(inc, 63); qbase += count;
     };
-    auto put_seq = [&](u32 idx, u32 ll, u32 off, u32 ml, u32 srcpos) {         // (wave-uniform arguments: one v_writelane per field)
-        const u32 l = uni(idx & 63u);
-        asm("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
-            : "+v"(q_ll), "+v"(q_off), "+v"(q_ml), "+v"(q_src) : "s"(uni(ll)), "s"(uni(off)), "s"(uni(ml)), "s"(uni(srcpos)), "s"(l) : "m0");
-        if ((idx & 63u) == 63u) flush_seq(idx - 63u, 64);
+    auto park_seq = [&](u32 ll, u32 off, u32 ml) {                      // (wave-uniform arguments: one v_writelane per field)
+        const u32 l = uni(nbSeq - qbase);
+        asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+            : "+v"(q_ll), "+v"(q_off), "+v"(q_ml) : "s"(uni(ll)), "s"(uni(off)), "s"(uni(ml)), "s"(l) : "m0");
+        nbSeq++;
     };
-    u32 nbSeq = 0, litSize = 0, anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
+    auto put_seq = [&](u32 ll, u32 off, u32 ml) {
+        park_seq(ll, off, ml);
+        if (nbSeq - qbase == 64u) flush_seq(64);
+    };
+    u32 anchor = bs, s = bs + (bs == prefixPos ? 1u : 0u), rep1 = 1, rep2 = 0;   // rep {1,4,8}: 4 > maxRep is parked (:484-489)
     u32 saved1 = 0, saved2 = 0;
 #ifdef ZSTD_PREFETCH
     u32 pfacc = 0, pfv = 0;
@@ -304,9 +516,8 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 const u64 vc = ld64(src + ip0);
                 const u32 hc = z_hash<MLS>(vc, hlog);
                 if (lane == 0) tput(hc, ip0 + 2);
-                put_seq(nbSeq, 0, 1, rLength, ip0);
+                put_seq(0, 1, rLength);
                 wave_fence();
-                nbSeq++;
                 ip0 += rLength;
                 hit = ip0 <= ilimit && uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
             }
@@ -379,8 +590,13 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                                 (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
                 const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
                 const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
-                const u32 infoV = near0 ? zchain::pack_info(FRAME ? 0u : c, 0, 7) : zchain::pack_info(FRAME ? 0u : c, fw, bk4);   // (frames: the position travels apart)
+                const u32 offv = pos - c;
+                const u32 infoV = near0 ? zchain::pack_info(FRAME ? 0u : offv, 0, 0)                      // (frames: the offset travels apart)
+                                        : zchain::pack_info(FRAME ? 0u : offv, fw, zchain::back_code(bk4, c - prefixPos));
                 const u64 okmask = ballot(lane < lim && ok);
+                // lanes that take the exact path whatever the parse looks like in front of them: candidate within 4 bytes of the
+                // prefix start, a run that leaves the 28-byte window, table writes that would fall behind lane 63
+                const u64 hard = ballot(near0 || fw >= 24 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62));
                 const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
                 ZSTAGE(6);
                 zchain::WalkOut wo;
@@ -388,14 +604,19 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
                     int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
                     for (;;) {
+                        if (nbSeq - qbase > 47u) flush_seq(nbSeq - qbase);  // (a walk parks at most 16 records)
+#ifdef ZSTD_WALK_CXX
                         if constexpr (FRAME)
-                            wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
-                                [&](int j) -> u64 { return ((u64)lane_get(c, j) << 32) | lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
-                                [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0, prefixPos);
+                            wo = zchain::walk(okmask, hard, lim, pos0, ar, r1, r2, e1, e2,
+                                [&](u32 j) -> u64 { return ((u64)lane_get(offv, (int)j) << 32) | lane_get(infoV, (int)j); }, [&](u32 j) { return lane_get(eqb, (int)j); },
+                                [&](u32 ll, u32 off, u32 ml) { park_seq(ll, off, ml); }, S0, c0);
                         else
-                            wo = zchain::walk(okmask, lim, pos0, ar, r1, r2, e1, e2,
-                                [&](int j) { return lane_get(infoV, j); }, [&](int j) { return lane_get(eqb, j); },
-                                [&](u32 ll, u32 off, u32 ml, u32 apos) { put_seq(nbSeq, ll, off, ml, apos); litSize += ll; nbSeq++; }, S0, c0);
+                            wo = zchain::walk(okmask, hard, lim, pos0, ar, r1, r2, e1, e2,
+                                [&](u32 j) { return lane_get(infoV, (int)j); }, [&](u32 j) { return lane_get(eqb, (int)j); },
+                                [&](u32 ll, u32 off, u32 ml) { park_seq(ll, off, ml); }, S0, c0);
+#else
+                        wo = walk_scalar<FRAME>(okmask, hard, lim, ar, r1, r2, e1, e2, infoV, eqb, offv, q_ll, q_off, q_ml, nbSeq, qbase, S0, c0);
+#endif
                         if (wo.outcome != zchain::ZC_REFRESH) break;
                         ZCOUNT(5);
                         // the map of the current rep1 came from a match's window and ends too early: one load round for full-width
@@ -554,8 +775,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
             ZSTAGE(4);
             {
                 const u32 ll = ip0 - anchor;
-                put_seq(nbSeq, ll, offcode, mLength, anchor);
-                litSize += ll; nbSeq++;
+                put_seq(ll, offcode, mLength);
             }
             ip0 += mLength; anchor = ip0;
             if (ip0 <= ilimit) {                                        // :678-702
@@ -583,12 +803,14 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
         *rep1io = rep1 ? rep1 : saved1;
         *rep2io = rep2 ? rep2 : saved2;
     }
-    flush_seq(nbSeq & ~63u, nbSeq & 63u);
+    flush_seq(nbSeq - qbase);
 #ifdef ZSTD_PREFETCH
     if ((pfacc ^ pfv) == 0x5A17C0DEu) ws->pad[0] = 1;                    // (keeps the prefetch loads alive)
 #endif
     wave_fence();
-    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    u32 seqLits = 0;
+    const u32 lastLits = gather_literals(src, n, ws, nbSeq, anchor, lane, &seqLits);
+    *litSizeOut = seqLits + lastLits;
     return nbSeq;
 }
 

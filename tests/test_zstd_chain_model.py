@@ -57,6 +57,9 @@ def check(model, orc, data: bytes, stats_acc=None):
         raise AssertionError(f"first difference at sequence {k}: model {got[k:k+3].tolist()} oracle {want[k:k+3].tolist()} (n={len(data)})")
     seq0, l0 = sequences(model.zchain_model_sequences, data, None, 0)          # the model's sequential path alone
     assert np.array_equal(seq0, want) and l0 == wl
+    for margin in (8, 1):                                                      # searches resumed inside the batch they start in
+        seq5, l5 = sequences(model.zchain_model_sequences, data, None, 5 | (margin << 8))
+        assert np.array_equal(seq5, want) and l5 == wl, f"resumed batches (margin {margin}) differ from the oracle"
 
 
 @pytest.mark.parametrize("kind", sorted(corpus.KINDS))

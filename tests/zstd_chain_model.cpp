@@ -50,6 +50,7 @@ struct Model {
     std::vector<Seq> seqs;
     u64 litSize = 0;
     u32 lastLits = 0;
+    int resumeMargin = 8;
     u64 stat[40] = {0};   // batches, fast sequences, specials, restarts, continues, sequential searches, tails, post checks; [8+why] specials by reason
     void put(u32 pos) { table[zhash(src + pos, hlog, mls)] = pos + 2; }
 };
@@ -87,18 +88,25 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
             }
             return ip0;
         };
+        // state of the newest chain batch: a search that starts inside it (behind a sequence of the exact path or the
+        // immediate rep2 test) is resumed in the same batch - its lanes below lim are untouched by every table write since
+        bool cb = false; u32 pos0 = 0; int lim = 64; u64 okmask = 0, hard = 0;
+        u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64], hd[64];
+        const bool resumable = (useChain & 4) != 0;
         for (;;) {
             int ev = 0; u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
-            if (useChain && i0 == 0 && s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit) {
+            const bool resume = resumable && cb && i0 == 0 && s > pos0 && (int)(s - pos0) + M.resumeMargin <= lim;
+            cb = false;
+            if (resume || (useChain && i0 == 0 && s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit)) {
                 // ---------------- chain batch: 64 consecutive probes ----------------
+                if (resume) M.stat[34]++; else {
                 M.stat[0]++;
-                const u32 pos0 = s;
-                u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64];
+                pos0 = s;
                 for (int j = 0; j < 64; ++j) {
                     const u32 p = pos0 + (u32)j;
                     h[j] = zhash(src + p, M.hlog, M.mls);
                     ent[j] = M.table[h[j]];
-                    ok[j] = false; eqbv[j] = 0; infov[j] = 0;
+                    ok[j] = false; hd[j] = false; eqbv[j] = 0; infov[j] = 0;
                     if (ent[j] >= prefixIdx) {
                         const u32 c = ent[j] - 2;
                         if (c - prefixPos >= 4) {
@@ -108,30 +116,36 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                             const u32 fw = (u32)__builtin_ctz(fwm);                       // <= 24
                             const u32 bkm = ~(e << 28);
                             const u32 bk4 = (u32)__builtin_clz(bkm);                      // <= 4
-                            eqbv[j] = e; infov[j] = zchain::pack_info_wide(c, fw, bk4);
+                            eqbv[j] = e; infov[j] = zchain::pack_info_wide(p - c, fw, zchain::back_code(bk4, c - prefixPos));
                             ok[j] = ((e >> 4) & 15u) == 15u;
+                            hd[j] = fw >= 24;                                             // the run leaves the window
                         } else {
                             ok[j] = rd32(src + c) == rd32(src + p);
-                            infov[j] = zchain::pack_info_wide(c, 0, 7);
+                            infov[j] = zchain::pack_info_wide(p - c, 0, 0);
+                            hd[j] = true;                                                 // candidate within 4 bytes of the prefix start
                         }
                     }
                 }
-                int lim = 64;
+                lim = 64;
                 for (int j = 1; j < 64 && lim == 64; ++j) for (int i = 0; i < j; ++i) if (h[i] == h[j]) { lim = j; break; }
-                u64 okmask = 0;
-                for (int j = 0; j < lim; ++j) if (ok[j]) okmask |= 1ull << j;
+                okmask = 0; hard = 0;
+                for (int j = 0; j < lim; ++j) if (ok[j]) {
+                    okmask |= 1ull << j;
+                    const int E = j + 4 + (int)(((u32)infov[j] >> 17) & 31u);
+                    if (hd[j] || (E - 2 >= lim && j + 2 >= 64)) hard |= 1ull << j;        // (table writes behind lane 63)
+                }
+                }
                 u64 eq1 = 0, eq2 = 0;
                 for (int j = 0; j < 64; ++j) {
                     const u32 p = pos0 + (u32)j;
-                    if (src[p] == src[p - rep1]) eq1 |= 1ull << j;
-                    if (rep2 && src[p] == src[p - rep2]) eq2 |= 1ull << j;
+                    if (p >= rep1 && src[p] == src[p - rep1]) eq1 |= 1ull << j;
+                    if (rep2 && p >= rep2 && src[p] == src[p - rep2]) eq2 |= 1ull << j;
                 }
-                auto emit = [&](u32 ll, u32 off, u32 ml, u32 apos) {
-                    (void)apos;
+                auto emit = [&](u32 ll, u32 off, u32 ml) {
                     M.seqs.push_back({ll, off, ml}); M.litSize += ll; M.stat[1]++;
                 };
-                zchain::WalkOut w = zchain::walk(okmask, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
-                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, 0, 0, prefixPos);
+                zchain::WalkOut w = zchain::walk(okmask, hard, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
+                    [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, resume ? (int)(s - pos0) : 0, 0);
                 while (w.outcome == zchain::ZC_REFRESH) {                                 // fresh full-width maps for the current repcodes
                     M.stat[33]++;
                     u64 e1 = 0, e2 = 0;
@@ -140,8 +154,8 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                         if (p >= w.rep1 && src[p] == src[p - w.rep1]) e1 |= 1ull << j;           // (lanes below S may lie before the offset's reach)
                         if (w.rep2 && p >= w.rep2 && src[p] == src[p - w.rep2]) e2 |= 1ull << j;
                     }
-                    w = zchain::walk(okmask, lim, pos0, w.arel, w.rep1, w.rep2, e1, e2,
-                        [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit, prefixPos);
+                    w = zchain::walk(okmask, hard, lim, pos0, w.arel, w.rep1, w.rep2, e1, e2,
+                        [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit);
                 }
                 for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
                 if (g_trace && g_trace_n < 4096) {
@@ -154,12 +168,12 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                     M.stat[3]++;
                     for (int t = 3 - w.ntail; t < 3; ++t) M.put(pos0 + (u32)w.tail[t]);
                     if (w.ntail) M.stat[6]++;
-                    if (w.post) { M.stat[7]++; s = rep_loop(s); anchor = s; }
+                    if (w.post) { M.stat[7]++; s = rep_loop(s); anchor = s; cb = true; }
                     continue;
                 }
                 if (w.outcome == zchain::ZC_CONTINUE) { M.stat[4]++; i0 = (u32)(w.R - w.S); }
                 else {
-                    M.stat[2]++; M.stat[8 + (w.why & 31)]++;
+                    M.stat[2]++; M.stat[8 + (w.why & 31)]++; cb = true;
                     ev = w.ev; e_pos = pos0 + (u32)w.el; e_cand = ent[w.el]; e_sig = 2; e_st = 2; e_half = (u32)(w.el - w.S) & 1u;
                 }
             }
@@ -217,6 +231,8 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
 extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, size_t* litSizeOut, u64* stats, int useChain)
 {
     Model M; M.src = src; M.n = (u32)n_;
+    if (useChain >> 8) M.resumeMargin = useChain >> 8;
+    useChain &= 255;
     const u32 n = M.n;
     {   // level1_params (oracle/zstd_oracle.c)
         const u32 srcLog = (n < 64) ? 6 : (u32)hb(n - 1) + 1;
@@ -231,7 +247,7 @@ extern "C" size_t zchain_model_sequences(const u8* src, size_t n_, u32* out, siz
     for (size_t i = 0; i < M.seqs.size(); ++i) { out[4 * i] = M.seqs[i].ll; out[4 * i + 1] = M.seqs[i].off; out[4 * i + 2] = M.seqs[i].ml; out[4 * i + 3] = 0; }
     *litSizeOut = (size_t)M.litSize;
     if (stats) memcpy(stats, M.stat, 8 * sizeof(u64));
-    if (stats && useChain == 2) memcpy(stats, M.stat, sizeof(M.stat));
+    if (stats && (useChain & 2)) memcpy(stats, M.stat, sizeof(M.stat));
     return M.seqs.size();
 }
 
