@@ -359,6 +359,9 @@ __device__ __forceinline__ zchain::WalkOut walk_scalar(const u64 okmask, const u
               [commit] "+s"(commit), [rl] "+s"(rl), [qll] "+v"(q_ll), [qoff] "+v"(q_off), [qml] "+v"(q_ml), [xw] "=&s"(xw)
             : [ok] "s"(okm), [hard] "s"(hardm), [lim] "s"(lim), [info] "v"(infoV), [eqb] "v"(eqbV)
             : "scc", "m0", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101");
+    // (the outputs of an asm statement with several results count as divergent; readfirstlane of a scalar register costs
+    //  nothing and gives what follows its scalar compares and branches back)
+    xw = uni(xw); S = uni(S); arel = uni(arel); rep1 = uni(rep1); rep2 = uni(rep2); ends = uni(ends); rl = uni(rl); commit = uni64(commit);
     nbSeq = qbase + rl;
     // how the chain ended (zstd_chain.h, behind the loop)
     const u32 how = xw & 7u, el = (xw >> 8) & 0xFFu, E = (xw >> 16) & 0xFFu, Sev = xw >> 24, end1 = ends & 0xFFu;
@@ -373,13 +376,12 @@ __device__ __forceinline__ zchain::WalkOut walk_scalar(const u64 okmask, const u
     }
     else if (how == 3) { commit |= zchain::span(S, el + 1); o.outcome = zchain::ZC_SPECIAL; o.ev = (xw & 8u) ? 1 : 2; o.el = (int)el; }
     else if (how == 4) {
-        const int w1 = (int)el + 1, w2 = (int)el + 2, w3 = (int)E - 2, l = (int)lim;
-        commit |= zchain::span(Sev, el + 1);
-        o.tail[0] = w1; o.tail[1] = w2; o.tail[2] = w3;
-        o.ntail = (w1 >= l) + (w2 >= l) + (w3 >= l);
-        if (w1 < l) commit |= zchain::lane_bit(w1);
-        if (w2 < l) commit |= zchain::lane_bit(w2);
-        if (w3 < l) commit |= zchain::lane_bit(w3);
+        const u32 w3 = E - 2;
+        u64 bits = (3ull << el) << 1;                                   // lanes el + 1, el + 2 (bits 64, 65 fall off)
+        if (w3 < 64u) bits |= 1ull << w3;
+        commit |= zchain::span(Sev, el + 1) | (bits & (~0ull >> (64u - lim)));   // (1 <= lim <= 64)
+        o.tail[0] = (int)el + 1; o.tail[1] = (int)el + 2; o.tail[2] = (int)w3;
+        o.ntail = (int)((el + 1 >= lim ? 1u : 0u) + (el + 2 >= lim ? 1u : 0u) + (w3 >= lim ? 1u : 0u));
         o.post = (xw & 16u) != 0;
     }
     o.commit = commit;
@@ -523,119 +525,149 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
             }
             return ip0;
         };
+        // State of the newest chain batch.  A search that starts inside it - behind a sequence of the exact path, behind the
+        // immediate rep2 matches of rep_loop - is RESUMED in the same batch: every table write since then was made for a lane
+        // in front of that search, and the lanes below lim have slots of their own, so what they read at the start of the
+        // batch is what the reference reads; only the equality maps of the current repcodes have to be loaded (one round).
+#ifndef ZSTD_RESUME_MARGIN
+#define ZSTD_RESUME_MARGIN 8
+#endif
+        bool cbv = false;
+        u32 b_pos0 = 0, b_h = 0, b_ent = 0, b_info = 0, b_eqb = 0, b_off = 0, b_pb0 = 0, b_flags = 0;   // flags: 1 match below lim, 2 hard
+        int b_lim = 0;
         for (;;) {                                                      // _start
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
             u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
             bool e_ok1 = false, e_ok2 = false;
-            if (chain && s >= bs + 4 && (!FRAME || rep1 > 0) && (u64)s + 100 < ilimit) {
+            bool resume = false;
+            if (cbv) {
+                const u32 d = uni(s - b_pos0);                          // (s > b_pos0: at least one sequence since the batch began)
+                resume = d + ZSTD_RESUME_MARGIN <= (u32)b_lim && (ballot((b_flags & 1u) != 0) >> d) != 0;
+            }
+            cbv = false;
+            if (resume || (chain && s >= bs + 4 && (!FRAME || rep1 > 0) && (u64)s + 100 < ilimit)) {
                 // ---------------- chain batch: the 64 consecutive probes a search starts with; every sequence they
                 //                  hold is resolved from registers by the scalar walk of zstd_chain.h ----------------
-                const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
-                typedef u32x4 __attribute__((aligned(1))) U4;
-                typedef const __attribute__((address_space(1))) U4* GP4;
-                // probe windows [pos-4, pos+28) from the source ring
-                const u32 rel0 = pos0 - 4 - bs;
-                const int32_t bl = (int32_t)(((u64)rel0 * 17895698ull) >> 32), bh = (int32_t)(((u64)(rel0 + 94) * 17895698ull) >> 32);   // / 240
-                if (!(bh <= rb && rb <= bl + 1)) {
-                    if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
-                    else {
-                        const u32 v0 = blk_load(bl), v1 = blk_load(bh);
-                        blk_store(bl, v0);
-                        if (bh != bl) blk_store(bh, v1);
-                        rb = bh;
+                u64 e1 = 0, e2 = 0;
+                if (!resume) {
+                    const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
+                    typedef u32x4 __attribute__((aligned(1))) U4;
+                    typedef const __attribute__((address_space(1))) U4* GP4;
+                    // probe windows [pos-4, pos+28) from the source ring
+                    const u32 rel0 = pos0 - 4 - bs;
+                    const int32_t bl = (int32_t)(((u64)rel0 * 17895698ull) >> 32), bh = (int32_t)(((u64)(rel0 + 94) * 17895698ull) >> 32);   // / 240
+                    if (!(bh <= rb && rb <= bl + 1)) {
+                        if (have_pend && rb + 1 == bh && bl >= rb) { blk_store(rb + 1, pend); rb++; }
+                        else {
+                            const u32 v0 = blk_load(bl), v1 = blk_load(bh);
+                            blk_store(bl, v0);
+                            if (bh != bl) blk_store(bh, v1);
+                            rb = bh;
+                        }
+                        pend = blk_load(rb + 1); have_pend = true;
+                        wave_fence();
                     }
-                    pend = blk_load(rb + 1); have_pend = true;
-                    wave_fence();
-                }
-                u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
-                if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
-                const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
-                // byte equality at the two repcode distances over the 64 lanes: one byte load per lane each
-                const u32 b1 = src[pos - rep1];
-                u32 b2 = 0x100;
-                if (rep2) b2 = src[pos - rep2];
-                ZSTAGE(0);
+                    u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
+                    if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
+                    const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
+                    // byte equality at the two repcode distances over the 64 lanes: one byte load per lane each
+                    const u32 b1 = src[pos - rep1];
+                    u32 b2 = 0x100;
+                    if (rep2) b2 = src[pos - rep2];
+                    ZSTAGE(0);
 #ifdef ZSTD_PROF
-                zbatches++;
+                    zbatches++;
 #endif
-                const u64 seq = pa.y | ((u64)pa.z << 32);
-                const u32 h = z_hash<MLS>(seq, hlog);
-                const u32 ent = tget(h);
-                const bool has = ent >= prefixIdx;
-                const u32 c = ent - 2;
-                const bool near0 = c - prefixPos < 4;                   // candidate within 4 bytes of the chunk / prefix start: exact path
-                u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
-                if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }   // candidate window [c-4, c+28)
-                wave_fence();
-                ZSTAGE(1);
-                const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
-                wave_fence();
-                table[h] = (T)ent;                                        // low halves only: the extra bits were not touched
-                wave_fence();
-                ZSTAGE(2);
+                    const u64 seq = pa.y | ((u64)pa.z << 32);
+                    const u32 h = z_hash<MLS>(seq, hlog);
+                    const u32 ent = tget(h);
+                    const bool has = ent >= prefixIdx;
+                    const u32 c = ent - 2;
+                    const bool near0 = c - prefixPos < 4;               // candidate within 4 bytes of the chunk / prefix start: exact path
+                    u32x4 ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+                    if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }   // candidate window [c-4, c+28)
+                    wave_fence();
+                    ZSTAGE(1);
+                    const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
+                    wave_fence();
+                    table[h] = (T)ent;                                    // low halves only: the extra bits were not touched
+                    wave_fence();
+                    ZSTAGE(2);
 #ifdef ZSTD_PREFETCH
-                {   // warm the cache with the NEXT batch's candidates (positions pos0+64 ..): their table entries are known now
-                    // (bar the few slots this batch commits), and the line is then on its way while this batch is resolved
-                    pfacc ^= pfv;
-                    const u32 pn = pos + 64;
-                    if (pn + 8 <= n) {
-                        const u32 en = tget(z_hash<MLS>(ld64(src + pn), hlog));
-                        if (en >= prefixIdx + 2) pfv = src[en - 2];
+                    {   // warm the cache with the NEXT batch's candidates (positions pos0+64 ..): their table entries are known now
+                        // (bar the few slots this batch commits), and the line is then on its way while this batch is resolved
+                        pfacc ^= pfv;
+                        const u32 pn = pos + 64;
+                        if (pn + 8 <= n) {
+                            const u32 en = tget(z_hash<MLS>(ld64(src + pn), hlog));
+                            if (en >= prefixIdx + 2) pfv = src[en - 2];
+                        }
                     }
-                }
 #endif
-                const int lim = first_lane(ballot(w != (u32)lane));
-                using zchain::zero_bytes;
-                const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
-                                (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
-                const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
-                const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
-                const u32 offv = pos - c;
-                const u32 infoV = near0 ? zchain::pack_info(FRAME ? 0u : offv, 0, 0)                      // (frames: the offset travels apart)
-                                        : zchain::pack_info(FRAME ? 0u : offv, fw, zchain::back_code(bk4, c - prefixPos));
-                const u64 okmask = ballot(lane < lim && ok);
-                // lanes that take the exact path whatever the parse looks like in front of them: candidate within 4 bytes of the
-                // prefix start, a run that leaves the 28-byte window, table writes that would fall behind lane 63
-                const u64 hard = ballot(near0 || fw >= 24 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62));
-                const u32 pb0 = pa.y & 0xFFu;                           // the byte at pos
-                ZSTAGE(6);
+                    const int lim = first_lane(ballot(w != (u32)lane));
+                    using zchain::zero_bytes;
+                    const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
+                                    (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
+                    const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
+                    const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
+                    const u32 offv = pos - c;
+                    // lanes that take the exact path whatever the parse looks like in front of them: candidate within 4 bytes of the
+                    // prefix start, a run that leaves the 28-byte window, table writes that would fall behind lane 63
+                    const bool hardl = near0 || fw >= 24 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62);
+                    b_pos0 = pos0; b_lim = lim; b_h = h; b_ent = ent; b_eqb = eqb; b_off = offv; b_pb0 = pa.y & 0xFFu;   // (the byte at pos)
+                    b_info = near0 ? zchain::pack_info(FRAME ? 0u : offv, 0, 0)                          // (frames: the offset travels apart)
+                                   : zchain::pack_info(FRAME ? 0u : offv, fw, zchain::back_code(bk4, c - prefixPos));
+                    b_flags = ((lane < lim && ok) ? 1u : 0u) | (hardl ? 2u : 0u);
+                    e1 = ballot(b_pb0 == b1); e2 = ballot(b_pb0 == b2);
+                    ZSTAGE(6);
+                }
+                const u32 pos0 = b_pos0, pos = pos0 + (u32)lane;
+                const int lim = b_lim;
+                const u64 okmask = ballot((b_flags & 1u) != 0), hard = ballot((b_flags & 2u) != 0);
                 zchain::WalkOut wo;
                 {
-                    u64 e1 = ballot(pb0 == b1), e2 = ballot(pb0 == b2), c0 = 0;
-                    int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = 0; u32 r1 = rep1, r2 = rep2;
+                    u64 c0 = 0;
+                    int32_t ar = (int32_t)anchor - (int32_t)pos0; int S0 = resume ? (int)(s - pos0) : 0; u32 r1 = rep1, r2 = rep2;
+                    bool need_maps = resume;                            // (a resumed search begins at the anchor: ar == S0)
                     for (;;) {
+                        if (need_maps) {
+                            // one load round for full-width maps of both repcodes (lanes below a repcode's reach are not needed)
+                            u32 nb1 = 0x100, nb2 = 0x100;
+                            if (pos >= r1) nb1 = src[pos - r1];
+                            if (r2 && pos >= r2) nb2 = src[pos - r2];
+                            e1 = ballot(b_pb0 == nb1); e2 = ballot(b_pb0 == nb2);
+                        }
                         if (nbSeq - qbase > 47u) flush_seq(nbSeq - qbase);  // (a walk parks at most 16 records)
 #ifdef ZSTD_WALK_CXX
                         if constexpr (FRAME)
                             wo = zchain::walk(okmask, hard, lim, pos0, ar, r1, r2, e1, e2,
-                                [&](u32 j) -> u64 { return ((u64)lane_get(offv, (int)j) << 32) | lane_get(infoV, (int)j); }, [&](u32 j) { return lane_get(eqb, (int)j); },
+                                [&](u32 j) -> u64 { return ((u64)lane_get(b_off, (int)j) << 32) | lane_get(b_info, (int)j); }, [&](u32 j) { return lane_get(b_eqb, (int)j); },
                                 [&](u32 ll, u32 off, u32 ml) { park_seq(ll, off, ml); }, S0, c0);
                         else
                             wo = zchain::walk(okmask, hard, lim, pos0, ar, r1, r2, e1, e2,
-                                [&](u32 j) { return lane_get(infoV, (int)j); }, [&](u32 j) { return lane_get(eqb, (int)j); },
+                                [&](u32 j) { return lane_get(b_info, (int)j); }, [&](u32 j) { return lane_get(b_eqb, (int)j); },
                                 [&](u32 ll, u32 off, u32 ml) { park_seq(ll, off, ml); }, S0, c0);
 #else
-                        wo = walk_scalar<FRAME>(okmask, hard, lim, ar, r1, r2, e1, e2, infoV, eqb, offv, q_ll, q_off, q_ml, nbSeq, qbase, S0, c0);
+                        wo = walk_scalar<FRAME>(okmask, hard, lim, ar, r1, r2, e1, e2, b_info, b_eqb, b_off, q_ll, q_off, q_ml, nbSeq, qbase, S0, c0);
 #endif
-                        if (wo.outcome != zchain::ZC_REFRESH) break;
-                        ZCOUNT(5);
-                        // the map of the current rep1 came from a match's window and ends too early: one load round for full-width
-                        // maps of both repcodes instead of a whole new batch (lanes below the repcode's reach are not needed)
-                        u32 nb1 = 0x100, nb2 = 0x100;
-                        if (pos >= wo.rep1) nb1 = src[pos - wo.rep1];
-                        if (wo.rep2 && pos >= wo.rep2) nb2 = src[pos - wo.rep2];
-                        e1 = ballot(pb0 == nb1); e2 = ballot(pb0 == nb2);
-                        S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2;
+                        if (wo.outcome == zchain::ZC_REFRESH) {
+                            // the map of the current rep1 came from a match's window and ends too early: fresh maps instead of a
+                            // whole new batch
+                            ZCOUNT(5);
+                            S0 = wo.S; c0 = wo.commit; ar = wo.arel; r1 = wo.rep1; r2 = wo.rep2; need_maps = true;
+                            continue;
+                        }
+                        break;
                     }
                 }
                 ZSTAGE(7);
-                if ((wo.commit >> lane) & 1) tput(h, pos + 2);
+                if ((wo.commit >> lane) & 1) tput(b_h, pos + 2);
                 wave_fence();
 #ifdef ZSTD_TRACE
                 if (lane == 0 && g_ztrace_n < 4096) {
                     unsigned long long* t = g_ztrace + 8 * g_ztrace_n++;
                     t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = wo.commit; t[4] = (u32)wo.outcome | ((u64)(u32)wo.S << 8) | ((u64)(u32)wo.ev << 16) | ((u64)(u32)wo.el << 24) | ((u64)(u32)wo.ntail << 32) | ((u64)wo.post << 40);
-                    t[5] = ballot(pb0 == b1); t[6] = ballot(pb0 == b2); t[7] = ((u64)rep1 << 32) | rep2;
+                    t[5] = e1; t[6] = e2; t[7] = ((u64)rep1 << 32) | rep2;
                 }
 #endif
                 anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
@@ -646,22 +678,22 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     for (int t = 0; t < 3; ++t) {                       // the chain's last table writes, one by one
                         if (t >= 3 - wo.ntail) {
                             const int idx = wo.tail[t];
-                            const u32 hh = idx < 64 ? lane_get(h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
+                            const u32 hh = idx < 64 ? lane_get(b_h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
                             if (lane == 0) tput(hh, pos0 + (u32)idx + 2);
                             wave_fence();
                         }
                     }
-                    if (wo.post) { s = rep_loop(s); anchor = s; }
+                    if (wo.post) { s = rep_loop(s); anchor = s; cbv = true; }
                     ZSTAGE(4);
                     continue;
                 }
                 if (wo.outcome == zchain::ZC_CONTINUE) i0 = (u32)(wo.R - wo.S);
                 else {
                     const int el = wo.el;
-                    ev = wo.ev;
-                    e_pos = pos0 + (u32)el; e_cand = lane_get(ent, el); e_sig = 2; e_st = 2; e_half = (u32)(el - wo.S) & 1u;
-                    e_ok1 = el + 1 < 64; e_p1 = e_pos + 1; e_h1 = lane_get(h, (el + 1) & 63);
-                    e_ok2 = el + 2 < 64; e_h2 = lane_get(h, (el + 2) & 63);
+                    ev = wo.ev; cbv = true;
+                    e_pos = pos0 + (u32)el; e_cand = lane_get(b_ent, el); e_sig = 2; e_st = 2; e_half = (u32)(el - wo.S) & 1u;
+                    e_ok1 = el + 1 < 64; e_p1 = e_pos + 1; e_h1 = lane_get(b_h, (el + 1) & 63);
+                    e_ok2 = el + 2 < 64; e_h2 = lane_get(b_h, (el + 2) & 63);
                 }
             }
             if (!ev) for (;;) {

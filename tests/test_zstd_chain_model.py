@@ -57,9 +57,11 @@ def check(model, orc, data: bytes, stats_acc=None):
         raise AssertionError(f"first difference at sequence {k}: model {got[k:k+3].tolist()} oracle {want[k:k+3].tolist()} (n={len(data)})")
     seq0, l0 = sequences(model.zchain_model_sequences, data, None, 0)          # the model's sequential path alone
     assert np.array_equal(seq0, want) and l0 == wl
-    for margin in (8, 1):                                                      # searches resumed inside the batch they start in
-        seq5, l5 = sequences(model.zchain_model_sequences, data, None, 5 | (margin << 8))
-        assert np.array_equal(seq5, want) and l5 == wl, f"resumed batches (margin {margin}) differ from the oracle"
+    # searches resumed inside the batch they start in (4), only when a matching lane is left (8), long matches that end inside
+    # the batch taken from the equality map of their own distance (16)
+    for mode in (5 | (8 << 8), 5 | (1 << 8), 29 | (8 << 8), 29 | (2 << 8)):
+        seq5, l5 = sequences(model.zchain_model_sequences, data, None, mode)
+        assert np.array_equal(seq5, want) and l5 == wl, f"resumed batches (mode {mode:#x}) differ from the oracle"
 
 
 @pytest.mark.parametrize("kind", sorted(corpus.KINDS))

@@ -91,14 +91,16 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
         // state of the newest chain batch: a search that starts inside it (behind a sequence of the exact path or the
         // immediate rep2 test) is resumed in the same batch - its lanes below lim are untouched by every table write since
         bool cb = false; u32 pos0 = 0; int lim = 64; u64 okmask = 0, hard = 0;
-        u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64], hd[64];
+        u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64], hd[64], lg[64];
         const bool resumable = (useChain & 4) != 0;
         for (;;) {
             int ev = 0; u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
-            const bool resume = resumable && cb && i0 == 0 && s > pos0 && (int)(s - pos0) + M.resumeMargin <= lim;
+            const bool resume = resumable && cb && i0 == 0 && s > pos0 && (int)(s - pos0) + M.resumeMargin <= lim &&
+                                (!(useChain & 8) || (okmask >> (s - pos0)) != 0);
             cb = false;
             if (resume || (useChain && i0 == 0 && s >= bs + 4 && rep1 > 0 && (u64)s + 100 < ilimit)) {
                 // ---------------- chain batch: 64 consecutive probes ----------------
+                const u64 seqs0 = M.stat[1];
                 if (resume) M.stat[34]++; else {
                 M.stat[0]++;
                 pos0 = s;
@@ -106,7 +108,7 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                     const u32 p = pos0 + (u32)j;
                     h[j] = zhash(src + p, M.hlog, M.mls);
                     ent[j] = M.table[h[j]];
-                    ok[j] = false; hd[j] = false; eqbv[j] = 0; infov[j] = 0;
+                    ok[j] = false; hd[j] = false; lg[j] = false; eqbv[j] = 0; infov[j] = 0;
                     if (ent[j] >= prefixIdx) {
                         const u32 c = ent[j] - 2;
                         if (c - prefixPos >= 4) {
@@ -119,6 +121,7 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                             eqbv[j] = e; infov[j] = zchain::pack_info_wide(p - c, fw, zchain::back_code(bk4, c - prefixPos));
                             ok[j] = ((e >> 4) & 15u) == 15u;
                             hd[j] = fw >= 24;                                             // the run leaves the window
+                            lg[j] = ok[j] && fw >= 24;
                         } else {
                             ok[j] = rd32(src + c) == rd32(src + p);
                             infov[j] = zchain::pack_info_wide(p - c, 0, 0);
@@ -157,6 +160,7 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                     w = zchain::walk(okmask, hard, lim, pos0, w.arel, w.rep1, w.rep2, e1, e2,
                         [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit);
                 }
+                if (resume && M.stat[1] > seqs0) M.stat[35]++;
                 for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
                 if (g_trace && g_trace_n < 4096) {
                     u64* t = g_trace + 8 * g_trace_n++;
@@ -172,6 +176,27 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                     continue;
                 }
                 if (w.outcome == zchain::ZC_CONTINUE) { M.stat[4]++; i0 = (u32)(w.R - w.S); }
+                else if ((useChain & 16) && w.ev == 1 && lg[w.el] && w.el <= 59 &&
+                         ((((u32)infov[w.el] >> 22) & 7u) < 5u || (u32)(w.el - w.arel) < 5u) &&
+                         [&]() {
+                    // a match that runs out of its lane's 28-byte window but ends inside the batch: its length is the run of the
+                    // equality map at the match's own distance (one byte load per lane) - no exact path, and the parse goes on in
+                    // this batch (the search behind it is resumed)
+                    const int j = w.el;
+                    const u32 off = (u32)(infov[j] >> 32), bk = ((u32)infov[j] >> 22) & 7u;
+                    const u32 room = (u32)(j - w.arel), back = bk < room ? bk : room;
+                    u64 m = 0;
+                    for (int i = 0; i < 64; ++i) { const u32 p = pos0 + (u32)i; if (p >= off && src[p] == src[p - off]) m |= 1ull << i; }
+                    const u32 run = zchain::ctz64u(~(m >> (j + 4))), E = (u32)j + 4 + run;
+                    if (E > 63) return false;                                             // reaches the end of the batch: length unknown
+                    M.stat[36]++;
+                    const u32 ip0 = pos0 + (u32)j - back;
+                    M.seqs.push_back({ip0 - anchor, off + 3, 4 + back + run}); M.litSize += ip0 - anchor;
+                    rep2 = rep1; rep1 = off;
+                    M.put(pos0 + (u32)j + 1); M.put(pos0 + (u32)j + 2); M.put(pos0 + E - 2);
+                    s = rep_loop(pos0 + E); anchor = s;
+                    return true;
+                }()) { cb = true; continue; }
                 else {
                     M.stat[2]++; M.stat[8 + (w.why & 31)]++; cb = true;
                     ev = w.ev; e_pos = pos0 + (u32)w.el; e_cand = ent[w.el]; e_sig = 2; e_st = 2; e_half = (u32)(w.el - w.S) & 1u;
