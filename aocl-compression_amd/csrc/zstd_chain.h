@@ -195,4 +195,15 @@ ZC_FN uint32_t zero_bytes(uint32_t x)
     return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 15u;
 }
 
+// 8-bit mask of the zero bytes of the pair (x0, x1): bit k <-> byte k of x0, bit 4 + k <-> byte k of x1.  The zero flags
+// (bit 7 of every zero byte) of x0 are moved into bit 3 of their bytes next to x1's in bit 7, and one multiplication gathers
+// the eight of them in the product's top byte: flag 8k+3 and flag 8k+7 both travel 21-7k bits up (to 24+k and 28+k), and no two
+// partial products share a bit, so there are no carries.
+ZC_FN uint32_t zero_bytes8(uint32_t x0, uint32_t x1)
+{
+    const uint32_t t0 = ((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0, t1 = ((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1;
+    const uint32_t f = ((~t0 >> 4) & 0x08080808u) | (~t1 & 0x80808080u);
+    return (f * 0x00204081u) >> 24;
+}
+
 }  // namespace zchain

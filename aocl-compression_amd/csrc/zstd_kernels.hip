@@ -548,6 +548,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
             if (resume || (chain && s >= bs + 4 && (!FRAME || rep1 > 0) && (u64)s + 100 < ilimit)) {
                 // ---------------- chain batch: the 64 consecutive probes a search starts with; every sequence they
                 //                  hold is resolved from registers by the scalar walk of zstd_chain.h ----------------
+                asm volatile("; batch begin");
                 u64 e1 = 0, e2 = 0;
                 if (!resume) {
                     const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
@@ -578,6 +579,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
 #ifdef ZSTD_PROF
                     zbatches++;
 #endif
+                asm volatile("; probe begin");
                     const u64 seq = pa.y | ((u64)pa.z << 32);
                     const u32 h = z_hash<MLS>(seq, hlog);
                     const u32 ent = tget(h);
@@ -588,6 +590,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     if (has) { const u32 a0 = near0 ? c : c - 4; ca = *(GP4)(src + a0); cb = *(GP4)(src + a0 + 16); }   // candidate window [c-4, c+28)
                     wave_fence();
                     ZSTAGE(1);
+                asm volatile("; slots begin");
                     const u32 w = lds_first_lane_per_slot((u32)(uintptr_t)&table[h], (u32)lane);
                     wave_fence();
                     table[h] = (T)ent;                                    // low halves only: the extra bits were not touched
@@ -604,10 +607,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                         }
                     }
 #endif
+                asm volatile("; masks begin");
                     const int lim = first_lane(ballot(w != (u32)lane));
-                    using zchain::zero_bytes;
-                    const u32 eqb = zero_bytes(pa.x ^ ca.x) | (zero_bytes(pa.y ^ ca.y) << 4) | (zero_bytes(pa.z ^ ca.z) << 8) | (zero_bytes(pa.w ^ ca.w) << 12) |
-                                    (zero_bytes(pb.x ^ cb.x) << 16) | (zero_bytes(pb.y ^ cb.y) << 20) | (zero_bytes(pb.z ^ cb.z) << 24) | (zero_bytes(pb.w ^ cb.w) << 28);
+                    using zchain::zero_bytes8;
+                    const u32 eqb = zero_bytes8(pa.x ^ ca.x, pa.y ^ ca.y) | (zero_bytes8(pa.z ^ ca.z, pa.w ^ ca.w) << 8) |
+                                    (zero_bytes8(pb.x ^ cb.x, pb.y ^ cb.y) << 16) | (zero_bytes8(pb.z ^ cb.z, pb.w ^ cb.w) << 24);
                     const u32 fw = (u32)__builtin_ctz(~(eqb >> 8)), bk4 = (u32)__builtin_clz(~(eqb << 28));
                     const bool ok = has && (near0 ? ca.x == pa.y : ((eqb >> 4) & 15u) == 15u);
                     const u32 offv = pos - c;
@@ -621,6 +625,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     e1 = ballot(b_pb0 == b1); e2 = ballot(b_pb0 == b2);
                     ZSTAGE(6);
                 }
+                asm volatile("; walk begin");
                 const u32 pos0 = b_pos0, pos = pos0 + (u32)lane;
                 const int lim = b_lim;
                 const u64 okmask = ballot((b_flags & 1u) != 0), hard = ballot((b_flags & 2u) != 0);
@@ -660,6 +665,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                         break;
                     }
                 }
+                asm volatile("; commit begin");
                 ZSTAGE(7);
                 if ((wo.commit >> lane) & 1) tput(b_h, pos + 2);
                 wave_fence();
@@ -673,6 +679,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 anchor = (u32)((int32_t)pos0 + wo.arel); rep1 = wo.rep1; rep2 = wo.rep2; s = pos0 + (u32)wo.S;
                 ZSTAGE(3);
                 ZCOUNT(wo.outcome == zchain::ZC_RESTART ? 0 : (wo.outcome == zchain::ZC_CONTINUE ? 1 : 2));
+                asm volatile("; outcome begin");
                 if (wo.outcome == zchain::ZC_RESTART) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {                       // the chain's last table writes, one by one
@@ -696,6 +703,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     e_ok2 = el + 2 < 64; e_h2 = lane_get(b_h, (el + 2) & 63);
                 }
             }
+            asm volatile("; onematch begin");
             if (!ev) for (;;) {
                 ZCOUNT(3);
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
@@ -754,6 +762,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 i0 += (u32)lim;
             }
             if (!ev) break;                                             // _cleanup
+            asm volatile("; exact begin");
             ZSTAGE(3);
             // table write of ip1 that accompanies the hit (:537, :557, :586-598)
             {
@@ -824,6 +833,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 if (chk && uni(r0 == r1 ? 1u : 0u) != 0) { ip0 = rep_loop(ip0); anchor = ip0; }
             }
             s = ip0;
+            asm volatile("; exact end");
         }
     }
 #ifdef ZSTD_PROF

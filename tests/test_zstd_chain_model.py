@@ -101,6 +101,13 @@ def lz_grammar(rng, nbytes, alphabet):
     return bytes(out[:nbytes])
 
 
+def test_zero_bytes8_matches_the_plain_form(model):
+    """csrc/zstd_chain.h zero_bytes8: the eight zero-byte flags of a dword pair gathered by one multiplication"""
+    model.zchain_model_zero_bytes8_check.restype = C.c_size_t
+    model.zchain_model_zero_bytes8_check.argtypes = [C.c_size_t, C.c_uint64]
+    assert model.zchain_model_zero_bytes8_check(20_000_000, 0x9E3779B97F4A7C15) == 0
+
+
 def test_search_that_starts_at_the_last_lane(model, orc):
     """tests/golden/zstd_walk_search_at_lane63.bin (found by tools/fuzz_campaign.py, seed 9903): a repcode match ends at lane 62
     of a batch, so the next search starts at lane 63 - its repcode test needs bytes behind the batch and the walk has to stop

@@ -299,3 +299,19 @@ extern "C" size_t zchain_model_frame_sequences(const u8* src, size_t n_, u32 win
     }
     return rows;
 }
+
+// zero_bytes8 (the multiply-gather form the kernel uses) against the plain per-dword zero_bytes on n pseudo-random pairs with
+// zero bytes planted at random; returns the number of disagreements
+extern "C" size_t zchain_model_zero_bytes8_check(size_t n, u64 seed)
+{
+    size_t bad = 0;
+    u64 x = seed | 1;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (size_t i = 0; i < n; ++i) {
+        const u64 r = next(), m = next();
+        u32 a = (u32)r, b = (u32)(r >> 32);
+        for (int k = 0; k < 4; ++k) { if ((m >> k) & 1) a &= ~(0xFFu << (8 * k)); if ((m >> (8 + k)) & 1) b &= ~(0xFFu << (8 * k)); }
+        if ((zchain::zero_bytes(a) | (zchain::zero_bytes(b) << 4)) != zchain::zero_bytes8(a, b)) bad++;
+    }
+    return bad;
+}
