@@ -833,9 +833,6 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             const bool x2 = (t & 15) == 15;
             const uint32_t mcode = (t & 15) + (x2 ? e2 : 0u);                 // match length - 4
             hard = hard || (x2 && e2 > 240);
-#ifdef LZ4D_SHORT
-            hard = hard || lit > 64 || mcode > 60;
-#endif
             const uint32_t nx = hard ? 0x80000000u : q + 2 + (x2 ? 1u : 0u) - (uint32_t)ip;   // the next token's lane
             DSTAGE(1); DCOUNT(0, 1);
             // walk the real token starts: mask |= 1 << cur; cur = nx[cur] until cur >= 64 or a token the scan does not take
@@ -875,18 +872,7 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             {
                 // (also: a long match that starts further in front of the block than the history kept there)
                 const int32_t srel_ = (int32_t)mst - (int32_t)off;
-#if defined(LZ4D_DBG_A)
-                const bool dbg_ = mlen > 64;
-#elif defined(LZ4D_DBG_B)
-                const bool dbg_ = lit > 64;
-#elif defined(LZ4D_DBG_C)
-                const bool dbg_ = mlen > 64 && srel_ + (int32_t)mlen > 0;      // long in-block matches
-#elif defined(LZ4D_DBG_D)
-                const bool dbg_ = mlen > 64 && srel_ + (int32_t)mlen <= 0;     // long far matches
-#else
-                const bool dbg_ = false;
-#endif
-                const uint64_t badm = ballot(act && (dbg_ || off == 0 || off > (uint32_t)op + mst || (srel_ + (int32_t)mlen > 0 && srel_ < -(int32_t)kDecHist)));
+                const uint64_t badm = ballot(act && (off == 0 || off > (uint32_t)op + mst || (srel_ + (int32_t)mlen > 0 && srel_ < -(int32_t)kDecHist)));
                 const uint32_t fb = badm ? (uint32_t)__builtin_ctzll(badm) : 64u;
                 if (fb < ng) { ng = fb; forced = true; }
                 else if (ng == 0) forced = true;              // the output buffer ends: the sequential path takes the next sequence
@@ -901,9 +887,6 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             const uint32_t total = ng ? lane_get(oinc, (int)ng - 1) : 0u;
             if (ng) {
                 DSTAGE(3); DCOUNT(2, 1); DCOUNT(3, ng);
-#ifdef LZ4D_NOHIST
-                hist_ok = false;
-#endif
                 op += (int32_t)lz_group_execute<false>(src, dst, cb, hist_ok, (uint32_t)op, ng, act, lit, mlen, off, litsrc, lpos, mst, total);
                 DSTAGE(6);
             }
