@@ -126,6 +126,16 @@ constexpr uint32_t kScratch = 1024;
 // of 2 or 3 bytes) are computed per lane.  A batch adds at most 17 copies (64 consecutive positions, a copy covers at least 4).
 constexpr uint32_t kSnRecCap = 60, kSnRecFlush = kSnRecCap - 17, kSnRecBytes = kSnRecCap * 8;
 
+// Experiment build (-DAOCLGPU_EXPERIMENTS -DSN_COUNT): memory accesses of the parser by origin, counted per lane and summed per
+// table kind (index 0-7 LDS-table waves, 8-15 HBM-table waves): batches, probe-window loads (two 16-byte loads each), table slot
+// reads, candidate-window loads (two 16-byte loads each), table slot writes, table bytes filled, extension-loop rounds.
+#if defined(AOCLGPU_EXPERIMENTS) && defined(SN_COUNT)
+__device__ unsigned long long g_sn_count[16];
+#define SNC(k, cond) do { if (cond) snc[k]++; } while (0)
+#else
+#define SNC(k, cond) do { } while (0)
+#endif
+
 template <bool GT, int TAG = 0>
 __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* __restrict__ in_, const uint32_t n_,
                                                                    gbyte* __restrict__ out_, uint16_t* table_, lu16* scr, lbyte* recs_, int lane)
@@ -145,13 +155,18 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
         if (GT) return __hip_atomic_load((uint32_t*)(table + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return table[h];
     };
+#if defined(AOCLGPU_EXPERIMENTS) && defined(SN_COUNT)
+    uint32_t snc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto tput = [&](uint32_t h, uint32_t v, uint32_t bytes4) {          // bytes4 = the 4 bytes at position v
+        SNC(4, true);
         if (GT) __hip_atomic_store((uint32_t*)(table + h), (v & 0xFFFFu) | chk(bytes4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else table[h] = (uint16_t)v;
     };
     uint32_t tsize = n > kMaxTable ? kMaxTable : (n < kMinTable ? kMinTable : (2u << log2floor(n - 1)));   // :619-632
     const int shift = 32 - log2floor(tsize);
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    SNC(5, lane == 0);
     if (GT) {
         const uint32_t fill = n >= 4 ? chk(ld32(in)) : 0u;
         for (uint32_t i = (uint32_t)lane; i < tsize / 4; i += kWave)
@@ -254,8 +269,9 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const bool act = valid && lane < width;
             const bool far = (uint64_t)pos + 32 <= n;                     // (a candidate lies below its probe: its second half is inside too)
             Win pw = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            SNC(0, lane == 0);
             if (i0 == 0 && have_pre) pw = pre;
-            else if (act) pw = load_win(in, pos, far);
+            else if (act) { pw = load_win(in, pos, far); SNC(1, true); }
             if (extra && i0 == 0) {                                       // back-fill ip-1 (:1016-1017)
                 const uint32_t fb = have_pre ? pre_fill : ld32(in + ip - 1);
                 const uint32_t h1 = sn_hash(fb, shift);
@@ -267,10 +283,12 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             const uint32_t h = sn_hash(seq, shift);
             uint32_t ent = 0;
             if (act) ent = tget(h);
+            SNC(2, act);
             const uint32_t cand = ent & 0xFFFFu;
             const bool plausible = act && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
             Win cw = {{~seq, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
             if (plausible) cw = load_win(in, cand, far);                  // the whole candidate window travels in one round of loads
+            SNC(3, plausible);
             wave_fence();
             uint32_t w = (uint32_t)lane;
             if (GT) w = lds_first_lane_per_slot((uint32_t)(uintptr_t)(scr + (h & (kScratch - 1))), (uint32_t)lane, act);
@@ -437,6 +455,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                             for (uint32_t t = 0; t < n - pa; ++t) x |= (uint32_t)(in[pa + t] ^ in[m_cand + o + t]) << (8 * t);
                             x |= 0xFFFFFFFFu << (8 * (n - pa));
                         }
+                        SNC(6, lane == 0);
                         const int l = first_lane(ballot(x != 0));
                         if (l == 64) { matched += 256; continue; }
                         matched += 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
@@ -470,6 +489,14 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
     }
     if (nrec) { wave_fence(); flush(); }
     if (anchor < n) op += emit_literal(out + op, in + anchor, n - anchor, lane);     // emit_remainder (:1039-1043)
+#if defined(AOCLGPU_EXPERIMENTS) && defined(SN_COUNT)
+    snc[5] *= GT ? tsize * 4u : tsize * 2u;
+    for (int k = 0; k < 8; ++k) {
+        uint32_t v = snc[k];
+        for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+        if (lane == 0 && v) atomicAdd(&g_sn_count[(GT ? 8 : 0) + k], (unsigned long long)v);
+    }
+#endif
     return op;
 }
 
@@ -808,6 +835,15 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     hipLaunchKernelGGL(aoclgpu::snappy_compress_kernel, dim3(b->nchunks), dim3(64), 0, (hipStream_t)stream, *b);
     return aoclgpu::check_launch("snappy_compress_kernel");
 }
+
+#if defined(AOCLGPU_EXPERIMENTS) && defined(SN_COUNT)
+extern "C" int aoclgpu_debug_snappy_counts(unsigned long long* host16)
+{   /* experiment build: accesses by origin accumulated by every compress launch since the last call (read and cleared) */
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_sn_count), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_sn_count), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream)
 {
