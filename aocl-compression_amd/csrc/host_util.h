@@ -22,7 +22,7 @@ struct DeviceScope {
     DeviceScope(const DeviceScope&) = delete; DeviceScope& operator=(const DeviceScope&) = delete;
 };
 // One block of an LZ4 stream (csrc/lz4_kernels.hip lz4_compress_stream_kernel, driven by csrc/lz4frame_api.cpp): bytes
-// [off, off + len) of the stream window; see lz4_linked_block for lowCand / lowPos / ext.
+// [off, off + len) of the stream window; see Lz4Link (lz4_kernels.hip) for lowCand / lowPos / ext.
 struct Lz4StreamJob { uint32_t off, len, lowCand, lowPos, ext, pad[3]; };
 int lz4_stream_blocks(const uint8_t* d_src, uint32_t idxBase, const Lz4StreamJob* d_jobs, uint32_t njobs, uint32_t* d_table, uint8_t* d_dst, uint32_t slot,
                       int32_t* d_len, uint32_t accel, void* stream);

@@ -111,11 +111,22 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
 // MODE 0: byU16 table (chunks < 65547 B), u16[8192].  MODE 1: byU32 table packed as u16[4096] + 2 extra bits per
 // slot (chunks <= 256 KiB): 9 KB of LDS instead of 16 KB, so 17 instead of 10 chunks are resident per CU.
 // MODE 2: byU32 table as u32[4096] whose spare high bits hold check bits (any chunk size).
-template <int MODE, bool PROF>
+//
+// LINKED (MODE 2 only): one block [lk->b0, n) of a STREAM whose bytes start at src[0] (LZ4_compress_fast_continue, lz4.c:3179-3254,
+// as LZ4F_compressUpdate / a frame with linked blocks drives it).  The table persists between blocks and holds stream indices
+// (window position + idxBase, no check bits), candidates below lowIdx are outside the dictionary (dictSmall, :1000, :1137) and
+// further than 64 KB are too far (:1124-1127), the catch-up stops at lowPos - the start of the dictionary - or, with ext
+// (usingExtDict: the block does not follow its dictionary in the caller's memory), at the block's start for a match inside the
+// block (:1112-1119, :1149).  Everything else - batches, records, formatter - is the chunk kernels' machinery.
+struct Lz4Link { uint32_t b0, idxBase, lowIdx, lowPos, ext; };
+template <int MODE, bool PROF, bool LINKED = false>
 __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_, const uint32_t n_,
                                  gbyte* __restrict__ dst_, const uint32_t cap_, lbyte* lds_, const uint32_t expf_,
-                                 uint32_t* last_run)
+                                 uint32_t* last_run, const Lz4Link* lk = nullptr)
 {
+    static_assert(!LINKED || MODE == 2, "linked blocks use the u32 table");
+    const uint32_t b0 = LINKED ? uni(lk->b0) : 0u, idxBase = LINKED ? uni(lk->idxBase) : 0u, lowIdx = LINKED ? uni(lk->lowIdx) : 0u;
+    const uint32_t lowPos = LINKED ? uni(lk->lowPos) : 0u; const bool ext = LINKED && uni(lk->ext) != 0;
     const gbyte* __restrict__ src = uni_ptr(src_);
     gbyte* __restrict__ dst = uni_ptr(dst_);
     lbyte* lds = uni_ptr(lds_);
@@ -160,10 +171,18 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     // they only spare the 64 speculative lanes a cache-line fetch each for candidates that cannot match.
     // posBits = bits needed for a position of this chunk; an empty slot aliases position 0 exactly as in the
     // reference's zero-filled table (lz4.c:2519), so the table is filled with entry(0).
-    const uint32_t posBits = MODE == 0 ? 16u : (MODE == 1 ? 18u : (32u - (uint32_t)__builtin_clz(n - 1)));
+    const uint32_t posBits = LINKED ? 32u : (MODE == 0 ? 16u : (MODE == 1 ? 18u : (32u - (uint32_t)__builtin_clz(n - 1))));
     const uint32_t posMask = (posBits >= 32) ? 0xFFFFFFFFu : ((1u << posBits) - 1);
-    auto chk = [&](uint32_t v4) -> uint32_t { return MODE != 2 ? 0u : (((v4 * 2654435761u) >> posBits) << posBits); };
-    {
+    auto chk = [&](uint32_t v4) -> uint32_t { return (MODE != 2 || LINKED) ? 0u : (((v4 * 2654435761u) >> posBits) << posBits); };
+    // table entry <-> position: a chunk's entry is its position (| check bits), a stream's the position's stream index
+    auto entry_of = [&](uint32_t p, uint32_t c) -> uint32_t { return LINKED ? p + idxBase : (p | c); };
+    auto cand_of = [&](uint32_t e) -> uint32_t { return LINKED ? e - idxBase : (e & posMask); };
+    auto usable = [&](uint32_t e, uint32_t c, uint32_t p, uint32_t mychk) -> bool {   // can this entry still pass the 4-byte test at p
+        if (LINKED) return e >= lowIdx && c + kDistMax >= p;
+        return (MODE != 2 || ((e ^ mychk) & ~posMask) == 0) && (U16 || c + kDistMax >= p);
+    };
+    auto low_of = [&](uint32_t c) -> uint32_t { return LINKED ? ((ext && c >= b0) ? b0 : lowPos) : 0u; };   // where a catch-up from c stops
+    if (!LINKED) {
         const uint32_t fill = (MODE == 2 && n >= 4) ? chk(ld32(src)) : 0u;
         const uint32_t bytes = MODE == 1 ? 8192u + 1024u : kTableBytes;
         for (uint32_t i = (uint32_t)lane; i < bytes / 16; i += kWave)
@@ -171,14 +190,25 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     }
     wave_fence();
 
-    const bool limited = cap < lz4_bound(n);              // lz4.c:2522
+    const bool limited = cap < lz4_bound(n - b0);         // lz4.c:2522
     const uint32_t mfl1 = n - kMfLimit + 1;               // mflimitPlusOne
     const uint32_t matchlimit = n - kLastLiterals;
-    uint32_t ip = 1, anchor = 0;
+    uint32_t ip = b0 + 1, anchor = b0;
     bool extra = false;                                   // next batch starts with the post-match probe
     // buffered sequence records [0, nrec): they describe src[f_anchor, anchor) and go to dst + f_op
     lbyte* recs = lds + (MODE == 1 ? 9216u : kTableBytes) + kSrcRing;
-    uint32_t nrec = 0, f_op = 0, f_anchor = 0;
+    uint32_t nrec = 0, f_op = 0, f_anchor = b0;
+    // LINKED: where the output stands behind the sequences recorded so far.  A block that does not fit its room is stored raw by
+    // the caller, but its table lives on: the reference gives up at the first sequence that does not fit (lz4.c:1139, :1215) with
+    // the table as it was when that sequence's match was found, and the next block must find exactly that.  So the parser checks
+    // every sequence's room itself, BEFORE the batch commits its table writes (the formatter's check is for the chunk kernels).
+    uint32_t rop = 0;
+    auto seq_size = [&](uint32_t lit, uint32_t mc) -> uint32_t { return 3u + (lit >= 15 ? (lit - 15) / 255 + 1 : 0u) + lit + (mc >= 15 ? (mc - 15) / 255 + 1 : 0u); };
+    auto seq_fits = [&](uint32_t tp, uint32_t lit, uint32_t mc) -> bool {
+        const uint32_t lb = lit >= 15 ? (lit - 15) / 255 + 1 : 0u;
+        return !((uint64_t)tp + 1 + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap || (uint64_t)tp + 1 + lb + lit + 2 + (1 + kLastLiterals) + (mc + 240) / 255 > cap);
+    };
+    bool overflow = false;
     typedef __attribute__((address_space(3))) uint64_t L64;
     typedef __attribute__((address_space(3))) u32x4 L128;
     typedef u32x4 __attribute__((aligned(1))) U128;
@@ -273,7 +303,12 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         if (!(b & 1) && lane < 8) *(L32*)(ring + 512u + 4u * (uint32_t)lane) = v;
     };
 
-    if (n >= kMinLength) {
+    if (n - b0 >= kMinLength) {
+        if (LINKED) {                                     // the block's first byte (:1042; a chunk's is the zero-filled table's position 0)
+            const uint64_t s8 = ld64(src + b0);
+            if (lane == 0) tput_blind(lz4_hash2<U16>((uint32_t)s8, (uint32_t)(s8 >> 32)), b0 + idxBase);
+            wave_fence();
+        }
         uint32_t i0 = 0;                                  // probes of the current search already examined
         for (;;) {
             asm volatile("; batch begin" ::: "memory");
@@ -312,17 +347,17 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 if (extra && i0 == 0) {                   // back-fill ip-2 (lz4.c:1750) before the batch reads the table: lane 0's window holds its bytes
                     const uint32_t f_lo = __builtin_amdgcn_alignbit(a.y, a.x, 16), f_hi = a.y >> 16;
                     const uint32_t h2 = lz4_hash2<U16>(f_lo, f_hi);
-                    if (lane == 0) tput_blind(h2, (ip - 2) | chk(f_lo));
+                    if (lane == 0) tput_blind(h2, entry_of(ip - 2, chk(f_lo)));
                     wave_fence();
                 }
                 STAGE(0);
                 const uint32_t my4 = a.y;
                 const uint32_t h = lz4_hash2<U16>(a.y, a.z);
                 const uint32_t ent = tget(h);
-                cand = ent & posMask;
+                cand = cand_of(ent);
                 const uint32_t mychk = chk(my4);
                 // only lanes that can still pass the test fetch their candidate window
-                const bool plausible = (MODE != 2 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
+                const bool plausible = usable(ent, cand, pos, mychk);
                 STAGE(1);
                 // candidate windows [c-4, c+28) (cand < pos, so they end inside the chunk): 4 bytes of catch-up, the 4 bytes of
                 // the match test and 24 bytes of forward extension arrive in one round trip
@@ -406,10 +441,18 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t qend = wave_shr1(wave_scan_max(marked ? endl : 0u));          // 0: no match starts below this lane
                 const int32_t la = qend ? (int32_t)qend : arel0;
                 const uint32_t room = (uint32_t)((int32_t)lane - la);                        // m_pos - anchor
-                const uint32_t maxback = room < cand ? room : cand;
+                const uint32_t cl = cand - low_of(cand);                                      // room for a catch-up on the candidate's side
+                const uint32_t maxback = room < cl ? room : cl;
                 {   // a catch-up that runs past the 4 bytes of the window needs the loop: cut the chain in front of it
                     const uint64_t need = ballot(marked && bk4 == 4 && maxback > 4);
                     if (need) { special = (int)__builtin_ctzll(need); marks &= ~(~0ull << special); marked = __builtin_amdgcn_inverse_ballot_w64(marks); }
+                }
+                if (LINKED && marks) {                        // the first sequence that does not fit ends the block, with the table as of its match
+                    const uint32_t bk = bk4 < maxback ? bk4 : maxback, lit = room - bk, mc = bk + fw;
+                    const uint32_t osz = marked ? seq_size(lit, mc) : 0u, oinc = wave_scan_incl(osz);
+                    const uint64_t bad = ballot(marked && !seq_fits(rop + oinc - osz, lit, mc));
+                    if (bad) { overflow = true; special = (int)__builtin_ctzll(bad); marks &= ~(~0ull << special); marked = __builtin_amdgcn_inverse_ballot_w64(marks); }
+                    else rop += lane_get(oinc, 63);
                 }
                 const uint64_t cover = ballot(marked || (uint32_t)lane < qend);               // lanes inside a match [m, endl) (below `special`: of the sequences kept)
                 uint32_t cur = 0;                             // first lane of the unfinished search
@@ -419,8 +462,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
                     const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
                     const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
-                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos | mychk, ent); }
-                    else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, pos | mychk, ent);
+                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, entry_of(pos, mychk), ent); }
+                    else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, entry_of(pos, mychk), ent);
                 }
                 wave_fence();
                 STAGE(4);
@@ -455,16 +498,16 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 if (extra && i0 == 0) {                   // back-fill ip-2 (lz4.c:1750) before the batch reads the table
                     const uint64_t fb = ld64(src + ip - 2);
                     const uint32_t h2 = lz4_hash2<U16>((uint32_t)fb, (uint32_t)(fb >> 32));
-                    if (lane == 0) tput_blind(h2, (ip - 2) | chk((uint32_t)fb));
+                    if (lane == 0) tput_blind(h2, entry_of(ip - 2, chk((uint32_t)fb)));
                     wave_fence();
                 }
                 const uint32_t my4 = (uint32_t)(pw.lo >> 32);
                 const uint32_t h = lz4_hash2<U16>(my4, (uint32_t)pw.hi);
                 uint32_t ent = 0;
                 if (valid) ent = tget(h);
-                cand = ent & posMask;
+                cand = cand_of(ent);
                 const uint32_t mychk = chk(my4);
-                const bool plausible = valid && (MODE != 2 || ((ent ^ mychk) & ~posMask) == 0) && (U16 || cand + kDistMax >= pos);
+                const bool plausible = valid && usable(ent, cand, pos, mychk);
                 Win cw = {~pw.lo, 0};
                 if (plausible) cw = load_win(src, cand);
                 wave_fence();
@@ -499,7 +542,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 {
                     const uint32_t R = special >= 0 ? (uint32_t)special + 1 : lim;
                     const uint64_t commit = R >= 64 ? ~0ull : ~(~0ull << R);
-                    if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos | mychk, ent);
+                    if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, entry_of(pos, mychk), ent);
                 }
                 wave_fence();
                 if (special < 0) {
@@ -508,6 +551,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 }
             }
             asm volatile("; general batch end");
+            if (LINKED && overflow) return 0;
             if (special >= 0) {
                 asm volatile("; special begin");
                 STAGE(7);                                 // (a general batch)
@@ -518,7 +562,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const bool more_fwd = lane_get((uint32_t)mf, m) != 0;
                 {   // the first round of the longer catch-up (64 bytes back) and of the longer extension (256 bytes forward)
                     // is issued together: one global round trip instead of two
-                    const uint32_t a = m_pos - anchor, maxback = a < m_cand ? a : m_cand;
+                    const uint32_t a = m_pos - anchor, mcl = m_cand - low_of(m_cand), maxback = a < mcl ? a : mcl;
                     const uint32_t b4 = lane_get(bk4, m);
                     back = b4 < maxback ? b4 : maxback;
                     const bool more_back = b4 == 4 && maxback > 4;
@@ -562,6 +606,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 }
                 const uint32_t mstart = m_pos - back;
                 const uint32_t mcode = back + fwd;
+                if (LINKED) {
+                    if (!seq_fits(rop, mstart - anchor, mcode)) return 0;
+                    rop += seq_size(mstart - anchor, mcode);
+                }
                 if (lane == 0) rec_put(nrec, mstart - anchor, mcode, m_pos - m_cand);
                 nrec++;
                 if (PROF) { cnt[1]++; cnt[4]++; }
@@ -993,148 +1041,30 @@ __global__ void __launch_bounds__(64) lz4_decompress_linked_kernel(aoclgpu_batch
 // order.  Uniform batch: chunk c is block c, its output goes to slot c with room for (block size - 1) bytes as
 // LZ4F_makeBlock asks (:747-749); out_len[c] = 0 when it does not fit (the caller stores the block) - the parse of such a
 // block stopped where the output ran out and the table keeps what was written until then (lz4.c:1139), as in the reference.
-// Same exact speculation as the chunk kernel, one match per batch: lane k evaluates probe i0 + k of the schedule, the batch
-// is cut at the first in-batch reuse of a table slot, the probes up to the first hit write the table.
+// The parser is the chunk kernels' (lz4_compress_wave<2, ., LINKED>: batches of 64 consecutive positions resolved sequence
+// after sequence, records, one-sequence-per-lane formatter) on stream indices; since round 4 - before that a one-match-per-batch
+// loop of its own, 14 MiB/s for a 4 MiB frame.
 // ------------------------------------------------------------------------------------------------
-__device__ uint32_t lz4_wave_count(const gbyte* __restrict__ src, uint32_t a, uint32_t b, uint32_t limit, int lane)
-{   // LZ4_count (lz4.c:656-679): common prefix of src[a..limit) and src[b..], 256 bytes per step
-    uint32_t n = 0;
-    for (;;) {
-        const uint32_t o = n + 4u * (uint32_t)lane, pa = a + o;
-        uint32_t x = 0xFFFFFFFFu;
-        if (pa + 4 <= limit) x = ld32(src + pa) ^ ld32(src + b + o);
-        else if (pa < limit) {
-            x = 0;
-            for (uint32_t t = 0; t < limit - pa; ++t) x |= (uint32_t)(src[pa + t] ^ src[b + o + t]) << (8 * t);
-            x |= 0xFFFFFFFFu << (8 * (limit - pa));
-        }
-        const int l = first_lane(ballot(x != 0));
-        if (l == 64) { n += 256; continue; }
-        return n + 4u * (uint32_t)l + ((uint32_t)__builtin_ctz(lane_get(x, l)) >> 3);
-    }
-}
-
-// one block [b0, iend) of the frame at src; returns its compressed size, 0 when it does not fit olimit bytes.
-// The last four arguments describe the block of a STREAM (LZ4_compress_fast_continue, lz4.c:3179-3254, as LZ4F_compressUpdate
-// drives it): src is a window of the stream whose byte 0 has stream index idxBase (the table holds stream indices),
-// candidates below lowCand are outside the dictionary (dictSmall, :1000, :1137), the catch-up stops at lowPos - the start
-// of the dictionary - or, with ext (usingExtDict: the block does not follow its dictionary in memory), at the block's start
-// for a match inside the block (:1112-1119, :1149).  A one-shot frame is the stream whose dictionary is the frame so far.
-__device__ uint32_t lz4_linked_block(const gbyte* __restrict__ src, const uint32_t b0, const uint32_t iend, uint32_t* table, const uint32_t accel,
-                                     gbyte* __restrict__ d, const uint32_t olimit, int lane,
-                                     const uint32_t idxBase = 0, const uint32_t lowCand = 0, const uint32_t lowPos = 0, const bool ext = false)
+// One block of a stream through the chunk kernels' parser (lz4_compress_wave<2, ., LINKED>): `lds` = the stream's u32 table
+// (16 KB, kept between blocks) followed by the source ring and the record buffer.  Returns the compressed size, 0 when it does
+// not fit olimit bytes.
+constexpr uint32_t kLinkLds = kTableBytes + kSrcRing + kRecCap * 16;
+__device__ __forceinline__ uint32_t lz4_stream_block(const gbyte* __restrict__ src, const uint32_t b0, const uint32_t iend, lbyte* lds, const uint32_t accel,
+                                                     gbyte* __restrict__ d, const uint32_t olimit, const uint32_t idxBase = 0, const uint32_t lowCand = 0,
+                                                     const uint32_t lowPos = 0, const bool ext = false)
 {
-    const uint32_t lowIdx = lowCand > idxBase ? lowCand : idxBase;      // (what lies below the window is further than 64 KB away)
-    typedef __attribute__((address_space(3))) uint32_t L32;
-    L32* T = (L32*)table;
-    const uint32_t bn = iend - b0;
-    const uint32_t mfl1 = iend - 12 + 1, matchlimit = iend - 5;          // mflimitPlusOne, matchlimit (lz4.c:1002-1003)
-    uint32_t ip = b0, anchor = b0;
-    uint64_t op = 0;
-    if (bn >= 13) {                                                      // LZ4_minLength (:1039)
-        if (lane == 0) T[lz4_hash<false>(ld64(src + ip))] = ip + idxBase;   // first byte (:1042)
-        wave_fence();
-        uint32_t s = ip + 1, i0 = 0;
-        for (;;) {
-            // ---------------- one batch of 64 speculative probes (:1077-1135) ----------------
-            const uint32_t j = i0 + (uint32_t)lane;
-            const uint64_t p64 = (uint64_t)s + sched(j, accel), nx64 = (uint64_t)s + sched(j + 1, accel);
-            const bool valid = nx64 <= mfl1;                             // forwardIp > mflimitPlusOne ends the search (:1090)
-            const uint32_t pos = (uint32_t)p64;
-            uint64_t seq = 0; uint32_t h = 0, cand = 0;
-            if (valid) { seq = ld64(src + pos); h = lz4_hash<false>(seq); cand = T[h]; }
-            uint32_t m4 = ~(uint32_t)seq;
-            if (valid && cand >= lowIdx && (uint64_t)cand + 65535u >= (uint64_t)pos + idxBase) m4 = ld32(src + (cand - idxBase));   // not "too far" (:1124-1127)
-            wave_fence();
-            const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&T[h], (uint32_t)lane, valid);
-            wave_fence();
-            if (valid) T[h] = cand;                                      // the rounds scribbled on the slots' low halves
-            wave_fence();
-            const int f = first_lane(ballot(valid && w != (uint32_t)lane));
-            const int e = first_lane(ballot(!valid));
-            const int lim = f < e ? f : e;
-            const int el = first_lane(ballot(lane < lim && m4 == (uint32_t)seq));
-            const int ncommit = el < 64 ? el + 1 : lim;
-            if (lane < ncommit) T[h] = pos + idxBase;                    // LZ4_putIndexOnHash (:1121)
-            wave_fence();
-            if (el == 64) {
-                if (e < 64 && e <= f) break;                             // _last_literals
-                i0 += (uint32_t)lim;
-                continue;
-            }
-            ip = lane_get(pos, el);
-            uint32_t match = lane_get(cand, el) - idxBase;
-            {   // catch up (:1139-1140): lowLimit is the dictionary's start (a one-shot frame: the frame's)
-                const uint32_t lowM = (ext && match >= b0) ? b0 : lowPos;
-                const uint32_t a = ip - anchor, bq = match - lowM, maxback = a < bq ? a : bq;
-                uint32_t back = 0;
-                while (back < maxback) {
-                    const uint32_t k = back + (uint32_t)lane;
-                    bool eq = false;
-                    if (k < maxback) eq = src[ip - 1 - k] == src[match - 1 - k];
-                    const int c = first_lane(ballot(!eq));
-                    back += (uint32_t)c;
-                    if (c < 64) break;
-                }
-                if (back > maxback) back = maxback;
-                ip -= back; match -= back;
-            }
-            // literals (:1142-1167)
-            const uint32_t lit = ip - anchor;
-            uint64_t token_pos = op++;
-            if (op + lit + (2 + 1 + 5) + lit / 255 > olimit) return 0;
-            uint32_t token;
-            if (lit >= 15) { token = 15u << 4; op += put_len_bytes(d + op, lit - 15, lane); }
-            else token = lit << 4;
-            wave_copy(d + op, src + anchor, lit, lane);
-            op += lit;
-            bool again;
-            do {                                                         // _next_match (:1169-1260)
-                if (lane == 0) { d[op] = (uint8_t)(ip - match); d[op + 1] = (uint8_t)((ip - match) >> 8); }
-                op += 2;
-                uint32_t mc = lz4_wave_count(src, ip + 4, match + 4, matchlimit, lane);
-                ip += mc + 4;
-                if (op + (1 + 5) + (mc + 240) / 255 > olimit) return 0;
-                if (mc >= 15) { token += 15; op += put_len_bytes(d + op, mc - 15, lane); }
-                else token += mc;
-                if (lane == 0) d[token_pos] = (uint8_t)token;
-                anchor = ip;
-                again = false;
-                if (ip >= mfl1) break;                                   // :1274
-                {   // fill the table (:1277), test the next position (:1279-1330)
-                    const uint64_t s2 = ld64(src + ip - 2), s0 = ld64(src + ip);
-                    const uint32_t h2 = lz4_hash<false>(s2), h0 = lz4_hash<false>(s0);
-                    if (lane == 0) T[h2] = ip - 2 + idxBase;
-                    wave_fence();
-                    const uint32_t c0 = T[h0];
-                    wave_fence();
-                    if (lane == 0) T[h0] = ip + idxBase;
-                    wave_fence();
-                    if (c0 >= lowIdx && (uint64_t)c0 + 65535u >= (uint64_t)ip + idxBase && uni(ld32(src + (c0 - idxBase)) == (uint32_t)s0 ? 1u : 0u)) {
-                        token_pos = op++; token = 0; match = c0 - idxBase; again = true;
-                    }
-                }
-            } while (again);
-            if (ip >= mfl1) break;
-            s = ip + 1; i0 = 0;                                          // forwardH = hash(++ip) (:1332)
-        }
-    }
-    {   // _last_literals (:1336-1358)
-        const uint32_t lastRun = iend - anchor;
-        if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) return 0;
-        if (lastRun >= 15) { if (lane == 0) d[op] = 15u << 4; op++; op += put_len_bytes(d + op, lastRun - 15, lane); }
-        else { if (lane == 0) d[op] = (uint8_t)(lastRun << 4); op++; }
-        wave_copy(d + op, src + anchor, lastRun, lane);
-        op += lastRun;
-    }
-    return (uint32_t)op;
+    const Lz4Link lk = {b0, idxBase, lowCand > idxBase ? lowCand : idxBase, lowPos, ext ? 1u : 0u};   // (what lies below the window is further than 64 KB away)
+    uint32_t last = 0;
+    const int r = lz4_compress_wave<2, false, true>(src, iend, d, olimit, lds, (accel - 1u) << 15, &last, &lk);
+    return r > 0 ? (uint32_t)r : 0u;
 }
 
 __global__ void __launch_bounds__(64) lz4_compress_linked_kernel(aoclgpu_batch b)
 {
-    __shared__ uint32_t table[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLinkLds];
+    typedef __attribute__((address_space(3))) uint32_t L32;
     const int lane = lane_id();
-    for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) table[i] = 0;  // LZ4_initStream
+    for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) ((L32*)(lbyte*)lds)[i] = 0;  // LZ4_initStream
     wave_fence();
     const uint32_t accel = (b.reserved >> 15) + 1;
     for (uint32_t c = 0; c < b.nchunks; ++c) {
@@ -1144,8 +1074,7 @@ __global__ void __launch_bounds__(64) lz4_compress_linked_kernel(aoclgpu_batch b
         uint32_t r = 0;
         if (bn >= 1) {
             const uint64_t room = b.slot_bytes < (uint64_t)bn - 1 ? b.slot_bytes : (uint64_t)bn - 1;
-            r = lz4_linked_block((const gbyte*)b.src, (uint32_t)b0, (uint32_t)b0 + bn, table, accel, (gbyte*)b.dst + (uint64_t)c * b.slot_bytes,
-                                 (uint32_t)room, lane);
+            r = lz4_stream_block((const gbyte*)b.src, (uint32_t)b0, (uint32_t)b0 + bn, (lbyte*)lds, accel, (gbyte*)b.dst + (uint64_t)c * b.slot_bytes, (uint32_t)room);
         }
         wave_fence();
         if (lane == 0) b.out_len[c] = (int32_t)r;
@@ -1158,7 +1087,9 @@ __global__ void __launch_bounds__(64) lz4_compress_linked_kernel(aoclgpu_batch b
 __global__ void __launch_bounds__(64) lz4_compress_stream_kernel(const uint8_t* src, uint32_t idxBase, const aoclgpu::Lz4StreamJob* jobs, uint32_t njobs,
                                                                  uint32_t* gtable, uint8_t* dst, uint32_t slot, int32_t* out_len, uint32_t accel)
 {
-    __shared__ uint32_t table[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLinkLds];
+    typedef __attribute__((address_space(3))) uint32_t L32;
+    L32* table = (L32*)(lbyte*)lds;
     const int lane = lane_id();
     for (uint32_t i = (uint32_t)lane; i < 4096; i += kWave) table[i] = gtable[i];
     wave_fence();
@@ -1167,7 +1098,7 @@ __global__ void __launch_bounds__(64) lz4_compress_stream_kernel(const uint8_t* 
         uint32_t r = 0;
         if (len >= 1) {
             const uint32_t room = slot < len - 1 ? slot : len - 1;
-            r = lz4_linked_block((const gbyte*)src, off, off + len, table, accel, (gbyte*)dst + (uint64_t)j * slot, room, lane, idxBase, lowCand, lowPos, ext != 0);
+            r = lz4_stream_block((const gbyte*)src, off, off + len, (lbyte*)lds, accel, (gbyte*)dst + (uint64_t)j * slot, room, idxBase, lowCand, lowPos, ext != 0);
         }
         wave_fence();
         if (lane == 0) out_len[j] = (int32_t)r;
