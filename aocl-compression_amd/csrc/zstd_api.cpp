@@ -3,12 +3,12 @@
 // ZSTD_getParams / ZSTD_CCtx_setParameter / ZSTD_compress_advanced / ZSTD_decompressDCtx) and the parameter tables.
 // Host buffers, no CPU fallback.
 //
-// What has a GPU backend: the "fast" and "double-fast" strategies (the parameters of levels 1-4 and of level -1, clevels.h:24-130,
-// 155-262, or any explicit parameter set of those strategies: hashLog / chainLog <= 24, minMatch 3-7, fast with targetLength
-// 0-1), with or without a content checksum, windows above or below the input size.  Inputs of at most 128 KiB with a
+// What has a GPU backend: the "fast" and "double-fast" strategies (the parameters of levels 1-4 and of every negative level,
+// clevels.h:24-130, 155-262, or any explicit parameter set of those strategies: hashLog / chainLog <= 24, minMatch 3-7, fast
+// with any targetLength), with or without a content checksum, windows above or below the input size.  Inputs of at most 128 KiB with a
 // level's own parameters are one block per frame on the chunk kernels; everything else - above all inputs LARGER than
 // 128 KiB - is ONE frame of blocks, byte-identical to the reference's ZSTD_compress_advanced, written by one wavefront
-// (aoclgpu_zstd_compress_frames): correct and slow, a few MiB/s for a lone input.  The opt-out for bulk callers is
+// (aoclgpu_zstd_compress_frames): correct and slow, ~20 MiB/s for a lone input.  The opt-out for bulk callers is
 // aoclgpu_zstd_set_large_input_mode(1) / AOCLGPU_ZSTD_LARGE_INPUTS=pieces: 128 KiB pieces as concatenated frames side by
 // side (a valid stream for every Zstd decoder, not the reference's bytes).  Other strategies, dictionaries and frames without a
 // content size return ZSTD_error_parameter_unsupported instead of silently compressing differently.
@@ -189,9 +189,10 @@ size_t compress_with(const ZSTD_compressionParameters& c, const ZSTD_frameParame
     if (!f.contentSizeFlag) return zerr(kErrParamUnsupported);
     const bool covers = ((unsigned long long)1 << c.windowLog) >= n;     // single-segment frame
     const int level = gpu_level_for(c, n);
-    // what the frame kernel parses: fast with stepSize 2 (zstd_fast.c:440), double-fast; tables of at most 2^24 entries
+    // what the frame kernel parses: fast with any step (targetLength + 1 above 1: the levels below -1, zstd_fast.c:440),
+    // double-fast; tables of at most 2^24 entries
     const bool frameable = n < ((size_t)1 << 31) && c.hashLog <= 24 &&
-                           ((c.strategy == ZSTD_fast && c.targetLength <= 1) || (c.strategy == ZSTD_dfast && c.chainLog <= 24));
+                           (c.strategy == ZSTD_fast || (c.strategy == ZSTD_dfast && c.chainLog <= 24));
     int64_t r;
     if (n <= (128u << 10) && level && covers && !f.checksumFlag) {
         // one block with a level's own parameters: the chunk kernels (hash table in LDS for "fast")

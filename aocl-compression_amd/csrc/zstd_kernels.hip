@@ -66,6 +66,16 @@ struct FastSched {
     }
 };
 __device__ const FastSched g_sched{};
+// the same schedule for another step size (levels below -1: stepSize = targetLength + 1, zstd_fast.c:440): three arrays of
+// kSchedLen words in the workspace, filled by zstd_fast_sched_kernel in front of the frame kernel; nullptr = step 2
+__device__ __forceinline__ void fast_sched_at(const u32* __restrict__ sched, const u32 m, u32& am, u32& sg, u32& st)
+{
+    am = 0x40000000u; sg = 2; st = 2;
+    if (sched == nullptr) {
+        if (m <= 62) am = 2 * m;
+        else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
+    } else if (m < kSchedLen) { am = sched[m]; sg = sched[kSchedLen + m]; st = sched[2 * kSchedLen + m]; }
+}
 
 // ---- per-workgroup workspace in global memory ----
 struct Workspace {
@@ -402,8 +412,9 @@ __device__ __forceinline__ u32 lowest_prefix(const FrameWindow& w, u32 curr)
 template <int MLS, typename T, bool HI, bool FRAME = false>
 __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u32 hlog_, lbyte* lds_, Workspace* ws_,
                           u32* litSizeOut, int lane, const u32 expf_, const u32 bs_ = 0, const FrameWindow* win = nullptr,
-                          u32* rep1io = nullptr, u32* rep2io = nullptr)
+                          u32* rep1io = nullptr, u32* rep2io = nullptr, const u32* sched_ = nullptr)
 {
+    const u32* __restrict__ sched = FRAME ? uni_ptr(sched_) : nullptr;   // (another step size than 2: frames only)
     static_assert(FRAME ? (sizeof(T) == 4 && !HI) : sizeof(T) == 2, "u16 slots for chunks, u32 slots for frames");
     // (arguments of a non-inlined function arrive in VGPRs and count as divergent: everything the control flow hangs on is
     //  made wave-uniform here, or the scalar walk below is compiled as exec-masked vector code - common.hip.h)
@@ -487,9 +498,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
     if (n >= 20) {
         const u32 ilimit = n - 16;                                      // iend - HASH_READ_SIZE - PREFETCH_SAFETY (:448)
 #ifdef AOCLGPU_EXPERIMENTS
-        const bool chain = !(expf & 32);                                // experiment build: one match per batch everywhere
+        const bool chain = !(expf & 32) && sched == nullptr;            // experiment build: one match per batch everywhere
 #else
-        constexpr bool chain = true; (void)expf;
+        const bool chain = sched == nullptr; (void)expf;                // (chain batches are 64 consecutive probes: step 2)
 #endif
         // Source ring of the chain batches.  Block b of the chunk (240 bytes) sits at ring offset (b & 1) * 240, the first
         // 32 bytes of the even block are mirrored behind the odd one so that a 32-byte read never wraps; the block after
@@ -708,9 +719,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 ZCOUNT(3);
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
                 u32 am, sg, st;
-                if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
-                else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
-                else { am = 0x40000000u; sg = 2; st = 2; }
+                fast_sched_at(sched, m, am, sg, st);
                 const bool valid = (u64)s + am + sg + 1 < ilimit;       // ip3 < ilimit (:503, :631)
                 const u32 pos = s + am + half;
                 ZSTAGE(5);
@@ -1607,8 +1616,9 @@ constexpr u32 kFrScratch = 1024;                // u16 slots for the slot-reuse 
 
 template <int MLS>
 __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, u32* tab, lbyte* scr,
-                                const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane)
+                                const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane, const u32* sched_ = nullptr)
 {
+    const u32* __restrict__ sched = uni_ptr(sched_);
     typedef __attribute__((address_space(1))) u32 gu32;
     typedef __attribute__((address_space(3))) uint16_t lu16;
     gu32* T = (gu32*)tab;
@@ -1656,9 +1666,7 @@ __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, con
             for (;;) {
                 const u32 K = i0 + (u32)lane, m = K >> 1, half = K & 1;
                 u32 am, sg, st;
-                if (m <= 62) { am = 2 * m; sg = 2; st = 2; }
-                else if (m < kSchedLen) { am = g_sched.a[m]; sg = g_sched.sigma[m]; st = g_sched.st[m]; }
-                else { am = 0x40000000u; sg = 2; st = 2; }
+                fast_sched_at(sched, m, am, sg, st);
                 const bool valid = (u64)s + am + sg + 1 < ilimit;       // ip3 < ilimit (:503, :631)
                 const u32 pos = s + am + half;
                 u64 seq = 0;
@@ -1791,10 +1799,10 @@ struct FrameLds {
 template <bool LT>
 __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, u8* __restrict__ dst, const u64 cap, const u32 strategy,
                                      const u32 windowLog, const u32 hlog, const u32 clog, const u32 mls, const u32 targetLength,
-                                     FrameLds* L, Workspace* ws, u32* tab, int lane)
+                                     FrameLds* L, Workspace* ws, u32* tab, int lane, const u32* sched = nullptr)
 {
     if (n64 >= (1ull << 31) || windowLog < 10 || windowLog > 31 || hlog < 6 || mls < 4 || mls > 7) return 0;
-    if (strategy == 1 ? targetLength > 1 : (strategy != 2 || clog < 6)) return 0;
+    if (strategy == 1 ? (targetLength > (1u << 17) || (targetLength > 1 && sched == nullptr)) : (strategy != 2 || clog < 6)) return 0;
     const u32 n = (u32)n64;
     const u32 blockMax = windowLog < 17 ? 1u << windowLog : kBlockMax;   // MIN(ZSTD_BLOCKSIZE_MAX, windowSize), zstd_compress.c:2129-2131
     const u32 single = ((1ull << windowLog) >= n64) ? 1u : 0u;
@@ -1839,10 +1847,10 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
             const gbyte* g = (const gbyte*)src;
             if constexpr (LT) {
                 lbyte* lt = (lbyte*)tab;
-                if (mls == 4) nbSeq = fast_block<4, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
-                else if (mls == 5) nbSeq = fast_block<5, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
-                else if (mls == 6) nbSeq = fast_block<6, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
-                else nbSeq = fast_block<7, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2);
+                if (mls == 4) nbSeq = fast_block<4, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2, sched);
+                else if (mls == 5) nbSeq = fast_block<5, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2, sched);
+                else if (mls == 6) nbSeq = fast_block<6, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2, sched);
+                else nbSeq = fast_block<7, u32, false, true>(g, bs + bn, hlog, lt, ws, &litSize, lane, 0u, bs, &win, &nr1, &nr2, sched);
             } else {
                 if (strategy == 2) {
                     lbyte* sc = (lbyte*)L->scratch;
@@ -1851,10 +1859,10 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
                     else if (mls == 6) nbSeq = dfast_block<6, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
                     else nbSeq = dfast_block<7, true>(g, bs + bn, hlog, clog, tab, sc, ws, &litSize, lane, bs, &win, &nr1, &nr2);
                 }
-                else if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-                else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-                else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
-                else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane);
+                else if (mls == 4) nbSeq = fast_frame_block<4>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane, sched);
+                else if (mls == 5) nbSeq = fast_frame_block<5>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane, sched);
+                else if (mls == 6) nbSeq = fast_frame_block<6>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane, sched);
+                else nbSeq = fast_frame_block<7>(g, bs, bs + bn, hlog, tab, (lbyte*)L->scratch, win, nr1, nr2, ws, &litSize, lane, sched);
             }
             wave_fence();
             cSize = entropy_compress<true>(ws->tmp, ws, litSize, nbSeq, &L->e, lane, strategy, &fh);
@@ -2837,7 +2845,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 }
 
 // (9 frames per CU by LDS need a SIMD to hold three waves: at most 170 VGPRs)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) zstd_frame_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, uint8_t* tabBase, uint32_t tabBytes)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) zstd_frame_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, uint8_t* tabBase, uint32_t tabBytes, const uint32_t* sched)
 {
     __shared__ FrameLds L;
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
@@ -2845,14 +2853,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int lane = lane_id();
     for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
         const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
-        const long long r = zstd_frame_wave<false>(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, &L, ws, tab, lane);
+        const long long r = zstd_frame_wave<false>(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, &L, ws, tab, lane, sched);
         if (lane == 0) f.out_len[i] = r;
         wave_fence();
     }
 }
 
 // the same with the fast finder's table and source ring in LDS (dynamic: 4 << hashLog bytes + ring + FrameLds): one frame per CU
-__global__ void __launch_bounds__(64) zstd_frame_lds_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase)
+__global__ void __launch_bounds__(64) zstd_frame_lds_kernel(aoclgpu_zstd_frames f, uint8_t* wsBase, const uint32_t* sched)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Workspace* ws = reinterpret_cast<Workspace*>(wsBase) + blockIdx.x;
@@ -2861,11 +2869,26 @@ __global__ void __launch_bounds__(64) zstd_frame_lds_kernel(aoclgpu_zstd_frames 
     for (uint32_t i = blockIdx.x; i < f.nframes; i += gridDim.x) {
         const uint64_t so = f.src_off[i], sn = f.src_off[i + 1] - so, d0 = f.dst_off[i], dc = f.dst_off[i + 1] - d0;
         const long long r = zstd_frame_wave<true>(f.src + so, sn, f.dst + d0, dc, f.strategy, f.windowLog, f.hashLog, f.chainLog, f.minMatch, f.targetLength, L, ws,
-                                                  reinterpret_cast<u32*>(lds), lane);
+                                                  reinterpret_cast<u32*>(lds), lane, sched);
         if (lane == 0) f.out_len[i] = r;
         wave_fence();
     }
 }
+
+// pair schedule of the fast parser for a step size other than 2 (FastSched's construction at run time): out[0..L) offsets,
+// out[L..2L) gaps to the repcode probe, out[2L..3L) the value of `step`, L = kSchedLen
+__global__ void zstd_fast_sched_kernel(uint32_t* out, uint32_t stepSize)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    u32 step = stepSize, nextStep = 128, A = 0, sig = stepSize;
+    for (u32 m = 0; m < kSchedLen; ++m) {
+        out[m] = A; out[kSchedLen + m] = sig; out[2 * kSchedLen + m] = step;
+        const u32 A2 = A + sig; sig = step;
+        if (A2 + step >= nextStep) { step++; nextStep += 128; }
+        A = A2;
+    }
+}
+constexpr size_t kFastSchedBytes = 3 * kSchedLen * sizeof(uint32_t);
 
 size_t zstd_workspace_bytes() { return sizeof(Workspace); }
 size_t zstd_frame_lds_bytes() { return sizeof(FrameLds); }
@@ -3170,9 +3193,9 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     if (!f || (f->nframes && (!f->src_off || !f->dst_off || !f->out_len || !f->dst))) { aoclgpu::set_error_msg("zstd frames: bad arguments"); return AOCLGPU_ERR_ARG; }
     const bool df = f->strategy == 2;
     if ((f->strategy != 1 && !df) || f->windowLog < 10 || f->windowLog > 31 || f->hashLog < 6 || f->hashLog > 24 || f->minMatch < 4 || f->minMatch > 7 ||
-        (df ? (f->chainLog < 6 || f->chainLog > 24) : f->targetLength > 1)) {
+        (df ? (f->chainLog < 6 || f->chainLog > 24) : f->targetLength > (1u << 17))) {
         aoclgpu::set_error_msg("zstd frames: parameters outside the GPU parses (strategy 1 fast / 2 double-fast, windowLog 10-31, hashLog 6-24, "
-                               "chainLog 6-24 for double-fast, minMatch 4-7, targetLength 0-1 for fast)");
+                               "chainLog 6-24 for double-fast, minMatch 4-7, targetLength 0-131072 for fast)");
         return AOCLGPU_ERR_ARG;
     }
     if (f->nframes == 0) return AOCLGPU_OK;
@@ -3184,18 +3207,24 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     const bool useLds = (f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_LDS) ? canLds
                       : ((f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_HBM) ? false : (canLds && f->nframes <= 2u * (uint32_t)prop.multiProcessorCount));
     if ((f->flags & AOCLGPU_ZSTD_FRAMES_FINDER_LDS) && !canLds) { aoclgpu::set_error_msg("zstd frames: the LDS finder serves the fast strategy with hashLog <= 14"); return AOCLGPU_ERR_ARG; }
+    // the fast parser's step: targetLength + !targetLength + 1 (zstd_fast.c:440); above 2 (levels below -1) the pair schedule is
+    // built on the device in front of the frames
+    const bool stepped = !df && f->targetLength > 1;
     aoclgpu::WsGuard guard;
     if (useLds) {
         const uint32_t ldsBytes = (uint32_t)(((size_t)4 << f->hashLog) + aoclgpu::kSrcRingBytes + aoclgpu::zstd_frame_lds_bytes());
         uint32_t grid = (uint32_t)prop.multiProcessorCount * ((160u << 10) / ldsBytes ? (160u << 10) / (((ldsBytes + 1279u) / 1280u) * 1280u) : 1u);
         if (grid > f->nframes) grid = f->nframes;
-        void* ws = get_workspace(guard, (size_t)grid * aoclgpu::zstd_workspace_bytes(), stream);
+        const size_t wsBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
+        void* ws = get_workspace(guard, wsBytes + (stepped ? aoclgpu::kFastSchedBytes : 0), stream);
         if (!ws) { aoclgpu::set_error_msg("zstd frames: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
+        uint32_t* sched = stepped ? (uint32_t*)((uint8_t*)ws + wsBytes) : nullptr;
+        if (stepped) hipLaunchKernelGGL(aoclgpu::zstd_fast_sched_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, f->targetLength + 1u);
         if (ldsBytes > 65536u) {
             hipError_t e = hipFuncSetAttribute((const void*)aoclgpu::zstd_frame_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
             if (e != hipSuccess) { aoclgpu::set_error("hipFuncSetAttribute", e); return AOCLGPU_ERR_HIP; }
         }
-        hipLaunchKernelGGL(aoclgpu::zstd_frame_lds_kernel, dim3(grid), dim3(64), ldsBytes, (hipStream_t)stream, *f, (uint8_t*)ws);
+        hipLaunchKernelGGL(aoclgpu::zstd_frame_lds_kernel, dim3(grid), dim3(64), ldsBytes, (hipStream_t)stream, *f, (uint8_t*)ws, (const uint32_t*)sched);
         return aoclgpu::check_launch("zstd_frame_lds_kernel");
     }
     // one wave per frame; as many frames per CU as its LDS holds (granules of 1280 bytes, 128 per CU), at most 12 (163 VGPRs)
@@ -3206,8 +3235,11 @@ extern "C" int aoclgpu_zstd_compress_frames(const aoclgpu_zstd_frames* f, void* 
     const size_t tabBytes = ((size_t)4 << f->hashLog) + (df ? (size_t)4 << f->chainLog : 0);
     if ((size_t)grid * tabBytes > ((size_t)1 << 30)) grid = (uint32_t)(((size_t)1 << 30) / tabBytes);   // at most 1 GiB of tables
     const size_t seqBytes = ((size_t)grid * aoclgpu::zstd_workspace_bytes() + 255) & ~(size_t)255;
-    void* ws = get_workspace(guard, seqBytes + (size_t)grid * tabBytes, stream);
+    const size_t allTabs = ((size_t)grid * tabBytes + 255) & ~(size_t)255;
+    void* ws = get_workspace(guard, seqBytes + allTabs + (stepped ? aoclgpu::kFastSchedBytes : 0), stream);
     if (!ws) { aoclgpu::set_error_msg("zstd frames: workspace allocation failed"); return AOCLGPU_ERR_HIP; }
-    hipLaunchKernelGGL(aoclgpu::zstd_frame_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *f, (uint8_t*)ws, (uint8_t*)ws + seqBytes, (uint32_t)tabBytes);
+    uint32_t* sched = stepped ? (uint32_t*)((uint8_t*)ws + seqBytes + allTabs) : nullptr;
+    if (stepped) hipLaunchKernelGGL(aoclgpu::zstd_fast_sched_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, f->targetLength + 1u);
+    hipLaunchKernelGGL(aoclgpu::zstd_frame_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *f, (uint8_t*)ws, (uint8_t*)ws + seqBytes, (uint32_t)tabBytes, (const uint32_t*)sched);
     return aoclgpu::check_launch("zstd_frame_kernel");
 }

@@ -141,8 +141,10 @@ typedef struct {
     int64_t*        out_len;
     uint32_t        nframes;
     uint32_t        windowLog, hashLog, minMatch;   /* ZSTD_compressionParameters */
-    uint32_t        targetLength;                   /* 0 or 1: both mean step 2 (zstd_fast.c:440); 1 (level -1, row 0 of the level
-                                                       tables) also leaves literals uncompressed (zstd_compress_internal.h:609-622) */
+    uint32_t        targetLength;                   /* fast: the parser's step is targetLength + !targetLength + 1 (zstd_fast.c:440): 2 for
+                                                       0 and 1, 1 - level for the levels below -1 (at most 2^17); any value above 0
+                                                       (row 0 of the level tables) leaves literals uncompressed
+                                                       (zstd_compress_internal.h:609-622) */
     uint32_t        strategy;                       /* 1 = fast (zstd_fast.c), 2 = double-fast (zstd_double_fast.c: hashLog = long
                                                        table, chainLog = short table, targetLength unused) */
     uint32_t        chainLog;

@@ -699,6 +699,9 @@ static u32 lowest_prefix(const zwin* w, u32 curr) { return (curr - w->dictLimit 
 
 /* One block [bs, be) of a frame whose bytes start at src[0]: `table` and `rep` carry over from the previous block.
  * Returns the number of sequences; positions are offsets into src, table entries position + 2. */
+/* stepSize of the fast parser (zstd_fast.c:440): targetLength + !targetLength + 1 - 2 for levels >= -1, 1 - level below
+ * (set by orc_zstd_compress_frame_cp for the frame it writes) */
+static u32 g_fast_step = 2;
 static size_t fast_block_at(const u8* src, u32 bs, u32 be, u32* table, u32 hlog, u32 mls, const zwin* w, u32 rep[2],
                             zseq* seqs, u8* lits, size_t* litSizeOut)
 {
@@ -713,7 +716,7 @@ static size_t fast_block_at(const u8* src, u32 bs, u32 be, u32* table, u32 hlog,
     if (n < 16 + 4) goto cleanup;                                     /* ilimit = n - 16 must leave room for ip3 */
     {   const u32 ilimit = n - 16;
         for (;;) {                                                    /* _start */
-            u32 step = 2, nextStep = ip0 + 128, ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
+            u32 step = g_fast_step, nextStep = ip0 + 128, ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
             u32 hash0, hash1, idx, current0 = 0, match0 = 0, offcode = 0, mLength = 0;
             int found = 0;
             if (ip3 >= ilimit) goto cleanup;
@@ -972,7 +975,8 @@ size_t orc_zstd_compress_frame_cp(const u8* src, size_t n, u8* dst, size_t dstCa
     /* blockSize = MIN(ZSTD_BLOCKSIZE_MAX, windowSize) (ZSTD_resetCCtx_internal, zstd_compress.c:2129-2131) */
     const size_t blockMax = windowLog < 17 ? (size_t)1 << windowLog : 128u << 10;
     if (n >= (1u << 31) || dstCap < orc_zstd_compress_bound(n) || dstCap < 18 || windowLog < 10 || windowLog > 31) return 0;
-    if (strategy == 1 ? targetLength > 1 : strategy != 2) return 0;
+    if (strategy != 1 && strategy != 2) return 0;
+    if (strategy == 1 && targetLength > (1u << 17)) return 0;
     /* ZSTD_writeFrameHeader (zstd_compress.c:4586-4632) */
     op[0] = 0x28; op[1] = 0xB5; op[2] = 0x2F; op[3] = 0xFD; op += 4;
     {   const u32 single = ((u64)1 << windowLog) >= n;
@@ -996,6 +1000,7 @@ size_t orc_zstd_compress_frame_cp(const u8* src, size_t n, u8* dst, size_t dstCa
         memset(&hprev, 0, sizeof(hprev));
         hprev.disabled = strategy == 1 && targetLength > 0;           /* fast with a target length: literals stay raw (zstd_compress_internal.h:609-622) */
         g_strategy = (u32)strategy;
+        g_fast_step = strategy == 1 ? targetLength + !targetLength + 1 : 2;
         for (bs = 0; bs < n; bs += blockMax) {
             const size_t bn = n - bs < blockMax ? n - bs : blockMax;
             const u32 last = bs + bn == n;
@@ -1032,6 +1037,7 @@ size_t orc_zstd_compress_frame_cp(const u8* src, size_t n, u8* dst, size_t dstCa
         }
         g_strategy = 1;
         free(table); free(tableS); free(seqs); free(lits); free(tmp);
+        g_fast_step = 2;
     }
     return (size_t)(op - dst);
 }

@@ -196,6 +196,30 @@ def test_zstd_multi_block_frames_bit_exact(oracle, ref, kind):
 
 
 @pytest.mark.parametrize("kind", zfc.KINDS)
+def test_zstd_fast_with_a_wider_step_bit_exact(oracle, ref, kind):
+    """the levels below -1 (and explicit targetLength > 1): the fast parser's pairs are targetLength + 1 bytes apart from the start
+    (zstd_fast.c:440, :491-506), literals stay raw (zstd_compress_internal.h:609-622) - the reference's level rows and explicit sets"""
+    import ctypes as C
+    f = oracle.L.orc_zstd_compress_frame_tl
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    checked = 0
+    for i, n in enumerate((1, 700, 20000, 131072, 131073, 400000, 1300000)):
+        data = zfc.make(kind, n, seed=900 + i)
+        cps = [zfc.ref_level_cparams(ref, level, n) for level in (-2, -3, -5, -7, -64, -1000, -131072)]
+        cps += [zfc.CParams(*row) for row in ((17, 13, 14, 1, 6, 2, 1), (19, 13, 12, 1, 4, 9, 1), (20, 13, 17, 1, 7, 300, 1))]
+        for cp in cps:
+            assert cp.strategy == 1 and cp.targetLength > 1
+            want = zfc.ref_frame(ref, data, cp)
+            cap = n + (n >> 8) + 64
+            out = C.create_string_buffer(cap)
+            r = f(data, n, out, cap, cp.windowLog, cp.hashLog, max(cp.minMatch, 4), cp.targetLength)
+            assert out.raw[:r] == want, (kind, n, cp.windowLog, cp.hashLog, cp.minMatch, cp.targetLength)
+            checked += 1
+    assert checked >= 60
+
+
+@pytest.mark.parametrize("kind", zfc.KINDS)
 def test_zstd_double_fast_multi_block_frames_bit_exact(oracle, ref, kind):
     """the same for "double-fast" (zstd_double_fast.c:332-573): both tables, the window and the repeat offsets carry from block
     to block - the levels' own rows (level 2 between 128 and 256 KiB, levels 3-4) and explicit parameters, minMatch 3 = 4"""

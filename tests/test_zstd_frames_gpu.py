@@ -122,7 +122,7 @@ def test_bad_parameters_are_refused(eng):
         with pytest.raises(a.EngineError):
             eng.zstd_compress_frames(src, [0, 16], wl, hl, mm)
     with pytest.raises(a.EngineError):
-        eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, target_length=2)
+        eng.zstd_compress_frames(src, [0, 16], 19, 14, 6, target_length=(1 << 17) + 1)      # ZSTD_TARGETLENGTH_MAX
     with pytest.raises(a.EngineError):
         eng.zstd_compress_frames(src, [0, 16], 19, 15, 6, flags=2)          # the LDS finder serves hashLog <= 14
     for (strategy, cl) in ((3, 14), (0, 14), (2, 5), (2, 25)):
