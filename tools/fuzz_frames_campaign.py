@@ -2,7 +2,7 @@
 """Random-seed parity campaign for whole-input frames on the GPU box (TEST INFRASTRUCTURE: loads oracle/).
 Zstd: batches of LZ-grammar / mixed-statistics inputs of 1 B - 3 MB compressed as frames by aoclgpu_zstd_compress_frames with
 random parameters (fast and double-fast, windows from 1 KiB to 8 MiB - below the block size, below the input, above it -
-hashLog / chainLog 6-18, minMatch 4-7, targetLength 0-1) against orc_zstd_compress_frame_cp, and decoded back by the GPU
+hashLog / chainLog 6-18, minMatch 4-7, targetLength 0-131072) against orc_zstd_compress_frame_cp, and decoded back by the GPU
 decoder.  LZ4: LZ4F_compressFrame with linked blocks (block sizes 64 KiB - 4 MiB, accelerations) against the oracle's linked
 blocks, decoded back through LZ4F_decompress.  usage: tools/fuzz_frames_campaign.py <seconds> [seed]"""
 import ctypes as C, os, struct, sys, time
@@ -59,7 +59,7 @@ while time.time() - t0 < budget:
     inputs = [make_input(rng) for _ in range(int(rng.integers(1, 9)))]
     strategy = int(rng.integers(1, 3))
     wl, hl, cl, mm = int(rng.integers(10, 24)), int(rng.integers(6, 19)), int(rng.integers(6, 19)), int(rng.integers(4, 8))
-    tl = int(rng.integers(0, 2)) if strategy == 1 else 0
+    tl = int(rng.choice([0, 1, 1, 2, 3, 4, 7, 8, 31, 127, 128, 129, 1000, 131072])) if strategy == 1 else 0   # step = tl + 1 above 1
     off = np.zeros(len(inputs) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(x) for x in inputs])
     src = torch.frombuffer(bytearray(b"".join(inputs)), dtype=torch.uint8).to(eng.device)
     flags = int(rng.choice([1, 2])) if strategy == 1 and hl <= 14 else 0         # both finders of the fast strategy
