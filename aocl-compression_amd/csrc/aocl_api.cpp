@@ -142,12 +142,36 @@ int64_t wrap_decompress(int t, const aocl_compression_desc* h)
 
 }  // namespace
 
+// Trace lines of the reference's logger (utils/utils.h:92-208, built with AOCL_ENABLE_LOG_FEATURE): the level comes from the
+// environment at every statement (AOCL_ENABLE_LOG = ERR | INFO | DEBUG | TRACE), errors go to stderr, everything else to stdout,
+// one line "[LEVEL] : file : function : line : text".  Always compiled in here; silent without the variable.
+namespace {
+enum { kLogErr = 1, kLogInfo = 2, kLogDebug = 3, kLogTrace = 4 };
+int log_max_level()
+{
+    const char* e = getenv("AOCL_ENABLE_LOG");
+    if (!e) return 0;
+    return !strcmp(e, "ERR") ? 1 : !strcmp(e, "INFO") ? 2 : !strcmp(e, "DEBUG") ? 3 : !strcmp(e, "TRACE") ? 4 : 0;
+}
+const char* codec_name(int t)
+{   // aocl_codec[].codec_name (api/codec.h:165-193)
+    static const char* const names[] = {"lz4", "lz4hc", "lzma", "bzip2", "snappy", "zlib", "zstd"};
+    return (t >= 0 && t < (int)(sizeof(names) / sizeof(names[0]))) ? names[t] : "?";
+}
+}  // namespace
+#define AOCL_LOG(level, ...) do { if ((level) <= log_max_level()) { \
+        FILE* f_ = (level) == kLogErr ? stderr : stdout; \
+        fprintf(f_, "[%s] : %s : %s : %d : ", (level) == kLogErr ? "ERR" : (level) == kLogInfo ? "INFO" : (level) == kLogDebug ? "DEBUG" : "TRACE", __FILE__, __func__, __LINE__); \
+        fprintf(f_, __VA_ARGS__); fprintf(f_, "\n"); } } while (0)
+
 extern "C" void aoclgpu_set_rap_geometry(int reference) { g_rap_geometry.store(reference ? 1 : 0); }
 extern "C" int aoclgpu_rap_geometry(void) { return rap_geometry(); }
 
 extern "C" int64_t aocl_llc_compress(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     if (!handle) return ERR_COMPRESSION_FAILED;
+    AOCL_LOG(kLogTrace, "Enter");
+    AOCL_LOG(kLogInfo, "Calling compression method: %s", codec_name(raw_type(codec_type)));   // api/api.cpp:54-57
     const uint64_t t0 = now_ns();
     const int64_t ret = wrap_compress(raw_type(codec_type), handle);
     const uint64_t t1 = now_ns();
@@ -156,12 +180,15 @@ extern "C" int64_t aocl_llc_compress(aocl_compression_desc* handle, aocl_compres
         handle->cTime = t1 - t0;
         handle->cSpeed = (float)((handle->inSize * 1000.0) / (double)handle->cTime);
     }
+    AOCL_LOG(kLogTrace, "Exit");
     return ret < 0 ? ERR_COMPRESSION_FAILED : ret;
 }
 
 extern "C" int64_t aocl_llc_decompress(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     if (!handle) return ERR_COMPRESSION_FAILED;
+    AOCL_LOG(kLogTrace, "Enter");
+    AOCL_LOG(kLogInfo, "Calling decompression method: %s", codec_name(raw_type(codec_type)));  // api/api.cpp:95-98
     const uint64_t t0 = now_ns();
     const int64_t ret = wrap_decompress(raw_type(codec_type), handle);
     const uint64_t t1 = now_ns();
@@ -170,16 +197,26 @@ extern "C" int64_t aocl_llc_decompress(aocl_compression_desc* handle, aocl_compr
         handle->dTime = t1 - t0;
         handle->dSpeed = (float)((handle->dSize * 1000.0) / (double)handle->dTime);
     }
+    AOCL_LOG(kLogTrace, "Exit");
     return ret < 0 ? ERR_COMPRESSION_FAILED : ret;
 }
 
 extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     const int ct = raw_type(codec_type);
-    if (ct < (int)LZ4 || ct >= (int)AOCL_COMPRESSOR_ALGOS_NUM)
+    AOCL_LOG(kLogTrace, "Enter");
+    if (ct < (int)LZ4 || ct >= (int)AOCL_COMPRESSOR_ALGOS_NUM) {
+        AOCL_LOG(kLogErr, "setup failed !! compression method is not supported.");
         return ERR_UNSUPPORTED_METHOD;                // api/api.cpp:133-138
+    }
+    if (handle) AOCL_LOG(kLogInfo, "All optimizations are turned %s", handle->optOff ? "off" : "on");   // :140-141
+    AOCL_LOG(kLogInfo, "Calling setup method for: %s", codec_name(ct));
     aoclgpu_codec c;
-    if (!gpu_codec(ct, &c)) return ERR_EXCLUDED_METHOD;   // api/api.cpp:155-161 (no backend in this build)
+    if (!gpu_codec(ct, &c)) {                         // api/api.cpp:155-161 (no backend in this build)
+        AOCL_LOG(kLogErr, "setup failed !! compression method is excluded from this library build.");
+        AOCL_LOG(kLogTrace, "Exit");
+        return ERR_EXCLUDED_METHOD;
+    }
     if (handle) {
         // utils/utils.cpp:148-175 derives optLevel from CPUID; host ISA levels are meaningless for the GPU
         // backend, so it reports 0 ("no host SIMD path selected").  workBuf: LZ4/Snappy keep no context
@@ -197,13 +234,20 @@ extern "C" int32_t aocl_llc_setup(aocl_compression_desc* handle, aocl_compressio
         // table (optOff -> upstream parameters, zstd_compress.c:7390-7425)
         if (ct == (int)ZSTD) (void)aocl_setup_zstd_encode(handle->optOff, 0, handle->inSize, handle->level, handle->optVar);
     }
-    if (aoclgpu_init(aoclgpu_host_device()) != AOCLGPU_OK) return ERR_EXCLUDED_METHOD;   // AOCLGPU_DEVICE / aoclgpu_set_host_device
+    if (aoclgpu_init(aoclgpu_host_device()) != AOCLGPU_OK) {   // AOCLGPU_DEVICE / aoclgpu_set_host_device
+        AOCL_LOG(kLogErr, "setup failed !! no gfx950 device for the GPU backend.");
+        AOCL_LOG(kLogTrace, "Exit");
+        return ERR_EXCLUDED_METHOD;
+    }
+    AOCL_LOG(kLogTrace, "Exit");
     return 0;
 }
 
 extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression_type codec_type)
 {
     if (!handle) return;
+    AOCL_LOG(kLogTrace, "Enter");
+    AOCL_LOG(kLogInfo, "Calling destroy method for: %s", codec_name(raw_type(codec_type)));   // api/api.cpp:172-175
     if (raw_type(codec_type) == (int)ZSTD && handle->workBuf) {          // api/codec.cpp:378-394
         void** ctx = (void**)handle->workBuf;
         ZSTD_freeCCtx((ZSTD_CCtx*)ctx[0]); ZSTD_freeDCtx((ZSTD_DCtx*)ctx[1]);
@@ -212,6 +256,7 @@ extern "C" void aocl_llc_destroy(aocl_compression_desc* handle, aocl_compression
     }
     handle->workBuf = NULL;
     aoclgpu_host_trim();                                  // staging buffers of idle host contexts go back to the device
+    AOCL_LOG(kLogTrace, "Exit");
 }
 
 extern "C" const char* aocl_llc_version(void)

@@ -69,7 +69,7 @@ def test_frame_entry_points_check_their_arguments_without_gpu():
             setattr(f, k, v)
         return lib.aoclgpu_zstd_compress_frames(C.byref(f), None)
 
-    for bad in (dict(windowLog=9), dict(windowLog=32), dict(hashLog=5), dict(hashLog=25), dict(minMatch=3), dict(minMatch=8), dict(targetLength=2),
+    for bad in (dict(windowLog=9), dict(windowLog=32), dict(hashLog=5), dict(hashLog=25), dict(minMatch=3), dict(minMatch=8), dict(targetLength=(1 << 17) + 1),
                 dict(strategy=0), dict(strategy=3), dict(strategy=2, chainLog=5), dict(strategy=2, chainLog=25), dict(src_off=None), dict(out_len=None)):
         assert frames(**bad) == -1, bad                                    # AOCLGPU_ERR_ARG
         assert b"zstd frames" in lib.aoclgpu_last_error()
@@ -81,6 +81,29 @@ def test_frame_entry_points_check_their_arguments_without_gpu():
     lib.aoclgpu_zstd_set_large_input_mode(1); lib.aoclgpu_lz4f_set_block_linking(0)
     assert lib.aoclgpu_zstd_large_input_mode() == 1 and lib.aoclgpu_lz4f_block_linking() == 0
     lib.aoclgpu_zstd_set_large_input_mode(0); lib.aoclgpu_lz4f_set_block_linking(1)
+
+
+def test_log_lines_follow_aocl_enable_log():
+    """AOCL_ENABLE_LOG = ERR | INFO | DEBUG | TRACE (utils/utils.h:92-208): one line per statement, "[LEVEL] : file : function :
+    line : text", errors on stderr, the rest on stdout, the level read from the environment at every statement; silent without it"""
+    import subprocess, sys
+    prog = ("import ctypes as C, sys; sys.path.insert(0, %r); from aocl_compression_amd import api; lib = api.load_library(); "
+            "d = api.LlcDesc(); print('rc', lib.aocl_llc_setup(C.byref(d), 9), flush=True); "
+            "print('rc', lib.aocl_llc_setup(C.byref(d), 2), flush=True)") % ROOT            # 9: no such method, 2 = LZMA: no backend
+    def run(level):
+        env = dict(os.environ); env.pop("AOCL_ENABLE_LOG", None)
+        if level: env["AOCL_ENABLE_LOG"] = level
+        return subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=120)
+    quiet = run(None)
+    assert quiet.returncode == 0 and "[" not in quiet.stdout and "[ERR]" not in quiet.stderr
+    err = run("ERR")
+    assert "[ERR] : " in err.stderr and "setup failed !! compression method is not supported." in err.stderr
+    assert "compression method is excluded from this library build." in err.stderr and "[TRACE]" not in err.stdout and "[INFO]" not in err.stdout
+    tr = run("TRACE")
+    lines = [l for l in tr.stdout.splitlines() if l.startswith("[")]
+    assert any(l.startswith("[TRACE] : ") and l.endswith(" : Enter") and " : aocl_llc_setup : " in l for l in lines)
+    assert any(l.startswith("[INFO] : ") and l.endswith("Calling setup method for: lzma") for l in lines)
+    assert any(l.endswith(" : Exit") for l in lines) and "[ERR] : " in tr.stderr
 
 
 def test_no_cpu_fallback():
