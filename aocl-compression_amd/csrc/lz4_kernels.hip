@@ -221,6 +221,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     // lane; false = the output does not fit (limitedOutput, :1660-1668 and :1711-1716 - the parse never depends on the
     // output position, so checking a whole buffer at once returns 0 for exactly the inputs the reference returns 0 for).
     auto flush = [&]() -> bool {
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOFLUSH)   /* timing only: what the parser costs without the formatter (output is garbage) */
+        f_anchor = anchor; nrec = 0; return true;
+#endif
         const uint32_t L = (uint32_t)lane;
         const bool act = L < nrec;
         uint32_t lit = 0, mc = 0, off = 0;
