@@ -3,7 +3,7 @@
  * Declarations mirror /root/reference/api/aocl_compression.h:95-231 (AOCL-Compression 4.2.0): same enum
  * values, same LP64 struct layout, same five functions with the same argument meaning and error
  * behaviour (api/api.cpp:45-189), so a program written against the reference header can be relinked
- * against this library.  LZ4, SNAPPY and ZSTD (levels -1 and 1-4: the "fast" and "double-fast" strategies, level 0 = 3,
+ * against this library.  LZ4, SNAPPY and ZSTD (levels 1-4 and every negative level: the "fast" and "double-fast" strategies, level 0 = 3,
  * inputs of any size) have a GPU backend (LZ4HC: decompression only - its streams are LZ4 blocks, api/codec.cpp:179-188;
  * compression fails);
  * other enumerators report ERR_EXCLUDED_METHOD from aocl_llc_setup exactly as a reference build
