@@ -109,7 +109,7 @@ int64_t wrap_compress(int t, const aocl_compression_desc* h)
         return r > 0 ? r : kCodecError;
     }
     // ZSTD: the call sequence of the reference's wrapper (api/codec.cpp:388-422) on this library's own Zstd entry points:
-    // parameters from the level table, optVar clamps windowLog, ZSTD_compress_advanced.  Levels -1 and 0-4 (fast and double-fast,
+    // parameters from the level table, optVar clamps windowLog, ZSTD_compress_advanced.  Levels 0-4 and the negative ones (fast and double-fast,
     // windows below the input size included) are compressed; greedy and above come back as
     // ZSTD_error_parameter_unsupported -> CODEC_ERROR, never as different bytes.
     ZSTD_parameters zp = ZSTD_getParams((int)h->level, h->inSize, 0);
