@@ -86,7 +86,7 @@ EXPORTS = [
     "aoclgpu_device_count", "aoclgpu_init", "aoclgpu_last_error", "aoclgpu_version", "aoclgpu_compress_bound",
     "aoclgpu_lz4_compress_chunks", "aoclgpu_lz4_decompress_chunks",
     "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
-    "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks",
+    "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks", "aoclgpu_zstd_last_split_slabs",
     "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_compress_host_ex", "aoclgpu_decompress_host",
     "aoclgpu_rap_pack", "aoclgpu_rap_unpack", "aoclgpu_rap_frame_bytes", "aoclgpu_rap_default_chunk",
     "aoclgpu_rap_compress_host", "aoclgpu_rap_decompress_host",

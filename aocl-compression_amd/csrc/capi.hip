@@ -128,7 +128,12 @@ void* get_workspace(const WsGuard&, size_t bytes, void* stream)
         if (e->dev != dev) (void)hipSetDevice(cur);
         e->p = nullptr; e->bytes = 0;
     }
-    if (hipMalloc(&e->p, bytes) != hipSuccess) {
+    size_t ask = bytes;
+    if (const char* f = getenv("AOCLGPU_FAULT_WORKSPACE_MB")) {   // test hook: requests above this size fail the way a full device fails them
+        const long long mb = atoll(f);
+        if (mb > 0 && bytes > ((size_t)mb << 20)) ask = (size_t)1 << 60;
+    }
+    if (hipMalloc(&e->p, ask) != hipSuccess) {
         (void)hipGetLastError();                          // the failure must not surface as the next launch's error (callers fall back)
         e->p = nullptr; return nullptr;
     }

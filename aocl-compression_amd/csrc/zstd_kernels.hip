@@ -27,6 +27,7 @@
 #include "zstd_hufspec.h"
 #include "host_util.h"
 #include <mutex>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -3031,8 +3032,10 @@ namespace {
 // slabs of at most AOCLGPU_ZSTD_DF_SLAB_MB (default: 32 GiB or a quarter of the device's memory, whichever is smaller).
 // Returns AOCLGPU_OK when enqueued, 1 when the caller should use the fused kernel (batch too small to gain, scratch not
 // available), an error code otherwise.
+std::atomic<int> g_df_last_slabs{0};                      // slabs of the newest double-fast launch, 0: the fused kernel ran
 int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size_t tabBytes, const aoclgpu::WsGuard& guard, hipStream_t s)
 {
+    g_df_last_slabs.store(0);
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
@@ -3073,6 +3076,7 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     const size_t ctrOff = (metaOff + (size_t)slab * 8 + 255) & ~(size_t)255;
     uint8_t* ws = (uint8_t*)get_workspace(guard, ctrOff + (size_t)nslab * 256, s);
     if (!ws) return 1;
+    g_df_last_slabs.store((int)nslab);
     if (hipMemsetAsync(ws + ctrOff, 0, (size_t)nslab * 256, s) != hipSuccess) { aoclgpu::set_error_msg("zstd: hipMemsetAsync failed"); return AOCLGPU_ERR_HIP; }
     for (uint32_t k = 0; k < nslab; ++k) {
         const uint32_t f0 = first + k * slab, m = (k + 1) * slab <= count ? slab : count - k * slab;
@@ -3085,6 +3089,8 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     return AOCLGPU_OK;
 }
 }  // namespace
+
+extern "C" int aoclgpu_zstd_last_split_slabs(void) { return g_df_last_slabs.load(); }
 
 extern "C" int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream)
 {

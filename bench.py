@@ -695,7 +695,7 @@ class Run:
         if (self.name, dom) == ("zstd3", "compress") and self.nchunks > 16 * 256:
             # large level-3 batches: finder kernel + entropy kernel per slab of <= 32 Ki chunks (csrc/zstd_kernels.hip df_split_launch);
             # avg_launch_ms below is the whole compress call = the sum of its launches (profiles/r03_zstd3_*_kernel_trace_and_pmc.txt)
-            nslab = -(-self.nchunks // 32768)
+            nslab = int(self.eng.lib.aoclgpu_zstd_last_split_slabs()) or 1   # what the launcher used (free memory decides the slab size)
             kernel = "zstd_df_find_kernel"
             launches = {"per_compress_call": {"zstd_df_find_kernel": nslab, "zstd_df_entropy_kernel": nslab},
                         "note": "avg_launch_ms = one compress call = all of these launches back to back"}

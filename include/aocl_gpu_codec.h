@@ -125,6 +125,9 @@ int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_decompress_chunks(const aoclgpu_batch* b, void* stream);
+/* levels 3-4 on a large batch run as finder kernel + entropy kernel per slab of chunks (the slab size follows the device's free
+ * memory): the number of slabs the newest such aoclgpu_zstd_compress_chunks call of this process used, 0 = one fused kernel */
+int aoclgpu_zstd_last_split_slabs(void);
 
 /* Zstd, one frame per input of ANY size below 2 GiB with the "fast" or "double-fast" strategy: what ZSTD_compress_advanced writes for these
  * compression parameters (zstd_compress.c:5388-5470 -> ZSTD_compress_frameChunk :4504-4583): blocks of min(128 KiB, window)

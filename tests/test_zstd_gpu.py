@@ -267,6 +267,37 @@ def test_search_that_starts_at_the_last_lane(eng, oracle):
     assert slots[:int(lens[0])].cpu().numpy().tobytes() == oracle.compress(ol.ZSTD, data)
 
 
+def test_double_fast_falls_back_when_the_slab_scratch_cannot_be_had(eng, oracle):
+    """the two-kernel path needs 1 MB of scratch per chunk in flight; when the device cannot give it (here: the test hook
+    AOCLGPU_FAULT_WORKSPACE_MB fails every request above 6 GB with the runtime's own out-of-memory error) the call falls back to
+    the fused kernel, and the failed allocation does not surface as that launch's error"""
+    import os
+    import ctypes as C
+    level, chunk, nchunks = 3, 65536, 8200
+    lib = eng.lib
+    lib.aocl_setup_zstd_encode.restype = C.c_void_p
+    lib.aocl_setup_zstd_encode.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.aoclgpu_zstd_last_split_slabs.restype = C.c_int
+    data = a.corpus.silesia_mix(chunk * nchunks, seed=9)
+    src = torch.from_numpy(data).to(eng.device)
+    lib.aocl_destroy_zstd_encode(); lib.aocl_setup_zstd_encode(0, 0, 0, level, 0)
+    try:
+        slots0, len0, slot = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.zstd_level(level, False))
+        assert lib.aoclgpu_zstd_last_split_slabs() >= 1                 # enough memory: finder + entropy kernels
+        os.environ["AOCLGPU_FAULT_WORKSPACE_MB"] = "6000"
+        side = torch.cuda.Stream()                                      # (another stream: its scratch has to be allocated)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            slots1, len1, _ = eng.compress_chunks(a.ZSTD, src, chunk, flags=a.api.zstd_level(level, False))
+        side.synchronize()
+        assert lib.aoclgpu_zstd_last_split_slabs() == 0                 # the fused kernel ran
+        assert torch.equal(len0, len1) and int((len1 <= 0).sum()) == 0
+        assert torch.equal(slots0, slots1)                              # same bytes either way
+    finally:
+        os.environ.pop("AOCLGPU_FAULT_WORKSPACE_MB", None)
+        lib.aocl_destroy_zstd_encode(); lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
+
+
 @pytest.mark.parametrize("slab_mb", [None, "2500"])
 def test_double_fast_large_batch_two_kernels(eng, oracle, slab_mb):
     """more chunks than the fused kernel holds at once: the finder and the entropy stage run as two kernels over slabs of
