@@ -124,7 +124,10 @@ constexpr uint32_t kScratch = 1024;
 // copies at once, ONE PER LANE: prefix sums give each its literal source and its output position, the literal tag, the literals
 // (four pieces per size class, lz_group.hip.h), and the copy elements (EmitCopy's 64-byte elements, the 60-byte one, the last one
 // of 2 or 3 bytes) are computed per lane.  A batch adds at most 17 copies (64 consecutive positions, a copy covers at least 4).
-constexpr uint32_t kSnRecCap = 60, kSnRecFlush = kSnRecCap - 17, kSnRecBytes = kSnRecCap * 8;
+#ifndef SN_REC_CAP
+#define SN_REC_CAP 60
+#endif
+constexpr uint32_t kSnRecCap = SN_REC_CAP, kSnRecFlush = kSnRecCap - 17, kSnRecBytes = kSnRecCap * 8;
 
 // Experiment build (-DAOCLGPU_EXPERIMENTS -DSN_COUNT): memory accesses of the parser by origin, counted per lane and summed per
 // table kind (index 0-7 LDS-table waves, 8-15 HBM-table waves): batches, probe-window loads (two 16-byte loads each), table slot
