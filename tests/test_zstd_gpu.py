@@ -292,7 +292,10 @@ def test_double_fast_falls_back_when_the_slab_scratch_cannot_be_had(eng, oracle)
         side.synchronize()
         assert lib.aoclgpu_zstd_last_split_slabs() == 0                 # the fused kernel ran
         assert torch.equal(len0, len1) and int((len1 <= 0).sum()) == 0
-        assert torch.equal(slots0, slots1)                              # same bytes either way
+        # same bytes either way (a slot's tail behind the chunk's compressed size is whatever the buffer held)
+        pos = torch.arange(slots0.numel(), device=slots0.device)
+        live = (pos % slot) < len1.to(torch.int64).repeat_interleave(slot)
+        assert torch.equal(slots0[live], slots1[live])
     finally:
         os.environ.pop("AOCLGPU_FAULT_WORKSPACE_MB", None)
         lib.aocl_destroy_zstd_encode(); lib.aocl_setup_zstd_encode(0, 0, 0, 1, 0)
