@@ -398,6 +398,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     const int j = (int)__builtin_ctzll(d);
                     const uint64_t before = (1ull << j) - 1;
                     const uint64_t same = ballot(h == lane_get(h, j)) & before;
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOCUT)   /* timing only: what in-batch duplicates cost - no batch is cut at one (wrong parse, same work per batch) */
+                    if ((same >> lane) & 1) later |= 1ull << j;
+                    continue;
+#endif
                     if (((tabok >> j) & 1) || (ballot(my4 == lane_get(my4, j)) & same) != 0) { lim = (uint32_t)j; break; }
                     if ((same >> lane) & 1) later |= 1ull << j;
                 }
