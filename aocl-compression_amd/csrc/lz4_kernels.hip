@@ -89,6 +89,10 @@ __device__ __forceinline__ uint32_t put_len_bytes(gbyte* d, uint32_t rem, int la
 
 #ifdef AOCLGPU_EXPERIMENTS
 __device__ unsigned long long g_lz4_prof[16];     // per-stage cycle sums of the PROF instantiation (tools/lz4_stage_prof.py)
+__device__ unsigned long long g_lz4_cond[8];      // conditional lanes: could-match duplicates, conditional ones, stops taken, stops cut, cut with no written lane on the slot
+#define LZ4_CC(k, n) (ccnt[k] += (n))
+#else
+#define LZ4_CC(k, n) ((void)0)
 #endif
 
 // 16-byte window [p-4, p+12) as two 64-bit halves (bytes before the chunk start read as 0)
@@ -155,6 +159,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         }
     };
     const int lane = lane_id();
+#ifdef AOCLGPU_EXPERIMENTS
+    uint32_t ccnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PROF: batches, sequences, stop: beyond-batch, lim, more_fwd, nomatch, sum(lim), -
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
@@ -373,6 +380,22 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 wave_fence();
                 const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane);
                 wave_fence();
+                // Slots named twice: the SECOND lane of a slot (the smallest of the duplicates, found by the same rounds among the
+                // duplicates) has exactly one earlier lane on its slot - the first one, w; the first lane learns its partner from the
+                // slot.  Third and later lanes of a slot are rare outside runs and always end the batch.
+                const uint64_t dups = ballot(w != (uint32_t)lane);
+                uint32_t w2 = (uint32_t)lane, partner = 64;
+                if (dups) {
+                    typedef __attribute__((address_space(3))) uint16_t LU16;
+                    const bool isdup = w != (uint32_t)lane;
+                    if (isdup) *(LU16*)&table[h] = 0xFFFFu;
+                    wave_fence();
+                    w2 = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane, isdup);
+                    wave_fence();
+                    const uint32_t sv = *(LU16*)&table[h];
+                    if (!isdup && sv != (uint32_t)lane) partner = sv;
+                    wave_fence();
+                }
                 table[h] = (T)ent;                        // undo the lane ids (the low halves; extra bits were not touched)
                 wave_fence();
                 if (ballot(plausible && cand < 4)) {      // window that starts before the chunk: loaded from byte 0, moved up 4 - cand bytes
@@ -390,20 +413,42 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 // holds the same 4 bytes: it is a probe that finds nothing, whoever its candidate is.  The batch is cut at the
                 // first duplicate that could match.  `later` = this lane's slot is named again by these later lanes (the last
                 // one whose write happens owns the slot when the batch commits).
-                const uint64_t tabok = ballot(plausible && A.y == my4);
-                uint64_t later = 0;
-                uint32_t lim = 64;
-                const uint64_t dups = ballot(w != (uint32_t)lane);
-                for (uint64_t d = dups; d; d &= d - 1) {
-                    const int j = (int)__builtin_ctzll(d);
-                    const uint64_t before = (1ull << j) - 1;
-                    const uint64_t same = ballot(h == lane_get(h, j)) & before;
+                // One kind of duplicate that could match IS decided (round 4, second half): the lane whose LATEST earlier lane on the
+                // slot holds the same 4 bytes - a repeat at a distance below 64, the usual reason two lanes of a batch share a slot
+                // (binary and record data are full of them).  Its candidate is that lane's position, provided that lane's table write
+                // happens, i.e. that lane is a probe and not a position inside one of the batch's matches - which the walk knows when
+                // it arrives there.  Such a "conditional" lane gets its candidate window from the source ring (it is the other
+                // lane's probe window), stops the walk like a special lane, and is either taken (the walk goes on from it) or, if
+                // its candidate lane turns out to lie inside a match, cuts the batch there as every could-match duplicate used to.
+                uint64_t tabok = ballot(plausible && A.y == my4);
+                uint64_t condm = 0;
+                uint32_t lim = 64, pv = w;
+                if (dups) {
+                    const bool isdup = w != (uint32_t)lane, second = isdup && w2 == (uint32_t)lane;
+                    const bool e1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)my4) == my4;     // the first lane's 4 bytes
+                    // cut at: a third lane on a slot; a second lane that could match the TABLE's candidate while the first lane holds
+                    // other bytes (its candidate depends on the parse and neither alternative is at hand); linked blocks: any second
+                    // lane that could match
+                    const bool cutl = isdup && (!second || (!e1 && plausible && A.y == my4) || (LINKED && e1));
 #if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOCUT)   /* timing only: what in-batch duplicates cost - no batch is cut at one (wrong parse, same work per batch) */
-                    if ((same >> lane) & 1) later |= 1ull << j;
-                    continue;
+                    const uint64_t cutm = 0;
+#else
+                    const uint64_t cutm = ballot(cutl);
 #endif
-                    if (((tabok >> j) & 1) || (ballot(my4 == lane_get(my4, j)) & same) != 0) { lim = (uint32_t)j; break; }
-                    if ((same >> lane) & 1) later |= 1ull << j;
+                    if (cutm) lim = (uint32_t)__builtin_ctzll(cutm);
+                    condm = ballot(second && e1 && !LINKED);
+                    LZ4_CC(0, (uint32_t)__builtin_popcountll(ballot(isdup && (e1 || (plausible && A.y == my4))))); LZ4_CC(1, (uint32_t)__builtin_popcountll(condm));
+                }
+                condm &= lim >= 64 ? ~0ull : ((1ull << lim) - 1);
+                bool isc = false;
+                if (condm) {                                  // conditional lanes: the candidate is lane pv's position, its window lane pv's probe window
+                    isc = __builtin_amdgcn_inverse_ballot_w64(condm);
+                    if (isc) {
+                        const uint32_t rc = (uint32_t)(w0 + (int32_t)pv) & 511u;
+                        A = lds_ld128(ring + rc); B = lds_ld128(ring + rc + 16);
+                        cand = s0 + pv;
+                    }
+                    tabok |= condm;
                 }
                 const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));   // lanes < lim are decided exactly as the sequential parse decides them
                 // forward extension (<= 24 bytes, LZ4_count lz4.c:656-679) and catch-up (<= 4 bytes), in registers
@@ -436,10 +481,35 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 uint64_t marks = 0;                           // lanes that start a sequence
                 {
                     const uint64_t first = okmask & (own >= 64 ? ~0ull : ((1ull << own) - 1));
-                    if (first) {                              // marks |= 1 << mw; mw = nxt[mw] until mw >= 64 or a lane of slowmask (lz_group.hip.h)
-                        uint32_t mw, stop;
-                        lz_walk_tokens(mf ? 0x80000000u : nxt, marks, mw, stop, (uint32_t)__builtin_ctzll(first));
-                        if (stop) special = (int)mw;
+                    if (first) {                              // marks |= 1 << mw; mw = nxt[mw] until mw >= 64 or a lane that stops the walk (lz_group.hip.h)
+                        uint32_t mw, stop, start = (uint32_t)__builtin_ctzll(first);
+                        uint32_t nxw = (mf || isc) ? 0x80000000u : nxt;
+                        for (;;) {
+                            uint64_t mk;
+                            lz_walk_tokens(nxw, mk, mw, stop, start);
+                            marks |= mk;
+                            if (!stop) break;
+                            if (!((condm >> mw) & 1)) { special = (int)mw; break; }
+                            // a conditional lane: is its candidate lane a probe (its table write happens), or a position inside a match?
+                            const uint32_t pi = lane_get(pv, (int)mw);
+                            const uint64_t lowm = marks & ((2ull << pi) - 1);                    // matches that start at or below it (pi <= 62)
+                            bool vis = true;
+                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); vis = (uint32_t)mm == pi || lane_get(endl, mm) <= pi; }
+#ifdef AOCLGPU_EXPERIMENTS
+                            if (!vis) {   // statistics: would the table candidate have been the answer (no lane on the slot written so far)?
+                                const uint64_t samec = ballot(h == lane_get(h, (int)mw)) & ((1ull << mw) - 1);
+                                uint64_t cov = 0, bf = 0;
+                                for (uint64_t q = marks; q; q &= q - 1) { const int m2 = (int)__builtin_ctzll(q); const uint32_t e2 = lane_get(endl, m2); const uint32_t e3 = e2 < 64 ? e2 : 64;
+                                    if (e3 > (uint32_t)m2 + 1) cov |= (e3 >= 64 ? ~0ull : ((1ull << e3) - 1)) & ~((2ull << m2) - 1); if (e2 >= 2 && e2 - 2 < 64) bf |= 1ull << (e2 - 2); }
+                                if ((samec & (~cov | bf)) == 0) LZ4_CC(4, 1);
+                                LZ4_CC(3, 1);
+                            } else LZ4_CC(2, 1);
+#endif
+                            if (!vis) { lim = mw; break; }                                       // not decidable here: the batch ends in front of it
+                            if (lane_get((uint32_t)mf, (int)mw)) { special = (int)mw; break; }   // taken, but its match leaves the window
+                            nxw = (uint32_t)lane == mw ? nxt : nxw;                              // taken: the walk goes on from it
+                            start = mw;
+                        }
                     }
                 }
                 // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it
@@ -469,7 +539,8 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
                     const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
                     const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
-                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, entry_of(pos, mychk), ent); }
+                    // (the first lane of a slot leaves the slot to its partner when that one writes: the later write wins)
+                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && !((commit >> (partner & 63u)) & (partner < 64 ? 1ull : 0ull))) tput(h, entry_of(pos, mychk), ent); }
                     else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, entry_of(pos, mychk), ent);
                 }
                 wave_fence();
@@ -647,6 +718,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     }
 #ifdef AOCLGPU_EXPERIMENTS
     if (PROF && lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
+    if (lane == 0) for (int k = 0; k < 8; ++k) if (ccnt[k]) atomicAdd(&g_lz4_cond[k], (unsigned long long)ccnt[k]);
 #endif
 #undef STAGE
     return (int)op;
@@ -1147,6 +1219,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4D_WA
 #include "host_util.h"
 
 #ifdef AOCLGPU_EXPERIMENTS
+extern "C" int aoclgpu_debug_lz4_cond(unsigned long long* host8)
+{   /* experiment build: conditional-lane statistics since the last call (read and cleared) */
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::g_lz4_cond), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_cond), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host16)
 {   /* experiment build: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_lz4_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
