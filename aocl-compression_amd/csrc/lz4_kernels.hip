@@ -420,48 +420,52 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 // it arrives there.  Such a "conditional" lane gets its candidate window from the source ring (it is the other
                 // lane's probe window), stops the walk like a special lane, and is either taken (the walk goes on from it) or, if
                 // its candidate lane turns out to lie inside a match, cuts the batch there as every could-match duplicate used to.
-                uint64_t tabok = ballot(plausible && A.y == my4);
-                uint64_t condm = 0;
-                uint32_t lim = 64, pv = w;
+                const uint64_t tabok = ballot(plausible && A.y == my4);
+                uint64_t condm = 0, e1m = 0;
+                uint32_t lim = 64;
+                const uint32_t pv = w;
                 if (dups) {
                     const bool isdup = w != (uint32_t)lane, second = isdup && w2 == (uint32_t)lane;
                     const bool e1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)my4) == my4;     // the first lane's 4 bytes
-                    // cut at: a third lane on a slot; a second lane that could match the TABLE's candidate while the first lane holds
-                    // other bytes (its candidate depends on the parse and neither alternative is at hand); linked blocks: any second
-                    // lane that could match
-                    const bool cutl = isdup && (!second || (!e1 && plausible && A.y == my4) || (LINKED && e1));
+                    const bool tok = plausible && A.y == my4;
+                    // cut at: a third lane on a slot; linked blocks: any second lane that could match
+                    const bool cutl = isdup && (!second || (LINKED && (e1 || tok)));
 #if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOCUT)   /* timing only: what in-batch duplicates cost - no batch is cut at one (wrong parse, same work per batch) */
                     const uint64_t cutm = 0;
 #else
                     const uint64_t cutm = ballot(cutl);
 #endif
                     if (cutm) lim = (uint32_t)__builtin_ctzll(cutm);
-                    condm = ballot(second && e1 && !LINKED);
-                    LZ4_CC(0, (uint32_t)__builtin_popcountll(ballot(isdup && (e1 || (plausible && A.y == my4))))); LZ4_CC(1, (uint32_t)__builtin_popcountll(condm));
+                    condm = ballot(second && (e1 || tok) && !LINKED);
+                    e1m = ballot(e1);
+                    LZ4_CC(0, (uint32_t)__builtin_popcountll(ballot(isdup && (e1 || tok)))); LZ4_CC(1, (uint32_t)__builtin_popcountll(condm));
                 }
                 condm &= lim >= 64 ? ~0ull : ((1ull << lim) - 1);
-                bool isc = false;
-                if (condm) {                                  // conditional lanes: the candidate is lane pv's position, its window lane pv's probe window
-                    isc = __builtin_amdgcn_inverse_ballot_w64(condm);
+                LZ4_CC(5, lim < 64 ? 1u : 0u); LZ4_CC(6, lim); LZ4_CC(7, 1);
+                const bool isc = condm != 0 && __builtin_amdgcn_inverse_ballot_w64(condm);
+                const uint64_t okmask = (tabok | condm) & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));   // lanes < lim are decided exactly as the sequential parse decides them
+                // forward extension (<= 24 bytes, LZ4_count lz4.c:656-679) and catch-up (<= 4 bytes), in registers
+                auto counts = [&](const u32x4& A_, const u32x4& B_, uint32_t& fw_, uint32_t& bk_) {
+                    const uint64_t x1 = (uint64_t)(a.z ^ A_.z) | ((uint64_t)(a.w ^ A_.w) << 32);
+                    const uint64_t x2 = (uint64_t)(b.x ^ B_.x) | ((uint64_t)(b.y ^ B_.y) << 32);
+                    const uint64_t x3 = (uint64_t)(b.z ^ B_.z) | ((uint64_t)(b.w ^ B_.w) << 32);
+                    fw_ = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                    if (fw_ == 8) fw_ += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
+                    if (fw_ == 16) fw_ += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
+                    const uint32_t yb = a.x ^ A_.x;
+                    bk_ = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
+                };
+                counts(A, B, fw, bk4);
+                mf = fw == 24;
+                // a conditional lane's other alternative: the first lane of its slot as the candidate (that lane's probe window,
+                // from the source ring); which of the two holds is decided when the walk arrives
+                uint32_t fw_c = 0, bk_c = 0;
+                if (condm & e1m) {
                     if (isc) {
                         const uint32_t rc = (uint32_t)(w0 + (int32_t)pv) & 511u;
-                        A = lds_ld128(ring + rc); B = lds_ld128(ring + rc + 16);
-                        cand = s0 + pv;
+                        const u32x4 Ac = lds_ld128(ring + rc), Bc = lds_ld128(ring + rc + 16);
+                        counts(Ac, Bc, fw_c, bk_c);
                     }
-                    tabok |= condm;
-                }
-                const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));   // lanes < lim are decided exactly as the sequential parse decides them
-                // forward extension (<= 24 bytes, LZ4_count lz4.c:656-679) and catch-up (<= 4 bytes), in registers
-                {
-                    const uint64_t x1 = (uint64_t)(a.z ^ A.z) | ((uint64_t)(a.w ^ A.w) << 32);
-                    const uint64_t x2 = (uint64_t)(b.x ^ B.x) | ((uint64_t)(b.y ^ B.y) << 32);
-                    const uint64_t x3 = (uint64_t)(b.z ^ B.z) | ((uint64_t)(b.w ^ B.w) << 32);
-                    fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
-                    if (fw == 8) fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
-                    if (fw == 16) fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
-                    mf = fw == 24;
-                    const uint32_t yb = a.x ^ A.x;
-                    bk4 = yb ? ((uint32_t)__builtin_clz(yb) >> 3) : 4;
                 }
                 if (PROF) { cnt[0]++; cnt[6] += lim; if (i0) cnt[3]++; }
                 STAGE(3);
@@ -472,7 +476,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 // anchor of every sequence, the table commit, the records) is derived from 64-bit lane masks once per batch.
                 // Sequences that need a loop (longer extension / catch-up than the windows hold) are "special": they end
                 // the walk (their `nxt` is negative) and take the one-at-a-time path below.
-                const uint32_t endl = (uint32_t)lane + kMinMatch + fw;                       // match end, in lanes (<= 91)
+                uint32_t endl = (uint32_t)lane + kMinMatch + fw;                             // match end, in lanes (<= 91)
                 uint32_t nxt;
                 {
                     const uint64_t t = (okmask >> (endl < 63 ? endl : 63)) | (1ull << 63);   // (endl >= 4: the shift clears bit 63)
@@ -490,25 +494,31 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                             marks |= mk;
                             if (!stop) break;
                             if (!((condm >> mw) & 1)) { special = (int)mw; break; }
-                            // a conditional lane: is its candidate lane a probe (its table write happens), or a position inside a match?
+                            // A conditional lane.  Was its slot written by the first lane of the slot - as a probe, or as the ip-2
+                            // back-fill of the match that covers it - or does it still hold the table's entry?
                             const uint32_t pi = lane_get(pv, (int)mw);
                             const uint64_t lowm = marks & ((2ull << pi) - 1);                    // matches that start at or below it (pi <= 62)
-                            bool vis = true;
-                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); vis = (uint32_t)mm == pi || lane_get(endl, mm) <= pi; }
-#ifdef AOCLGPU_EXPERIMENTS
-                            if (!vis) {   // statistics: would the table candidate have been the answer (no lane on the slot written so far)?
-                                const uint64_t samec = ballot(h == lane_get(h, (int)mw)) & ((1ull << mw) - 1);
-                                uint64_t cov = 0, bf = 0;
-                                for (uint64_t q = marks; q; q &= q - 1) { const int m2 = (int)__builtin_ctzll(q); const uint32_t e2 = lane_get(endl, m2); const uint32_t e3 = e2 < 64 ? e2 : 64;
-                                    if (e3 > (uint32_t)m2 + 1) cov |= (e3 >= 64 ? ~0ull : ((1ull << e3) - 1)) & ~((2ull << m2) - 1); if (e2 >= 2 && e2 - 2 < 64) bf |= 1ull << (e2 - 2); }
-                                if ((samec & (~cov | bf)) == 0) LZ4_CC(4, 1);
-                                LZ4_CC(3, 1);
-                            } else LZ4_CC(2, 1);
-#endif
-                            if (!vis) { lim = mw; break; }                                       // not decidable here: the batch ends in front of it
-                            if (lane_get((uint32_t)mf, (int)mw)) { special = (int)mw; break; }   // taken, but its match leaves the window
-                            nxw = (uint32_t)lane == mw ? nxt : nxw;                              // taken: the walk goes on from it
-                            start = mw;
+                            bool written = true;
+                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); written = (uint32_t)mm == pi || em <= pi || em == pi + 2; }
+                            const bool hit = written ? ((e1m >> mw) & 1) != 0 : ((tabok >> mw) & 1) != 0;
+                            LZ4_CC(written ? 2 : 3, 1); if (!hit) LZ4_CC(4, 1);
+                            uint32_t from;                                                        // where the walk goes on
+                            if (hit) {
+                                if (written && (uint32_t)lane == mw) { fw = fw_c; bk4 = bk_c; mf = fw_c == 24; cand = s0 + pv; endl = (uint32_t)lane + kMinMatch + fw_c; }
+                                if (lane_get((uint32_t)mf, (int)mw)) { special = (int)mw; break; }   // taken, but its match leaves the window
+                                const uint32_t e = lane_get(endl, (int)mw);
+                                const uint64_t t = (okmask >> (e < 63 ? e : 63)) | (1ull << 63);
+                                const uint32_t nx1 = e + (uint32_t)__builtin_ctzll(t);
+                                nxw = (uint32_t)lane == mw ? nx1 : nxw;                          // taken: the walk goes on from it
+                                from = mw;
+                            } else {
+                                // a probe that finds nothing: the search goes on at the next matching lane (the first search of the batch
+                                // only owns `own` lanes)
+                                const uint64_t rest = okmask & (marks == 0 && own < 64 ? ((1ull << own) - 1) : ~0ull) & ~((2ull << mw) - 1);
+                                if (!rest) break;
+                                from = (uint32_t)__builtin_ctzll(rest);
+                            }
+                            start = from;
                         }
                     }
                 }

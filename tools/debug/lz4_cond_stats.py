@@ -13,4 +13,4 @@ for kind in ("text", "binary", "database", "image16", "mix"):
     eng.lib.aoclgpu_debug_lz4_cond(buf)
     eng._check(eng._fn(m.LZ4, "compress")(C.byref(cb), eng._stream()), "c"); torch.cuda.synchronize()
     eng.lib.aoclgpu_debug_lz4_cond(buf)
-    print(kind, "could-match dups", buf[0], "conditional", buf[1], "stops taken", buf[2], "stops cut", buf[3], "cut with nothing written on the slot", buf[4])
+    print(kind, "could-match dups", buf[0], "conditional", buf[1], "stops with the slot written", buf[2], "not written", buf[3], "no hit", buf[4], "| batches", buf[7], "cut by a third lane", buf[5], "mean lim %.1f" % (buf[6] / max(buf[7], 1)))
