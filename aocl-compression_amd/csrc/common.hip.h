@@ -100,6 +100,25 @@ __device__ __forceinline__ uint32_t lds_first_lane_per_slot(uint32_t slot, uint3
     return w;
 }
 
+// Last lane per LDS slot: the mirror image (w = the LARGEST lane id among the valid lanes that named the slot).  The slots of
+// the valid lanes must hold a value below every lane id of theirs that matters - callers write 0 first.
+__device__ __forceinline__ uint32_t lds_last_lane_per_slot(uint32_t slot, uint32_t lane, bool valid)
+{
+    uint64_t pend = __ballot(valid), saved;
+    uint32_t w;
+    do {
+        asm volatile("s_and_saveexec_b64 %1, %3\n\t"
+                     "ds_write_b16 %2, %4\n\t"
+                     "s_mov_b64 exec, %1\n\t"
+                     "ds_read_u16 %0, %2\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(w), "=&s"(saved) : "v"(slot), "s"(pend), "v"(lane) : "memory");
+        pend = __ballot(valid && lane > w);
+        asm volatile("" : "+s"(pend));
+    } while (pend != 0);
+    return w;
+}
+
 // Inclusive prefix sum over the 64 lanes with DPP adds: four row shifts settle each row of 16 lanes, row_bcast15 /
 // row_bcast31 carry the row totals into rows 1, 3 and 2-3.  All lanes must be active.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)

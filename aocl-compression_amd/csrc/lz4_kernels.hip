@@ -380,22 +380,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 wave_fence();
                 const uint32_t w = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane);
                 wave_fence();
-                // Slots named twice: the SECOND lane of a slot (the smallest of the duplicates, found by the same rounds among the
-                // duplicates) has exactly one earlier lane on its slot - the first one, w; the first lane learns its partner from the
-                // slot.  Third and later lanes of a slot are rare outside runs and always end the batch.
                 const uint64_t dups = ballot(w != (uint32_t)lane);
-                uint32_t w2 = (uint32_t)lane, partner = 64;
-                if (dups) {
-                    typedef __attribute__((address_space(3))) uint16_t LU16;
-                    const bool isdup = w != (uint32_t)lane;
-                    if (isdup) *(LU16*)&table[h] = 0xFFFFu;
-                    wave_fence();
-                    w2 = lds_first_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane, isdup);
-                    wave_fence();
-                    const uint32_t sv = *(LU16*)&table[h];
-                    if (!isdup && sv != (uint32_t)lane) partner = sv;
-                    wave_fence();
-                }
                 table[h] = (T)ent;                        // undo the lane ids (the low halves; extra bits were not touched)
                 wave_fence();
                 if (ballot(plausible && cand < 4)) {      // window that starts before the chunk: loaded from byte 0, moved up 4 - cand bytes
@@ -421,28 +406,15 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 // lane's probe window), stops the walk like a special lane, and is either taken (the walk goes on from it) or, if
                 // its candidate lane turns out to lie inside a match, cuts the batch there as every could-match duplicate used to.
                 const uint64_t tabok = ballot(plausible && A.y == my4);
-                uint64_t condm = 0, e1m = 0;
                 uint32_t lim = 64;
-                const uint32_t pv = w;
-                if (dups) {
-                    const bool isdup = w != (uint32_t)lane, second = isdup && w2 == (uint32_t)lane;
-                    const bool e1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)my4) == my4;     // the first lane's 4 bytes
-                    const bool tok = plausible && A.y == my4;
-                    // cut at: a third lane on a slot; linked blocks: any second lane that could match
-                    const bool cutl = isdup && (!second || (LINKED && (e1 || tok)));
-#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOCUT)   /* timing only: what in-batch duplicates cost - no batch is cut at one (wrong parse, same work per batch) */
-                    const uint64_t cutm = 0;
-#else
-                    const uint64_t cutm = ballot(cutl);
+                uint64_t condm = dups;
+                if (LINKED && dups) { lim = (uint32_t)__builtin_ctzll(dups); condm = 0; }       // (linked blocks keep the plain rule: cut at a duplicate)
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_EXP_NOCUT)   /* timing only: what in-batch duplicates cost - every duplicate is an ordinary lane (wrong parse) */
+                condm = 0;
 #endif
-                    if (cutm) lim = (uint32_t)__builtin_ctzll(cutm);
-                    condm = ballot(second && (e1 || tok) && !LINKED);
-                    e1m = ballot(e1);
-                    LZ4_CC(0, (uint32_t)__builtin_popcountll(ballot(isdup && (e1 || tok)))); LZ4_CC(1, (uint32_t)__builtin_popcountll(condm));
-                }
-                condm &= lim >= 64 ? ~0ull : ((1ull << lim) - 1);
+                LZ4_CC(0, (uint32_t)__builtin_popcountll(dups));
                 LZ4_CC(5, lim < 64 ? 1u : 0u); LZ4_CC(6, lim); LZ4_CC(7, 1);
-                const bool isc = condm != 0 && __builtin_amdgcn_inverse_ballot_w64(condm);
+                const bool isc = condm != 0 && __builtin_amdgcn_inverse_ballot_w64(condm);   // (stops the walk: resolved when it arrives)
                 const uint64_t okmask = (tabok | condm) & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));   // lanes < lim are decided exactly as the sequential parse decides them
                 // forward extension (<= 24 bytes, LZ4_count lz4.c:656-679) and catch-up (<= 4 bytes), in registers
                 auto counts = [&](const u32x4& A_, const u32x4& B_, uint32_t& fw_, uint32_t& bk_) {
@@ -457,16 +429,6 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 };
                 counts(A, B, fw, bk4);
                 mf = fw == 24;
-                // a conditional lane's other alternative: the first lane of its slot as the candidate (that lane's probe window,
-                // from the source ring); which of the two holds is decided when the walk arrives
-                uint32_t fw_c = 0, bk_c = 0;
-                if (condm & e1m) {
-                    if (isc) {
-                        const uint32_t rc = (uint32_t)(w0 + (int32_t)pv) & 511u;
-                        const u32x4 Ac = lds_ld128(ring + rc), Bc = lds_ld128(ring + rc + 16);
-                        counts(Ac, Bc, fw_c, bk_c);
-                    }
-                }
                 if (PROF) { cnt[0]++; cnt[6] += lim; if (i0) cnt[3]++; }
                 STAGE(3);
                 asm volatile("; resolve begin" ::: "memory");   // scheduling fence: keeps the batch's loads/LDS traffic above the walk
@@ -494,17 +456,33 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                             marks |= mk;
                             if (!stop) break;
                             if (!((condm >> mw) & 1)) { special = (int)mw; break; }
-                            // A conditional lane.  Was its slot written by the first lane of the slot - as a probe, or as the ip-2
-                            // back-fill of the match that covers it - or does it still hold the table's entry?
-                            const uint32_t pi = lane_get(pv, (int)mw);
-                            const uint64_t lowm = marks & ((2ull << pi) - 1);                    // matches that start at or below it (pi <= 62)
-                            bool written = true;
-                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); written = (uint32_t)mm == pi || em <= pi || em == pi + 2; }
-                            const bool hit = written ? ((e1m >> mw) & 1) != 0 : ((tabok >> mw) & 1) != 0;
+                            // A duplicate lane: its candidate is the position of the LATEST earlier lane on its slot whose table write has
+                            // happened - as a probe, or as the ip-2 back-fill of the match that covers it - else the table's entry.
+                            uint32_t il = 64;
+                            {
+                                uint64_t L = ballot(h == lane_get(h, (int)mw)) & ((1ull << mw) - 1);
+                                while (L) {
+                                    const uint32_t x = 63u - (uint32_t)__builtin_clzll(L);
+                                    const uint64_t lowm = marks & ((2ull << x) - 1);             // matches that start at or below it (x <= 62)
+                                    bool wr = true;
+                                    if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); wr = (uint32_t)mm == x || em <= x || em == x + 2; }
+                                    if (wr) { il = x; break; }
+                                    L &= ~(1ull << x);
+                                }
+                            }
+                            const bool written = il < 64;
+                            const bool hit = written ? lane_get(my4, (int)il) == lane_get(my4, (int)mw) : ((tabok >> mw) & 1) != 0;
                             LZ4_CC(written ? 2 : 3, 1); if (!hit) LZ4_CC(4, 1);
                             uint32_t from;                                                        // where the walk goes on
                             if (hit) {
-                                if (written && (uint32_t)lane == mw) { fw = fw_c; bk4 = bk_c; mf = fw_c == 24; cand = s0 + pv; endl = (uint32_t)lane + kMinMatch + fw_c; }
+                                if (written) {                        // that lane's probe window (from the source ring) is the candidate window
+                                    if ((uint32_t)lane == mw) {
+                                        const uint32_t rc = (uint32_t)(w0 + (int32_t)il) & 511u;
+                                        const u32x4 Ac = lds_ld128(ring + rc), Bc = lds_ld128(ring + rc + 16);
+                                        counts(Ac, Bc, fw, bk4);
+                                        mf = fw == 24; cand = s0 + il; endl = (uint32_t)lane + kMinMatch + fw;
+                                    }
+                                }
                                 if (lane_get((uint32_t)mf, (int)mw)) { special = (int)mw; break; }   // taken, but its match leaves the window
                                 const uint32_t e = lane_get(endl, (int)mw);
                                 const uint64_t t = (okmask >> (e < 63 ? e : 63)) | (1ull << 63);
@@ -549,8 +527,17 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
                     const uint64_t ends = (cover << 1) & (~cover | marks);                    // lanes where a match ends
                     const uint64_t commit = (belowR & ~(cover & ~marks)) | ((ends & belowR) >> 2);
-                    // (the first lane of a slot leaves the slot to its partner when that one writes: the later write wins)
-                    if (dups) { if (__builtin_amdgcn_inverse_ballot_w64(commit) && !((commit >> (partner & 63u)) & (partner < 64 ? 1ull : 0ull))) tput(h, entry_of(pos, mychk), ent); }
+                    // several writers of one slot: the latest of them owns it (rounds of "the largest id sticks" over the slots'
+                    // low halves, ids = lane + 1 over a zero)
+                    if (dups) {
+                        typedef __attribute__((address_space(3))) uint16_t LU16;
+                        const bool cm = __builtin_amdgcn_inverse_ballot_w64(commit);
+                        if (cm) *(LU16*)&table[h] = 0;
+                        wave_fence();
+                        const uint32_t top = lds_last_lane_per_slot((uint32_t)(uintptr_t)&table[h], (uint32_t)lane + 1u, cm);
+                        wave_fence();
+                        if (cm && top == (uint32_t)lane + 1u) tput(h, entry_of(pos, mychk), ent);
+                    }
                     else if (__builtin_amdgcn_inverse_ballot_w64(commit)) tput(h, entry_of(pos, mychk), ent);
                 }
                 wave_fence();
