@@ -321,7 +321,9 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const int j = (int)__builtin_ctzll(d);
                 const uint64_t same = ballot(act && h == lane_get(h, j)) & ((1ull << j) - 1);
                 if (!same) continue;
+#if !(defined(AOCLGPU_EXPERIMENTS) && defined(SN_EXP_NOCUT))   /* (timing only: no batch is cut at a duplicate - wrong parse, same work per batch) */
                 if (((tabok >> j) & 1) || (ballot(seq == lane_get(seq, j)) & same) != 0) { f = j; break; }
+#endif
                 if ((same >> lane) & 1) later |= 1ull << j;
             }
             const int lim0 = f < e ? f : e, lim = lim0 < width ? lim0 : width;

@@ -620,7 +620,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     }
 #endif
                 asm volatile("; masks begin");
+#if defined(AOCLGPU_EXPERIMENTS) && defined(ZSTD_EXP_NOCUT)   /* timing only: what the cut at the first in-batch slot reuse costs (wrong parse) */
+                    const int lim = 64; (void)w;
+#else
                     const int lim = first_lane(ballot(w != (u32)lane));
+#endif
                     using zchain::zero_bytes8;
                     const u32 eqb = zero_bytes8(pa.x ^ ca.x, pa.y ^ ca.y) | (zero_bytes8(pa.z ^ ca.z, pa.w ^ ca.w) << 8) |
                                     (zero_bytes8(pb.x ^ cb.x, pb.y ^ cb.y) << 16) | (zero_bytes8(pb.z ^ cb.z, pb.w ^ cb.w) << 24);
