@@ -287,7 +287,7 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             uint32_t ent = 0;
             if (act) ent = tget(h);
             SNC(2, act);
-            const uint32_t cand = ent & 0xFFFFu;
+            uint32_t cand = ent & 0xFFFFu;
             const bool plausible = act && (!GT || (ent & 0xFFFF0000u) == chk(seq));   // only these can pass the 4-byte test
             Win cw = {{~seq, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
             if (plausible) cw = load_win(in, cand, far);                  // the whole candidate window travels in one round of loads
@@ -308,48 +308,61 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             }
             wave_fence();
             const int e = first_lane(ballot(!valid));
-            // Lanes that share their slot with an earlier lane of the batch have a candidate that depends on the parse (the
-            // earlier lane's position if its table write happens, else the table entry).  Such a lane is still decided when
-            // neither can match: its table candidate fails the 4-byte test and no earlier lane on its slot holds its 4 bytes.
-            // The batch is cut at the first one that could match.  (With the 10-bit scratch of the HBM-table waves `w` also
-            // flags lanes whose full hashes differ: those are ordinary lanes.)  `later` = this lane's slot is named again by
-            // these later lanes; within one table commit the last of them owns the slot.
+            // Lanes that share their slot with an earlier lane of the batch ("duplicates") have a candidate that depends on the
+            // parse: the position of the latest earlier lane on the slot whose table write has happened, else the table entry.
+            // (With the 10-bit scratch of the HBM-table waves `w` also flags lanes whose full hashes differ: those turn out to
+            // be ordinary lanes when they are looked at.)
+            // In a batch of consecutive positions a duplicate STOPS the chain walk below, and is decided when the walk arrives
+            // (round 4; lz4_kernels.hip has the same rule): the lanes below it are then known to be probes, copies or back-fills.
+            // Every other batch keeps the plain rule: a duplicate is still an ordinary lane when NEITHER candidate can match
+            // - the table's fails the 4-byte test and no earlier lane on the slot holds its 4 bytes - and the batch is cut at
+            // the first one that could.
             const uint64_t tabok = ballot(act && cw.a.x == seq);
-            uint64_t later = 0;
+#if defined(AOCLGPU_EXPERIMENTS) && defined(SN_EXP_NOCUT)   /* (timing only: no duplicate is looked at - wrong parse, same work per batch) */
+            const uint64_t dups = 0;
+#else
+            const uint64_t dups = ballot(act && w != (uint32_t)lane);
+#endif
             int f = 64;
-            for (uint64_t d = ballot(act && w != (uint32_t)lane); d; d &= d - 1) {
+            if (!consb) for (uint64_t d = dups; d; d &= d - 1) {
                 const int j = (int)__builtin_ctzll(d);
                 const uint64_t same = ballot(act && h == lane_get(h, j)) & ((1ull << j) - 1);
                 if (!same) continue;
-#if !(defined(AOCLGPU_EXPERIMENTS) && defined(SN_EXP_NOCUT))   /* (timing only: no batch is cut at a duplicate - wrong parse, same work per batch) */
                 if (((tabok >> j) & 1) || (ballot(seq == lane_get(seq, j)) & same) != 0) { f = j; break; }
-#endif
-                if ((same >> lane) & 1) later |= 1ull << j;
             }
-            const int lim0 = f < e ? f : e, lim = lim0 < width ? lim0 : width;
-            const uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
-            auto owns = [&](int a, int b) -> bool {       // lane in [a, b) and no later lane of [a, b) names its slot
-                const uint64_t r = (b >= 64 ? ~0ull : ((1ull << b) - 1)) & ~((1ull << a) - 1);
-                return ((r >> lane) & 1) && (later & r) == 0;
+            const int lim_e = e < width ? e : width;      // what the batch probes
+            int lim = f < lim_e ? f : lim_e;              // lanes [0, lim) are decided exactly as the sequential parse decides them
+            uint64_t okmask = tabok & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
+            // table writes of lanes [a, b) U extra: a slot named by several of them goes to the latest (their writes happen in lane order)
+            auto commit_lanes = [&](uint64_t r) -> bool {
+                for (uint64_t d = dups & r; d; d &= d - 1) {
+                    const int j = (int)__builtin_ctzll(d);
+                    r &= ~(ballot(act && h == lane_get(h, j)) & ((1ull << j) - 1));
+                }
+                return (r >> lane) & 1;
+            };
+            auto owns = [&](int a, int b) -> bool {
+                return commit_lanes((b >= 64 ? ~0ull : ((1ull << b) - 1)) & ~((1ull << a) - 1));
             };
             const uint32_t pos0 = lane_get(pos, 0);
             // lanes [0, linlim) probe consecutive positions pos0 + lane (the schedule's first 33 steps are 1 byte)
             // in-lane forward extension (<= 24 bytes beyond the 4 tested), FindMatchLength snappy-internal.h:228-352
             uint32_t fw; bool mf;
-            {
-                const uint64_t x1 = (uint64_t)(pw.a.y ^ cw.a.y) | ((uint64_t)(pw.a.z ^ cw.a.z) << 32);
-                const uint64_t x2 = (uint64_t)(pw.a.w ^ cw.a.w) | ((uint64_t)(pw.b.x ^ cw.b.x) << 32);
-                const uint64_t x3 = (uint64_t)(pw.b.y ^ cw.b.y) | ((uint64_t)(pw.b.z ^ cw.b.z) << 32);
-                const uint32_t x4 = pw.b.w ^ cw.b.w;
+            auto extend = [&](const Win& c, uint32_t& fw_, bool& mf_) {
+                const uint64_t x1 = (uint64_t)(pw.a.y ^ c.a.y) | ((uint64_t)(pw.a.z ^ c.a.z) << 32);
+                const uint64_t x2 = (uint64_t)(pw.a.w ^ c.a.w) | ((uint64_t)(pw.b.x ^ c.b.x) << 32);
+                const uint64_t x3 = (uint64_t)(pw.b.y ^ c.b.y) | ((uint64_t)(pw.b.z ^ c.b.z) << 32);
+                const uint32_t x4 = pw.b.w ^ c.b.w;
                 const uint32_t avail = far ? 28u : 8u;
-                fw = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
-                if (fw == 8 && far) fw += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
-                if (fw == 16 && far) fw += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
-                if (fw == 24 && far) fw += x4 ? ((uint32_t)__builtin_ctz(x4) >> 3) : 4;
+                fw_ = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8;
+                if (fw_ == 8 && far) fw_ += x2 ? ((uint32_t)__builtin_ctzll(x2) >> 3) : 8;
+                if (fw_ == 16 && far) fw_ += x3 ? ((uint32_t)__builtin_ctzll(x3) >> 3) : 8;
+                if (fw_ == 24 && far) fw_ += x4 ? ((uint32_t)__builtin_ctz(x4) >> 3) : 4;
                 const uint32_t maxfwd = n - (pos + 4);
-                mf = fw == avail && maxfwd > avail;
-                fw = fw < maxfwd ? fw : maxfwd;
-            }
+                mf_ = fw_ == avail && maxfwd > avail;
+                fw_ = fw_ < maxfwd ? fw_ : maxfwd;
+            };
+            extend(cw, fw, mf);
 
             asm volatile("; chain begin" ::: "memory");
             // -------- resolve as many copies as this batch holds --------
@@ -371,26 +384,73 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
             // the one-copy-at-a-time loop below, which starts where the fast-forward stopped.
             if (consb) {
                 const int hi2 = lim < linlim ? lim : linlim;
-                const uint64_t okv = okmask & (hi2 >= 64 ? ~0ull : ((1ull << hi2) - 1));
-                const uint32_t endl = (uint32_t)lane + 4u + fw;                        // match end, in lanes
-                const uint64_t slowmask = ballot(mf);
+                const uint64_t below2 = hi2 >= 64 ? ~0ull : ((1ull << hi2) - 1);
+                const uint64_t dupv = dups & below2;
+                const uint64_t okv = (tabok | dups) & below2;                          // matching lanes and the lanes that stop the walk
+                uint32_t endl = (uint32_t)lane + 4u + fw;                              // match end, in lanes
+                uint64_t slowmask = ballot(mf);
                 // the 34th probe of a search is followed by a 2-byte step: it is only made if that step stays inside (:946-950)
                 auto own_lanes = [&](uint32_t s0) -> uint32_t { return (uint64_t)pos0 + s0 + 35 > ip_limit ? kSearchLanes - 1 : kSearchLanes; };
-                uint32_t nxt;
-                {
-                    const uint64_t t = endl < 64 ? okv >> endl : 0;
+                auto next_of = [&](uint32_t en) -> uint32_t {                          // where the walk goes after a copy that ends at lane en
+                    const uint64_t t = en < 64 ? okv >> en : 0;
                     const uint32_t cz = t ? (uint32_t)__builtin_ctzll(t) : 64u;
-                    nxt = cz < own_lanes(endl) ? endl + cz : 64u;                     // 64: no match among the lanes of the search that starts at endl
-                    if (endl >= (uint32_t)hi2) nxt = 65;                              // 65: the next search leaves the consecutive lanes
-                    if (pos0 + endl >= ip_limit) nxt = 66;                            // 66: end of the fragment's searches (:1006-1008)
-                }
-                uint64_t marks = 0;
+                    uint32_t nx = cz < own_lanes(en) ? en + cz : 64u;                 // 64: no match among the lanes of the search that starts at en
+                    if (en >= (uint32_t)hi2) nx = 65;                                 // 65: the next search leaves the consecutive lanes
+                    if (pos0 + en >= ip_limit) nx = 66;                               // 66: end of the fragment's searches (:1006-1008)
+                    return nx;
+                };
+                uint32_t nxt = next_of(endl);
+                uint64_t marks = 0, hitm = 0;
+                uint32_t fr = 0, ss = 0;                   // every duplicate below fr is decided or lies inside a copy; ss = where the search in progress began
                 uint32_t mw = okv ? (uint32_t)__builtin_ctzll(okv) : 64u;
                 if (mw >= own_lanes(0)) mw = 64;
                 while (mw < 64) {
+                    if ((dupv >> mw) & 1) {
+                        // A duplicate: its candidate is the position of the LATEST earlier lane on its slot whose table write has
+                        // happened - as a probe, or as the ip-1 back-fill of the copy that covers it (:1016-1017) - else the table's entry.
+                        uint32_t il = 64;
+                        for (uint64_t L = ballot(act && h == lane_get(h, (int)mw)) & ((1ull << mw) - 1); L; ) {
+                            const uint32_t x = 63u - (uint32_t)__builtin_clzll(L);
+                            const uint64_t lowm = marks & ((2ull << x) - 1);             // copies that start at or below it (x <= 62)
+                            bool wr = true;
+                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); wr = (uint32_t)mm == x || em <= x || em == x + 1; }
+                            if (wr) { il = x; break; }
+                            L &= ~(1ull << x);
+                        }
+                        const bool written = il < 64;
+                        const bool hit = written ? lane_get(seq, (int)il) == lane_get(seq, (int)mw) : ((tabok >> mw) & 1) != 0;
+                        fr = mw + 1;
+                        if (!hit) {                        // a probe that finds nothing: the search goes on with its remaining lanes
+                            const uint32_t ol = ss + own_lanes(ss);
+                            const uint64_t rest = okv & ~((2ull << mw) - 1) & (ol >= 64 ? ~0ull : ((1ull << ol) - 1));
+                            mw = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+                            continue;
+                        }
+                        hitm |= 1ull << mw;
+                        if (written) {                     // that lane's probe window is the candidate window
+                            Win c2 = cw;
+                            const uint32_t c0 = lane_get(pw.a.x, (int)il), c1 = lane_get(pw.a.y, (int)il), c2_ = lane_get(pw.a.z, (int)il), c3 = lane_get(pw.a.w, (int)il);
+                            const uint32_t c4 = lane_get(pw.b.x, (int)il), c5 = lane_get(pw.b.y, (int)il), c6 = lane_get(pw.b.z, (int)il), c7 = lane_get(pw.b.w, (int)il);
+                            const bool me = (uint32_t)lane == mw;
+                            if (me) { c2.a = u32x4{c0, c1, c2_, c3}; c2.b = u32x4{c4, c5, c6, c7}; }
+                            uint32_t fw2; bool mf2;
+                            extend(c2, fw2, mf2);
+                            if (me) { fw = fw2; mf = mf2; cand = pos0 + il; endl = (uint32_t)lane + 4u + fw2; }
+                            const uint32_t en = lane_get(endl, (int)mw), nx = next_of(en);
+                            if (me) nxt = nx;
+                            slowmask = (slowmask & ~(1ull << mw)) | ((uint64_t)lane_get((uint32_t)mf, (int)mw) << mw);
+                        }
+                    }
                     if ((slowmask >> mw) & 1) break;                                  // needs the longer compare: the loop below
                     marks |= 1ull << mw;
+                    ss = lane_get(endl, (int)mw); fr = ss;
                     mw = lane_get(nxt, (int)mw);
+                }
+                {   // what the loop below may look at: the lanes in front of the first duplicate nobody has decided
+                    const uint64_t und = fr >= 64 ? 0ull : (dups & (~0ull << fr));
+                    const int f2 = und ? (int)__builtin_ctzll(und) : 64;
+                    lim = f2 < lim_e ? f2 : lim_e; f = f2;
+                    okmask = ((tabok & ~dups) | hitm) & (lim >= 64 ? ~0ull : ((1ull << lim) - 1));
                 }
                 if (marks) {
                     const int lastm = 63 - (int)__builtin_clzll(marks);
@@ -401,14 +461,14 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     const bool mb_ = qend != 0;
                     const bool covered = marked || (uint32_t)lane < qend;
                     const uint64_t cover = ballot(covered);
-                    const bool cont = mw != 66 && cur < (uint32_t)hi2;               // the loop below goes on inside this batch
+                    const bool cont = mw != 66 && cur < (uint32_t)(lim < linlim ? lim : linlim);   // the loop below goes on inside this batch
                     {   // table writes the reference performs: every probed lane, and lane end-1 behind every copy (:1016-1017) - for
                         // the last copy only if its successor search is resolved from this batch (else the next batch's back-fill)
                         const uint64_t belowCur = cur >= 64 ? ~0ull : ~(~0ull << cur);
                         uint64_t ends = (cover << 1) & (~cover | marks);
                         if (!cont && cur < 64) ends &= ~(1ull << cur);
                         const uint64_t commit = (belowCur & ~(cover & ~marks)) | ((ends >> 1) & belowCur);
-                        if (__builtin_amdgcn_inverse_ballot_w64(commit) && (later & commit) == 0) tput(h, pos, seq);
+                        if (commit_lanes(commit)) tput(h, pos, seq);
                     }
                     wave_fence();
                     // one record per copy, in order behind the buffered ones (a batch of consecutive positions starts at the
