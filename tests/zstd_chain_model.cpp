@@ -3,6 +3,10 @@
 // (csrc/zstd_chain.h) on the host.  tests/test_zstd_chain_model.py compares its sequences with the oracle's sequential
 // parser (oracle/zstd_oracle.c, fast_block) on many inputs, so the batching logic - which lanes are trustworthy, which
 // table writes are committed, when a chain has to stop - is validated without a GPU.
+// Mode bits (useChain): 1 chain batches, 2 full statistics, 4 resumed batches, 8 resume only in front of a matching lane,
+// 16 long matches inside the batch, 32 duplicate lanes (a slot named by an earlier lane of the batch) do not cut the batch:
+// the walk stops at them and they are probed again with the writes made since (the kernel runs 1 | 4 | 8; 16 and 32 were
+// measured on the GPU and rejected - tools/experiments/README.md - and stay here as the statement of their rules).
 //
 // Build: g++ -O2 -shared -fPIC -I aocl-compression_amd/csrc tests/zstd_chain_model.cpp -o tests/_build/libzchain_model.so
 #include "zstd_chain.h"
@@ -90,9 +94,43 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
         };
         // state of the newest chain batch: a search that starts inside it (behind a sequence of the exact path or the
         // immediate rep2 test) is resumed in the same batch - its lanes below lim are untouched by every table write since
-        bool cb = false; u32 pos0 = 0; int lim = 64; u64 okmask = 0, hard = 0;
+        bool cb = false; u32 pos0 = 0; int lim = 64; u64 okmask = 0, hard = 0, dupu = 0;   // dupu: duplicate lanes nobody has looked at (mode 32)
         u32 h[64], ent[64], eqbv[64]; u64 infov[64]; bool ok[64], hd[64], lg[64];
         const bool resumable = (useChain & 4) != 0;
+        // lane j of the batch reads its slot and classifies its candidate (kernel: "probe begin" .. "masks begin")
+        auto probe = [&](int j, u32 entry) {
+            const u32 p = pos0 + (u32)j;
+            ent[j] = entry;
+            ok[j] = false; hd[j] = false; lg[j] = false; eqbv[j] = 0; infov[j] = 0;
+            if (ent[j] >= prefixIdx) {
+                const u32 c = ent[j] - 2;
+                if (c - prefixPos >= 4) {
+                    u32 e = 0;
+                    for (int i = 0; i < 32; ++i) if (src[p - 4 + i] == src[c - 4 + i]) e |= 1u << i;
+                    const u32 fwm = ~(e >> 8);
+                    const u32 fw = (u32)__builtin_ctz(fwm);                       // <= 24
+                    const u32 bkm = ~(e << 28);
+                    const u32 bk4 = (u32)__builtin_clz(bkm);                      // <= 4
+                    eqbv[j] = e; infov[j] = zchain::pack_info_wide(p - c, fw, zchain::back_code(bk4, c - prefixPos));
+                    ok[j] = ((e >> 4) & 15u) == 15u;
+                    hd[j] = fw >= 24;                                             // the run leaves the window
+                    lg[j] = ok[j] && fw >= 24;
+                } else {
+                    ok[j] = rd32(src + c) == rd32(src + p);
+                    infov[j] = zchain::pack_info_wide(p - c, 0, 0);
+                    hd[j] = true;                                                 // candidate within 4 bytes of the prefix start
+                }
+            }
+        };
+        auto lane_flags = [&](int j, int lim_) {                                  // okmask / hard bits of a lane that was classified
+            okmask &= ~(1ull << j); hard &= ~(1ull << j);
+            if (!ok[j]) return;
+            okmask |= 1ull << j;
+            const int E = j + 4 + (int)(((u32)infov[j] >> 17) & 31u);
+            if (hd[j] || (E - 2 >= lim_ && j + 2 >= 64)) hard |= 1ull << j;        // (table writes behind lane 63)
+        };
+        // table writes of a batch: in lane order, so a slot named by several lanes goes to the latest
+        auto commit_table = [&](u64 cm) { for (int j = 0; j < 64; ++j) if ((cm >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2; };
         for (;;) {
             int ev = 0; u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0;
             const bool resume = resumable && cb && i0 == 0 && s > pos0 && (int)(s - pos0) + M.resumeMargin <= lim &&
@@ -104,38 +142,20 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                 if (resume) M.stat[34]++; else {
                 M.stat[0]++;
                 pos0 = s;
-                for (int j = 0; j < 64; ++j) {
-                    const u32 p = pos0 + (u32)j;
-                    h[j] = zhash(src + p, M.hlog, M.mls);
-                    ent[j] = M.table[h[j]];
-                    ok[j] = false; hd[j] = false; lg[j] = false; eqbv[j] = 0; infov[j] = 0;
-                    if (ent[j] >= prefixIdx) {
-                        const u32 c = ent[j] - 2;
-                        if (c - prefixPos >= 4) {
-                            u32 e = 0;
-                            for (int i = 0; i < 32; ++i) if (src[p - 4 + i] == src[c - 4 + i]) e |= 1u << i;
-                            const u32 fwm = ~(e >> 8);
-                            const u32 fw = (u32)__builtin_ctz(fwm);                       // <= 24
-                            const u32 bkm = ~(e << 28);
-                            const u32 bk4 = (u32)__builtin_clz(bkm);                      // <= 4
-                            eqbv[j] = e; infov[j] = zchain::pack_info_wide(p - c, fw, zchain::back_code(bk4, c - prefixPos));
-                            ok[j] = ((e >> 4) & 15u) == 15u;
-                            hd[j] = fw >= 24;                                             // the run leaves the window
-                            lg[j] = ok[j] && fw >= 24;
-                        } else {
-                            ok[j] = rd32(src + c) == rd32(src + p);
-                            infov[j] = zchain::pack_info_wide(p - c, 0, 0);
-                            hd[j] = true;                                                 // candidate within 4 bytes of the prefix start
-                        }
-                    }
-                }
-                lim = 64;
-                for (int j = 1; j < 64 && lim == 64; ++j) for (int i = 0; i < j; ++i) if (h[i] == h[j]) { lim = j; break; }
-                okmask = 0; hard = 0;
-                for (int j = 0; j < lim; ++j) if (ok[j]) {
-                    okmask |= 1ull << j;
-                    const int E = j + 4 + (int)(((u32)infov[j] >> 17) & 31u);
-                    if (hd[j] || (E - 2 >= lim && j + 2 >= 64)) hard |= 1ull << j;        // (table writes behind lane 63)
+                for (int j = 0; j < 64; ++j) { h[j] = zhash(src + pos0 + (u32)j, M.hlog, M.mls); probe(j, M.table[h[j]]); }
+                u64 dups = 0;
+                for (int j = 1; j < 64; ++j) for (int i = 0; i < j; ++i) if (h[i] == h[j]) { dups |= 1ull << j; break; }
+                lim = 64; okmask = 0; hard = 0; dupu = 0;
+                if (useChain & 32) {
+                    // mode 32 (the kernel since round 4): a duplicate lane - its slot is named by an earlier lane of the batch -
+                    // does not cut the batch.  The walk gets it as a match that takes the exact path, so it stops there if it
+                    // gets there, and the lane is probed again then (below).
+                    dupu = dups;
+                    for (int j = 0; j < 64; ++j) if (!((dups >> j) & 1)) lane_flags(j, 64);
+                    okmask |= dups; hard |= dups;
+                } else {
+                    if (dups) lim = __builtin_ctzll(dups);
+                    for (int j = 0; j < lim; ++j) lane_flags(j, lim);
                 }
                 }
                 u64 eq1 = 0, eq2 = 0;
@@ -149,7 +169,22 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                 };
                 zchain::WalkOut w = zchain::walk(okmask, hard, lim, pos0, (int32_t)anchor - (int32_t)pos0, rep1, rep2, eq1, eq2,
                     [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, resume ? (int)(s - pos0) : 0, 0);
-                while (w.outcome == zchain::ZC_REFRESH) {                                 // fresh full-width maps for the current repcodes
+                for (;;) {
+                    if (w.outcome == zchain::ZC_SPECIAL && w.ev == 1 && ((dupu >> w.el) & 1)) {
+                        // the search has reached a duplicate lane: every write the reference made before it reads this slot is
+                        // known now - they go to the table, the lane probes again, the walk starts over at the search's first lane
+                        M.stat[37]++;
+                        const int el = w.el;
+                        // (the probes of the search in progress, lanes [S, el), are NOT written yet: the walk may still ask for a
+                        //  fresh batch at S, which probes them again - the latest of them on the slot is the candidate, from registers)
+                        commit_table(w.commit & ((1ull << w.S) - 1));
+                        int il = -1;
+                        for (int y = w.S; y < el; ++y) if (h[y] == h[el]) il = y;
+                        probe(el, il >= 0 ? pos0 + (u32)il + 2 : M.table[h[el]]);
+                        lane_flags(el, 64); dupu &= ~(1ull << el);
+                        w.outcome = zchain::ZC_REFRESH; w.commit &= (1ull << w.S) - 1;
+                    }
+                    if (w.outcome != zchain::ZC_REFRESH) break;
                     M.stat[33]++;
                     u64 e1 = 0, e2 = 0;
                     for (int j = 0; j < 64; ++j) {
@@ -161,7 +196,7 @@ static void model_block(Model& M, const u32 bs, const u32 n, const Win& win, u32
                         [&](int j) { return infov[j]; }, [&](int j) { return eqbv[j]; }, emit, w.S, w.commit);
                 }
                 if (resume && M.stat[1] > seqs0) M.stat[35]++;
-                for (int j = 0; j < 64; ++j) if ((w.commit >> j) & 1) M.table[h[j]] = pos0 + (u32)j + 2;
+                commit_table(w.commit);
                 if (g_trace && g_trace_n < 4096) {
                     u64* t = g_trace + 8 * g_trace_n++;
                     t[0] = pos0; t[1] = (u32)lim; t[2] = okmask; t[3] = w.commit; t[4] = (u32)w.outcome | ((u64)(u32)w.S << 8) | ((u64)(u32)w.ev << 16) | ((u64)(u32)w.el << 24) | ((u64)(u32)w.ntail << 32) | ((u64)w.post << 40);
