@@ -101,8 +101,7 @@ __device__ __forceinline__ Win load_win(const gbyte* __restrict__ src, uint32_t 
     typedef const __attribute__((address_space(1))) U* GP;
     Win w;
     w.a = *(GP)(src + p);
-    w.b = u32x4{0u, 0u, 0u, 0u};
-    if (far) w.b = *(GP)(src + p + 16);
+    w.b = *(GP)(src + (far ? p + 16 : p));               // (no branch: a lane near the end reads its first half twice and never looks at b)
     return w;
 }
 
