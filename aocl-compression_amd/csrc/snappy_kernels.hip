@@ -387,7 +387,6 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                 const uint64_t dupv = dups & below2;
                 const uint64_t okv = (tabok | dups) & below2;                          // matching lanes and the lanes that stop the walk
                 uint32_t endl = (uint32_t)lane + 4u + fw;                              // match end, in lanes
-                uint64_t slowmask = ballot(mf);
                 // the 34th probe of a search is followed by a 2-byte step: it is only made if that step stays inside (:946-950)
                 auto own_lanes = [&](uint32_t s0) -> uint32_t { return (uint64_t)pos0 + s0 + 35 > ip_limit ? kSearchLanes - 1 : kSearchLanes; };
                 auto next_of = [&](uint32_t en) -> uint32_t {                          // where the walk goes after a copy that ends at lane en
@@ -399,51 +398,57 @@ __device__ __attribute__((noinline)) uint32_t sn_compress_fragment(const gbyte* 
                     return nx;
                 };
                 uint32_t nxt = next_of(endl);
-                uint64_t marks = 0, hitm = 0;
+                uint64_t marks = 0, hitm = 0, dleft = dupv;   // dleft: duplicates nobody has looked at
                 uint32_t fr = 0, ss = 0;                   // every duplicate below fr is decided or lies inside a copy; ss = where the search in progress began
                 uint32_t mw = okv ? (uint32_t)__builtin_ctzll(okv) : 64u;
                 if (mw >= own_lanes(0)) mw = 64;
+                // the links the scalar walk follows (lz_group.hip.h: one readlane per copy); negative: the walk stops in front of
+                // this lane - a duplicate (decided here, then the walk goes on) or a copy that needs the longer compare
+                uint32_t nxw = (mf || ((dupv >> lane) & 1)) ? 0x80000000u : nxt;
                 while (mw < 64) {
-                    if ((dupv >> mw) & 1) {
-                        // A duplicate: its candidate is the position of the LATEST earlier lane on its slot whose table write has
-                        // happened - as a probe, or as the ip-1 back-fill of the copy that covers it (:1016-1017) - else the table's entry.
-                        uint32_t il = 64;
-                        for (uint64_t L = ballot(act && h == lane_get(h, (int)mw)) & ((1ull << mw) - 1); L; ) {
-                            const uint32_t x = 63u - (uint32_t)__builtin_clzll(L);
-                            const uint64_t lowm = marks & ((2ull << x) - 1);             // copies that start at or below it (x <= 62)
-                            bool wr = true;
-                            if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); wr = (uint32_t)mm == x || em <= x || em == x + 1; }
-                            if (wr) { il = x; break; }
-                            L &= ~(1ull << x);
-                        }
-                        const bool written = il < 64;
-                        const bool hit = written ? lane_get(seq, (int)il) == lane_get(seq, (int)mw) : ((tabok >> mw) & 1) != 0;
-                        fr = mw + 1;
-                        if (!hit) {                        // a probe that finds nothing: the search goes on with its remaining lanes
-                            const uint32_t ol = ss + own_lanes(ss);
-                            const uint64_t rest = okv & ~((2ull << mw) - 1) & (ol >= 64 ? ~0ull : ((1ull << ol) - 1));
-                            mw = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
-                            continue;
-                        }
-                        hitm |= 1ull << mw;
-                        if (written) {                     // that lane's probe window is the candidate window
-                            Win c2 = cw;
-                            const uint32_t c0 = lane_get(pw.a.x, (int)il), c1 = lane_get(pw.a.y, (int)il), c2_ = lane_get(pw.a.z, (int)il), c3 = lane_get(pw.a.w, (int)il);
-                            const uint32_t c4 = lane_get(pw.b.x, (int)il), c5 = lane_get(pw.b.y, (int)il), c6 = lane_get(pw.b.z, (int)il), c7 = lane_get(pw.b.w, (int)il);
-                            const bool me = (uint32_t)lane == mw;
-                            if (me) { c2.a = u32x4{c0, c1, c2_, c3}; c2.b = u32x4{c4, c5, c6, c7}; }
-                            uint32_t fw2; bool mf2;
-                            extend(c2, fw2, mf2);
-                            if (me) { fw = fw2; mf = mf2; cand = pos0 + il; endl = (uint32_t)lane + 4u + fw2; }
-                            const uint32_t en = lane_get(endl, (int)mw), nx = next_of(en);
-                            if (me) nxt = nx;
-                            slowmask = (slowmask & ~(1ull << mw)) | ((uint64_t)lane_get((uint32_t)mf, (int)mw) << mw);
-                        }
+                    {
+                        uint64_t mk; uint32_t stop, at;
+                        lz_walk_tokens(nxw, mk, at, stop, uni(mw));
+                        // (the results of an asm statement with several outputs count as divergent: readfirstlane of a scalar is free)
+                        mw = uni(at); stop = uni(stop); mk = ((uint64_t)uni((uint32_t)(mk >> 32)) << 32) | uni((uint32_t)mk);
+                        if (mk) { marks |= mk; ss = lane_get(endl, 63 - (int)__builtin_clzll(mk)); fr = ss; }
+                        if (!stop) break;                  // 64 / 65 / 66: the walk is over
                     }
-                    if ((slowmask >> mw) & 1) break;                                  // needs the longer compare: the loop below
-                    marks |= 1ull << mw;
-                    ss = lane_get(endl, (int)mw); fr = ss;
-                    mw = lane_get(nxt, (int)mw);
+                    if (!((dleft >> mw) & 1)) break;       // needs the longer compare: the loop below
+                    // A duplicate: its candidate is the position of the LATEST earlier lane on its slot whose table write has
+                    // happened - as a probe, or as the ip-1 back-fill of the copy that covers it (:1016-1017) - else the table's entry.
+                    uint32_t il = 64;
+                    for (uint64_t L = ballot(act && h == lane_get(h, (int)mw)) & ((1ull << mw) - 1); L; ) {
+                        const uint32_t x = 63u - (uint32_t)__builtin_clzll(L);
+                        const uint64_t lowm = marks & ((2ull << x) - 1);             // copies that start at or below it (x <= 62)
+                        bool wr = true;
+                        if (lowm) { const int mm = 63 - (int)__builtin_clzll(lowm); const uint32_t em = lane_get(endl, mm); wr = (uint32_t)mm == x || em <= x || em == x + 1; }
+                        if (wr) { il = x; break; }
+                        L &= ~(1ull << x);
+                    }
+                    const bool written = il < 64;
+                    const bool hit = written ? lane_get(seq, (int)il) == lane_get(seq, (int)mw) : ((tabok >> mw) & 1) != 0;
+                    fr = mw + 1; dleft &= ~(1ull << mw);
+                    if (!hit) {                            // a probe that finds nothing: the search goes on with its remaining lanes
+                        const uint32_t ol = ss + own_lanes(ss);
+                        const uint64_t rest = okv & ~((2ull << mw) - 1) & (ol >= 64 ? ~0ull : ((1ull << ol) - 1));
+                        mw = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+                        continue;
+                    }
+                    hitm |= 1ull << mw;
+                    const bool me = (uint32_t)lane == mw;
+                    if (written) {                         // that lane's probe window is the candidate window
+                        Win c2 = cw;
+                        const uint32_t c0 = lane_get(pw.a.x, (int)il), c1 = lane_get(pw.a.y, (int)il), c2_ = lane_get(pw.a.z, (int)il), c3 = lane_get(pw.a.w, (int)il);
+                        const uint32_t c4 = lane_get(pw.b.x, (int)il), c5 = lane_get(pw.b.y, (int)il), c6 = lane_get(pw.b.z, (int)il), c7 = lane_get(pw.b.w, (int)il);
+                        if (me) { c2.a = u32x4{c0, c1, c2_, c3}; c2.b = u32x4{c4, c5, c6, c7}; }
+                        uint32_t fw2; bool mf2;
+                        extend(c2, fw2, mf2);
+                        if (me) { fw = fw2; mf = mf2; cand = pos0 + il; endl = (uint32_t)lane + 4u + fw2; }
+                        const uint32_t en = lane_get(endl, (int)mw), nx = next_of(en);
+                        if (me) nxt = nx;
+                    }
+                    if (me) nxw = mf ? 0x80000000u : nxt;  // taken: the walk goes on from this lane (or stops at it for the longer compare)
                 }
                 {   // what the loop below may look at: the lanes in front of the first duplicate nobody has decided
                     const uint64_t und = fr >= 64 ? 0ull : (dups & (~0ull << fr));
