@@ -804,25 +804,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 }
 
-// Mixed residency: one workgroup = four independent wavefronts (no barrier anywhere): wave 0 keeps its hash table in this
-// workgroup's LDS, waves 1-3 keep theirs in HBM (check-bit slots, 2 KB LDS scratch each).  38 KB of LDS per workgroup = 31 of
-// the CU's 128 LDS granules: 4 workgroups per CU = 4 LDS-table waves (the fast ones, no table traffic) + 12 HBM-table waves,
-// which is also what the registers allow (4 waves per SIMD).  Chunks are handed out through an atomic counter, so the faster
-// waves simply take more of them.
+// Mixed residency: one workgroup = three independent wavefronts (no barrier anywhere): wave 0 keeps its hash table in this
+// workgroup's LDS, waves 1-2 keep theirs in HBM (check-bit slots, 2 KB LDS scratch each).  37.4 KB of LDS per workgroup: 4
+// workgroups per CU = 4 LDS-table waves (the fast ones, no table traffic) + 8 HBM-table waves.  Chunks are handed out through
+// an atomic counter, so the faster waves simply take more of them.  The HBM-table waves share the memory system's rate of
+// scattered slot reads: with the round-4 parser eight of them per CU are faster than twelve (138.4 against 143.8 ms per 8 GiB;
+// four per CU 167 ms, sixteen 160.8 ms - tools/experiments/README.md).
 #ifndef SN_MIX_HBM
-#define SN_MIX_HBM 3
+#define SN_MIX_HBM 2
 #endif
 #ifndef SN_MIX_WAVES_PER_SIMD
-#define SN_MIX_WAVES_PER_SIMD 4
+#define SN_MIX_WAVES_PER_SIMD 3
 #endif
-// (the register budget of 4 waves per SIMD reaches the two non-inlined fragments only because they are instantiations of
+// (the kernel's register budget reaches the two non-inlined fragments only because they are instantiations of
 //  their own - TAG 1 - that nobody else calls: the backend hands a callee the loosest budget among its callers, and shared with
-//  the single-wave kernels the HBM-table fragment took 132 VGPRs, i.e. 3 workgroups per CU instead of 4)
+//  the single-wave kernels the HBM-table fragment took 132 VGPRs when the budget was 128)
 __global__ void __launch_bounds__(64 * (1 + SN_MIX_HBM)) __attribute__((amdgpu_waves_per_eu(SN_MIX_WAVES_PER_SIMD, SN_MIX_WAVES_PER_SIMD))) snappy_compress_mix_kernel(aoclgpu_batch b, uint32_t* tables, uint32_t* counter)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
     __shared__ __attribute__((aligned(16))) uint16_t scr[SN_MIX_HBM][kScratch];
-    __shared__ __attribute__((aligned(16))) uint8_t recs[1 + SN_MIX_HBM][kSnRecBytes];   // (32 KB + 3 x 2 KB + 4 x 480 B = 31.9 of the CU's 128 granules)
+    __shared__ __attribute__((aligned(16))) uint8_t recs[1 + SN_MIX_HBM][kSnRecBytes];   // (32 KB + 2 x 2 KB + 3 x 480 B = 37.4 KB: four workgroups per CU)
     const uint32_t w = threadIdx.x >> 6;
     uint32_t* gt = tables + ((size_t)blockIdx.x * SN_MIX_HBM + (w ? w - 1 : 0)) * kMaxTable;
     for (;;) {
@@ -871,7 +872,7 @@ extern "C" int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stre
     const bool forceLds = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_LDS) != 0, forceHbm = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_HBM) != 0;
     const bool forceMix = (b->reserved & AOCLGPU_FLAG_SNAPPY_TABLES_MIXED) != 0;
     if ((!forceLds && !forceHbm && b->nchunks > 16u * cus) || forceMix) {
-        // large batches: the mixed kernel, 4 workgroups of 4 waves per CU (see snappy_compress_mix_kernel)
+        // large batches: the mixed kernel, 4 workgroups of 1 + SN_MIX_HBM waves per CU (see snappy_compress_mix_kernel)
         uint32_t grid = 4u * cus;
         if (grid > (b->nchunks + SN_MIX_HBM) / (1 + SN_MIX_HBM)) grid = (b->nchunks + SN_MIX_HBM) / (1 + SN_MIX_HBM);
 #ifdef AOCLGPU_EXPERIMENTS
