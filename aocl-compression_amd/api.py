@@ -94,9 +94,9 @@ EXPORTS = [
     "aoclgpu_rap_assemble", "aoclgpu_zstd_compress_frames", "aoclgpu_zstd_compress_host_frame",
     "aoclgpu_zstd_set_large_input_mode", "aoclgpu_zstd_large_input_mode", "aoclgpu_lz4f_set_block_linking", "aoclgpu_lz4f_block_linking",
     "aocl_llc_compress", "aocl_llc_decompress", "aocl_llc_setup", "aocl_llc_destroy", "aocl_llc_version",
-    "aoclgpu_probe_copy", "aoclgpu_probe_scatter8", "aoclgpu_host_trim",
+    "aoclgpu_probe_copy", "aoclgpu_probe_copy_variant", "aoclgpu_probe_scatter8", "aoclgpu_host_trim", "aoclgpu_host_cache_bytes",
     "aoclgpu_rap_compress_host_ex", "aoclgpu_zstd_rap_compress_host_parts", "aoclgpu_rap_assemble_slabs", "aoclgpu_set_rap_geometry", "aoclgpu_rap_geometry",
-    "aoclgpu_comm_unique_id", "aoclgpu_comm_create", "aoclgpu_comm_destroy", "aoclgpu_exchange_segments", "aoclgpu_allgather_words",
+    "aoclgpu_comm_unique_id", "aoclgpu_comm_create", "aoclgpu_comm_destroy", "aoclgpu_comm_count", "aoclgpu_exchange_segments", "aoclgpu_allgather_words",
 ]
 
 
@@ -118,9 +118,11 @@ def load_library() -> C.CDLL:
     lib.aoclgpu_compact_slots.restype = C.c_int
     lib.aoclgpu_compact_slots.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.aoclgpu_time_batch.restype = C.c_double
+    lib.aoclgpu_host_cache_bytes.restype = C.c_uint64
     lib.aoclgpu_comm_unique_id.argtypes = [C.c_void_p]
     lib.aoclgpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.aoclgpu_comm_destroy.argtypes = [C.c_void_p]
+    lib.aoclgpu_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.aoclgpu_exchange_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.aoclgpu_allgather_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     lib.aoclgpu_rap_assemble_slabs.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

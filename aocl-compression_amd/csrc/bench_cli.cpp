@@ -30,7 +30,7 @@ struct Method { const char* name; aocl_compression_type type; long lower, upper,
 const Method kMethods[] = {                       // codec_list, test/codec_bench.h
     {"LZ4", LZ4, 0, 0, 0, true}, {"LZ4HC", LZ4HC, 1, 12, 9, false}, {"LZMA", LZMA, 0, 9, 1, false},
     {"BZIP2", BZIP2, 1, 9, 6, false}, {"SNAPPY", SNAPPY, 0, 0, 0, true}, {"ZLIB", ZLIB, 1, 9, 6, false},
-    {"ZSTD", ZSTD, 1, 22, 1, true},        // default level of the GPU build: 1 (the only level with a backend)
+    {"ZSTD", ZSTD, 1, 22, 1, true},        // default level of the GPU build: 1 (GPU backend: levels 1-4 and the negative levels)
 };
 enum { RUN_DEFAULT, RUN_COMPRESS, RUN_DECOMPRESS };
 
@@ -67,7 +67,7 @@ void list_methods()
     printf("===========================================\nMethod Name\tLower Level\tUpper Level\n===========================================\n");
     for (const Method& m : kMethods) {
         if (m.lower == m.upper) printf("%s\t\t %s\t\t%s%s\n", m.name, "NA", "NA", m.gpu ? "" : "\t(no GPU backend)");
-        else printf("%s\t\t %ld\t\t%ld%s\n", m.name, m.lower, m.upper, m.gpu ? (m.type == ZSTD ? "\t(GPU backend: level 1)" : "") : "\t(no GPU backend)");
+        else printf("%s\t\t %ld\t\t%ld%s\n", m.name, m.lower, m.upper, m.gpu ? (m.type == ZSTD ? "\t(GPU backend: levels 1-4 and negative levels)" : "") : "\t(no GPU backend)");
     }
     printf("\n");
 }

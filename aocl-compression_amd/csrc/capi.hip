@@ -208,16 +208,51 @@ extern "C" int aoclgpu_compact_slots(const uint8_t* slots, uint64_t slot_bytes, 
 // probe_scatter8_kernel: every lane issues dependent-free 8-byte loads at pseudo-random 8-byte-aligned addresses of a large
 // buffer (the codecs' candidate-window pattern); run under rocprofv3 --pmc FETCH_SIZE it calibrates that counter for
 // scattered loads (bytes fetched per load).
-__global__ void __launch_bounds__(256) probe_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16)
-{   // four 16-byte loads in flight per lane (a single load per lane and trip leaves the memory pipeline a third empty)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+// Variants of the copy (the probe reports the fastest: it asks what the memory system can do, not what one loop shape does):
+// TILE = 16-byte loads in flight per lane; NT = non-temporal loads and stores (streamed data is not kept in L2 / MALL);
+// BLOCKED = a workgroup walks whole tiles of 256 x TILE x 16 bytes (each wave instruction covers 1 KiB of consecutive bytes,
+// a workgroup 4 KiB x TILE) instead of a grid-wide stride between a lane's loads.
+typedef uint32_t __attribute__((ext_vector_type(4))) probe_u4;
+template <int TILE, bool NT, bool BLOCKED>
+__global__ void __launch_bounds__(256) probe_copy_kernel(probe_u4* __restrict__ dst, const probe_u4* __restrict__ src, size_t n16)
+{
+    if (BLOCKED) {
+        const size_t per = (size_t)256 * TILE, ntiles = n16 / per;
+        for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const size_t o = t * per + threadIdx.x;
+            probe_u4 v[TILE];
+#pragma unroll
+            for (int k = 0; k < TILE; ++k) v[k] = NT ? __builtin_nontemporal_load(src + o + (size_t)k * 256) : src[o + (size_t)k * 256];
+#pragma unroll
+            for (int k = 0; k < TILE; ++k) { if (NT) __builtin_nontemporal_store(v[k], dst + o + (size_t)k * 256); else dst[o + (size_t)k * 256] = v[k]; }
+        }
+        for (size_t i = ntiles * per + (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    } else {
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + (TILE - 1) * stride < n16; i += TILE * stride) {
+            probe_u4 v[TILE];
+#pragma unroll
+            for (int k = 0; k < TILE; ++k) v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+            for (int k = 0; k < TILE; ++k) { if (NT) __builtin_nontemporal_store(v[k], dst + i + k * stride); else dst[i + k * stride] = v[k]; }
+        }
+        for (; i < n16; i += stride) dst[i] = src[i];
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
 }
+typedef void (*probe_copy_fn)(probe_u4*, const probe_u4*, size_t);
+struct ProbeCopyVariant { const char* name; probe_copy_fn fn; int wg_per_cu; };
+const ProbeCopyVariant kProbeCopy[] = {
+    {"stride x4, 8 WG/CU", probe_copy_kernel<4, false, false>, 8},          // round 4's probe (4.5 TB/s)
+    {"blocked x4 nt, 8 WG/CU", probe_copy_kernel<4, true, true>, 8},
+    {"blocked x4 nt, 16 WG/CU", probe_copy_kernel<4, true, true>, 16},
+    {"blocked x8 nt, 8 WG/CU", probe_copy_kernel<8, true, true>, 8},
+    {"blocked x4, 16 WG/CU", probe_copy_kernel<4, false, true>, 16},
+    {"stride x4 nt, 16 WG/CU", probe_copy_kernel<4, true, false>, 16},
+    {"blocked x2 nt, 32 WG/CU", probe_copy_kernel<2, true, true>, 32},
+    {"blocked x1 nt, one tile per WG", probe_copy_kernel<1, true, true>, 0},   // grid = number of tiles: no loop at all
+};
+constexpr int kProbeCopyVariants = (int)(sizeof(kProbeCopy) / sizeof(kProbeCopy[0]));
 template <int UNROLL>
 __global__ void __launch_bounds__(256) probe_scatter8_kernel(const uint64_t* __restrict__ src, size_t mask8, uint32_t loads_per_lane, uint64_t* __restrict__ sink)
 {   // UNROLL independent loads per trip: twice the loads in flight must not change the rate if the memory system is the limit
@@ -232,6 +267,10 @@ __global__ void __launch_bounds__(256) probe_scatter8_kernel(const uint64_t* __r
     if (acc == 0x1234567887654321ull) *sink = acc;                 // (keeps the loads alive)
 }
 
+// ms per copy of `bytes` bytes of the FASTEST variant (each: one warm-up launch, then `iters` launches between two events);
+// AOCLGPU_PROBE_COPY_VARIANT=<k> runs variant k only, AOCLGPU_PROBE_TRACE=1 lists every variant's rate on stderr.
+static int g_probe_copy_best = -1;
+extern "C" const char* aoclgpu_probe_copy_variant(void) { return g_probe_copy_best >= 0 ? kProbeCopy[g_probe_copy_best].name : ""; }
 extern "C" double aoclgpu_probe_copy(void* dst, const void* src, size_t bytes, int iters, void* stream)
 {
     if (!dst || !src || bytes < 16 || iters <= 0) { set_error_msg("probe_copy: bad arguments"); return -1.0; }
@@ -241,18 +280,29 @@ extern "C" double aoclgpu_probe_copy(void* dst, const void* src, size_t bytes, i
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) { set_error_msg("hipEventCreate failed"); return -1.0; }
     if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); set_error_msg("hipEventCreate failed"); return -1.0; }
-    const dim3 g((unsigned)prop.multiProcessorCount * 8), t(256);
-    hipLaunchKernelGGL(probe_copy_kernel, g, t, 0, s, (uint4*)dst, (const uint4*)src, bytes / 16);       // warm-up
-    hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(probe_copy_kernel, g, t, 0, s, (uint4*)dst, (const uint4*)src, bytes / 16);
-    hipEventRecord(e1, s);
-    double ms = -1.0;
-    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) {
-        float f = 0.f;
-        if (hipEventElapsedTime(&f, e0, e1) == hipSuccess) ms = (double)f / iters;
+    const char* only = getenv("AOCLGPU_PROBE_COPY_VARIANT");
+    const bool trace = getenv("AOCLGPU_PROBE_TRACE") != nullptr;
+    double best = -1.0;
+    for (int k = 0; k < kProbeCopyVariants; ++k) {
+        if (only && atoi(only) != k) continue;
+        const ProbeCopyVariant& v = kProbeCopy[k];
+        const size_t n16 = bytes / 16;
+        const size_t tiles = n16 / 256 ? n16 / 256 : 1;
+        const dim3 g(v.wg_per_cu ? (unsigned)prop.multiProcessorCount * v.wg_per_cu : (unsigned)(tiles > 0x7FFFFFFFu ? 0x7FFFFFFFu : tiles)), t(256);
+        hipLaunchKernelGGL(v.fn, g, t, 0, s, (probe_u4*)dst, (const probe_u4*)src, n16);       // warm-up
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(v.fn, g, t, 0, s, (probe_u4*)dst, (const probe_u4*)src, n16);
+        hipEventRecord(e1, s);
+        double ms = -1.0;
+        if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) {
+            float f = 0.f;
+            if (hipEventElapsedTime(&f, e0, e1) == hipSuccess) ms = (double)f / iters;
+        }
+        if (trace) fprintf(stderr, "probe_copy[%d] %-32s %8.3f ms  %7.1f GB/s\n", k, v.name, ms, ms > 0 ? 2.0 * bytes / ms / 1e6 : 0.0);
+        if (ms > 0 && (best < 0 || ms < best)) { best = ms; g_probe_copy_best = k; }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    return ms;
+    return best;
 }
 
 extern "C" double aoclgpu_probe_scatter8(const void* src, size_t bytes, uint32_t loads_per_lane, uint64_t* total_loads, void* stream)
@@ -391,8 +441,10 @@ bool host_grow(uint8_t** p, size_t* cap, size_t need)
 }  // namespace
 
 // Frees the device buffers of every idle host context (aocl_llc_destroy calls it); contexts in use keep theirs.
+namespace aoclgpu { size_t rap_host_cache_trim(); }             // rap.hip: the RAP host calls' cached buffer set
 extern "C" void aoclgpu_host_trim(void)
 {
+    (void)aoclgpu::rap_host_cache_trim();
     {
         std::lock_guard<std::mutex> lk(g_host_mu);
         for (HostCtx* c : g_host_ctx) {

@@ -30,12 +30,14 @@ typedef int (*fn_send)(const void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_recv)(void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, Comm, hipStream_t);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(Comm, int*);
 enum { kNcclUint8 = 1, kNcclUint32 = 3 };           // ncclDataType_t (rccl.h)
 
 struct Rccl {
     void* h = nullptr;
     fn_getid getid = nullptr; fn_init init = nullptr; fn_destroy destroy = nullptr; fn_void gstart = nullptr, gend = nullptr;
     fn_send send = nullptr; fn_recv recv = nullptr; fn_allgather allgather = nullptr; fn_errstr errstr = nullptr;
+    fn_count count = nullptr;                       // optional: ncclCommCount (aoclgpu_comm_count reports an error without it)
     bool ok = false;
 };
 Rccl g_rccl;
@@ -52,6 +54,7 @@ const Rccl& rccl()
         g_rccl.gstart = (fn_void)dlsym(g_rccl.h, "ncclGroupStart"); g_rccl.gend = (fn_void)dlsym(g_rccl.h, "ncclGroupEnd");
         g_rccl.send = (fn_send)dlsym(g_rccl.h, "ncclSend"); g_rccl.recv = (fn_recv)dlsym(g_rccl.h, "ncclRecv");
         g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather"); g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+        g_rccl.count = (fn_count)dlsym(g_rccl.h, "ncclCommCount");
         g_rccl.ok = g_rccl.getid && g_rccl.init && g_rccl.destroy && g_rccl.gstart && g_rccl.gend && g_rccl.send && g_rccl.recv && g_rccl.allgather;
     });
     return g_rccl;
@@ -93,6 +96,16 @@ extern "C" int aoclgpu_comm_destroy(void* comm)
     const Rccl& r = rccl();
     if (!r.ok || !comm) return fail("comm_destroy", 0);
     if (int rc = r.destroy((Comm)comm)) return fail("ncclCommDestroy", rc);
+    return AOCLGPU_OK;
+}
+
+extern "C" int aoclgpu_comm_count(void* comm, int* nranks)
+{
+    const Rccl& r = rccl();
+    if (!r.ok || !r.count || !comm || !nranks) return fail("comm_count", 0);
+    int n = 0;
+    if (int rc = r.count((Comm)comm, &n)) return fail("ncclCommCount", rc);
+    *nranks = n;
     return AOCLGPU_OK;
 }
 

@@ -921,7 +921,7 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
 #define DCOUNT(k, v) do { } while (0)
 #endif
     for (;;) {
-        // ---- keep >= 160 staged bytes ahead of ip (requested one iteration early) ----
+        // ---- keep the scan's 352 staged bytes ahead of ip (requested one iteration early; stored at once when the scan could not run) ----
         if (ip > rend) { rend = ip & ~15; have_pend = false; }
         if (have_pend) {
             *(__attribute__((address_space(3))) u32x4*)(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
@@ -932,7 +932,7 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
         if (rend - ip < 640 && rend + 1024 <= iend) {
             pend = *(const G128*)(src + rend + 16 * lane);
             have_pend = true;
-            if (rend - ip < 160) {
+            if (rend - ip < 352) {
                 *(__attribute__((address_space(3))) u32x4*)(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
                 if (((uint32_t)(rend + 16 * lane) & kRingMask) == 0) *(__attribute__((address_space(3))) u32x4*)(ring + kRing) = pend;
                 wave_fence();

@@ -410,13 +410,38 @@ struct HostPathCache {
 };
 HostPathCache* g_hp = new HostPathCache;                       // (never destroyed: the HIP runtime may be gone before static destructors run)
 
+// What the cache may keep between calls: the buffer set of one call on <= 1 GiB of input (the slab size of the reference's bench,
+// test/codec_bench.h:58) is ~3.4 GiB; a call that needed more gives everything back when it returns, as host_release does for
+// the one-shot contexts (capi.hip kHostCtxKeepBytes).  AOCLGPU_HOST_CACHE_KEEP_MB overrides (0 = keep nothing).
+size_t host_cache_keep_bytes()
+{
+    static const size_t v = [] { const char* e = getenv("AOCLGPU_HOST_CACHE_KEEP_MB"); return e ? (size_t)atoll(e) << 20 : (size_t)4096 << 20; }();
+    return v;
+}
+void host_cache_free_buffers(HostPathCache& c)                  // caller holds c.mu; the streams are kept (they hold no HBM)
+{
+    if (c.dev < 0) return;
+    aoclgpu::DeviceScope ds(c.dev);
+    for (int i = 0; i < 5; ++i) { if (c.buf[i]) (void)hipFree(c.buf[i]); c.buf[i] = nullptr; c.cap[i] = 0; }
+}
+
 struct HostBufs {                                             // the five buffers of one call: the cache's when it is free, else the call's own
     void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t work[kHostStreams] = {}, copy = nullptr;
     bool cached = false;
     ~HostBufs()
     {
-        if (cached) { g_hp->mu.unlock(); return; }
+        // every way out of a call - the error returns too - first waits for what it put on the streams: kernels of earlier slabs
+        // may still be writing these buffers, and the next caller gets them the moment the mutex is released
+        for (hipStream_t q : work) if (q) (void)hipStreamSynchronize(q);
+        if (copy) (void)hipStreamSynchronize(copy);
+        if (cached) {
+            size_t held = 0;
+            for (size_t v : g_hp->cap) held += v;
+            if (held > host_cache_keep_bytes()) host_cache_free_buffers(*g_hp);
+            g_hp->mu.unlock();
+            return;
+        }
         for (void* q : p) if (q) (void)hipFree(q);
         for (hipStream_t q : work) if (q) (void)hipStreamDestroy(q);
         if (copy) (void)hipStreamDestroy(copy);
@@ -429,7 +454,12 @@ struct HostBufs {                                             // the five buffer
             cached = true;
             HostPathCache& c = *g_hp;
             if (c.dev != dev) {                                // another device than last time: start over (rare: the host device is a process-wide setting)
-                for (int i = 0; i < 5; ++i) { c.buf[i] = nullptr; c.cap[i] = 0; }
+                if (c.dev >= 0) {                              // the old device's buffers and streams are released THERE, not dropped
+                    host_cache_free_buffers(c);
+                    aoclgpu::DeviceScope ds(c.dev);
+                    for (hipStream_t& q : c.work) { if (q) (void)hipStreamDestroy(q); q = nullptr; }
+                    if (c.copy) (void)hipStreamDestroy(c.copy);
+                }
                 for (hipStream_t& q : c.work) q = nullptr;
                 c.copy = nullptr; c.dev = dev;
             }
@@ -454,6 +484,29 @@ struct HostBufs {                                             // the five buffer
     }
 };
 }  // namespace
+
+namespace aoclgpu {
+// aoclgpu_host_trim's share of this file: the cached buffer set of the RAP host calls goes back to the device unless a call
+// is using it right now (that call's own exit applies the keep limit).  Returns the bytes released.
+size_t rap_host_cache_trim()
+{
+    if (!g_hp->mu.try_lock()) return 0;
+    size_t held = 0;
+    for (size_t v : g_hp->cap) held += v;
+    host_cache_free_buffers(*g_hp);
+    g_hp->mu.unlock();
+    return held;
+}
+size_t rap_host_cache_bytes()                                   // (tests) what the cache holds now; ~0 = in use
+{
+    if (!g_hp->mu.try_lock()) return ~(size_t)0;
+    size_t held = 0;
+    for (size_t v : g_hp->cap) held += v;
+    g_hp->mu.unlock();
+    return held;
+}
+}  // namespace aoclgpu
+extern "C" uint64_t aoclgpu_host_cache_bytes(void) { return (uint64_t)aoclgpu::rap_host_cache_bytes(); }
 
 // flags: the codec's AOCLGPU_FLAG_* / AOCLGPU_ZSTD_LEVEL(l) / AOCLGPU_LZ4_ACCELERATION(a) for every partition.
 // The input goes to the device in up to four slabs (whole chunks) and every slab's chunks are compressed as soon as they have

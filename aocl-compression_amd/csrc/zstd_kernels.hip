@@ -3068,7 +3068,13 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     }
     if (const char* e = getenv("AOCLGPU_ZSTD_DF_SLAB_MB")) { const long long mb = atoll(e); if (mb > 0) budget = (size_t)mb << 20; }
     const size_t wsz = aoclgpu::zstd_workspace_bytes();
-    uint32_t slab = (uint32_t)(budget / wsz < count ? budget / wsz : count);
+    // the allocation is more than the per-chunk workspaces: the resident workgroups' hash tables (perA x CUs tables of
+    // 384-768 KiB), 8 bytes of meta per chunk, the slab counters and the alignment of the three regions - all of it has to
+    // fit the budget, or the hipMalloc below fails exactly when free memory is what limits the slab
+    const size_t fixed = (size_t)perA * cus * tabBytes + (size_t)64 * 256 + 3 * 256;
+    if (budget <= fixed) return 1;
+    const size_t fit = (budget - fixed) / (wsz + 8);
+    uint32_t slab = (uint32_t)(fit < count ? fit : count);
     if (slab < 8u * cus) return 1;                       // too few chunks in flight to beat the fused kernel
     // equal slabs (the last one is not a remainder of a few chunks)
     const uint32_t nslab = (count + slab - 1) / slab;
@@ -3078,6 +3084,7 @@ int df_split_launch(const aoclgpu_batch* b, uint32_t first, uint32_t count, size
     const size_t seqBytes = ((size_t)slab * wsz + 255) & ~(size_t)255;
     const size_t tabOff = seqBytes, metaOff = (tabOff + (size_t)gridA * tabBytes + 255) & ~(size_t)255;
     const size_t ctrOff = (metaOff + (size_t)slab * 8 + 255) & ~(size_t)255;
+    if (nslab > 64) return 1;                            // (the counters' share of `fixed` above)
     uint8_t* ws = (uint8_t*)get_workspace(guard, ctrOff + (size_t)nslab * 256, s);
     if (!ws) return 1;
     g_df_last_slabs.store((int)nslab);

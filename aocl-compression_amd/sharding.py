@@ -67,6 +67,11 @@ class CExchange:
                                                              self.side.cuda_stream), "allgather_words")
         cur.wait_stream(self.side)
 
+    def nranks(self):
+        """the number of ranks RCCL holds for this communicator (ncclCommCount), or None when the library cannot say"""
+        n = C.c_int(0)
+        return int(n.value) if self.eng.lib.aoclgpu_comm_count(self.comm, C.byref(n)) == 0 else None
+
     def close(self):
         if self.comm:
             self.eng.lib.aoclgpu_comm_destroy(self.comm)

@@ -65,6 +65,32 @@ def parse():
     return p.parse_args()
 
 
+def self_launch(args):
+    """`python3 bench.py --gpus N` (N > 1) started WITHOUT a launcher: this process starts the N ranks itself, as one child
+    process (`python -m torch.distributed.run`, which spawns one worker per GPU), and only relays - the children's stdout and
+    stderr are inherited, so rank 0's JSON line is this command's JSON line, and their exit code is this command's exit code.
+    The parent never imports torch and never makes a HIP call (no exec of anything from a GPU-initialised process); the
+    reference's caller does not launch workers by hand either (threads/threads.c:121-153, lz4.c:2684-2731)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):          # a stale launcher variable without RANK: the launcher sets its own
+        env.pop(k, None)
+    env["AOCLGPU_BENCH_SELF_LAUNCHED"] = "1"
+    if os.environ.get("AOCLGPU_BENCH_LAUNCH_DRYRUN") == "1":
+        print(json.dumps({"launch": cmd, "torch_imported_by_parent": "torch" in sys.modules}), flush=True)
+        return 0
+    p = subprocess.run(cmd, env=env)
+    assert "torch" not in sys.modules
+    return p.returncode
+
+
 def host_cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -302,6 +328,11 @@ def memory_probes(eng):
     b_ = torch.ones(n, dtype=torch.uint8, device=eng.device)
     ms = eng.lib.aoclgpu_probe_copy(a_.data_ptr(), b_.data_ptr(), n, 5, eng._stream())
     out = {"hbm_copy_GBps": round(2.0 * n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None, "hbm_copy_bytes": n}
+    try:
+        eng.lib.aoclgpu_probe_copy_variant.restype = C.c_char_p
+        out["hbm_copy_variant"] = eng.lib.aoclgpu_probe_copy_variant().decode()
+    except AttributeError:
+        pass
     tot = C.c_uint64(0)
     ms2 = eng.lib.aoclgpu_probe_scatter8(b_.data_ptr(), n, 256, C.byref(tot), eng._stream())
     if ms2 > 0:
@@ -437,6 +468,9 @@ class Run:
             self.cb.reserved |= a.api.zstd_level(ZSTD_LEVEL[name])
         self.db = eng.uniform_decompress_batch(self.slots, self.clen, slot, self.dst, chunk, self.dlen)
         self.kt = {"c": [], "d": []}
+        self.df_slabs = 0
+        self.exchange_requested = args.exchange
+        self.fallbacks = []                 # every change of the exchange away from the requested one, with its reason
         if world > 1:
             self.setup_exchange()
 
@@ -475,6 +509,7 @@ class Run:
         self.all_gather_vec(self.aux_all, self.aux)
         if self.args.exchange == "c" and self.gloo:
             self.args.exchange = "sendrecv"           # host-staged validation runs (1 GPU / CPU) have no RCCL communicator
+            self.fallbacks.append("c -> sendrecv: torch.distributed backend is gloo (host-staged validation run, no RCCL communicator)")
         if self.args.exchange == "c" and not getattr(self, "cx", None):
             # the product path: the communicator and the exchange are the C library's (csrc/exchange.cpp).  Every rank learns
             # together whether it came up; if not, all of them use torch.distributed's grouped send / recv instead.
@@ -484,6 +519,7 @@ class Run:
                 self.cx = sharding.CExchange(eng, dist, self.rank, self.world)
             except Exception as e:  # noqa: BLE001
                 ok = 0
+                why = repr(e)
                 if self.rank == 0:
                     print(f"bench: C exchange unavailable ({e!r}); using torch.distributed send/recv", file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -491,6 +527,8 @@ class Run:
             if int(flag.item()) == 0:
                 self.cx = None
                 self.args.exchange = "sendrecv"
+                self.fallbacks.append("c -> sendrecv: the library's RCCL communicator did not come up on every rank"
+                                      + (f" (this rank: {why})" if not ok else " (another rank)"))
         if self.args.exchange == "allgather":
             # RCCL has no all-gatherv: every segment is padded to the largest one (the ring moves the padding too)
             self.seg_cap = (max(self.seg) + (1 << 20)) & ~0xFFFFF
@@ -530,6 +568,7 @@ class Run:
                 nxt = "sendrecv" if self.args.exchange == "c" else "allgather"
                 if self.rank == 0:
                     print(f"bench: {self.args.exchange} exchange failed ({e!r}); using {nxt}", file=sys.stderr)
+                self.fallbacks.append(f"{self.args.exchange} -> {nxt}: the first (untimed) exchange raised {e!r}")
                 self.args.exchange = nxt
                 self.cx = None
                 self.setup_exchange()
@@ -551,6 +590,8 @@ class Run:
     def step(self, record):
         eng = self.eng
         tc = eng.time_batch(self.codec, 0, self.cb, 1)          # HIP events around the compress kernel, same stream
+        if self.name == "zstd3":                                # read right behind the call, on the calling thread (a process-wide value)
+            self.df_slabs = int(eng.lib.aoclgpu_zstd_last_split_slabs())
         works = []
         if self.world > 1:
             rc = eng.lib.aoclgpu_compact_slots(self.slots.data_ptr(), self.slot, self.clen.data_ptr(), self.nchunks,
@@ -586,6 +627,49 @@ class Run:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed
+
+    def exchange_report(self, ms_step, ms_c, ms_d):
+        """N > 1, outside the timed region, every rank: the exchange ALONE (no kernel beside it) - barrier, one exchange of the
+        compacted segments as the step issues it, wait, synchronize; max over ranks, best of 3 - so that a scaling shortfall can
+        be split into kernels and links.  `exchange_GBps` = bytes one GPU RECEIVES (all other ranks' segments) over that time,
+        next to what its links carry inbound ((N-1) peers x ~153 GB/s xGMI, MI355X_MICROARCH.md); `exchange_exposed_ms` = step
+        time minus the two kernels (HIP events, max over ranks) = what the exchange, the compaction and the size gather cost
+        the step after overlapping with decompress.  `rccl_nranks` = ncclCommCount of the library's communicator."""
+        torch, dist = self.torch, self.dist
+        best = None
+        for _ in range(3):
+            self.barrier()
+            t0 = time.perf_counter()
+            for w in self.exchange():
+                w.wait()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.eng.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = float(tt.item()) if best is None else min(best, float(tt.item()))
+        total = float(sum(self.seg))
+        if self.args.exchange == "allgather":
+            recv = float(self.seg_cap) * (self.world - 1)             # the ring moves every padded segment to every rank
+        else:
+            recv = (total - min(self.seg)) if self.world > 1 else 0.0  # the rank with the smallest own segment receives the most
+        cx = getattr(self, "cx", None)
+        links = min(self.world - 1, 7)
+        return {
+            "exchange": {"c": "aoclgpu_exchange_segments (C library, own RCCL communicator, grouped exact-size send/recv)",
+                         "sendrecv": "torch.distributed batch_isend_irecv of exact sizes" + (" (host-staged over gloo)" if self.gloo else ""),
+                         "allgather": "all-gather of segments padded to the largest" + (" (host-staged over gloo)" if self.gloo else "")}[self.args.exchange],
+            "exchange_requested": self.exchange_requested,
+            "exchange_fell_back": bool(self.fallbacks), "exchange_fallback_reason": "; ".join(self.fallbacks) or None,
+            "rccl_nranks": cx.nranks() if cx else None,
+            "torch_distributed_backend": dist.get_backend(),
+            "exchange_ms": round(best * 1e3, 3), "exchange_recv_bytes_per_gpu": recv,
+            "exchange_GBps": round(recv / best / 1e9, 2) if best > 0 else None,
+            "exchange_GBps_all_gpus": round(recv * self.world / best / 1e9, 2) if best > 0 else None,
+            "xgmi_inbound_peak_GBps_per_gpu": 153.0 * links,
+            "exchange_frac_of_xgmi_peak": round(recv / best / 1e9 / (153.0 * links), 4) if best > 0 and links else None,
+            "exchange_exposed_ms": round(ms_step - ms_c - ms_d, 3),
+            "exchange_note": "exchange_ms: one exchange alone (nothing overlapped), max over ranks, best of 3; exchange_exposed_ms: "
+                             "step - compress kernel - decompress kernel (includes compaction and the per-chunk size gather)",
+        }
 
     # ---- checks outside the timed region ----
     def verify_local(self):
@@ -695,10 +779,14 @@ class Run:
         if (self.name, dom) == ("zstd3", "compress") and self.nchunks > 16 * 256:
             # large level-3 batches: finder kernel + entropy kernel per slab of <= 32 Ki chunks (csrc/zstd_kernels.hip df_split_launch);
             # avg_launch_ms below is the whole compress call = the sum of its launches (profiles/r03_zstd3_*_kernel_trace_and_pmc.txt)
-            nslab = int(self.eng.lib.aoclgpu_zstd_last_split_slabs()) or 1   # what the launcher used (free memory decides the slab size)
-            kernel = "zstd_df_find_kernel"
-            launches = {"per_compress_call": {"zstd_df_find_kernel": nslab, "zstd_df_entropy_kernel": nslab},
-                        "note": "avg_launch_ms = one compress call = all of these launches back to back"}
+            nslab = self.df_slabs                 # what the launcher used in the timed steps (free memory decides the slab size)
+            if nslab:
+                kernel = "zstd_df_find_kernel"
+                launches = {"per_compress_call": {"zstd_df_find_kernel": nslab, "zstd_df_entropy_kernel": nslab},
+                            "note": "avg_launch_ms = one compress call = all of these launches back to back"}
+            else:                                 # the launcher fell back to the fused kernel (scratch not available): say so
+                launches = {"per_compress_call": {"zstd_compress_kernel<double-fast>": 1},
+                            "note": "df_split_launch did not run (workspace not available); the fused double-fast kernel did"}
         out = {
             "value": round(unc_total / GIB / (elapsed / args.steps), 3), "unit": "GiB/s", "ms_per_step": round(ms_step, 3),
             "config": {
@@ -722,6 +810,8 @@ class Run:
         }
         if launches:
             out["roofline"]["launches"] = launches
+        if world > 1:
+            out.update(self.exchange_report(ms_step, ms_c, ms_d))
         # HBM-side traffic of the dominant kernel: not measurable from inside this process; taken from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/traffic.json), raw counter
         # bytes per launch, only when this run has the profiled shape.
@@ -740,6 +830,8 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(json.loads(args.cpu_worker))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import aocl_compression_amd as a
@@ -761,7 +853,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert args.gpus == world, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"
 
     eng = a.Engine(local)
     names = [args.codec] if args.codec != "all" else (["lz4", "snappy", "zstd", "zstd3"] if world == 1 else ["lz4", "zstd"])
@@ -825,11 +917,17 @@ def main():
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
+        if world > 1:                                              # the headline codec's exchange record, at the top level too
+            for k in ("exchange", "exchange_requested", "exchange_fell_back", "exchange_fallback_reason", "rccl_nranks",
+                      "torch_distributed_backend", "exchange_ms", "exchange_GBps", "xgmi_inbound_peak_GBps_per_gpu", "exchange_exposed_ms"):
+                out[k] = head.get(k)
+            out["launched_by"] = "bench.py itself (child torch.distributed.run)" if os.environ.get("AOCLGPU_BENCH_SELF_LAUNCHED") == "1" else "external launcher"
         out["codecs"] = results
         if world == 1:
             try:
                 probes = memory_probes(eng)
                 out["hbm_copy_GBps"] = probes.get("hbm_copy_GBps")
+                out["hbm_copy_variant"] = probes.get("hbm_copy_variant")
                 out["fetch_calibration"] = probes.get("fetch_calibration")
                 for r in [out["roofline"]] + [v["roofline"] for v in results.values()]:
                     r["measured_copy_GBps"] = probes.get("hbm_copy_GBps")

@@ -256,11 +256,14 @@ int64_t aoclgpu_zstd_rap_compress_host_parts(const void* host_src, size_t n, voi
  * aoclgpu_exchange_segments: afterwards gather_buf[seg_off[r], +seg_bytes[r]) holds rank r's segment on every rank (this
  * rank's own must already be there); one group of exact-size ncclSend / ncclRecv pairs on `stream`, every pair of ranks over
  * its own xGMI link.  seg_bytes / seg_off: host arrays of nranks entries, the same on all ranks.
- * aoclgpu_allgather_words: all_dev[r * nwords ..] = rank r's mine_dev[0 .. nwords) (32-bit words, ncclAllGather). */
+ * aoclgpu_allgather_words: all_dev[r * nwords ..] = rank r's mine_dev[0 .. nwords) (32-bit words, ncclAllGather).
+ * aoclgpu_comm_count: *nranks = the number of ranks RCCL itself holds for `comm` (ncclCommCount) - what a bench line records so
+ * that a run whose communicator came up smaller than the launch says so. */
 #define AOCLGPU_COMM_ID_BYTES 128
 int aoclgpu_comm_unique_id(uint8_t id[AOCLGPU_COMM_ID_BYTES]);
 int aoclgpu_comm_create(const uint8_t id[AOCLGPU_COMM_ID_BYTES], int nranks, int rank, void** comm);
 int aoclgpu_comm_destroy(void* comm);
+int aoclgpu_comm_count(void* comm, int* nranks);
 int aoclgpu_exchange_segments(void* comm, void* gather_buf, const uint64_t* seg_bytes, const uint64_t* seg_off,
                               int nranks, int rank, void* stream);
 int aoclgpu_allgather_words(void* comm, const void* mine_dev, void* all_dev, size_t nwords, int nranks, int rank, void* stream);
@@ -281,11 +284,13 @@ int aoclgpu_rap_assemble_slabs(aoclgpu_codec codec, const uint8_t* gathered, con
 double aoclgpu_time_batch(aoclgpu_codec codec, int op, const aoclgpu_batch* b, int iters, void* stream);
 
 /* Memory-system probes for bench.py's roofline ("a device-to-device copy kernel gives the achievable ceiling").
- * aoclgpu_probe_copy: average milliseconds of one device-to-device copy of `bytes` (16-byte lanes, coalesced); the achievable
- * HBM rate is 2 * bytes / time.  aoclgpu_probe_scatter8: one launch of `loads_per_lane` independent 8-byte loads per lane at
+ * aoclgpu_probe_copy: average milliseconds of one device-to-device copy of `bytes` (16-byte lanes, coalesced) - of the fastest
+ * of a few loop shapes (tile depth, non-temporal or not, workgroups per CU; aoclgpu_probe_copy_variant names the winner); the
+ * achievable HBM rate is 2 * bytes / time.  aoclgpu_probe_scatter8: one launch of `loads_per_lane` independent 8-byte loads per lane at
  * pseudo-random addresses of src[0, bytes) - the codecs' candidate-window pattern; returns its milliseconds, *total_loads =
  * loads issued (under rocprofv3 --pmc FETCH_SIZE this calibrates the counter for scattered loads).  Negative on error. */
 double aoclgpu_probe_copy(void* dst_dev, const void* src_dev, size_t bytes, int iters, void* stream);
+const char* aoclgpu_probe_copy_variant(void);
 double aoclgpu_probe_scatter8(const void* src_dev, size_t bytes, uint32_t loads_per_lane, uint64_t* total_loads, void* stream);
 
 /* Host-buffer convenience (H2D, one launch of ONE chunk, D2H).  Return value = the per-chunk result of the
@@ -312,11 +317,15 @@ int64_t aoclgpu_zstd_decompress_host_frames(const void* host_src, size_t n, void
 int aoclgpu_set_host_device(int device);
 int aoclgpu_host_device(void);
 /* The host-buffer entry points keep their device staging buffers between calls (up to 256 MiB each; larger ones are freed when
- * the call returns), and the launchers keep one scratch allocation per (device, stream) - hash tables and sequence stores of
+ * the call returns); the RAP host calls (aoclgpu_rap_compress_host*, aocl_llc_compress with numThreads > 1) keep ONE buffer set
+ * per process - ~3.3x the input - while it is at most AOCLGPU_HOST_CACHE_KEEP_MB (default 4096: one <= 1 GiB call, the slab
+ * of the reference's bench; a call that needed more frees everything on return).  aoclgpu_host_cache_bytes() = what that
+ * cache holds now.  The launchers keep one scratch allocation per (device, stream) - hash tables and sequence stores of
  * the resident chunks; after a Zstd level 3-4 batch of thousands of chunks up to AOCLGPU_ZSTD_DF_SLAB_MB (default 32 GiB) of
  * per-chunk workspaces.  aoclgpu_host_trim frees the staging buffers of every idle context and all launcher scratch (it waits
  * for the work that still uses it); aocl_llc_destroy calls it. */
 void aoclgpu_host_trim(void);
+uint64_t aoclgpu_host_cache_bytes(void);
 
 int64_t aoclgpu_compress_host_ex(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_compress_host(aoclgpu_codec codec, const void* host_src, size_t n, void* host_dst, size_t cap);

@@ -2,13 +2,15 @@
  * path, exported by libaocl_compression_gpu.so with the reference's names, argument meaning and return conventions
  * (the reference .so is also linked as liblz4 / libsnappy / libzstd, CMakeLists.txt:616-635).
  *
- * Buffers are HOST buffers exactly as in the reference; one call = one chunk on the GPU (upload, one wavefront,
- * download).  Bulk work should use the device-resident batch API of aocl_gpu_codec.h.  There is no CPU fallback:
- * without a gfx950 device compression returns the codec's failure value.
+ * Buffers are HOST buffers exactly as in the reference; one call = one input on the GPU (upload, one wavefront per
+ * chunk / frame, download).  Bulk work should use the device-resident batch API of aocl_gpu_codec.h.  There is no CPU
+ * fallback: without a gfx950 device compression returns the codec's failure value.
  *
- * Scope is the north-star path only: LZ4 (any acceleration), Snappy, Zstd levels 1-2 ("fast" strategy); anything else
- * fails loudly with the codec's error convention instead of silently doing something different (INTEGRATION.md lists
- * every deviation from the reference).
+ * Scope is the north-star path and the rows next to it: LZ4 (any acceleration) and its frame format with linked or
+ * independent blocks, Snappy, Zstd with the "fast" strategy (levels 1-2 and every negative level) and the
+ * "double-fast" strategy (levels 3-4; level 0 = 3) at any input size; anything else fails loudly with the codec's
+ * error convention instead of silently doing something different (INTEGRATION.md lists every deviation from the
+ * reference).
  */
 #ifndef AOCL_NATIVE_API_H
 #define AOCL_NATIVE_API_H
@@ -30,8 +32,11 @@ char*       aocl_setup_lz4(int optOff, int optLevel, size_t insize, size_t level
 void        aocl_destroy_lz4(void);
 
 /* ---- LZ4 frame format (algos/lz4/lz4frame.h:100-260, 380-470; lz4frame.c:373-460, 1398-1860) on the GPU block codec.
- *      Types mirror lz4frame.h.  LZ4F_compressFrame: the fast compressor only (compressionLevel 0..2), blocks always
- *      independent (byte-identical to the reference for LZ4F_blockIndependent and for single-block inputs);
+ *      Types mirror lz4frame.h.  LZ4F_compressFrame: the fast compressor only (compressionLevel < 3; negative = acceleration),
+ *      the reference's bytes for LZ4F_blockLinked (the format's default: the blocks of a frame are one wavefront's work, in
+ *      order, with the 64 KiB history across blocks) and for LZ4F_blockIndependent alike; aoclgpu_lz4f_set_block_linking(0) /
+ *      AOCLGPU_LZ4F_LINKED=independent writes independent blocks whatever the preferences ask (throughput instead of the
+ *      reference's bytes).  The streaming calls (LZ4F_compressBegin / Update / End) write independent blocks.
  *      LZ4F_decompress: independent and linked blocks, all checksums verified; whole frames are decoded in place, frames fed in
  *      pieces are collected and decoded once complete. ---- */
 typedef size_t LZ4F_errorCode_t;
@@ -83,10 +88,13 @@ snappy_status snappy_uncompressed_length(const char* compressed, size_t compress
 snappy_status snappy_validate_compressed_buffer(const char* compressed, size_t compressed_length);
 
 /* ---- Zstd 1.5.5 (algos/zstd/lib/zstd.h:184,201,261,291,353,423-452,487-489,542,581,606-615,657-764,2416-2435,3115-3166).
- *      GPU backend: the "fast" strategy with the parameters of levels 1 and 2, frames with content size and no checksum.
- *      srcSize <= 128 KiB -> one block per frame, the reference's bytes; larger inputs -> concatenated independent
- *      128 KiB frames (valid Zstandard, not the reference's bytes).  Every other request returns
- *      ZSTD_error_parameter_unsupported (see INTEGRATION.md for the full deviation list). ---- */
+ *      GPU backend: the "fast" strategy (levels 1-2, every negative level, and through ZSTD_compress_advanced any "fast"
+ *      parameter set) and the "double-fast" strategy (levels 3-4; level 0 = 3), with or without content size / content checksum.
+ *      An input of ANY size is ONE frame, the reference's bytes: srcSize <= 128 KiB is a single block; a larger input is the
+ *      reference's frame of several blocks with its window across blocks (zstd_compress.c:4504-4583), which is one wavefront's
+ *      sequential work.  aoclgpu_zstd_set_large_input_mode / AOCLGPU_ZSTD_LARGE_INPUTS=pieces writes concatenated independent
+ *      128 KiB frames instead (valid Zstandard at GiB/s, not the reference's bytes).  Levels 5-22, dictionaries and every other
+ *      request return ZSTD_error_parameter_unsupported (see INTEGRATION.md for the full deviation list). ---- */
 typedef enum { ZSTD_fast = 1, ZSTD_dfast = 2, ZSTD_greedy = 3, ZSTD_lazy = 4, ZSTD_lazy2 = 5, ZSTD_btlazy2 = 6, ZSTD_btopt = 7,
                ZSTD_btultra = 8, ZSTD_btultra2 = 9 } ZSTD_strategy;
 typedef struct { unsigned windowLog, chainLog, hashLog, searchLog, minMatch, targetLength; ZSTD_strategy strategy; } ZSTD_compressionParameters;
@@ -134,7 +142,8 @@ void        aocl_destroy_zstd_decode(void);
 /* ---- Block-level external sequence producer for libzstd (algos/zstd/lib/zstd.h:4065-4098): has the ZSTD_sequenceProducer_F
  *      signature (outSeqs is a ZSTD_Sequence*); a user of upstream / reference libzstd registers it with
  *      ZSTD_registerSequenceProducer(cctx, NULL, (ZSTD_sequenceProducer_F*)aoclgpu_zstd_sequence_producer)
- *      and the GPU match finder (level-1 "fast" parse, one block at a time, no history) feeds zstd's own entropy stage.
+ *      and the GPU match finder (the level-1 "fast" parse whatever compressionLevel says, one block at a time, no history
+ *      across blocks) feeds zstd's own entropy stage.
  *      Offsets are real offsets: set ZSTD_c_searchForExternalRepcodes = ZSTD_ps_enable so that zstd turns them back into repcodes
  *      (it only does so by default from level 10 on).
  *      Returns the number of sequences incl. the closing block delimiter, or ZSTD_SEQUENCE_PRODUCER_ERROR ((size_t)-1). ---- */

@@ -1,4 +1,4 @@
-/* tests/fake_rccl.c -- TEST-ONLY stand-in for librccl.so.1: the eight entry points csrc/exchange.cpp binds with dlsym, moving
+/* tests/fake_rccl.c -- TEST-ONLY stand-in for librccl.so.1: the entry points csrc/exchange.cpp binds with dlsym, moving
  * bytes between PROCESSES OF ONE HOST through POSIX shared memory (buffers are host memory, streams are ignored), so that the
  * exchange's rank arithmetic, offsets, group structure and error paths run with nranks > 1 on a box without GPUs
  * (tests/test_exchange_fake_rccl.py).  Not part of the product; never installed. */
@@ -96,6 +96,7 @@ int ncclCommDestroy(Comm* c)
     free(c);
     return 0;
 }
+int ncclCommCount(Comm* c, int* n) { if (!c || !n) return 4; *n = c->nranks; return 0; }
 int ncclGroupStart(void) { g_group++; return 0; }
 int ncclGroupEnd(void) { if (g_group > 0) g_group--; return g_group ? 0 : run_ops(); }
 int ncclSend(const void* buf, size_t count, int type, int peer, Comm* c, void* stream) { (void)stream; return post(1, (void*)buf, count * kTypeSize[type & 15], peer, c); }

@@ -32,6 +32,10 @@ WORKER = textwrap.dedent('''
         ident = (C.c_uint8 * 128).from_buffer_copy(open(idfile, "rb").read())
     comm = C.c_void_p()
     chk(lib.aoclgpu_comm_create(ident, world, rank, C.byref(comm)), "comm_create")
+    nr = C.c_int(0)
+    chk(lib.aoclgpu_comm_count(comm, C.byref(nr)), "comm_count")
+    assert nr.value == world, nr.value
+    assert lib.aoclgpu_comm_count(None, C.byref(nr)) != 0
     # per-chunk sizes: every rank contributes 5 words
     mine = (C.c_uint32 * 5)(*[1000 * rank + k for k in range(5)])
     allw = (C.c_uint32 * (5 * world))()

@@ -221,3 +221,30 @@ def test_assemble_all_literal_partitions_carry_across_ranks(eng, ref, ref_mt):
     got = bytes(eng.rap_assemble(a.LZ4, gathered, off, ln, sl, ax).cpu().numpy())
     assert got == want
     assert ref.decompress(ol.LZ4, got[ref_mt.skip(got):], len(data)) == data
+
+
+def test_host_trim_releases_the_rap_host_cache(eng):
+    """the process-wide buffer set of the RAP host calls must go back to the device on aoclgpu_host_trim (which
+    aocl_llc_destroy calls), and a call above the keep limit must not leave its buffers behind."""
+    import ctypes as C
+    import numpy as np
+    import aocl_compression_amd as a
+    lib = eng.lib
+    n = 8 << 20
+    data = a.corpus.silesia_mix(n, seed=11)
+    cap = a.compress_bound(a.LZ4, n) + 4096 + (n >> 8)
+    out = np.empty(cap, np.uint8)
+    r = lib.aoclgpu_rap_compress_host_ex(a.LZ4, data.ctypes.data, n, out.ctypes.data, cap, 0, 0)
+    assert r > 0
+    held = lib.aoclgpu_host_cache_bytes()
+    assert held >= n, held                                     # kept for the next call of this size ...
+    lib.aoclgpu_host_trim()
+    assert lib.aoclgpu_host_cache_bytes() == 0                 # ... and released on request
+    r2 = lib.aoclgpu_rap_compress_host_ex(a.LZ4, data.ctypes.data, n, out.ctypes.data, cap, 0, 0)
+    assert r2 == r
+    back = np.empty(n, np.uint8)
+    lib.aoclgpu_rap_decompress_host.restype = C.c_int64
+    lib.aoclgpu_rap_decompress_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    assert lib.aoclgpu_rap_decompress_host(a.LZ4, out.ctypes.data, r2, back.ctypes.data, n) == n and np.array_equal(back, data)
+    lib.aoclgpu_host_trim()
+    assert lib.aoclgpu_host_cache_bytes() == 0
