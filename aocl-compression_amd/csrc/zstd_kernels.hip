@@ -37,7 +37,8 @@ using namespace zs;
 
 constexpr u32 kBlockMax = 128u << 10;
 constexpr u32 kMaxSeq = kBlockMax / 4 + 8;
-constexpr u32 kDecWs = kBlockMax + 64 + 8192;   // decoder workspace per resident block: literal buffer + a 12-bit Huffman table
+constexpr u32 kDecHufPark = kBlockMax + 64 + 8192, kDecFsePark = kDecHufPark + 4096;   // (see DecLds: tables of a frame's earlier blocks)
+constexpr u32 kDecWs = kDecFsePark + 5120;      // decoder workspace per resident block: literal buffer + a 12-bit Huffman table + the parked tables
 constexpr u32 kSchedLen = 960;
 constexpr u32 kRingBlk = 240;                   // source ring of the chain batches: two 240-byte blocks + a 32-byte mirror
 }
@@ -1981,16 +1982,26 @@ __device__ __forceinline__ u32x4 stream16(const gbyte* p, u32 n, int off)
 
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
-struct DecLds {                     // 12.4 KB = 10 LDS granules of 1280 bytes: 12 blocks resident per CU (the serial entropy loops are
-                                    // latency chains: throughput follows residency)
-    u16 huf[2048];                  // symbol | nbBits << 8, table logs <= 11; a 12-bit table (accepted by the reference,
+struct DecLds {                     // 8.4 KB = 7 LDS granules of 1280 bytes (round 5; 12.4 KB = 10 granules before): the serial entropy
+                                    // loops are latency chains and throughput follows residency - 6 / 9 / 12 blocks per CU decode the
+                                    // 8 GiB bench in 108.7 / 78.5 / 63.7 ms - so the Huffman table and the three FSE tables, which are
+                                    // never read in the same phase of a block, share their LDS.  What a LATER block of the frame may
+                                    // reuse (treeless literals, repeat-mode sequence tables) is parked in the block's global workspace
+                                    // (kDecHufPark / kDecFsePark) by the blocks that are not the frame's last, and fetched back by the
+                                    // block that asks for it; a frame of one block - every chunk of a batch - never does either.
+    union {
+        u16 huf[2048];              // literals: symbol | nbBits << 8, table logs <= 11; a 12-bit table (accepted by the reference,
                                     // never produced by zstd) lives in the block's global workspace instead
-    FseD ll[512], of[256], ml[512];
+        struct { FseD ll[512], of[256], ml[512]; };   // sequences
+    };
     u32 llLog, ofLog, mlLog, hufLog;
     u32 haveLL, haveOF, haveML, haveHuf;
     u32 rep[3];
     u32 seqLL[64], seqML[64], seqOff[64];
     u32 zeroWord, dumpWord, pad_[2];                          // a cell of zeros / a sink for the idle lanes of the sequence loop
+#ifdef ZSTD_DEC_LDS_PAD                                      /* residency experiments: fewer blocks per CU */
+    u8 residencyPad[ZSTD_DEC_LDS_PAD];
+#endif
     u8 bswin[768] __attribute__((aligned(16)));             // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes + the 8-byte container)
     union {                                                  // never live at the same time
         u8 hwin[4][480] __attribute__((aligned(16)));       // decoding the literals: windows of the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
@@ -2110,7 +2121,7 @@ __device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tabl
 // inside its weight class from ballots, the class starts from an unrolled scan over the 12 weights (no indexed local array:
 // those live in scratch memory), the cells of short codes by whole-wave fills and those of long codes by their own lanes.
 // (noinline: inlined, the table builders held the whole decoder at 2 waves per SIMD)
-__device__ __attribute__((noinline)) u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big, int lane)
+__device__ __forceinline__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big, int lane)
 {
     u8* w = L->weights;
     if (!n) return 0xFFFFFFFFu;
@@ -2339,7 +2350,7 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
 
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705).  All lanes call it: lane 0 reads a transmitted description (the bit
 // positions of its values depend on the values before them), the table itself is built by the wave, one symbol per lane.
-__device__ __attribute__((noinline)) bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
+__device__ __forceinline__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
                           const s16* defNorm, u32 defMax, u32 defLog, DecLds* L, int lane)
 {
     u8* occ = L->bswin; u16* next = (u16*)(L->bswin + 512);
@@ -2397,8 +2408,20 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int 
 
 // one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
 __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
-                            u8* litBuf, int lane)
-{
+                            u8* litBuf, int lane, const bool keep)
+{   // keep: another block of the frame follows and may reuse this block's tables (DecLds)
+    typedef __attribute__((address_space(3))) u32x4 LV4;
+    auto park = [&](u32 at, const void* tab, u32 bytes) {                // LDS -> workspace
+        gbyte* g = (gbyte*)litBuf + at;
+        for (u32 i = (u32)lane; i < bytes / 16; i += kWave) *(__attribute__((address_space(1))) u32x4*)(g + 16 * i) = *(const LV4*)((const lbyte*)tab + 16 * i);
+        wave_fence();
+    };
+    auto fetch = [&](void* tab, u32 at, u32 bytes) {                     // workspace -> LDS
+        const gbyte* g = (const gbyte*)litBuf + at;
+        wave_fence();
+        for (u32 i = (u32)lane; i < bytes / 16; i += kWave) *(LV4*)((lbyte*)tab + 16 * i) = *(const __attribute__((address_space(1))) u32x4*)(g + 16 * i);
+        wave_fence();
+    };
 #ifdef ZSTD_PROF
     unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = __builtin_amdgcn_s_memtime();
     struct Flush { unsigned long long* a; int lane; __device__ ~Flush() { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_dprof[k], a[k]); } } flush_{dacc, lane};
@@ -2433,7 +2456,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 if (used == 0xFFFFFFFFu) return 0xFFFFFFFFu;
                 if (lane == 0) L->haveHuf = 1;
                 hoff += used; hsz -= used;
-            } else if (!uni(L->haveHuf)) return 0xFFFFFFFFu;
+            } else {
+                if (!uni(L->haveHuf)) return 0xFFFFFFFFu;
+                if (uni(L->hufLog) <= 11) fetch(L->huf, kDecHufPark, sizeof(L->huf));   // (the block that made it was not the frame's last)
+            }
             wave_fence();
             bool ok = true;
             const u16* big = (const u16*)(litBuf + kBlockMax + 64);
@@ -2461,6 +2487,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             }
             if (ballot(!ok) != 0) return 0xFFFFFFFFu;
             wave_fence();
+            if (keep && type == 2 && uni(L->hufLog) <= 11) park(kDecHufPark, L->huf, sizeof(L->huf));
             litPtr = litBuf; ip = lh + csize;
         }
     }
@@ -2478,6 +2505,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (ip >= n) return 0xFFFFFFFFu;
         const u32 modes = src[ip++];
         if (modes & 3) return 0xFFFFFFFFu;
+        if ((modes >> 6) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) {
+            if (!uni(L->haveLL | L->haveOF | L->haveML)) return 0xFFFFFFFFu;   // nothing to repeat
+            fetch(L->ll, kDecFsePark, 5120);                                    // the three tables as the frame's last block with sequences left them
+        }
         if (!seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return 0xFFFFFFFFu;
         if (!seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return 0xFFFFFFFFu;
         if (!seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return 0xFFFFFFFFu;
@@ -2674,6 +2705,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             DSTAGE(4);
         }
         if (pos > 0) return 0xFFFFFFFFu;                                         // bitstream not fully consumed
+        if (keep) park(kDecFsePark, L->ll, 5120);
     }
     const u32 rest = litSize - litPos;
     if ((u64)out + rest > cap || (u64)(out - opos) + rest > blockMax) return 0xFFFFFFFFu;
@@ -2742,7 +2774,7 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
                 ip += bsz; op += bsz;
             } else {
                 if (bsz > n - ip || bsz > kBlockMax) return -1;
-                const u32 r = decode_block(L, src + ip, bsz, dst + frameStart, op - frameStart, cap - frameStart, blockMax, litBuf, lane);
+                const u32 r = decode_block(L, src + ip, bsz, dst + frameStart, op - frameStart, cap - frameStart, blockMax, litBuf, lane, last == 0);
                 if (r == 0xFFFFFFFFu) return -1;
                 ip += bsz; op += r;
             }
@@ -2832,7 +2864,10 @@ __global__ void __launch_bounds__(64) zstd_df_entropy_kernel(aoclgpu_batch b, ui
     }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase, uint32_t* counter)
+#ifndef ZSTD_DEC_WAVES
+#define ZSTD_DEC_WAVES 5
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSTD_DEC_WAVES, ZSTD_DEC_WAVES))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase, uint32_t* counter)
 {
     __shared__ DecLds L;
     uint8_t* litBuf = litBase + (size_t)blockIdx.x * kDecWs;       // literals, then room for a 12-bit Huffman table
