@@ -882,7 +882,10 @@ __device__ __forceinline__ uint64_t ext64(uint64_t v0, uint64_t v1, uint64_t v2,
 // itself - or the 64 bytes in front of it, kept as history in front of the block - follow in sequence order as LDS-to-LDS
 // copies (130 cycles each instead of a trip to memory); the block then leaves with 16-byte stores.  Whatever the scan does
 // not take goes through the sequential one-sequence path, which implements every check of the reference.
-constexpr uint32_t kDecRecs = 64, kDecBlock = kGrpBlock, kDecHist = kGrpHist;
+#ifndef LZ4D_RECS
+#define LZ4D_RECS 96        // round 5: more records than lanes - a group runs with all 64 lanes busy (45 of 64 with a buffer of 64)
+#endif
+constexpr uint32_t kDecRecs = LZ4D_RECS, kDecBlock = kGrpBlock, kDecHist = kGrpHist;
 constexpr uint32_t kDecLds = kRing + 16 + kDecRecs * 4 + kGrpLds;
 
 template <bool RAP, bool HIST = false>
@@ -1017,11 +1020,13 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             if (forced) nrec = 0;
             else {                                            // records that did not fit the block move to the front
                 const uint32_t left = nrec - ng;
-                uint32_t r = 0;
-                if (L < left) r = *(const L32*)(recs + 4u * (ng + L));
-                wave_fence();
-                if (L < left) *(L32*)(recs + 4u * L) = r;
-                wave_fence();
+                for (uint32_t b0 = 0; b0 < left; b0 += kWave) {           // (front to back: a pass writes below what the next one reads)
+                    uint32_t r = 0;
+                    if (b0 + L < left) r = *(const L32*)(recs + 4u * (ng + b0 + L));
+                    wave_fence();
+                    if (b0 + L < left) *(L32*)(recs + 4u * (b0 + L)) = r;
+                    wave_fence();
+                }
                 gbase += lane_get(cinc, (int)ng - 1);
                 nrec = left;
                 if (why == 0) break;                          // the buffer has room again: scan on

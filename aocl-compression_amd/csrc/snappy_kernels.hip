@@ -635,7 +635,10 @@ __device__ int sn_decode_one(const gbyte* __restrict__ src, const uint32_t n, gb
 // a literal run or a copy - and up to 64 buffered elements are EXECUTED at once, one per lane, through a 2 KB output block
 // in LDS; everything else (literals with 2 - 4 length bytes, the end of the input, every rule that is broken) goes through
 // the one-element path, which implements all checks of DecompressAllTags / SnappyArrayWriter.
-constexpr uint32_t kSnRecs = 64;
+#ifndef SND_RECS
+#define SND_RECS 96         // round 5: more records than lanes - a group runs with all 64 lanes busy
+#endif
+constexpr uint32_t kSnRecs = SND_RECS;
 constexpr uint32_t kSnDecLds = kRing + 32 + kSnRecs * 8 + kGrpLds;
 
 __device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_, const uint32_t n_, gbyte* dst_, const uint32_t cap_,
@@ -756,11 +759,13 @@ __device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_
             if (forced) nrec = 0;
             else {                                            // records that did not fit the block move to the front
                 const uint32_t left = nrec - ng;
-                uint64_t r = 0;
-                if (L < left) r = *(const L64*)(recs + 8u * (ng + L));
-                wave_fence();
-                if (L < left) *(L64*)(recs + 8u * L) = r;
-                wave_fence();
+                for (uint32_t b0 = 0; b0 < left; b0 += kWave) {           // (front to back: a pass writes below what the next one reads)
+                    uint64_t r = 0;
+                    if (b0 + L < left) r = *(const L64*)(recs + 8u * (ng + b0 + L));
+                    wave_fence();
+                    if (b0 + L < left) *(L64*)(recs + 8u * (b0 + L)) = r;
+                    wave_fence();
+                }
                 gbase += lane_get(cinc, (int)ng - 1);
                 nrec = left;
                 if (why == 0) break;                          // the buffer has room again: scan on

@@ -58,6 +58,8 @@ def parse():
     p.add_argument("--cpu-reps", type=int, default=5)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-by-kind", action="store_true", help="skip codecs.lz4.by_kind (kernel rates per corpus kind, 1 GiB each)")
+    p.add_argument("--by-kind-all", action="store_true", help="by_kind for every codec of the run, not only lz4")
     p.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     p.add_argument("--exchange", default="c", choices=["c", "sendrecv", "allgather"],
                    help="N>1: the C library's exchange (aoclgpu_exchange_segments over its own RCCL communicator, default), "
@@ -391,6 +393,42 @@ def host_path(eng, gib=1.0):
     res["decompress_GiBps"] = round(n / (1 << 30) / best, 2); res["decompress_ms"] = round(best * 1e3, 1)
     res["round_trip"] = bool(np.array_equal(back, src))
     return res
+
+
+def by_kind(eng, name, gib=1.0, base_mib=32):
+    """Kernel rates of one codec per corpus kind (the Silesia-shaped mix is 43 % text, 26 % binary, 12 % JSON/log, 8 % database,
+    9 % 16-bit image, 2 % random): 1 GiB of each kind alone, HBM-resident, compress and decompress launches timed with HIP events
+    (best of 2).  A regression on one kind is visible here before it moves the mix.  Outside the timed region, rank 0, N = 1."""
+    import torch
+    import aocl_compression_amd as a
+    codec, chunk = CODECS[name]
+    out = {}
+    total = int(gib * GIB) // chunk * chunk
+    n = total // chunk
+    slot = (a.compress_bound(codec, chunk) + 15) & ~15
+    slots = torch.empty(n * slot, dtype=torch.uint8, device=eng.device)
+    clen = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    dst = torch.empty(total, dtype=torch.uint8, device=eng.device)
+    dlen = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    for kind in a.corpus.KINDS:
+        base = torch.from_numpy(a.corpus.make(kind, int(base_mib) << 20, seed=7)).to(eng.device)
+        src = base.repeat(-(-total // base.numel()))[:total].contiguous()
+        cb = eng.uniform_compress_batch(src, chunk, slots, clen, slot)
+        if ZSTD_LEVEL.get(name, 1) != 1:
+            cb.reserved |= a.api.zstd_level(ZSTD_LEVEL[name])
+        db = eng.uniform_decompress_batch(slots, clen, slot, dst, chunk, dlen)
+        eng.time_batch(codec, 0, cb, 1)
+        tc = min(eng.time_batch(codec, 0, cb, 1) for _ in range(2))
+        eng.time_batch(codec, 1, db, 1)
+        td = min(eng.time_batch(codec, 1, db, 1) for _ in range(2))
+        ok = bool(torch.equal(dst, src))
+        out[kind] = {"ratio": round(total / max(int(clen.sum().item()), 1), 3), "compress_GiBps": round(total / GIB / (tc * 1e-3), 1),
+                     "decompress_GiBps": round(total / GIB / (td * 1e-3), 1), "round_trip": ok}
+        del src, base
+    out["note"] = f"{gib:g} GiB per kind ({base_mib} MiB base, tiled), {chunk // 1024} KiB chunks, kernel launches only (HIP events, best of 2)"
+    del slots, dst
+    torch.cuda.empty_cache()
+    return out
 
 
 def config1_latency(eng, reps=20):
@@ -904,6 +942,11 @@ def main():
         results[name] = res
         del run
         torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not args.no_by_kind and (name == "lz4" or args.by_kind_all):
+            try:
+                res["by_kind"] = by_kind(eng, name)
+            except Exception as e:
+                res["by_kind"] = {"error": repr(e)}
 
     if rank == 0:
         head = results[names[0]]

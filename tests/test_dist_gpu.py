@@ -55,7 +55,7 @@ def test_bench_starts_its_own_ranks():
 
 def test_n1_line_has_no_exchange_keys():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--gib", "0.0625",
-                        "--base-mib", "24", "--codec", "lz4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--base-mib", "24", "--codec", "lz4", "--no-cpu-baseline", "--no-by-kind"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and "exchange_ms" not in out and "launched_by" not in out

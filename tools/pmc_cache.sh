@@ -19,7 +19,7 @@ for c in $codecs; do
              "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_WRITE_sum" \
              "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_$c/$i -o p -- python3 $R/bench.py --codec $c --gib 2 --steps 1 --warmup 0 --no-cpu-baseline --base-mib 64 > $out/pmc_$c/$i.log 2>&1
+    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_$c/$i -o p -- python3 $R/bench.py --codec $c --gib 2 --steps 1 --warmup 0 --no-cpu-baseline --no-by-kind --base-mib 64 > $out/pmc_$c/$i.log 2>&1
   done
   python3 $R/tools/pmc_summary.py $out/pmc_$c ${c}_ > $out/cache_$c.txt 2>&1
   rm -rf $out/pmc_$c

@@ -15,9 +15,9 @@ for c in $codecs; do
 done
 cd /tmp && export TMPDIR=/tmp
 for c in $codecs; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$c -o $c -- python3 $R/bench.py --codec $c --no-cpu-baseline > $out/trace_bench_$c.json 2> $out/trace_$c.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$c -o $c -- python3 $R/bench.py --codec $c --no-cpu-baseline --no-by-kind > $out/trace_bench_$c.json 2> $out/trace_$c.err
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${c}_$ctr -o p -- python3 $R/bench.py --codec $c --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_${c}_$ctr.json 2> $out/pmc_${c}_$ctr.err
+    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${c}_$ctr -o p -- python3 $R/bench.py --codec $c --no-cpu-baseline --no-by-kind --steps 1 --warmup 0 > $out/pmc_${c}_$ctr.json 2> $out/pmc_${c}_$ctr.err
   done
 done
 # FETCH_SIZE calibration for scattered 8-byte loads (bench.py `fetch_calibration`)
