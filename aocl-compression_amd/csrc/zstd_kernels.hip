@@ -1982,7 +1982,7 @@ __device__ __forceinline__ u32x4 stream16(const gbyte* p, u32 n, int off)
 
 struct FseD { u16 newState; u8 symbol; u8 nbBits; };
 
-struct DecLds {                     // 8.4 KB = 7 LDS granules of 1280 bytes (round 5; 12.4 KB = 10 granules before): the serial entropy
+struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (round 5; 12.4 KB = 10 granules before): the serial entropy
                                     // loops are latency chains and throughput follows residency - 6 / 9 / 12 blocks per CU decode the
                                     // 8 GiB bench in 108.7 / 78.5 / 63.7 ms - so the Huffman table and the three FSE tables, which are
                                     // never read in the same phase of a block, share their LDS.  What a LATER block of the frame may
@@ -1997,23 +1997,30 @@ struct DecLds {                     // 8.4 KB = 7 LDS granules of 1280 bytes (ro
     u32 llLog, ofLog, mlLog, hufLog;
     u32 haveLL, haveOF, haveML, haveHuf;
     u32 rep[3];
-    u32 seqLL[64], seqML[64], seqOff[64];
     u32 zeroWord, dumpWord, pad_[2];                          // a cell of zeros / a sink for the idle lanes of the sequence loop
 #ifdef ZSTD_DEC_LDS_PAD                                      /* residency experiments: fewer blocks per CU */
     u8 residencyPad[ZSTD_DEC_LDS_PAD];
 #endif
-    u8 bswin[768] __attribute__((aligned(16)));             // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes + the 8-byte container)
-    union {                                                  // never live at the same time
-        u8 hwin[4][480] __attribute__((aligned(16)));       // decoding the literals: windows of the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
+    // 2304 bytes that three phases of a block use one after the other (7488 bytes in all = 6 granules: 20 blocks per CU, the
+    // register bound):
+    union {
+        u8 hwin[4][480] __attribute__((aligned(16)));       // literals by one lane per stream (12-bit tables, single streams): windows of
+                                                             // the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
         struct {                                             // reading a table description (Huffman weights before the streams, FSE tables after them)
             s16 norm[256];
             u16 next[256];
             u8 weights[256];
             FseD wdt[64];
-            u32 llTab[36], mlTab[53];                        // decoding the sequences: base | additional bits << 24 per length code
-        };                                                   // (filled after the literals of the block are decoded)
+            u8 scratch[768];                                 // staged description / occupancy + next-state scratch of the table builders
+        };
+        struct {                                             // decoding and executing the sequences (filled after the tables are built)
+            u8 bswin[768];                                   // window of the sequence bitstream (one tile of 64 sequences needs <= 712 bytes + the 8-byte container)
+            u32 seqLL[64], seqML[64], seqOff[64];
+            u32 llTab[36], mlTab[53];                        // base | additional bits << 24 per length code
+        };
     };
 };
+static_assert(sizeof(DecLds) <= 7680 || sizeof(DecLds) > 20000, "six LDS granules per block");
 
 // FSE_readNCount (entropy_common.c:40-186), lane-serial; bytes consumed or 0xFFFFFFFF
 __device__ u32 fse_read_ncount(s16* norm, u32* maxSym, u32* tableLog, const u8* src, u32 n, u32 maxLog)
@@ -2135,7 +2142,7 @@ __device__ __forceinline__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u
         const u32 isz = h0;
         used = 1 + isz;
         if (used > n || isz < 2) return 0xFFFFFFFFu;
-        u8* stg = L->bswin;                                                  // (the sequence bitstream's window: not in use yet)
+        u8* stg = L->scratch;
         for (u32 b = (u32)lane; b < isz; b += kWave) stg[b] = src[1 + b];
         wave_fence();
         u32 res = 0;
@@ -2353,7 +2360,7 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
 __device__ __forceinline__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
                           const s16* defNorm, u32 defMax, u32 defLog, DecLds* L, int lane)
 {
-    u8* occ = L->bswin; u16* next = (u16*)(L->bswin + 512);
+    u8* occ = L->scratch; u16* next = (u16*)(L->scratch + 512);
     if (mode == 0) {
         const int norm = (u32)lane <= defMax ? (int)defNorm[lane] : 0;
         fse_build_dtable_wave(dt, norm, defMax, defLog, occ, next, lane);
@@ -2865,7 +2872,7 @@ __global__ void __launch_bounds__(64) zstd_df_entropy_kernel(aoclgpu_batch b, ui
 }
 
 #ifndef ZSTD_DEC_WAVES
-#define ZSTD_DEC_WAVES 5
+#define ZSTD_DEC_WAVES 6
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZSTD_DEC_WAVES, ZSTD_DEC_WAVES))) zstd_decompress_kernel(aoclgpu_batch b, uint8_t* litBase, uint32_t* counter)
 {
