@@ -2127,7 +2127,10 @@ __device__ bool fse_build_dtable(FseD* dt, const s16* norm, u32 maxSym, u32 tabl
 // after the weights is the wave's: four symbols per lane (symbol = 64 k + lane), the weight histogram and each symbol's rank
 // inside its weight class from ballots, the class starts from an unrolled scan over the 12 weights (no indexed local array:
 // those live in scratch memory), the cells of short codes by whole-wave fills and those of long codes by their own lanes.
-// (noinline: inlined, the table builders held the whole decoder at 2 waves per SIMD)
+// (Inlined since round 5.  Round 2 had made this and seq_table calls because, inlined, they held the decoder at 2 waves per SIMD;
+//  but values that live across a call sit in callee-saved VGPRs, which are numbered sparsely up to v143, and the kernel then
+//  counts 147 VGPRs whatever amdgpu_waves_per_eu asks for.  Inlined, the budget of 6 waves per SIMD is met with 85 VGPRs and
+//  69 dwords of scratch, and the decoder's residency is what its LDS allows: DESIGN.md section 4.)
 __device__ __forceinline__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u16* big, int lane)
 {
     u8* w = L->weights;

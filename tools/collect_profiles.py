@@ -17,7 +17,7 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
     dom = bench["roofline"]["kernel"]
     name = f"{RND}_{c}_{ver}_kernel_trace_and_pmc.txt"
     with open(os.path.join(P, name), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --codec {c} --no-cpu-baseline  ({RND}, {ver} kernels, 1x MI355X, 8 GiB)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats of: python3 bench.py --codec {c} --no-cpu-baseline --no-by-kind  ({RND}, {ver} kernels, 1x MI355X, 8 GiB)\n")
         rows = list(csv.reader(open(os.path.join(O, f"trace_{c}", f"{c}_kernel_stats.csv"))))
         f.write(",".join(f'"{x}"' for x in rows[0]) + "\n")
         for r in rows[1:]:
@@ -25,7 +25,7 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
                 f.write(",".join(f'"{x}"' if i == 0 else x for i, x in enumerate(r)) + "\n")
         f.write("# (kernels of the bench harness itself - torch copies, compares, reductions - left out)\n\n# bench.py line of the same (profiled) run\n")
         f.write([l for l in open(os.path.join(O, f"trace_bench_{c}.json")) if l.startswith("{")][-1])
-        f.write(f"\n# separate --pmc passes (one counter per pass, kernel-trace only), python3 bench.py --codec {c} --no-cpu-baseline --steps 1 --warmup 0; raw counter values (KB) per launch\n")
+        f.write(f"\n# separate --pmc passes (one counter per pass, kernel-trace only), python3 bench.py --codec {c} --no-cpu-baseline --no-by-kind --steps 1 --warmup 0; raw counter values (KB) per launch\n")
         kb = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, f"pmc_{c}_{ctr}"), c + "_"], capture_output=True, text=True).stdout
