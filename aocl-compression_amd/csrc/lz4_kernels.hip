@@ -1189,7 +1189,7 @@ __global__ void __launch_bounds__(64) lz4_compress_stream_kernel(const uint8_t* 
 }
 
 #ifndef LZ4D_WAVES
-#define LZ4D_WAVES 7
+#define LZ4D_WAVES 6
 #endif
 template <bool RAP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZ4D_WAVES, LZ4D_WAVES))) lz4_decompress_kernel(aoclgpu_batch b)
