@@ -178,15 +178,71 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
     // they only spare the 64 speculative lanes a cache-line fetch each for candidates that cannot match.
     // posBits = bits needed for a position of this chunk; an empty slot aliases position 0 exactly as in the
     // reference's zero-filled table (lz4.c:2519), so the table is filled with entry(0).
-    const uint32_t posBits = LINKED ? 32u : (MODE == 0 ? 16u : (MODE == 1 ? 18u : (32u - (uint32_t)__builtin_clz(n - 1))));
+    // MODE 1 (round 5): 17 position bits + ONE CHECK BIT in the 18 bits of an entry.  A chunk of up to 256 KiB needs 18 bits for a
+    // position, but a candidate further than 65535 bytes back is rejected anyway (lz4.c:1556-1564): an entry is kept modulo 2^17
+    // and stands for the latest position with that residue - exact as long as no entry is older than 2^17 when it is read, which
+    // the age sweeps below see to (a chunk of at most 128 KiB never needs one).  The freed bit holds a hash bit of the 4 bytes at
+    // the entry's position: half of the candidates that cannot match are not fetched at all (-45 % FETCH_SIZE, -6 % time on 128
+    // KiB chunks where the bit was free to try: profiles/r05_kbench_steps.txt).  -DLZ4_NO_CHK1 restores the plain 18-bit entries.
+#ifdef LZ4_NO_CHK1
+    constexpr bool kChk1 = false;
+#else
+    constexpr bool kChk1 = MODE == 1;
+#endif
+    const uint32_t posBits = LINKED ? 32u : (MODE == 0 ? 16u : (MODE == 1 ? (kChk1 ? 17u : 18u) : (32u - (uint32_t)__builtin_clz(n - 1))));
     const uint32_t posMask = (posBits >= 32) ? 0xFFFFFFFFu : ((1u << posBits) - 1);
-    auto chk = [&](uint32_t v4) -> uint32_t { return (MODE != 2 || LINKED) ? 0u : (((v4 * 2654435761u) >> posBits) << posBits); };
+    auto chk = [&](uint32_t v4) -> uint32_t { return kChk1 ? (((v4 * 2654435761u) >> 31) << 17) : ((MODE != 2 || LINKED) ? 0u : (((v4 * 2654435761u) >> posBits) << posBits)); };
     // table entry <-> position: a chunk's entry is its position (| check bits), a stream's the position's stream index
-    auto entry_of = [&](uint32_t p, uint32_t c) -> uint32_t { return LINKED ? p + idxBase : (p | c); };
-    auto cand_of = [&](uint32_t e) -> uint32_t { return LINKED ? e - idxBase : (e & posMask); };
+    auto entry_of = [&](uint32_t p, uint32_t c) -> uint32_t { return LINKED ? p + idxBase : ((kChk1 ? (p & 0x1FFFFu) : p) | c); };
+    // kChk1: the candidate of a probe at p is the latest position below p with the entry's residue (distance 1 .. 2^17)
+    auto cand_of = [&](uint32_t e, uint32_t p) -> uint32_t {
+        if (kChk1) { const uint32_t d = (p - e) & 0x1FFFFu; return p - (d ? d : 0x20000u); }
+        return LINKED ? e - idxBase : (e & posMask);
+    };
     auto usable = [&](uint32_t e, uint32_t c, uint32_t p, uint32_t mychk) -> bool {   // can this entry still pass the 4-byte test at p
         if (LINKED) return e >= lowIdx && c + kDistMax >= p;
+        if (kChk1) return ((e ^ mychk) & 0x20000u) == 0 && p - c <= kDistMax;          // (p - c = 1 .. 2^17)
         return (MODE != 2 || ((e ^ mychk) & ~posMask) == 0) && (U16 || c + kDistMax >= p);
+    };
+    // Age sweeps (kChk1, chunks above 128 KiB).  age_sweep(ref): every entry more than 65535 bytes behind `ref` - dead for every
+    // probe at or behind ref - is replaced by one exactly 65536 behind it.  The main loop sweeps at its lowest read position
+    // whenever that has moved 32 KiB since the last sweep, so an entry is at most 65536 + 32 KiB + a batch's reach (< 8 KB) old
+    // when it is read and at most 65536 + 40 KiB when the next sweep looks at it: never 2^17, where it would look young again.
+    // Entries written by the lanes of the previous batch may lie a few bytes AHEAD of ref: their distance comes out just below
+    // 2^17 (or 0) and is taken for what it is.  The one step that moves far in one go - a long match of the one-at-a-time path -
+    // sweeps at its own position for what will be dead at its END (jump), or wipes the table when the match alone is longer than
+    // any candidate may be away (kill_all).  A lane takes the 16 slots of one word of extra bits; ~8 sweeps per 256 KiB chunk,
+    // 0.2 % of its time.  (Found by the campaign, seed 19130: a match of 63 470 bytes whose successor matches 65 535 bytes back.)
+    uint32_t sweep_ref = b0;
+    constexpr uint32_t kSweepEvery = 32768u, kSweepAhead = 256u, kJumpMax = 60000u;
+    auto age_sweep = [&](uint32_t ref, uint32_t jump) {                // every entry is at most 2^17 - kSweepAhead behind ref, none more than kSweepAhead ahead of it
+        typedef __attribute__((address_space(3))) u32x4 LQ;              // afterwards: nothing is more than 65536 behind ref + jump
+        const uint32_t mk = (ref + jump - 65536u) & 0x1FFFFu;
+        for (uint32_t w = (uint32_t)lane; w < 256; w += kWave) {
+            uint32_t hb = hib[w];
+            u32x4 t0 = *(LQ*)(lds + 32u * w), t1 = *(LQ*)(lds + 32u * w + 16);
+            uint32_t tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t low = (tv[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, c17 = low | (((hb >> (2 * k)) & 1u) << 16);
+                const uint32_t d = (ref - c17) & 0x1FFFFu;
+                const int32_t age = d >= 0x20000u - kSweepAhead ? (int32_t)d - 0x20000 : (int32_t)d;   // (negative: written by the batch before, ahead of ref)
+                if (age + (int32_t)jump > (int32_t)kDistMax) {
+                    tv[k >> 1] = (k & 1) ? ((tv[k >> 1] & 0xFFFFu) | (mk << 16)) : ((tv[k >> 1] & 0xFFFF0000u) | (mk & 0xFFFFu));
+                    hb = (hb & ~(3u << (2 * k))) | ((mk >> 16) << (2 * k));
+                }
+            }
+            *(LQ*)(lds + 32u * w) = u32x4{tv[0], tv[1], tv[2], tv[3]};
+            *(LQ*)(lds + 32u * w + 16) = u32x4{tv[4], tv[5], tv[6], tv[7]};
+            hib[w] = hb;
+        }
+        wave_fence();
+    };
+    auto kill_all = [&](uint32_t ref) {                                // every entry is more than 65535 bytes behind ref
+        const uint32_t mk = (ref - 65536u) & 0x1FFFFu, lo2 = (mk & 0xFFFFu) * 0x10001u, hb = (mk >> 16) ? 0x55555555u : 0u;
+        for (uint32_t i = (uint32_t)lane; i < 8192 / 16; i += kWave) ((__attribute__((address_space(3))) u32x4*)lds)[i] = u32x4{lo2, lo2, lo2, lo2};
+        for (uint32_t i = (uint32_t)lane; i < 256; i += kWave) hib[i] = hb;
+        wave_fence();
     };
     auto low_of = [&](uint32_t c) -> uint32_t { return LINKED ? ((ext && c >= b0) ? b0 : lowPos) : 0u; };   // where a catch-up from c stops
     if (!LINKED) {
@@ -194,6 +250,10 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
         const uint32_t bytes = MODE == 1 ? 8192u + 1024u : kTableBytes;
         for (uint32_t i = (uint32_t)lane; i < bytes / 16; i += kWave)
             ((__attribute__((address_space(3))) u32x4*)lds)[i] = u32x4{fill, fill, fill, fill};
+        if (kChk1 && n >= 4 && chk(ld32(src))) {                      // the empty slots alias position 0: their check bit is position 0's
+            wave_fence();
+            for (uint32_t i = (uint32_t)lane; i < 256; i += kWave) hib[i] = 0xAAAAAAAAu;
+        }
     }
     wave_fence();
 
@@ -324,6 +384,12 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
             asm volatile("; batch begin" ::: "memory");
             const uint32_t ex = extra ? 1u : 0u;
             const uint32_t s0 = uni(ip + i0);             // position of lane 0 while the schedule's steps are 1 byte
+            if (kChk1 && n > 0x20000u && (i0 > 66u || ip + 80u - sweep_ref >= kSweepEvery)) {   // (i0 <= 66: the lowest read is at most ip + 66)
+                // the batch reads the table at the positions of probes i0 - 1 .. i0 + 63 of the search that began at ip; every later
+                // batch reads at or behind this one's lowest position
+                const uint32_t lo = ip + sched(i0 > 1 ? i0 - 2 : 0, accel) - 2;
+                if (lo - sweep_ref >= kSweepEvery) { age_sweep(lo, 0); sweep_ref = lo; }
+            }
             bool done = false;
             int special = -1;                             // lane whose sequence takes the one-at-a-time path below
             uint32_t pos, cand, fw, bk4; bool mf;         // per lane, read by that path
@@ -364,7 +430,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t my4 = a.y;
                 const uint32_t h = lz4_hash2<U16>(a.y, a.z);
                 const uint32_t ent = tget(h);
-                cand = cand_of(ent);
+                cand = cand_of(ent, pos);
                 const uint32_t mychk = chk(my4);
                 // only lanes that can still pass the test fetch their candidate window
                 const bool plausible = usable(ent, cand, pos, mychk);
@@ -580,7 +646,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint32_t h = lz4_hash2<U16>(my4, (uint32_t)pw.hi);
                 uint32_t ent = 0;
                 if (valid) ent = tget(h);
-                cand = cand_of(ent);
+                cand = cand_of(ent, pos);
                 const uint32_t mychk = chk(my4);
                 const bool plausible = valid && usable(ent, cand, pos, mychk);
                 Win cw = {~pw.lo, 0};
@@ -690,6 +756,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 if (PROF) { cnt[1]++; cnt[4]++; }
                 ip = mstart + kMinMatch + mcode;
                 anchor = ip;
+                if (kChk1 && n > 0x20000u && ip - sweep_ref > kJumpMax) {          // a long step: see age_sweep
+                    if (ip - m_pos > kDistMax + kSweepAhead) kill_all(ip);          // (every entry is at most a few bytes behind m_pos)
+                    else age_sweep(m_pos, ip - m_pos);                              // what is dead at ip goes now, while ages are unambiguous
+                    sweep_ref = ip;
+                }
                 if (ip >= mfl1) done = true;              // lz4.c:1747
                 else { extra = true; i0 = 0; }
                 STAGE(6);
@@ -1073,7 +1144,7 @@ __global__ void __launch_bounds__(64) lz4_compress_kernel(aoclgpu_batch b, uint3
     }
     else if (MODE == 3) {
         if (n < k64KLimit) r = lz4_compress_wave<0, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
-        else if (n <= (1u << 18)) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
+        else if (n <= (1u << 18) && !((b.reserved >> 15) != 0 && n > (1u << 17))) r = lz4_compress_wave<1, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);   // (accelerations: see mode_for)
         else r = lz4_compress_wave<2, false>(v.src, n, v.dst, v.dst_cap, (lbyte*)lds, b.reserved, &lastrun);
     }
     else if ((MODE == 0) != (n < k64KLimit) || (MODE == 1 && n > (1u << 18))) r = 0;   // launcher picked the wrong mode
@@ -1258,7 +1329,10 @@ extern "C" int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream)
     const bool prof = false; (void)prof;
 #endif
     const bool forceU32 = (b->reserved & AOCLGPU_FLAG_LZ4_TABLE_U32) != 0;
-    auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !forceU32) ? 1 : 2); };
+    // (the packed table's 17-bit entries are swept for batches that span a few KB - acceleration 1; with LZ4_compress_fast's larger
+    //  steps a batch of a chunk above 128 KiB may reach further than the sweeps allow: those take the u32 table)
+    const bool accelerated = (b->reserved >> 15) != 0;
+    auto mode_for = [&](uint64_t n) -> int { return n < 65547 ? 0 : ((n <= (1u << 18) && !forceU32 && !(accelerated && n > (1u << 17))) ? 1 : 2); };
     struct Launch { uint32_t first, count; int mode; } L[2]; int nl = 0;
     if (b->src_off) L[nl++] = { 0, b->nchunks, 3 };
     else {

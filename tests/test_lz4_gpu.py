@@ -242,3 +242,77 @@ def test_acceleration_bit_exact(eng, oracle, acc):
     g = C.create_string_buffer(cap); w = C.create_string_buffer(cap)
     assert lib.LZ4_compress_fast(part, g, len(part), cap, acc) == oracle.L.orc_lz4_compress_fast(part, len(part), w, cap, acc)
     assert g.raw == w.raw
+
+
+def _aliasing_inputs():
+    """Inputs for the packed table's 17-bit entries (round 5): a position and the one 2^17 bytes behind it share an entry value,
+    candidates further than 65535 bytes back must be rejected as the reference rejects them, and the age sweeps must have
+    neutralised every entry before it turns 2^17 old - also across matches that jump over tens of KiB at once."""
+    rng = np.random.default_rng(505)
+    n = 262144
+    out = {}
+    # the same 2 KiB of text at distances of exactly / around 2^16 and 2^17
+    for name, gaps in (("repeat_64k", (65535, 65536, 65537)), ("repeat_128k", (131071, 131072, 131073)), ("repeat_both", (65536, 65536, 65536))):
+        buf = rng.integers(0, 256, n, dtype=np.uint8)
+        blk = a.corpus.make("text", 2048, seed=3)
+        pos = 1000
+        buf[pos:pos + 2048] = blk
+        for g in gaps:
+            pos += g
+            if pos + 2048 <= n:
+                buf[pos:pos + 2048] = blk
+        out[name] = buf
+    # compressible data in front of and behind a run the match finder crosses in ONE step (100 KiB of zeros, then the same text again)
+    t = a.corpus.make("text", n, seed=5)
+    z = t.copy(); z[60000:60000 + 102400] = 0; z[60000 + 102400:] = t[:n - 60000 - 102400]
+    out["jump_100k"] = z
+    z2 = t.copy(); z2[1000:1000 + 200000] = 7
+    out["jump_200k"] = z2
+    # incompressible: long searches, batches of the schedule that span KiB
+    out["random"] = rng.integers(0, 256, n, dtype=np.uint8)
+    # records that repeat with a period just below / above the distance limit
+    for per in (65530, 65540, 131060, 131080):
+        rec = a.corpus.make("binary", per, seed=per)
+        out[f"period_{per}"] = np.tile(rec, n // per + 1)[:n].copy()
+    # a sparse page: few table writes per byte, slots outlive 2^16 positions
+    sp = np.zeros(n, np.uint8); idx = rng.integers(0, n - 8, 3000); 
+    for i in idx: sp[i:i + 8] = rng.integers(1, 256, 8, dtype=np.uint8)
+    out["sparse"] = sp
+    return out
+
+
+@pytest.mark.parametrize("size", [131072, 131073, 196608, 200001, 262144])
+def test_packed_table_aliasing_and_sweeps(eng, oracle, size):
+    for name, buf in _aliasing_inputs().items():
+        raw = buf[:size].tobytes()
+        got = eng.compress_host(a.LZ4, raw)
+        want = oracle.compress(ol.LZ4, raw)
+        assert got == want, (name, size, len(got), len(want))
+        assert eng.decompress_host(a.LZ4, got, len(raw)) == raw
+
+
+def test_packed_table_batch_of_aliasing_chunks(eng, oracle):
+    """the same inputs as chunks of one batch (256 KiB and a ragged tail), so that chunks in every sweep state run side by side"""
+    bufs = list(_aliasing_inputs().values())
+    data = np.concatenate(bufs + [bufs[0][:77777]])
+    _compress_and_check(eng, oracle, data, 262144)
+
+
+@pytest.mark.parametrize("jump", [59990, 60001, 63470, 65279, 65535, 65536, 65537, 65600, 65791, 65792, 65800, 70000, 131072])
+def test_packed_table_long_jumps(eng, oracle, jump):
+    """One match that jumps `jump` bytes (a period of 1993), followed at once by data that repeats what lies 65535 / 65534 / 40000
+    bytes behind the jump's end - candidates written BEFORE the jump that are still (or just no longer) in range behind it: the
+    age sweep of the one-at-a-time path must keep exactly those (fuzz campaign seed 19130, round 5)."""
+    n = 262144
+    for back in (65535, 65534, 40000):
+        buf = a.corpus.make("text", n, seed=jump ^ back).copy()
+        s0 = 74055
+        e = min(s0 + jump, n - 6000)
+        for i in range(s0, e):
+            buf[i] = buf[i - 1993]
+        if e - back >= 0:
+            buf[e:e + 4537] = buf[e - back:e - back + 4537]
+        raw = buf.tobytes()
+        got = eng.compress_host(a.LZ4, raw)
+        want = oracle.compress(ol.LZ4, raw)
+        assert got == want, (jump, back, len(got), len(want))
