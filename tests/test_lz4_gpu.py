@@ -316,3 +316,43 @@ def test_packed_table_long_jumps(eng, oracle, jump):
         got = eng.compress_host(a.LZ4, raw)
         want = oracle.compress(ol.LZ4, raw)
         assert got == want, (jump, back, len(got), len(want))
+
+
+@pytest.mark.parametrize("acc", [1, 5])
+def test_packed_table_explicit_batch_and_accelerations(eng, oracle, acc):
+    """the aliasing inputs through the per-chunk dispatching kernel (explicit batch), plain and with an acceleration - accelerated
+    chunks above 128 KiB must take the u32 table (the packed table's sweeps are timed for acceleration 1)"""
+    import ctypes as C
+    ins = _aliasing_inputs()
+    parts = [ins["jump_100k"].tobytes(), ins["period_131080"][:200001].tobytes(), ins["random"].tobytes(), ins["repeat_128k"].tobytes(),
+             ins["sparse"][:140000].tobytes(), ins["jump_200k"].tobytes()]
+    lens = [len(p) for p in parts]
+    raw = b"".join(parts)
+    offs = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    caps = [a.compress_bound(a.LZ4, n) for n in lens]
+    doffs = np.cumsum([0] + caps[:-1]).astype(np.uint64)
+    t = torch; dev = eng.device
+    src = t.frombuffer(bytearray(raw), dtype=t.uint8).to(dev)
+    dst = t.zeros(int(sum(caps)), dtype=t.uint8, device=dev)
+    out_len = t.zeros(len(lens), dtype=t.int32, device=dev)
+    d_so = t.from_numpy(offs.view(np.int64)).to(dev); d_sl = t.tensor(lens, dtype=t.int32, device=dev)
+    d_do = t.from_numpy(doffs.view(np.int64)).to(dev); d_dc = t.tensor(caps, dtype=t.int32, device=dev)
+    b = a.Batch(src=src.data_ptr(), dst=dst.data_ptr(), src_off=d_so.data_ptr(), src_len=d_sl.data_ptr(),
+                dst_off=d_do.data_ptr(), dst_cap=d_dc.data_ptr(), out_len=out_len.data_ptr(), nchunks=len(lens))
+    b.reserved = a.api.lz4_acceleration(acc)
+    assert eng.lib.aoclgpu_lz4_compress_chunks(C.byref(b), None) == 0
+    t.cuda.synchronize()
+    got_len = out_len.cpu().tolist(); host = dst.cpu().numpy()
+    L = oracle.L
+    L.orc_lz4_compress_fast.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    for i, p in enumerate(parts):
+        w = C.create_string_buffer(caps[i])
+        r = L.orc_lz4_compress_fast(p, len(p), w, caps[i], acc)
+        assert host[int(doffs[i]):int(doffs[i]) + got_len[i]].tobytes() == w.raw[:r], (acc, i)
+    # the same chunks as a uniform batch with the acceleration (mode_for picks the table per launch)
+    for p in (parts[0], parts[2]):
+        s = t.frombuffer(bytearray(p), dtype=t.uint8).to(dev)
+        slots, ol_, slot = eng.compress_chunks(a.LZ4, s, 262144, flags=a.api.lz4_acceleration(acc))
+        w = C.create_string_buffer(a.compress_bound(a.LZ4, len(p)))
+        r = L.orc_lz4_compress_fast(p, len(p), w, len(w), acc)
+        assert slots[:int(ol_[0])].cpu().numpy().tobytes() == w.raw[:r], acc
