@@ -547,7 +547,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
 #endif
         bool cbv = false;
         u32 b_pos0 = 0, b_h = 0, b_ent = 0, b_info = 0, b_eqb = 0, b_off = 0, b_pb0 = 0, b_flags = 0;   // flags: 1 match below lim, 2 hard
-        int b_lim = 0;
+        int b_lim = 0; u64 b_later = 0;                                 // b_later: later lanes of the batch on this lane's slot
         for (;;) {                                                      // _start
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
             u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
@@ -622,9 +622,30 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
 #endif
                 asm volatile("; masks begin");
 #if defined(AOCLGPU_EXPERIMENTS) && defined(ZSTD_EXP_NOCUT)   /* timing only: what the cut at the first in-batch slot reuse costs (wrong parse) */
-                    const int lim = 64; (void)w;
+                    const int lim = 64; (void)w; const u64 later = 0;
+#elif defined(ZSTD_CUT_ANY_DUP)                               /* round 4: the batch ends at ANY slot reuse */
+                    const int lim = first_lane(ballot(w != (u32)lane)); const u64 later = 0;
 #else
-                    const int lim = first_lane(ballot(w != (u32)lane));
+                    // Round 5: a lane whose slot an earlier lane of the batch names has a candidate that depends on the parse (that
+                    // lane's position if its table write happens, else the table's entry) - but it is still decided when NEITHER can
+                    // match: its own table candidate fails the 4-byte test and no earlier lane on its slot holds the same 4 bytes.  It
+                    // stays in the batch as a probe that finds nothing; the batch is cut at the first duplicate that could match (the
+                    // rule LZ4 and Snappy got in round 2).  `later`: the later lanes that name this lane's slot - when the batch commits,
+                    // a slot goes to the last of its lanes that writes.
+                    int lim = 64; u64 later = 0;
+                    {
+                        u64 dm = ballot(w != (u32)lane);
+                        if (dm) {
+                            const u32 c4 = near0 ? ca.x : ca.y;                       // the 4 bytes at the candidate
+                            const u64 okb = ballot(has && c4 == pa.y);
+                            for (; dm; dm &= dm - 1) {
+                                const int k = (int)__builtin_ctzll(dm);
+                                const u64 same = ballot(h == lane_get(h, k)) & ((1ull << k) - 1);
+                                if (((okb >> k) & 1) || (ballot(pa.y == lane_get(pa.y, k)) & same) != 0) { lim = k; break; }
+                                if ((same >> lane) & 1) later |= 1ull << k;
+                            }
+                        }
+                    }
 #endif
                     using zchain::zero_bytes8;
                     const u32 eqb = zero_bytes8(pa.x ^ ca.x, pa.y ^ ca.y) | (zero_bytes8(pa.z ^ ca.z, pa.w ^ ca.w) << 8) |
@@ -636,6 +657,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     // prefix start, a run that leaves the 28-byte window, table writes that would fall behind lane 63
                     const bool hardl = near0 || fw >= 24 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62);
                     b_pos0 = pos0; b_lim = lim; b_h = h; b_ent = ent; b_eqb = eqb; b_off = offv; b_pb0 = pa.y & 0xFFu;   // (the byte at pos)
+                    b_later = later;
                     b_info = near0 ? zchain::pack_info(FRAME ? 0u : offv, 0, 0)                          // (frames: the offset travels apart)
                                    : zchain::pack_info(FRAME ? 0u : offv, fw, zchain::back_code(bk4, c - prefixPos));
                     b_flags = ((lane < lim && ok) ? 1u : 0u) | (hardl ? 2u : 0u);
@@ -684,7 +706,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 }
                 asm volatile("; commit begin");
                 ZSTAGE(7);
-                if ((wo.commit >> lane) & 1) tput(b_h, pos + 2);
+                if (((wo.commit >> lane) & 1) && (b_later & wo.commit) == 0) tput(b_h, pos + 2);   // (a slot goes to the last of its lanes that writes)
                 wave_fence();
 #ifdef ZSTD_TRACE
                 if (lane == 0 && g_ztrace_n < 4096) {
