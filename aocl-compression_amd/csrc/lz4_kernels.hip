@@ -1003,8 +1003,17 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             wave_fence();
             rend += 1024; have_pend = false;
         }
-        if (rend - ip < 640 && rend + 1024 <= iend) {
-            pend = *(const G128*)(src + rend + 16 * lane);
+        if (rend - ip < 640 && rend < iend) {
+            // (round 5: the chunk's last KiB is staged as well - zeros behind its end - and the scan stops at the tokens that reach
+            //  the end instead of leaving the whole tail, ~120 sequences of a 256 KiB chunk, to the one-sequence path)
+            const int32_t a_ = rend + 16 * lane;
+            if (a_ + 16 <= iend) pend = *(const G128*)(src + a_);
+            else {
+                uint32_t w_[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int t_ = 0; t_ < 16; ++t_) if (a_ + t_ < iend) w_[t_ >> 2] |= (uint32_t)src[a_ + t_] << (8 * (t_ & 3));
+                pend = u32x4{w_[0], w_[1], w_[2], w_[3]};
+            }
             have_pend = true;
             if (rend - ip < 352) {
                 *(__attribute__((address_space(3))) u32x4*)(ring + ((uint32_t)(rend + 16 * lane) & kRingMask)) = pend;
@@ -1031,6 +1040,8 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             const bool x2 = (t & 15) == 15;
             const uint32_t mcode = (t & 15) + (x2 ? e2 : 0u);                 // match length - 4
             hard = hard || (x2 && e2 > 240);
+            hard = hard || q + 2 + (x2 ? 1u : 0u) + 6u > (uint32_t)iend;      // (a sequence that is not the block's last leaves 6 bytes behind it:
+                                                                             //  what reaches the end is the one-sequence path's, with the reference's end rules)
             const uint32_t nx = hard ? 0x80000000u : q + 2 + (x2 ? 1u : 0u) - (uint32_t)ip;   // the next token's lane
             DSTAGE(1); DCOUNT(0, 1);
             // walk the real token starts: mask |= 1 << cur; cur = nx[cur] until cur >= 64 or a token the scan does not take

@@ -686,8 +686,17 @@ __device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_
         if (ip < n && why == 3) {
             if (ip > rend) { rend = ip & ~15u; have_pend = false; }
             if (have_pend) ring_put();
-            if ((int32_t)(rend - ip) < 640 && (uint64_t)rend + 1024 <= n) {
-                pend = *(const G128*)(src + (rend + 16u * L));
+            if ((int32_t)(rend - ip) < 640 && rend < n) {
+                // (round 5: the fragment stream's last KiB is staged as well - zeros behind its end - and the scan stops at the first
+                //  element that does not lie inside the input instead of leaving the whole tail to the one-element path)
+                const uint32_t a_ = rend + 16u * L;
+                if ((uint64_t)a_ + 16 <= n) pend = *(const G128*)(src + a_);
+                else {
+                    uint32_t w_[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int t_ = 0; t_ < 16; ++t_) if (a_ + (uint32_t)t_ < n) w_[t_ >> 2] |= (uint32_t)src[a_ + t_] << (8 * (t_ & 3));
+                    pend = u32x4{w_[0], w_[1], w_[2], w_[3]};
+                }
                 have_pend = true;
                 if ((int32_t)(rend - ip) < 352) ring_put();
             }
@@ -706,6 +715,7 @@ __device__ __forceinline__ int sn_decompress_wave(const gbyte* __restrict__ src_
                 } else if (type == 1) { len = 4 + ((t >> 2) & 7); off = ((t >> 5) << 8) | b1; adv = 2; }
                 else if (type == 2) { len = (t >> 2) + 1; off = ((uint32_t)w >> 8) & 0xFFFFu; adv = 3; }
                 else { len = (t >> 2) + 1; off = (uint32_t)(w >> 8); adv = 5; }
+                hard = hard || (uint64_t)p + adv > n;          // (an element that does not lie inside the input: the one-element path reports it)
                 const uint32_t nx = hard ? 0x80000000u : L + adv;
                 uint64_t mask; uint32_t cur, stop;
                 lz_walk_tokens(nx, mask, cur, stop);
