@@ -655,7 +655,11 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     const u32 offv = pos - c;
                     // lanes that take the exact path whatever the parse looks like in front of them: candidate within 4 bytes of the
                     // prefix start, a run that leaves the 28-byte window, table writes that would fall behind lane 63
+#if defined(AOCLGPU_EXPERIMENTS) && defined(ZSTD_EXP_NOLONG)   /* timing only: what the exact path costs for matches that outrun the window (wrong parse: cut at 28 bytes) */
+                    const bool hardl = near0 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62);
+#else
                     const bool hardl = near0 || fw >= 24 || ((u32)lane + 2 + fw >= (u32)lim && lane >= 62);
+#endif
                     b_pos0 = pos0; b_lim = lim; b_h = h; b_ent = ent; b_eqb = eqb; b_off = offv; b_pb0 = pa.y & 0xFFu;   // (the byte at pos)
                     b_later = later;
                     b_info = near0 ? zchain::pack_info(FRAME ? 0u : offv, 0, 0)                          // (frames: the offset travels apart)
