@@ -2685,10 +2685,17 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             };
             {   // literals: runs of up to 32 bytes one sequence per lane (four 8-byte loads, exact-length stores), longer runs by the wave
                 gbyte* gd = (gbyte*)dst; const gbyte* gl = (const gbyte*)litPtr;     // output and literal buffer are global memory
-                const bool shortl = ll <= 32 && (u64)myLit + 32 <= litSize + 0ull;   // the 32-byte read stays inside the literals
+                // (round 5: runs of 33 .. 64 bytes - 3 % of the runs, 15 % of the matches on the bench corpus - go one per lane as well,
+                //  as two overlapping 32-byte halves, instead of one after the other by the whole wave with a round trip each)
+                const bool shortl = ll <= 64 && (u64)myLit + 32 <= litSize + 0ull;   // the 32-byte read stays inside the literals
                 if (ll && shortl) {
                     const u64 v0 = ld64(gl + myLit), v1 = ld64(gl + myLit + 8), v2 = ld64(gl + myLit + 16), v3 = ld64(gl + myLit + 24);
-                    put32(gd + myOut, ll, v0, v1, v2, v3);
+                    if (ll > 32) {
+                        const u32 t = ll - 32;
+                        const u64 w0 = ld64(gl + myLit + t), w1 = ld64(gl + myLit + t + 8), w2 = ld64(gl + myLit + t + 16), w3 = ld64(gl + myLit + t + 24);
+                        put32(gd + myOut + t, 32, w0, w1, w2, w3);
+                    }
+                    put32(gd + myOut, ll < 32 ? ll : 32, v0, v1, v2, v3);
                 }
                 for (u64 lm = ballot(ll && !shortl); lm; lm &= lm - 1) {
                     const int k = (int)__builtin_ctzll(lm);
@@ -2706,7 +2713,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 gbyte* gd = (gbyte*)dst;
                 const u32 mo = myOut + ll, spos = mo - off;
                 const bool mine = (u32)lane < cnt && ml != 0;
-                const bool small = mine && ml <= 32 && off >= ml && (u64)spos + 32 <= cap;
+                const bool small = mine && ml <= 64 && off >= ml && (u64)spos + 32 <= cap;
                 // level 0: every match whose source lies before this tile's output; only the others can be blocked, and only by
                 // one another (whatever blocks them among the level-0 matches is done by then)
                 const u64 inTile = ballot(mine && spos + ml > out);
@@ -2727,7 +2734,12 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     const bool go = (ready >> lane) & 1;
                     if (go && small) {
                         const u64 v0 = ld64(gd + spos), v1 = ld64(gd + spos + 8), v2 = ld64(gd + spos + 16), v3 = ld64(gd + spos + 24);
-                        put32(gd + mo, ml, v0, v1, v2, v3);
+                        if (ml > 32) {                                              // (source and destination do not overlap: off >= ml)
+                            const u32 t = ml - 32;
+                            const u64 w0 = ld64(gd + spos + t), w1 = ld64(gd + spos + t + 8), w2 = ld64(gd + spos + t + 16), w3 = ld64(gd + spos + t + 24);
+                            put32(gd + mo + t, 32, w0, w1, w2, w3);
+                        }
+                        put32(gd + mo, ml < 32 ? ml : 32, v0, v1, v2, v3);
                     }
                     for (u64 dm = ready & ballot(!small); dm; dm &= dm - 1) {
                         const int k = (int)__builtin_ctzll(dm);
