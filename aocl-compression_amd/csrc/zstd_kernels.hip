@@ -2443,6 +2443,71 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int 
 }
 
 // one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
+
+// The offset history of 64 sequences at once (ZSTD_decodeSequence :1370-1400 runs it one sequence after the other).  What a
+// sequence does to the history (r0, r1, r2) is a small map: every new entry is an old entry, an old entry minus one (offset
+// value 3 after a zero literal length; the reference forces a 0 to 1, and max(max(x - a, 1) - b, 1) = max(x - a - b, 1) keeps
+// that closed), or the sequence's own new offset.  Such maps compose, so a prefix scan over the lanes gives every sequence the
+// history in front of it in six steps instead of 64 dependent ones on one lane; the sequence's offset is the front entry after
+// its own map.  A map is three entries of {kind: old entry 0..2 or 3 = constant, k: how often one was subtracted, constant};
+// meta holds (kind - j) & 3 and k per entry j, nine bits each, so that the identity is all zeros (what a row shift fills in).
+struct RepMap { u32 meta, c0, c1, c2; };
+__device__ __forceinline__ RepMap rep_compose(const RepMap E, const RepMap M)    // first E, then M
+{
+    RepMap R; u32 meta = 0;
+    #pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const u32 fm = (M.meta >> (9 * j)) & 0x1FFu, km = ((fm & 3u) + (u32)j) & 3u;
+        const u32 fe = (E.meta >> (9u * (km & 3u))) & 0x1FFu;                    // (km == 3: unused)
+        const u32 ke = ((fe & 3u) + km) & 3u, kk = (fe >> 2) + (fm >> 2);
+        const u32 ce = km == 0 ? E.c0 : (km == 1 ? E.c1 : E.c2);
+        const u32 mc = j == 0 ? M.c0 : (j == 1 ? M.c1 : M.c2);
+        const bool own = km == 3;
+        const u32 f = own ? fm : (((ke - (u32)j) & 3u) | (kk << 2));
+        const u32 c = own ? mc : ce;
+        meta |= f << (9 * j);
+        if (j == 0) R.c0 = c; else if (j == 1) R.c1 = c; else R.c2 = c;
+    }
+    R.meta = meta;
+    return R;
+}
+__device__ __forceinline__ u32 rep_entry(const RepMap A, int j, u32 R0, u32 R1, u32 R2)
+{
+    const u32 f = (A.meta >> (9 * j)) & 0x1FFu, kind = ((f & 3u) + (u32)j) & 3u, k = f >> 2;
+    const u32 c = j == 0 ? A.c0 : (j == 1 ? A.c1 : A.c2);
+    const u32 base = kind == 3 ? c : (kind == 0 ? R0 : (kind == 1 ? R1 : R2));
+    return k ? (base > k ? base - k : 1u) : base;
+}
+// val: the offset value of this lane's sequence (1..3 = repeat codes), ll its literal length; returns its offset and moves the
+// history (wave-uniform R0..R2) past the tile.  Lanes without a sequence pass the identity.
+__device__ __forceinline__ u32 rep_resolve(u32 val, u32 ll, bool active, u32& R0, u32& R1, u32& R2)
+{
+    const bool isRep = val <= 3;
+    const u32 idx = val - 1 + (ll == 0 ? 1u : 0u);
+    RepMap m; m.c0 = val - 3; m.c1 = 0; m.c2 = 0;
+    m.meta = !isRep ? (3u | 3u << 9 | 3u << 18)
+           : idx == 0 ? 0u
+           : idx == 1 ? (1u | 3u << 9)
+           : idx == 2 ? (2u | 3u << 9 | 3u << 18)
+           :            (1u << 2 | 3u << 9 | 3u << 18);
+    if (!active) { m.meta = 0; }
+    auto step = [&](auto shifted) {
+        RepMap E;
+        E.meta = shifted(m.meta); E.c0 = shifted(m.c0); E.c1 = shifted(m.c1); E.c2 = shifted(m.c2);
+        m = rep_compose(E, m);
+    };
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); });
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); });
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); });
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); });
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); });
+    step([](u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); });
+    const u32 off = rep_entry(m, 0, R0, R1, R2);
+    const u32 n1 = rep_entry(m, 1, R0, R1, R2), n2 = rep_entry(m, 2, R0, R1, R2);
+    R0 = lane_get(off, 63); R1 = lane_get(n1, 63); R2 = lane_get(n2, 63);
+    return active ? off : 0u;
+}
+
 __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
                             u8* litBuf, int lane, const bool keep)
 {   // keep: another block of the frame follows and may reuse this block's tables (DecLds)
@@ -2603,6 +2668,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             r0 = L->rep[0]; r1 = L->rep[1]; r2 = L->rep[2];
         }
         if (!uni(okB)) return 0xFFFFFFFFu;
+        u32 R0 = lane_get(r0, 0), R1 = lane_get(r1, 0), R2 = lane_get(r2, 0);    // the offset history entering the next tile (wave-uniform)
         pos = (int)lane_get((u32)b.pos, 0);
         // per-lane roles of the sequence loop
         typedef __attribute__((address_space(3))) u32 L32;
@@ -2635,6 +2701,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     const u32 t = *(L32*)(uintptr_t)(auxA + 4u * sym);
                     const u32 val = (isOF ? 1u << sym : t & 0xFFFFFFu) + field(pos - (int)offE, nbE);
                     const u32 fs = field(pos - Etot - (int)offS, nbS);
+#ifdef ZSTD_DEC_SERIAL_REPS
                     // offset history (ZSTD_decodeSequence :1370-1400), meaningful on lane 0 where val is the offset value
                     const u32 ll0 = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0x102, 0xF, 0xF, true) == 0 ? 1u : 0u;
                     const bool isRep = val <= 3;
@@ -2646,10 +2713,15 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     const bool shift2 = !isRep || idx >= 2;
                     r2 = shift2 ? r1 : r2; r1 = shift ? r0 : r1; r0 = shift ? offset : r0;
                     *(L32*)(uintptr_t)(outA + k * outStride) = isOF ? offset : val;
+#else
+                    *(L32*)(uintptr_t)(outA + k * outStride) = val;              // the offset VALUE; the history resolves it after the loop
+#endif
                     st = ns + fs;
                     pos -= Etot + (q0 + k + 1 < nbSeq ? Stot : 0);
                 }
+#ifdef ZSTD_DEC_SERIAL_REPS
                 if (lane == 0 && q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
+#endif
             }
             pos = (int)uni((u32)pos);
             wave_fence();
@@ -2657,6 +2729,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;
             if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
+#ifndef ZSTD_DEC_SERIAL_REPS
+            off = rep_resolve(off, ll, (u32)lane < cnt, R0, R1, R2);
+            if (q0 + cnt >= nbSeq && lane == 0) { L->rep[0] = R0; L->rep[1] = R1; L->rep[2] = R2; }
+#endif
             u32 incL = ll, incO = ll + ml;
             for (int d = 1; d < 64; d <<= 1) {
                 const u32 tl = __shfl_up(incL, d), to = __shfl_up(incO, d);
