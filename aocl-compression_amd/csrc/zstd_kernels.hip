@@ -2684,6 +2684,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
             if (q0) refill();
+#ifdef ZSTD_DEC_SERIAL_REPS
             if (lane < 8) {
                 const bool isOF = lane == 0;
                 const u32 winRel = winA - (u32)wbase;                            // LDS address of stream byte 0 (may lie below the window)
@@ -2723,6 +2724,32 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 if (lane == 0 && q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
 #endif
             }
+#else
+            // The loop carries only what the next state needs: the cell, the state bits and the bit positions.  The VALUES (base
+            // of the code plus its additional bits) are read after the loop, every lane for its own sequence, from the code and
+            // the position of its additional bits that the loop leaves behind (positions relative to the window: 13 bits).
+            const int wb8 = wbase * 8;
+            if (lane < 8) {
+                auto field = [&](int p, u32 nb) -> u32 {                         // the nb (<= 32) bits right below window bit p
+                    const int q = p - (int)nb;
+                    const uint64_t w = lds_ld64((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
+                    return __builtin_amdgcn_ubfe((u32)(w >> (q & 7)), 0u, nb);
+                };
+                int prel = pos - wb8;
+                for (u32 k = 0; k < cnt; ++k) {
+                    const u32 cell = *(L32*)(uintptr_t)(tabA + 4u * st);
+                    const u32 nbE = (cell >> 10) & 31u, nbS = cell >> 24, ns = cell & 0x3FFu, sym = (cell >> 16) & 0xFFu;
+                    const u32 offE = (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x111, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x112, 0xF, 0xF, true);
+                    const u32 offS = (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x102, 0xF, 0xF, true);
+                    const int Etot = (int)lane_get(offE + nbE, 2), Stot = (int)lane_get(offS + nbS, 0);
+                    const u32 fs = field(prel - Etot - (int)offS, nbS);
+                    *(L32*)(uintptr_t)(outA + k * outStride) = sym | ((u32)(prel - (int)offE) << 8);
+                    st = ns + fs;
+                    prel -= Etot + (q0 + k + 1 < nbSeq ? Stot : 0);
+                }
+                pos = prel + wb8;
+            }
+#endif
             pos = (int)uni((u32)pos);
             wave_fence();
             DSTAGE(2);
@@ -2730,6 +2757,17 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             u32 ll = 0, ml = 0, off = 0;
             if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
 #ifndef ZSTD_DEC_SERIAL_REPS
+            if ((u32)lane < cnt) {                                               // code and position -> value
+                auto value = [&](u32 w, u32 base, u32 nb) -> u32 {
+                    const int q = (int)(w >> 8) - (int)nb;
+                    const uint64_t x = lds_ld64((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
+                    return base + __builtin_amdgcn_ubfe((u32)(x >> (q & 7)), 0u, nb);
+                };
+                const u32 tl = L->llTab[ll & 0xFFu], tm = L->mlTab[ml & 0xFFu], so = off & 0xFFu;
+                ll = value(ll, tl & 0xFFFFFFu, tl >> 24);
+                ml = value(ml, tm & 0xFFFFFFu, tm >> 24);
+                off = value(off, 1u << so, so);
+            }
             off = rep_resolve(off, ll, (u32)lane < cnt, R0, R1, R2);
             if (q0 + cnt >= nbSeq && lane == 0) { L->rep[0] = R0; L->rep[1] = R1; L->rep[2] = R2; }
 #endif
