@@ -2018,7 +2018,12 @@ struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (ro
     union {
         u16 huf[2048];              // literals: symbol | nbBits << 8, table logs <= 11; a 12-bit table (accepted by the reference,
                                     // never produced by zstd) lives in the block's global workspace instead
-        struct { FseD ll[512], of[256], ml[512]; };   // sequences
+        // Sequences: three-byte cells - new state base (9 bits) | additional bits of the code (5) | code (6) | state bits (4) -
+        // so that the three tables take 3840 bytes, not 5120, and a block five LDS granules, not six (24 blocks per CU instead
+        // of 21).  A table is built with four-byte cells where it will stand and packed in place (seq_table); building one may
+        // run over the tables behind it, which are built or fetched after it, and the last one runs into seqBuild.
+        struct { u8 ll3[1536], of3[768], ml3[1536], seqBuild[512]; };
+        struct { s16 wnorm[256]; u16 wnext[256]; };           // reading the FSE table of the Huffman weights (before huf is built)
     };
     u32 llLog, ofLog, mlLog, hufLog;
     u32 haveLL, haveOF, haveML, haveHuf;
@@ -2027,14 +2032,12 @@ struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (ro
 #ifdef ZSTD_DEC_LDS_PAD                                      /* residency experiments: fewer blocks per CU */
     u8 residencyPad[ZSTD_DEC_LDS_PAD];
 #endif
-    // 2304 bytes that three phases of a block use one after the other (7488 bytes in all = 6 granules: 20 blocks per CU, the
-    // register bound):
+    // 1920 bytes that three phases of a block use one after the other (6336 bytes in all = 5 granules):
     union {
         u8 hwin[4][480] __attribute__((aligned(16)));       // literals by one lane per stream (12-bit tables, single streams): windows of
                                                              // the four Huffman streams (256 symbols need <= 352 bytes + the 8-byte container)
         struct {                                             // reading a table description (Huffman weights before the streams, FSE tables after them)
-            s16 norm[256];
-            u16 next[256];
+            s16 norm[64];                                    // (sequence tables: codes <= 52; the weights' table may name 256 symbols: wnorm)
             u8 weights[256];
             FseD wdt[64];
             u8 scratch[768];                                 // staged description / occupancy + next-state scratch of the table builders
@@ -2046,7 +2049,7 @@ struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (ro
         };
     };
 };
-static_assert(sizeof(DecLds) <= 7680 || sizeof(DecLds) > 20000, "six LDS granules per block");
+static_assert(sizeof(DecLds) <= 6400 || sizeof(DecLds) > 20000, "five LDS granules per block");
 
 // FSE_readNCount (entropy_common.c:40-186), lane-serial; bytes consumed or 0xFFFFFFFF
 __device__ u32 fse_read_ncount(s16* norm, u32* maxSym, u32* tableLog, const u8* src, u32 n, u32 maxLog)
@@ -2178,8 +2181,8 @@ __device__ __forceinline__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u
         if (lane == 0) {
             u32 maxSym = 255, tl; BitR b;
             res = 0xFFFFFFFFu;
-            const u32 h = fse_read_ncount(L->norm, &maxSym, &tl, stg, isz, 6);
-            if (h != 0xFFFFFFFFu && h < isz && fse_build_dtable(L->wdt, L->norm, maxSym, tl, L->next) && b.init(stg + h, isz - h)) {
+            const u32 h = fse_read_ncount(L->wnorm, &maxSym, &tl, stg, isz, 6);
+            if (h != 0xFFFFFFFFu && h < isz && fse_build_dtable(L->wdt, L->wnorm, maxSym, tl, L->wnext) && b.init(stg + h, isz - h)) {
                 u32 s1 = b.read((int)tl), s2 = b.read((int)tl), k = 0;
                 for (;;) {                                                   // FSE_decompress_usingDTable tail (fse_decompress.c:220-245)
                     if (k > 253) { k = 0xFFFFFFFFu; break; }
@@ -2386,20 +2389,47 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
 
 // ZSTD_buildSeqTable (zstd_decompress_block.c:659-705).  All lanes call it: lane 0 reads a transmitted description (the bit
 // positions of its values depend on the values before them), the table itself is built by the wave, one symbol per lane.
-__device__ __forceinline__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
+__device__ __forceinline__ bool seq_table(u8* tab3, const int kind, u32* log, u32* have, u32 mode, const u8* src, u32* ip, u32 iend, u32 maxSym, u32 maxLog,
                           const s16* defNorm, u32 defMax, u32 defLog, DecLds* L, int lane)
-{
+{   // kind: 0 offsets, 1 match lengths, 2 literal lengths (how many additional bits a code reads)
     u8* occ = L->scratch; u16* next = (u16*)(L->scratch + 512);
+    FseD* dt = (FseD*)tab3;                                              // built with four-byte cells, then packed in place
+    typedef __attribute__((address_space(3))) u32 L32;
+    typedef __attribute__((address_space(3))) u16 L16;
+    typedef __attribute__((address_space(3))) u8 L8;
+    auto cell3 = [&](u32 c) -> u32 {                                     // FseD (newState | symbol << 16 | nbBits << 24) -> the three-byte cell
+        const u32 sym = (c >> 16) & 0xFFu;
+        const u32 eb = kind == 0 ? sym : (kind == 1 ? (u32)kMLbits[sym < 53 ? sym : 0] : (u32)kLLbits[sym < 36 ? sym : 0]);
+        return (c & 0x1FFu) | (eb & 31u) << 9 | (sym & 63u) << 14 | ((c >> 24) & 15u) << 20;
+    };
+    auto pack = [&](u32 tl) {                                            // tile by tile, upwards: the packed cells trail the cells still to read
+        lbyte* t = (lbyte*)tab3;
+        const u32 size = 1u << tl;
+        for (u32 u0 = 0; u0 < size; u0 += kWave) {
+            const u32 u = u0 + (u32)lane;
+            u32 c = 0;
+            if (u < size) c = *(L32*)(t + 4 * u);
+            wave_fence();
+            if (u < size) { const u32 v = cell3(c); *(L8*)(t + 3 * u) = (u8)v; *(L8*)(t + 3 * u + 1) = (u8)(v >> 8); *(L8*)(t + 3 * u + 2) = (u8)(v >> 16); }
+            wave_fence();
+        }
+    };
     if (mode == 0) {
         const int norm = (u32)lane <= defMax ? (int)defNorm[lane] : 0;
         fse_build_dtable_wave(dt, norm, defMax, defLog, occ, next, lane);
+        pack(defLog);
         if (lane == 0) { *log = defLog; *have = 1; }
         wave_fence();
         return true;
     }
     if (mode == 1) {
         if (*ip >= iend || src[*ip] > maxSym) return false;
-        if (lane == 0) { dt[0].symbol = src[*ip]; dt[0].nbBits = 0; dt[0].newState = 0; *log = 0; *have = 1; }
+        if (lane == 0) {
+            const u32 v = cell3((u32)src[*ip] << 16);
+            lbyte* t = (lbyte*)tab3;
+            *(L8*)(t) = (u8)v; *(L8*)(t + 1) = (u8)(v >> 8); *(L8*)(t + 2) = (u8)(v >> 16);
+            *log = 0; *have = 1;
+        }
         wave_fence();
         (*ip)++; return true;
     }
@@ -2416,11 +2446,12 @@ __device__ __forceinline__ bool seq_table(FseD* dt, u32* log, u32* have, u32 mod
         if (h == 0xFFFFFFFFu) return false;
         const int norm = (u32)lane <= ms ? (int)L->norm[lane] : 0;
         if (!fse_build_dtable_wave(dt, norm, ms, tl, occ, next, lane)) return false;
+        pack(tl);
         if (lane == 0) { *log = tl; *have = 1; }
         wave_fence();
         *ip += h; return true;
     }
-    return uni(*have) != 0;
+    return uni(*have) != 0;                                              // repeat: the caller fetches the table after the builds
 }
 
 // copy of `len` bytes inside dst from distance `offset` back (overlap allowed), whole wave
@@ -2441,8 +2472,6 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 len, int 
     }
     wave_fence();
 }
-
-// one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
 
 // The offset history of 64 sequences at once (ZSTD_decodeSequence :1370-1400 runs it one sequence after the other).  What a
 // sequence does to the history (r0, r1, r2) is a small map: every new entry is an old entry, an old entry minus one (offset
@@ -2508,6 +2537,7 @@ __device__ __forceinline__ u32 rep_resolve(u32 val, u32 ll, bool active, u32& R0
     return active ? off : 0u;
 }
 
+// one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
 __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
                             u8* litBuf, int lane, const bool keep)
 {   // keep: another block of the frame follows and may reuse this block's tables (DecLds)
@@ -2606,45 +2636,31 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (ip >= n) return 0xFFFFFFFFu;
         const u32 modes = src[ip++];
         if (modes & 3) return 0xFFFFFFFFu;
-        if ((modes >> 6) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3) {
-            if (!uni(L->haveLL | L->haveOF | L->haveML)) return 0xFFFFFFFFu;   // nothing to repeat
-            fetch(L->ll, kDecFsePark, 5120);                                    // the three tables as the frame's last block with sequences left them
-        }
-        if (!seq_table(L->ll, &L->llLog, &L->haveLL, modes >> 6, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return 0xFFFFFFFFu;
-        if (!seq_table(L->of, &L->ofLog, &L->haveOF, (modes >> 4) & 3, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return 0xFFFFFFFFu;
-        if (!seq_table(L->ml, &L->mlLog, &L->haveML, (modes >> 2) & 3, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return 0xFFFFFFFFu;
+        const u32 mLL = modes >> 6, mOF = (modes >> 4) & 3, mML = (modes >> 2) & 3;
+        if ((mLL == 3 || mOF == 3 || mML == 3) && !uni(L->haveLL | L->haveOF | L->haveML)) return 0xFFFFFFFFu;   // nothing to repeat
+        if (!seq_table(L->ll3, 2, &L->llLog, &L->haveLL, mLL, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return 0xFFFFFFFFu;
+        if (!seq_table(L->of3, 0, &L->ofLog, &L->haveOF, mOF, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return 0xFFFFFFFFu;
+        if (!seq_table(L->ml3, 1, &L->mlLog, &L->haveML, mML, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return 0xFFFFFFFFu;
+        // repeated tables, as the frame's last block with sequences left them (after the builds: building a table runs over the
+        // places of the tables behind it)
+        if (mLL == 3) fetch(L->ll3, kDecFsePark, sizeof(L->ll3));
+        if (mOF == 3) fetch(L->of3, kDecFsePark + sizeof(L->ll3), sizeof(L->of3));
+        if (mML == 3) fetch(L->ml3, kDecFsePark + sizeof(L->ll3) + sizeof(L->of3), sizeof(L->ml3));
         wave_fence();
         for (u32 i = (u32)lane; i < 36 + 53; i += kWave) {                       // length-code tables (they share LDS with the Huffman windows)
             if (i < 36) L->llTab[i] = kLLbase[i] | ((u32)kLLbits[i] << 24);
             else L->mlTab[i - 36] = kMLbase[i - 36] | ((u32)kMLbits[i - 36] << 24);
         }
+        if (lane == 0) { L->zeroWord = 0; }
         wave_fence();
-        // The FSE cells carry, in the spare bits of newState (values < 512), how many additional bits their symbol reads, so the
-        // serial chain below needs one table read per state, not two (idempotent: a repeated table is already marked).
-        {
-            typedef __attribute__((address_space(3))) u16 L16;
-            typedef __attribute__((address_space(3))) u8 L8;
-            typedef __attribute__((address_space(3))) u32 L32;
-            auto mark = [&](FseD* dt, u32 log, int kind) {
-                lbyte* t = (lbyte*)dt;
-                for (u32 u = (u32)lane; u < (1u << log); u += kWave) {
-                    const u32 sym = *(L8*)(t + 4 * u + 2);
-                    const u32 eb = kind == 0 ? sym : (kind == 1 ? *(L32*)((lbyte*)&L->mlTab[sym]) >> 24 : *(L32*)((lbyte*)&L->llTab[sym]) >> 24);
-                    *(L16*)(t + 4 * u) = (u16)((*(L16*)(t + 4 * u) & 0x3FFu) | (eb << 10));
-                }
-            };
-            mark(L->of, uni(L->ofLog), 0); mark(L->ml, uni(L->mlLog), 1); mark(L->ll, uni(L->llLog), 2);
-            if (lane == 0) { L->zeroWord = 0; }
-            wave_fence();
-        }
         // Sequences (ZSTD_decodeSequence :1339-1460), 64 per tile, then the wave executes the tile (:1007-1108).  The three FSE
         // states advance in lock step on three lanes - lane 0 offsets, 1 match lengths, 2 literal lengths (lanes 3-7 idle on a
         // cell of zeros so that every row shift reads a defined value) - instead of one after the other on one lane: one table
-        // read, one additional-bits field and one state field per lane and sequence, the fields' bit positions from row-shift
-        // prefix sums (additional bits are stored offset, match, literal; state bits literal, match, offset), branch-free.
+        // read and one state field per lane and sequence, the fields' bit positions from row-shift prefix sums (additional bits
+        // are stored offset, match, literal; state bits literal, match, offset), branch-free.  What the chain does not need to
+        // go on - the additional bits' values, the offset history - is done after the loop by all lanes (round 5).
         // Over-reading a damaged stream reads the zeros the window holds below bit 0, as BIT_reloadDStream leaves them.
         BitL b; b.pos = 0; b.wb = 0; b.c = 0; u32 sLL = 0, sOF = 0, sML = 0, okB = 1;
-        u32 r0 = 0, r1 = 0, r2 = 0;                                              // repcodes live in lane 0's registers
         const gbyte* bsp = (const gbyte*)(src + ip); const u32 bsn = n - ip;      // the sequence bitstream
         const lbyte* win = (const lbyte*)&L->bswin[0];
         int pos;                                                                 // unread bits of the sequence bitstream (wave-uniform)
@@ -2665,16 +2681,14 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (lane == 0) {
             b.pos = pos; b.wb = wbase;
             b.grab(win); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0;
-            r0 = L->rep[0]; r1 = L->rep[1]; r2 = L->rep[2];
         }
         if (!uni(okB)) return 0xFFFFFFFFu;
-        u32 R0 = lane_get(r0, 0), R1 = lane_get(r1, 0), R2 = lane_get(r2, 0);    // the offset history entering the next tile (wave-uniform)
+        u32 R0 = uni(L->rep[0]), R1 = uni(L->rep[1]), R2 = uni(L->rep[2]);       // the offset history entering the next tile (wave-uniform)
         pos = (int)lane_get((u32)b.pos, 0);
         // per-lane roles of the sequence loop
         typedef __attribute__((address_space(3))) u32 L32;
         const u32 zeroA = (u32)(uintptr_t)(lbyte*)&L->zeroWord;
-        const u32 tabA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->of[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->ml[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->ll[0] : zeroA;
-        const u32 auxA = lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->llTab[0] : lane < 2 ? (u32)(uintptr_t)(lbyte*)&L->mlTab[0] : zeroA;
+        const u32 tabA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->of3[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->ml3[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->ll3[0] : zeroA;
         const u32 outA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->seqOff[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->seqML[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->seqLL[0]
                                    : (u32)(uintptr_t)(lbyte*)&L->dumpWord;
         const u32 outStride = lane < 3 ? 4u : 0u;
@@ -2684,47 +2698,6 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
             if (q0) refill();
-#ifdef ZSTD_DEC_SERIAL_REPS
-            if (lane < 8) {
-                const bool isOF = lane == 0;
-                const u32 winRel = winA - (u32)wbase;                            // LDS address of stream byte 0 (may lie below the window)
-                auto field = [&](int p, u32 nb) -> u32 {                         // the nb (<= 32) bits right below stream bit p
-                    const int q = p - (int)nb;
-                    const uint64_t w = lds_ld64((const lbyte*)(uintptr_t)(winRel + (u32)(q >> 3)));
-                    return __builtin_amdgcn_ubfe((u32)(w >> (q & 7)), 0u, nb);
-                };
-                for (u32 k = 0; k < cnt; ++k) {
-                    const u32 cell = *(L32*)(uintptr_t)(tabA + 4u * st);
-                    const u32 nbE = (cell >> 10) & 31u, nbS = cell >> 24, ns = cell & 0x3FFu, sym = (cell >> 16) & 0xFFu;
-                    const u32 offE = (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x111, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x112, 0xF, 0xF, true);
-                    const u32 offS = (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x102, 0xF, 0xF, true);
-                    const int Etot = (int)lane_get(offE + nbE, 2), Stot = (int)lane_get(offS + nbS, 0);
-                    const u32 t = *(L32*)(uintptr_t)(auxA + 4u * sym);
-                    const u32 val = (isOF ? 1u << sym : t & 0xFFFFFFu) + field(pos - (int)offE, nbE);
-                    const u32 fs = field(pos - Etot - (int)offS, nbS);
-#ifdef ZSTD_DEC_SERIAL_REPS
-                    // offset history (ZSTD_decodeSequence :1370-1400), meaningful on lane 0 where val is the offset value
-                    const u32 ll0 = (u32)__builtin_amdgcn_update_dpp(0, (int)val, 0x102, 0xF, 0xF, true) == 0 ? 1u : 0u;
-                    const bool isRep = val <= 3;
-                    const u32 idx = val - 1 + ll0;
-                    u32 tt = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
-                    tt += tt == 0 ? 1u : 0u;
-                    const u32 offset = isRep ? (idx == 0 ? r0 : tt) : val - 3;
-                    const bool shift = !(isRep && idx == 0);
-                    const bool shift2 = !isRep || idx >= 2;
-                    r2 = shift2 ? r1 : r2; r1 = shift ? r0 : r1; r0 = shift ? offset : r0;
-                    *(L32*)(uintptr_t)(outA + k * outStride) = isOF ? offset : val;
-#else
-                    *(L32*)(uintptr_t)(outA + k * outStride) = val;              // the offset VALUE; the history resolves it after the loop
-#endif
-                    st = ns + fs;
-                    pos -= Etot + (q0 + k + 1 < nbSeq ? Stot : 0);
-                }
-#ifdef ZSTD_DEC_SERIAL_REPS
-                if (lane == 0 && q0 + cnt >= nbSeq) { L->rep[0] = r0; L->rep[1] = r1; L->rep[2] = r2; }
-#endif
-            }
-#else
             // The loop carries only what the next state needs: the cell, the state bits and the bit positions.  The VALUES (base
             // of the code plus its additional bits) are read after the loop, every lane for its own sequence, from the code and
             // the position of its additional bits that the loop leaves behind (positions relative to the window: 13 bits).
@@ -2737,8 +2710,8 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 };
                 int prel = pos - wb8;
                 for (u32 k = 0; k < cnt; ++k) {
-                    const u32 cell = *(L32*)(uintptr_t)(tabA + 4u * st);
-                    const u32 nbE = (cell >> 10) & 31u, nbS = cell >> 24, ns = cell & 0x3FFu, sym = (cell >> 16) & 0xFFu;
+                    const u32 cell = *(L32*)(uintptr_t)(tabA + 3u * st);         // three-byte cells (DecLds); the top byte is the next cell's
+                    const u32 nbE = (cell >> 9) & 31u, nbS = (cell >> 20) & 15u, ns = cell & 0x1FFu, sym = (cell >> 14) & 63u;
                     const u32 offE = (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x111, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x112, 0xF, 0xF, true);
                     const u32 offS = (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x102, 0xF, 0xF, true);
                     const int Etot = (int)lane_get(offE + nbE, 2), Stot = (int)lane_get(offS + nbS, 0);
@@ -2749,14 +2722,12 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 }
                 pos = prel + wb8;
             }
-#endif
             pos = (int)uni((u32)pos);
             wave_fence();
             DSTAGE(2);
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;
             if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
-#ifndef ZSTD_DEC_SERIAL_REPS
             if ((u32)lane < cnt) {                                               // code and position -> value
                 auto value = [&](u32 w, u32 base, u32 nb) -> u32 {
                     const int q = (int)(w >> 8) - (int)nb;
@@ -2770,12 +2741,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             }
             off = rep_resolve(off, ll, (u32)lane < cnt, R0, R1, R2);
             if (q0 + cnt >= nbSeq && lane == 0) { L->rep[0] = R0; L->rep[1] = R1; L->rep[2] = R2; }
-#endif
-            u32 incL = ll, incO = ll + ml;
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 tl = __shfl_up(incL, d), to = __shfl_up(incO, d);
-                if (lane >= d) { incL += tl; incO += to; }
-            }
+            const u32 incL = wave_scan_incl(ll), incO = wave_scan_incl(ll + ml);
             const u32 totL = lane_get(incL, 63), totO = lane_get(incO, 63);
             if (totL > litSize - litPos) return 0xFFFFFFFFu;
             if ((u64)out + totO > cap || (u64)(out - opos) + totO > blockMax) return 0xFFFFFFFFu;
@@ -2867,7 +2833,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             DSTAGE(4);
         }
         if (pos > 0) return 0xFFFFFFFFu;                                         // bitstream not fully consumed
-        if (keep) park(kDecFsePark, L->ll, 5120);
+        if (keep) park(kDecFsePark, L->ll3, 3840);
     }
     const u32 rest = litSize - litPos;
     if ((u64)out + rest > cap || (u64)(out - opos) + rest > blockMax) return 0xFFFFFFFFu;
