@@ -27,6 +27,7 @@
 #include "zstd_hufspec.h"
 #include "host_util.h"
 #include <mutex>
+#include <type_traits>
 #include <atomic>
 #include <stdlib.h>
 #include <string.h>
@@ -2555,7 +2556,11 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
     };
 #ifdef ZSTD_PROF
     unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dprev = __builtin_amdgcn_s_memtime();
-    struct Flush { unsigned long long* a; int lane; __device__ ~Flush() { if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_dprof[k], a[k]); } } flush_{dacc, lane};
+    unsigned long long dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tiles, match levels, blocked-loop trips, whole-wave literal runs, whole-wave matches, sequences, one-per-lane matches
+    struct Flush { unsigned long long* a; unsigned long long* c; int lane; __device__ ~Flush() { if (lane == 0) for (int k = 0; k < 8; ++k) { atomicAdd(&g_zstd_dprof[k], a[k]); atomicAdd(&g_zstd_dprof[8 + k], c[k]); } } } flush_{dacc, dcnt, lane};
+#define DCOUNT(k, n) (dcnt[k] += (n))
+#else
+#define DCOUNT(k, n) ((void)0)
 #endif
     if (n < 1) return 0xFFFFFFFFu;
     u32 ip = 0, litSize = 0; const u8* litPtr = nullptr;
@@ -2630,6 +2635,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
         if (nbSeq == 0xFF) { if (ip + 2 > n) return 0xFFFFFFFFu; nbSeq = ld16(src + ip) + 0x7F00; ip += 2; }
         else { if (ip >= n) return 0xFFFFFFFFu; nbSeq = ((nbSeq - 0x80) << 8) + src[ip++]; }
     }
+    nbSeq = uni(nbSeq);                                                          // (wave-uniform: loop counts stay in scalar registers)
     u32 out = opos, litPos = 0;
     if (nbSeq == 0) { if (ip != n) return 0xFFFFFFFFu; }
     else {
@@ -2700,44 +2706,52 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             if (q0) refill();
             // The loop carries only what the next state needs: the cell, the state bits and the bit positions.  The VALUES (base
             // of the code plus its additional bits) are read after the loop, every lane for its own sequence, from the code and
-            // the position of its additional bits that the loop leaves behind (positions relative to the window: 13 bits).
-            const int wb8 = wbase * 8;
+            // the position of the sequence's additional bits that the loop leaves behind (positions relative to the window: 13 bits).
+            // Trip count and bit position are wave-uniform (readfirstlane): counters and branches stay in scalar registers.  Eight
+            // lanes, not 64: an LDS instruction costs by its active lanes (all 64 lanes in this loop: 38 -> 70 ms for the bench).
+            const int posU = (int)uni((u32)pos), wbU = (int)uni((u32)wbase);
+            int posOut = posU;
             if (lane < 8) {
-                auto field = [&](int p, u32 nb) -> u32 {                         // the nb (<= 32) bits right below window bit p
-                    const int q = p - (int)nb;
+                auto field = [&](int q, u32 nb) -> u32 {                         // the nb (<= 32) bits from window bit q upwards
                     const uint64_t w = lds_ld64((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
                     return __builtin_amdgcn_ubfe((u32)(w >> (q & 7)), 0u, nb);
                 };
-                int prel = pos - wb8;
+                const int wb8 = wbU * 8;
+                int prel = posU - wb8;
+                const u32 last = nbSeq - q0 - 1;                                 // the frame's last sequence reads no state bits
                 for (u32 k = 0; k < cnt; ++k) {
-                    const u32 cell = *(L32*)(uintptr_t)(tabA + 3u * st);         // three-byte cells (DecLds); the top byte is the next cell's
+                    const u32 cell = *(L32*)(uintptr_t)(tabA + __umul24(st, 3u));   // three-byte cells (DecLds); the top byte is the next cell's
                     const u32 nbE = (cell >> 9) & 31u, nbS = (cell >> 20) & 15u, ns = cell & 0x1FFu, sym = (cell >> 14) & 63u;
-                    const u32 offE = (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x111, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbE, 0x112, 0xF, 0xF, true);
-                    const u32 offS = (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)nbS, 0x102, 0xF, 0xF, true);
-                    const int Etot = (int)lane_get(offE + nbE, 2), Stot = (int)lane_get(offS + nbS, 0);
-                    const u32 fs = field(prel - Etot - (int)offS, nbS);
-                    *(L32*)(uintptr_t)(outA + k * outStride) = sym | ((u32)(prel - (int)offE) << 8);
+                    // both bit counts in one register (additional bits <= 3 x 31 stay below 256): one row-shift sum gives lane j the
+                    // counts of lanes j .. j+2, lane 0 the sequence's totals, and its high byte where lane j's state field begins
+                    const u32 x = nbE | (nbS << 8);
+                    const u32 P = x + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
+                    const u32 tot = lane_get(P, 0);
+                    const int Etot = (int)(tot & 0xFFu), Stot = (int)(tot >> 8);
+                    const u32 fs = field(prel - Etot - (int)(P >> 8), nbS);
+                    *(L32*)(uintptr_t)(outA + k * outStride) = sym | ((u32)prel << 8);   // the code, and where the sequence's additional bits begin
                     st = ns + fs;
-                    prel -= Etot + (q0 + k + 1 < nbSeq ? Stot : 0);
+                    prel -= Etot + (k != last ? Stot : 0);
                 }
-                pos = prel + wb8;
+                posOut = prel + wb8;
             }
-            pos = (int)uni((u32)pos);
+            pos = (int)uni((u32)posOut);
             wave_fence();
             DSTAGE(2);
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;
             if ((u32)lane < cnt) { ll = L->seqLL[lane]; ml = L->seqML[lane]; off = L->seqOff[lane]; }
             if ((u32)lane < cnt) {                                               // code and position -> value
-                auto value = [&](u32 w, u32 base, u32 nb) -> u32 {
-                    const int q = (int)(w >> 8) - (int)nb;
-                    const uint64_t x = lds_ld64((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
+                auto value = [&](u32 p, u32 base, u32 nb) -> u32 {               // base + the nb bits right below window bit p
+                    const u32 q = p - nb;
+                    const uint64_t x = lds_ld64((const lbyte*)(uintptr_t)(winA + (q >> 3)));
                     return base + __builtin_amdgcn_ubfe((u32)(x >> (q & 7)), 0u, nb);
                 };
-                const u32 tl = L->llTab[ll & 0xFFu], tm = L->mlTab[ml & 0xFFu], so = off & 0xFFu;
-                ll = value(ll, tl & 0xFFFFFFu, tl >> 24);
-                ml = value(ml, tm & 0xFFFFFFu, tm >> 24);
-                off = value(off, 1u << so, so);
+                // (additional bits are stored offset, match length, literal length from the top)
+                const u32 tl = L->llTab[ll & 0xFFu], tm = L->mlTab[ml & 0xFFu], so = off & 0xFFu, top = off >> 8;
+                off = value(top, 1u << so, so);
+                ml = value(top - so, tm & 0xFFFFFFu, tm >> 24);
+                ll = value(top - so - (tm >> 24), tl & 0xFFFFFFu, tl >> 24);
             }
             off = rep_resolve(off, ll, (u32)lane < cnt, R0, R1, R2);
             if (q0 + cnt >= nbSeq && lane == 0) { L->rep[0] = R0; L->rep[1] = R1; L->rep[2] = R2; }
@@ -2777,7 +2791,9 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     }
                     put32(gd + myOut, ll < 32 ? ll : 32, v0, v1, v2, v3);
                 }
+                DCOUNT(0, 1); DCOUNT(5, cnt);
                 for (u64 lm = ballot(ll && !shortl); lm; lm &= lm - 1) {
+                    DCOUNT(3, 1);
                     const int k = (int)__builtin_ctzll(lm);
                     wave_copy(gd + lane_get(myOut, k), gl + lane_get(myLit, k), lane_get(ll, k), lane);
                 }
@@ -2801,8 +2817,10 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 bool first = true;
                 while (pend) {
                     bool blocked = false;
+                    DCOUNT(1, 1);
                     if (first) blocked = (inTile >> lane) & 1;
                     else {
+                        DCOUNT(2, __builtin_popcountll(pend));
                         for (u64 m = pend; m; m &= m - 1) {
                             const int j = (int)__builtin_ctzll(m);
                             const u32 mj = lane_get(mo, j), lj = lane_get(ml, j);
@@ -2821,7 +2839,9 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                         }
                         put32(gd + mo, ml < 32 ? ml : 32, v0, v1, v2, v3);
                     }
+                    DCOUNT(6, __builtin_popcountll(ready & ballot(small)));
                     for (u64 dm = ready & ballot(!small); dm; dm &= dm - 1) {
+                        DCOUNT(4, 1);
                         const int k = (int)__builtin_ctzll(dm);
                         wave_match_copy(dst + lane_get(mo, k), lane_get(off, k), lane_get(ml, k), lane);
                     }

@@ -29,3 +29,7 @@ dn += ["lit: before the streams (table)", "lit: speculative count rounds", "lit:
 print("---- decoder (entropy stage skipped on the compress side -> raw blocks!)" if ZEXP == 16 else "---- decoder")
 for n, v in zip(dn, buf[:8]):
     print(f"{n:48s} {v/tot*100:6.2f}%")
+c = list(buf[8:16])
+if c[0]:
+    print("tiles %d  sequences/tile %.1f  match levels/tile %.2f  blocked-loop trips/tile %.1f  whole-wave literal runs/tile %.2f  whole-wave matches/tile %.2f  one-per-lane matches/tile %.1f"
+          % (c[0], c[5] / c[0], c[1] / c[0], c[2] / c[0], c[3] / c[0], c[4] / c[0], c[6] / c[0]))
