@@ -2783,7 +2783,12 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                 //  as two overlapping 32-byte halves, instead of one after the other by the whole wave with a round trip each)
                 const bool shortl = ll <= 64 && (u64)myLit + 32 <= litSize + 0ull;   // the 32-byte read stays inside the literals
                 if (ll && shortl) {
-                    const u64 v0 = ld64(gl + myLit), v1 = ld64(gl + myLit + 8), v2 = ld64(gl + myLit + 16), v3 = ld64(gl + myLit + 24);
+                    // (a lane loads what its length needs: every 8-byte load of a lane is a trip through the vector memory pipe)
+                    const u64 v0 = ld64(gl + myLit);
+                    u64 v1 = 0, v2 = 0, v3 = 0;
+                    if (ll > 8) v1 = ld64(gl + myLit + 8);
+                    if (ll > 16) v2 = ld64(gl + myLit + 16);
+                    if (ll > 24) v3 = ld64(gl + myLit + 24);
                     if (ll > 32) {
                         const u32 t = ll - 32;
                         const u64 w0 = ld64(gl + myLit + t), w1 = ld64(gl + myLit + t + 8), w2 = ld64(gl + myLit + t + 16), w3 = ld64(gl + myLit + t + 24);
@@ -2831,7 +2836,11 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
                     const u64 ready = pend & ~ballot(blocked);
                     const bool go = (ready >> lane) & 1;
                     if (go && small) {
-                        const u64 v0 = ld64(gd + spos), v1 = ld64(gd + spos + 8), v2 = ld64(gd + spos + 16), v3 = ld64(gd + spos + 24);
+                        const u64 v0 = ld64(gd + spos);
+                        u64 v1 = 0, v2 = 0, v3 = 0;
+                        if (ml > 8) v1 = ld64(gd + spos + 8);
+                        if (ml > 16) v2 = ld64(gd + spos + 16);
+                        if (ml > 24) v3 = ld64(gd + spos + 24);
                         if (ml > 32) {                                              // (source and destination do not overlap: off >= ml)
                             const u32 t = ml - 32;
                             const u64 w0 = ld64(gd + spos + t), w1 = ld64(gd + spos + t + 8), w2 = ld64(gd + spos + t + 16), w3 = ld64(gd + spos + t + 24);
