@@ -77,14 +77,33 @@ HS_FN int run_count(Ld ld, Tab tab, const uint32_t tl, const int start, const in
     return p;
 }
 
-// The writing run: same walk; St4: void st4(uint32_t index, uint32_t fourSymbols) stores 4 bytes at out[index..index+3],
-// St1: void st1(uint32_t index, uint32_t symbol).  Returns the exit position.
-template <class Ld, class Tab, class St4, class St1>
-HS_FN int run_write(Ld ld, Tab tab, const uint32_t tl, const int start, const int limit, St4 st4, St1 st1)
+// The writing run: same walk; St16: void st16(uint32_t index, uint32_t a, uint32_t b, uint32_t c, uint32_t d) stores 16 bytes at
+// out[index..index+15] (a first), St4: void st4(uint32_t index, uint32_t fourSymbols), St1: void st1(uint32_t index, uint32_t symbol).
+// Sixteen symbols per store while the segment lasts: a lane's output is a cursor of its own, and 64 cursors that advance four
+// bytes at a time keep 64 cache lines half-written for long (the decoder's HBM write traffic was 3x its output).
+// Returns the exit position.
+template <class Ld, class Tab, class St16, class St4, class St1>
+HS_FN int run_write(Ld ld, Tab tab, const uint32_t tl, const int start, const int limit, St16 st16, St4 st4, St1 st1)
 {
     int p = start; uint32_t i = 0;
     if (p > limit) {
         Window<Ld> w; w.init(ld, p);
+        const int guard16 = limit + 15 * (int)tl;   // above it, sixteen codes cannot carry the position past the limit's code
+        while (p > guard16) {
+            uint32_t acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint64_t c = w.container(ld, p);
+                uint32_t a = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t cell = tab((uint32_t)(c >> (64 - tl))), nb = cell >> 8;
+                    a |= (cell & 0xFFu) << (8 * k); c <<= nb; p -= (int)nb;
+                }
+                acc[g] = a;
+            }
+            st16(i, acc[0], acc[1], acc[2], acc[3]); i += 16;
+        }
         const int guard = limit + 3 * (int)tl;
         while (p > guard) {
             uint64_t c = w.container(ld, p);

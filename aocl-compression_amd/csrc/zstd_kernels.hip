@@ -2383,7 +2383,9 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
     ok = ok && lastex == 0 && total == no;
     if (ballot(!ok) != 0) return false;
     const u32 off = oo + inc - cnt;
-    hufspec::run_write(ld, tab, tl, start, limit, [&](u32 i, u32 v) { st32(out + off + i, v); }, [&](u32 i, u32 v) { out[off + i] = (u8)v; });
+    hufspec::run_write(ld, tab, tl, start, limit,
+                       [&](u32 i, u32 a, u32 b, u32 c, u32 d) { typedef u32x4 __attribute__((aligned(1))) U4; u32x4 v = {a, b, c, d}; *(__attribute__((address_space(1))) U4*)((gbyte*)out + off + i) = v; },
+                       [&](u32 i, u32 v) { st32(out + off + i, v); }, [&](u32 i, u32 v) { out[off + i] = (u8)v; });
     DSTAGE(7);
     return true;
 }

@@ -75,6 +75,7 @@ extern "C" int hufspec_model_decode(const uint8_t* s, uint32_t n, const uint16_t
     for (int j = 0; j < lanes; ++j) {
         uint8_t* o = out + off;
         const int e = hufspec::run_write(ld, tab, tl, start[j], limit[j],
+            [&](uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { const uint32_t v[4] = {a, b, c, d}; memcpy(o + i, v, 16); },
             [&](uint32_t i, uint32_t v) { memcpy(o + i, &v, 4); }, [&](uint32_t i, uint32_t v) { o[i] = (uint8_t)v; });
         if (e != exitp[j]) return -3;
         off += cnt[j];
