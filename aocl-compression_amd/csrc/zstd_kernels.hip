@@ -2541,9 +2541,14 @@ __device__ __forceinline__ u32 rep_resolve(u32 val, u32 ll, bool active, u32& R0
 }
 
 // one compressed block (ZSTD_decompressBlock_internal :2444-2552); returns decoded size or 0xFFFFFFFF
-__device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* dst, u32 opos, u32 cap, u32 blockMax,
-                            u8* litBuf, int lane, const bool keep)
+__device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8* dst_, u32 opos_, u32 cap_, u32 blockMax_,
+                            u8* litBuf_, int lane, const bool keep_)
 {   // keep: another block of the frame follows and may reuse this block's tables (DecLds)
+    // (a call, not inlined: inlined, the kernel's own state competes for the 80 registers and the tile loop spills ten times as
+    //  often; the arguments of a call arrive in vector registers and are made scalar again here)
+    DecLds* L = uni_ptr(L_); const u8* src = uni_ptr(src_); const u32 n = uni(n_); u8* dst = uni_ptr(dst_);
+    const u32 opos = uni(opos_), cap = uni(cap_), blockMax = uni(blockMax_); u8* litBuf = uni_ptr(litBuf_);
+    const bool keep = uni(keep_ ? 1u : 0u) != 0;
     typedef __attribute__((address_space(3))) u32x4 LV4;
     auto park = [&](u32 at, const void* tab, u32 bytes) {                // LDS -> workspace
         gbyte* g = (gbyte*)litBuf + at;
@@ -2567,26 +2572,26 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
     if (n < 1) return 0xFFFFFFFFu;
     u32 ip = 0, litSize = 0; const u8* litPtr = nullptr;
     {   // ---- literals (ZSTD_decodeLiteralsBlock :162-364) ----
-        const u32 b0 = src[0], type = b0 & 3, fmt = (b0 >> 2) & 3;
+        const u32 b0 = uni(src[0]), type = b0 & 3, fmt = (b0 >> 2) & 3;
         if (type < 2) {
             u32 lh;
             if (fmt == 0 || fmt == 2) { lh = 1; litSize = b0 >> 3; }
-            else if (fmt == 1) { if (n < 2) return 0xFFFFFFFFu; lh = 2; litSize = (b0 | ((u32)src[1] << 8)) >> 4; }
-            else { if (n < 3) return 0xFFFFFFFFu; lh = 3; litSize = (b0 | ((u32)src[1] << 8) | ((u32)src[2] << 16)) >> 4; }
+            else if (fmt == 1) { if (n < 2) return 0xFFFFFFFFu; lh = 2; litSize = (b0 | (uni(src[1]) << 8)) >> 4; }
+            else { if (n < 3) return 0xFFFFFFFFu; lh = 3; litSize = (b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16)) >> 4; }
             if (litSize > blockMax) return 0xFFFFFFFFu;
             if (type == 0) { if (lh + litSize > n) return 0xFFFFFFFFu; litPtr = src + lh; ip = lh + litSize; }
             else {
                 if (lh + 1 > n) return 0xFFFFFFFFu;
-                const u8 v = src[lh];
+                const u8 v = (u8)uni(src[lh]);
                 for (u32 i = (u32)lane; i < litSize; i += kWave) litBuf[i] = v;
                 wave_fence();
                 litPtr = litBuf; ip = lh + 1;
             }
         } else {
             u32 lh, csize; bool streams4 = true;
-            if (fmt < 2) { if (n < 3) return 0xFFFFFFFFu; const u32 v = b0 | ((u32)src[1] << 8) | ((u32)src[2] << 16); lh = 3; streams4 = (fmt == 1); litSize = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
-            else if (fmt == 2) { if (n < 4) return 0xFFFFFFFFu; const u32 v = ld32(src); lh = 4; litSize = (v >> 4) & 0x3FFF; csize = v >> 18; }
-            else { if (n < 5) return 0xFFFFFFFFu; const u32 v = ld32(src); lh = 5; litSize = (v >> 4) & 0x3FFFF; csize = (v >> 22) + ((u32)src[4] << 10); }
+            if (fmt < 2) { if (n < 3) return 0xFFFFFFFFu; const u32 v = b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16); lh = 3; streams4 = (fmt == 1); litSize = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+            else if (fmt == 2) { if (n < 4) return 0xFFFFFFFFu; const u32 v = uni(ld32(src)); lh = 4; litSize = (v >> 4) & 0x3FFF; csize = v >> 18; }
+            else { if (n < 5) return 0xFFFFFFFFu; const u32 v = uni(ld32(src)); lh = 5; litSize = (v >> 4) & 0x3FFFF; csize = (v >> 22) + (uni(src[4]) << 10); }
             if (litSize > blockMax || litSize == 0 || lh + csize > n) return 0xFFFFFFFFu;
             u32 hoff = lh, hsz = csize;
             if (type == 2) {
@@ -2604,7 +2609,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             if (!streams4) ok = huf_decode_streams(L, litBuf, litSize, src + hoff, hsz, big, lane == 0, lane);
             else {
                 if (litSize < 6 || hsz < 10) return 0xFFFFFFFFu;
-                const u32 s1 = ld16(src + hoff), s2 = ld16(src + hoff + 2), s3 = ld16(src + hoff + 4), seg = (litSize + 3) / 4;
+                const u32 s1 = uni(ld16(src + hoff)), s2 = uni(ld16(src + hoff + 2)), s3 = uni(ld16(src + hoff + 4)), seg = (litSize + 3) / 4;
                 if (6 + s1 + s2 + s3 > hsz || 3 * seg > litSize) return 0xFFFFFFFFu;
                 const u32 s4 = hsz - 6 - s1 - s2 - s3;
                 const u32 j = (u32)lane & 3;
@@ -2632,17 +2637,17 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
     DSTAGE(0);
     // ---- sequences header (ZSTD_decodeSeqHeaders :707-790) ----
     if (ip >= n) return 0xFFFFFFFFu;
-    u32 nbSeq = src[ip++];
+    u32 nbSeq = uni(src[ip++]);
     if (nbSeq > 0x7F) {
-        if (nbSeq == 0xFF) { if (ip + 2 > n) return 0xFFFFFFFFu; nbSeq = ld16(src + ip) + 0x7F00; ip += 2; }
-        else { if (ip >= n) return 0xFFFFFFFFu; nbSeq = ((nbSeq - 0x80) << 8) + src[ip++]; }
+        if (nbSeq == 0xFF) { if (ip + 2 > n) return 0xFFFFFFFFu; nbSeq = uni(ld16(src + ip)) + 0x7F00; ip += 2; }
+        else { if (ip >= n) return 0xFFFFFFFFu; nbSeq = ((nbSeq - 0x80) << 8) + uni(src[ip++]); }
     }
     nbSeq = uni(nbSeq);                                                          // (wave-uniform: loop counts stay in scalar registers)
     u32 out = opos, litPos = 0;
     if (nbSeq == 0) { if (ip != n) return 0xFFFFFFFFu; }
     else {
         if (ip >= n) return 0xFFFFFFFFu;
-        const u32 modes = src[ip++];
+        const u32 modes = uni(src[ip++]);
         if (modes & 3) return 0xFFFFFFFFu;
         const u32 mLL = modes >> 6, mOF = (modes >> 4) & 3, mML = (modes >> 2) & 3;
         if ((mLL == 3 || mOF == 3 || mML == 3) && !uni(L->haveLL | L->haveOF | L->haveML)) return 0xFFFFFFFFu;   // nothing to repeat
@@ -2681,7 +2686,7 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
             wave_fence();
         };
         {
-            const int bits = bit_stream_bits(src + ip, n - ip);
+            const int bits = (int)uni((u32)bit_stream_bits(src + ip, n - ip));
             if (bits < 0) return 0xFFFFFFFFu;
             pos = bits;
             refill();
@@ -2874,42 +2879,48 @@ __device__ u32 decode_block(DecLds* L, const u8* __restrict__ src, u32 n, u8* ds
     return out - opos;
 }
 
-__device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8* dst, const u32 cap, DecLds* L,
-                                    u8* litBuf, int lane)
+__device__ __forceinline__ int zstd_decompress_wave(const u8* __restrict__ src_, const u32 n_, u8* dst_, const u32 cap_, DecLds* L,
+                                    u8* litBuf_, int lane)
 {
+    // Everything that steers the decoder is wave-uniform, and said so (readfirstlane): what is read from the stream - frame and
+    // block headers, section sizes, modes - would otherwise count as divergent, and with it every position, every loop and every
+    // address derived from it (vector registers, exec-mask loops, 64-bit vector address arithmetic; the spills of that cost the
+    // decoder more HBM traffic than its output).
+    const u8* src = uni_ptr(src_); const u32 n = uni(n_); u8* dst = uni_ptr(dst_); const u32 cap = uni(cap_); u8* litBuf = uni_ptr(litBuf_);
     u32 ip = 0, op = 0;
     if (n == 0) return cap == 0 ? 0 : -1;
     while (ip < n) {
         if (n - ip < 4) return -1;
-        const u32 magic = ld32(src + ip);
+        const u32 magic = uni(ld32(src + ip));
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                              // skippable frame
             if (n - ip < 8) return -1;
-            const u32 sz = ld32(src + ip + 4);
+            const u32 sz = uni(ld32(src + ip + 4));
             if ((u64)sz + 8 > n - ip) return -1;
             ip += 8 + sz; continue;
         }
         if (magic != 0xFD2FB528u) return -1;
         if (n - ip < 5) return -1;
-        const u32 fhd = src[ip + 4]; ip += 5;                                    // ZSTD_getFrameHeader_advanced :438-560
+        const u32 fhd = uni(src[ip + 4]); ip += 5;                                    // ZSTD_getFrameHeader_advanced :438-560
         const u32 fcsId = fhd >> 6, single = (fhd >> 5) & 1, hasCk = (fhd >> 2) & 1, dictIdSz = fhd & 3;
         if (fhd & 0x08) return -1;
         u64 windowSize = 0, fcs = 0; bool haveFcs = false;
         if (!single) {
             if (ip >= n) return -1;
-            const u32 wb = src[ip++], wl = (wb >> 3) + 10;
+            const u32 wb = uni(src[ip++]), wl = (wb >> 3) + 10;
             if (wl > 31) return -1;
             windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wb & 7);
         }
         {   const u32 dsz = dictIdSz == 3 ? 4 : dictIdSz; u32 id = 0;
             if (n - ip < dsz) return -1;
             for (u32 k = 0; k < dsz; ++k) id |= (u32)src[ip + k] << (8 * k);
+            id = uni(id);
             ip += dsz;
             if (id != 0) return -1;                                              // no dictionary support
         }
-        if (fcsId == 0) { if (single) { if (ip >= n) return -1; fcs = src[ip++]; haveFcs = true; } }
-        else if (fcsId == 1) { if (n - ip < 2) return -1; fcs = (u64)ld16(src + ip) + 256; ip += 2; haveFcs = true; }
-        else if (fcsId == 2) { if (n - ip < 4) return -1; fcs = ld32(src + ip); ip += 4; haveFcs = true; }
-        else { if (n - ip < 8) return -1; fcs = ld64(src + ip); ip += 8; haveFcs = true; }
+        if (fcsId == 0) { if (single) { if (ip >= n) return -1; fcs = uni(src[ip++]); haveFcs = true; } }
+        else if (fcsId == 1) { if (n - ip < 2) return -1; fcs = (u64)uni(ld16(src + ip)) + 256; ip += 2; haveFcs = true; }
+        else if (fcsId == 2) { if (n - ip < 4) return -1; fcs = uni(ld32(src + ip)); ip += 4; haveFcs = true; }
+        else { if (n - ip < 8) return -1; const u64 f8 = ld64(src + ip); fcs = ((u64)uni((u32)(f8 >> 32)) << 32) | uni((u32)f8); ip += 8; haveFcs = true; }
         if (single) windowSize = fcs;
         const u32 frameStart = op;
         if (lane == 0) { L->rep[0] = 1; L->rep[1] = 4; L->rep[2] = 8; L->haveLL = L->haveOF = L->haveML = L->haveHuf = 0; }
@@ -2917,12 +2928,12 @@ __device__ int zstd_decompress_wave(const u8* __restrict__ src, const u32 n, u8*
         const u32 blockMax = windowSize < kBlockMax ? (u32)windowSize : kBlockMax;
         for (;;) {                                                               // ZSTD_decompressFrame :1005-1111
             if (n - ip < 3) return -1;
-            const u32 bh = src[ip] | ((u32)src[ip + 1] << 8) | ((u32)src[ip + 2] << 16); ip += 3;
+            const u32 bh = uni(src[ip] | ((u32)src[ip + 1] << 8) | ((u32)src[ip + 2] << 16)); ip += 3;
             const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
             if (type == 3) return -1;
             if (type == 1) {
                 if (ip >= n || bsz > cap - op || bsz > blockMax) return -1;
-                const u8 v = src[ip];
+                const u8 v = (u8)uni(src[ip]);
                 for (u32 i = (u32)lane; i < bsz; i += kWave) dst[op + i] = v;
                 wave_fence();
                 ip += 1; op += bsz;
