@@ -20,8 +20,9 @@ namespace aoclgpu {
 constexpr uint32_t kGrpBlock = 2048, kGrpHist = 64;
 constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | block | slack for the history read behind a full block
 
-// TINY: copies shorter than 4 bytes exist (Snappy).  Returns the group's output bytes (= what `op` advances by).
-template <bool TINY>
+// TINY: copies shorter than 4 bytes exist (Snappy, Zstd).  SPLIT: literals and far copies in two rounds of loads instead of one (half
+// the registers in flight).  Returns the group's output bytes (= what `op` advances by).
+template <bool TINY, bool SPLIT = false>
 __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ src, gbyte* dst, lbyte* cb, bool& hist_ok, const uint32_t op,
                                                      const uint32_t ng, const bool act, const uint32_t lit, const uint32_t mlen, const uint32_t off,
                                                      const uint32_t litsrc, const uint32_t lpos, const uint32_t mst, const uint32_t total)
@@ -49,6 +50,35 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
     const uint32_t le4 = lit - 4, lp4a = le4 < 4 ? le4 : 4u, lp4b = le4 < 8 ? le4 : 8u;
     const uint32_t me16 = mlen - 16, mp16a = me16 < 16 ? me16 : 16u, mp16b = me16 < 32 ? me16 : 32u;
     const uint32_t me4 = mlen - 4, mp4a = me4 < 4 ? me4 : 4u, mp4b = me4 < 8 ? me4 : 8u;
+    lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
+    if constexpr (SPLIT) {
+        // two rounds - the literals, then the far copies - with half the registers in flight (the Zstd decoder's budget)
+        {
+            u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            uint8_t b0 = 0, b1 = 0, b2 = 0;
+            if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
+            if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
+            if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
+            asm volatile("" ::: "memory");
+            if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
+            if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
+            if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
+        }
+        asm volatile("" ::: "memory");
+        {
+            u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
+            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+            uint8_t c0 = 0, c1 = 0, c2 = 0;
+            if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
+            if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
+            if (m1) { c0 = dst[mo]; c1 = dst[mo + (mlen >> 1)]; c2 = dst[mo + mlen - 1]; }
+            asm volatile("" ::: "memory");
+            if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
+            if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
+            if (m1) { md_[0] = c0; md_[mlen >> 1] = c1; md_[mlen - 1] = c2; }
+        }
+    } else {
     u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     uint8_t b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
@@ -59,13 +89,13 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
     if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
     if (m1) { c0 = dst[mo]; c1 = dst[mo + (mlen >> 1)]; c2 = dst[mo + mlen - 1]; }
     asm volatile("" ::: "memory");
-    lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
     if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
     if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
     if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
     if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
     if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
     if (m1) { md_[0] = c0; md_[mlen >> 1] = c1; md_[mlen - 1] = c2; }
+    }
     // runs of 65 .. 259 bytes (rare): the whole wave, 4 bytes per lane, one after the other
     for (uint64_t m = ballot(act && lit > 64); m; m &= m - 1) {
         const int k = (int)__builtin_ctzll(m);

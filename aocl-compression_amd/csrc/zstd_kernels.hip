@@ -25,6 +25,7 @@
 #include "zstd_entropy.hip.h"
 #include "zstd_chain.h"
 #include "zstd_hufspec.h"
+#include "lz_group.hip.h"
 #include "host_util.h"
 #include <mutex>
 #include <type_traits>
@@ -2026,13 +2027,6 @@ struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (ro
         struct { u8 ll3[1536], of3[768], ml3[1536], seqBuild[512]; };
         struct { s16 wnorm[256]; u16 wnext[256]; };           // reading the FSE table of the Huffman weights (before huf is built)
     };
-    u32 llLog, ofLog, mlLog, hufLog;
-    u32 haveLL, haveOF, haveML, haveHuf;
-    u32 rep[3];
-    u32 zeroWord, dumpWord, pad_[2];                          // a cell of zeros / a sink for the idle lanes of the sequence loop
-#ifdef ZSTD_DEC_LDS_PAD                                      /* residency experiments: fewer blocks per CU */
-    u8 residencyPad[ZSTD_DEC_LDS_PAD];
-#endif
     // 1920 bytes that three phases of a block use one after the other (6336 bytes in all = 5 granules):
     union {
         u8 hwin[4][480] __attribute__((aligned(16)));       // literals by one lane per stream (12-bit tables, single streams): windows of
@@ -2049,7 +2043,19 @@ struct DecLds {                     // 7.3 KB = 6 LDS granules of 1280 bytes (ro
             u32 llTab[36], mlTab[53];                        // base | additional bits << 24 per length code
         };
     };
+    // (behind the unions: seqBuild, bswin and the seq arrays - 2048 bytes in a row, all of them dead while a tile of sequences is
+    //  executed - hold the tile's output block then: lz_group.hip.h, 64 bytes of history + kDecGrpBlock + 16)
+    u32 llLog, ofLog, mlLog, hufLog;
+    u32 haveLL, haveOF, haveML, haveHuf;
+    u32 rep[3];
+    u32 zeroWord, dumpWord, pad_[2];                          // a cell of zeros / a sink for the idle lanes of the sequence loop
+#ifdef ZSTD_DEC_LDS_PAD                                      /* residency experiments: fewer blocks per CU */
+    u8 residencyPad[ZSTD_DEC_LDS_PAD];
+#endif
 };
+constexpr u32 kDecGrpBlock = 1920;
+static_assert(offsetof(DecLds, bswin) == offsetof(DecLds, seqBuild) + 512 && offsetof(DecLds, llTab) >= offsetof(DecLds, seqBuild) + kGrpHist + kDecGrpBlock + 16,
+              "the output block of a tile runs from seqBuild to the end of the seq arrays");
 static_assert(sizeof(DecLds) <= 6400 || sizeof(DecLds) > 20000, "five LDS granules per block");
 
 // FSE_readNCount (entropy_common.c:40-186), lane-serial; bytes consumed or 0xFFFFFFFF
@@ -2635,6 +2641,7 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
         }
     }
     DSTAGE(0);
+    litPtr = uni_ptr(litPtr); litSize = uni(litSize); ip = uni(ip);               // (scalar base: the tile's loads take a 32-bit offset each)
     // ---- sequences header (ZSTD_decodeSeqHeaders :707-790) ----
     if (ip >= n) return 0xFFFFFFFFu;
     u32 nbSeq = uni(src[ip++]);
@@ -2700,14 +2707,11 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
         pos = (int)lane_get((u32)b.pos, 0);
         // per-lane roles of the sequence loop
         typedef __attribute__((address_space(3))) u32 L32;
-        const u32 zeroA = (u32)(uintptr_t)(lbyte*)&L->zeroWord;
-        const u32 tabA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->of3[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->ml3[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->ll3[0] : zeroA;
-        const u32 outA = lane == 0 ? (u32)(uintptr_t)(lbyte*)&L->seqOff[0] : lane == 1 ? (u32)(uintptr_t)(lbyte*)&L->seqML[0] : lane == 2 ? (u32)(uintptr_t)(lbyte*)&L->seqLL[0]
-                                   : (u32)(uintptr_t)(lbyte*)&L->dumpWord;
-        const u32 outStride = lane < 3 ? 4u : 0u;
         const u32 winA = (u32)(uintptr_t)win;
         u32 st = lane == 0 ? lane_get(sOF, 0) : lane == 1 ? lane_get(sML, 0) : lane == 2 ? lane_get(sLL, 0) : 0u;
         DSTAGE(1);
+        lbyte* cb = (lbyte*)&L->seqBuild[0];                                      // history + output block of the tiles (lz_group.hip.h)
+        bool hist_ok = false;
         for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
             const u32 cnt = nbSeq - q0 < kWave ? nbSeq - q0 : kWave;
             if (q0) refill();
@@ -2716,6 +2720,14 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             // the position of the sequence's additional bits that the loop leaves behind (positions relative to the window: 13 bits).
             // Trip count and bit position are wave-uniform (readfirstlane): counters and branches stay in scalar registers.  Eight
             // lanes, not 64: an LDS instruction costs by its active lanes (all 64 lanes in this loop: 38 -> 70 ms for the bench).
+            // (the lanes' roles are worked out anew for every tile: kept across the tile's execution they are three registers the
+            //  executor needs - the opaque copy of the lane number keeps the compiler from hoisting them)
+            int lane_o = lane; asm volatile("" : "+v"(lane_o));
+            const u32 zeroA = (u32)(uintptr_t)(lbyte*)&L->zeroWord;
+            const u32 tabA = lane_o == 0 ? (u32)(uintptr_t)(lbyte*)&L->of3[0] : lane_o == 1 ? (u32)(uintptr_t)(lbyte*)&L->ml3[0] : lane_o == 2 ? (u32)(uintptr_t)(lbyte*)&L->ll3[0] : zeroA;
+            const u32 outA = lane_o == 0 ? (u32)(uintptr_t)(lbyte*)&L->seqOff[0] : lane_o == 1 ? (u32)(uintptr_t)(lbyte*)&L->seqML[0] : lane_o == 2 ? (u32)(uintptr_t)(lbyte*)&L->seqLL[0]
+                                         : (u32)(uintptr_t)(lbyte*)&L->dumpWord;
+            const u32 outStride = lane_o < 3 ? 4u : 0u;
             const int posU = (int)uni((u32)pos), wbU = (int)uni((u32)wbase);
             int posOut = posU;
             if (lane < 8) {
@@ -2769,101 +2781,45 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             const u32 myLit = litPos + incL - ll, myOut = out + incO - (ll + ml);
             // offsets must point inside what is already produced
             if (ballot((u32)lane < cnt && off > myOut + ll) != 0) return 0xFFFFFFFFu;
-            // exact-length copy of len <= 32 bytes held in v0..v3 (overlapping stores, never past d + len)
-            auto put32 = [&](gbyte* d, u32 len, u64 v0, u64 v1, u64 v2, u64 v3) {
-                auto ext = [&](u32 o) -> u64 {                                    // bytes [o, o+8) of v0|v1|v2|v3, o <= 24
-                    const u64 a = o < 8 ? v0 : (o < 16 ? v1 : (o < 24 ? v2 : v3)), bb = o < 8 ? v1 : (o < 16 ? v2 : v3);
-                    const u32 sh = (o & 7) * 8;
-                    return sh ? (a >> sh) | (bb << (64 - sh)) : a;
-                };
-                if (len >= 8) {
-                    st64(d, v0);
-                    if (len > 8) st64(d + (len > 16 ? 8 : len - 8), ext(len > 16 ? 8 : len - 8));
-                    if (len > 16) st64(d + (len > 24 ? 16 : len - 8), ext(len > 24 ? 16 : len - 8));
-                    if (len > 24) st64(d + len - 8, ext(len - 8));
-                } else if (len >= 4) { st32(d, (u32)v0); st32(d + len - 4, (u32)(v0 >> (8 * (len - 4)))); }
-                else for (u32 i = 0; i < len; ++i) d[i] = (u8)(v0 >> (8 * i));
-            };
-            {   // literals: runs of up to 32 bytes one sequence per lane (four 8-byte loads, exact-length stores), longer runs by the wave
-                gbyte* gd = (gbyte*)dst; const gbyte* gl = (const gbyte*)litPtr;     // output and literal buffer are global memory
-                // (round 5: runs of 33 .. 64 bytes - 3 % of the runs, 15 % of the matches on the bench corpus - go one per lane as well,
-                //  as two overlapping 32-byte halves, instead of one after the other by the whole wave with a round trip each)
-                const bool shortl = ll <= 64 && (u64)myLit + 32 <= litSize + 0ull;   // the 32-byte read stays inside the literals
-                if (ll && shortl) {
-                    // (a lane loads what its length needs: every 8-byte load of a lane is a trip through the vector memory pipe)
-                    const u64 v0 = ld64(gl + myLit);
-                    u64 v1 = 0, v2 = 0, v3 = 0;
-                    if (ll > 8) v1 = ld64(gl + myLit + 8);
-                    if (ll > 16) v2 = ld64(gl + myLit + 16);
-                    if (ll > 24) v3 = ld64(gl + myLit + 24);
-                    if (ll > 32) {
-                        const u32 t = ll - 32;
-                        const u64 w0 = ld64(gl + myLit + t), w1 = ld64(gl + myLit + t + 8), w2 = ld64(gl + myLit + t + 16), w3 = ld64(gl + myLit + t + 24);
-                        put32(gd + myOut + t, 32, w0, w1, w2, w3);
+            // The tile is executed by the LZ4 / Snappy decoders' group machinery (lz_group.hip.h): the sequences that fit an output
+            // block in LDS go one per lane - literals and every match whose source ends in front of the block in ONE round of
+            // loads, matches that read the block itself (or the 64 bytes of history in front of it) as LDS-to-LDS copies in
+            // sequence order - and the block leaves with 16-byte stores: every output line is written once, and a chain of matches
+            // that feed each other does not pay a trip to memory and back per link (4.4 dependency levels per tile on the bench
+            // corpus; with 24 blocks per CU the half-written lines did not live in L2 until their last store, and the decoder
+            // wrote 3x its output to HBM).  A sequence that does not fit a block, or whose match starts further in front of the
+            // block than the history and still reaches into it, goes by the whole wave through global memory.  The block stands
+            // where the tile's bitstream window and sequence arrays were (DecLds): both are dead by now.
+            {
+                const gbyte* gl = (const gbyte*)litPtr; gbyte* gd = (gbyte*)dst;
+                const u32 relOut = incO - (ll + ml);                                      // tile-relative output offset
+                u32 start = 0;
+                while (start < cnt) {
+                    const u32 g0 = lane_get(relOut, (int)start);                          // tile-relative output offset of this group
+                    const bool in = (u32)lane >= start && (u32)lane < cnt;
+                    const u32 lpos = relOut - g0, mst = lpos + ll, endrel = mst + ml;    // block-relative
+                    const int32_t srel = (int32_t)mst - (int32_t)off;
+                    const u64 fit = ballot(in && endrel <= kDecGrpBlock);                 // (a prefix of [start, cnt): endrel grows)
+                    const u64 slow = ballot(in && ml != 0 && srel + (int32_t)ml > 0 && srel < -(int32_t)kGrpHist);
+                    u32 ng = (u32)__builtin_popcountll(fit);
+                    if (slow) { const u32 fsl = (u32)__builtin_ctzll(slow) - start; ng = fsl < ng ? fsl : ng; }
+                    DCOUNT(1, 1);
+                    if (ng == 0) {                                                        // one sequence by the whole wave
+                        const u32 o_ = out + g0, l_ = lane_get(ll, (int)start), m_ = lane_get(ml, (int)start);
+                        DCOUNT(4, 1);
+                        wave_copy(gd + o_, gl + lane_get(myLit, (int)start), l_, lane);
+                        wave_fence();
+                        if (m_) wave_match_copy(dst + o_ + l_, lane_get(off, (int)start), m_, lane);
+                        hist_ok = false;
+                        start++;
+                        continue;
                     }
-                    put32(gd + myOut, ll < 32 ? ll : 32, v0, v1, v2, v3);
+                    const bool act = in && (u32)lane < start + ng;
+                    const u32 total = lane_get(endrel, (int)(start + ng - 1));
+                    (void)lz_group_execute<true, true>(gl, gd, cb, hist_ok, out + g0, ng, act, ll, ml, off, myLit, lpos, mst, total);
+                    start += ng;
                 }
                 DCOUNT(0, 1); DCOUNT(5, cnt);
-                for (u64 lm = ballot(ll && !shortl); lm; lm &= lm - 1) {
-                    DCOUNT(3, 1);
-                    const int k = (int)__builtin_ctzll(lm);
-                    wave_copy(gd + lane_get(myOut, k), gl + lane_get(myLit, k), lane_get(ll, k), lane);
-                }
-            }
-            wave_fence();
-            DSTAGE(3);
-            {   // Matches, in dependency levels.  A match is READY when its source does not overlap the destination of a match of
-                // this tile that is still pending (literals are all in place by now; earlier tiles are complete).  All ready
-                // matches of a level go at once: the short ones that do not overlap themselves one per lane (one global round
-                // trip for all of them), the long or self-overlapping ones by the whole wave.  The lowest pending match is always
-                // ready, so every level makes progress; chains of matches that feed each other are two or three levels deep
-                // where an in-order loop pays a round trip per match.
-                gbyte* gd = (gbyte*)dst;
-                const u32 mo = myOut + ll, spos = mo - off;
-                const bool mine = (u32)lane < cnt && ml != 0;
-                const bool small = mine && ml <= 64 && off >= ml && (u64)spos + 32 <= cap;
-                // level 0: every match whose source lies before this tile's output; only the others can be blocked, and only by
-                // one another (whatever blocks them among the level-0 matches is done by then)
-                const u64 inTile = ballot(mine && spos + ml > out);
-                u64 pend = ballot(mine);
-                bool first = true;
-                while (pend) {
-                    bool blocked = false;
-                    DCOUNT(1, 1);
-                    if (first) blocked = (inTile >> lane) & 1;
-                    else {
-                        DCOUNT(2, __builtin_popcountll(pend));
-                        for (u64 m = pend; m; m &= m - 1) {
-                            const int j = (int)__builtin_ctzll(m);
-                            const u32 mj = lane_get(mo, j), lj = lane_get(ml, j);
-                            blocked = blocked || (j < lane && spos < mj + lj && mj < spos + ml);
-                        }
-                    }
-                    first = false;
-                    const u64 ready = pend & ~ballot(blocked);
-                    const bool go = (ready >> lane) & 1;
-                    if (go && small) {
-                        const u64 v0 = ld64(gd + spos);
-                        u64 v1 = 0, v2 = 0, v3 = 0;
-                        if (ml > 8) v1 = ld64(gd + spos + 8);
-                        if (ml > 16) v2 = ld64(gd + spos + 16);
-                        if (ml > 24) v3 = ld64(gd + spos + 24);
-                        if (ml > 32) {                                              // (source and destination do not overlap: off >= ml)
-                            const u32 t = ml - 32;
-                            const u64 w0 = ld64(gd + spos + t), w1 = ld64(gd + spos + t + 8), w2 = ld64(gd + spos + t + 16), w3 = ld64(gd + spos + t + 24);
-                            put32(gd + mo + t, 32, w0, w1, w2, w3);
-                        }
-                        put32(gd + mo, ml < 32 ? ml : 32, v0, v1, v2, v3);
-                    }
-                    DCOUNT(6, __builtin_popcountll(ready & ballot(small)));
-                    for (u64 dm = ready & ballot(!small); dm; dm &= dm - 1) {
-                        DCOUNT(4, 1);
-                        const int k = (int)__builtin_ctzll(dm);
-                        wave_match_copy(dst + lane_get(mo, k), lane_get(off, k), lane_get(ml, k), lane);
-                    }
-                    wave_fence();
-                    pend &= ~ready;
-                }
             }
             litPos += totL; out += totO;
             DSTAGE(4);
