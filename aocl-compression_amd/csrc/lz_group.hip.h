@@ -18,6 +18,18 @@
 namespace aoclgpu {
 
 constexpr uint32_t kGrpBlock = 2048, kGrpHist = 64;
+
+// Loads with a scalar base and a 32-bit lane offset, written out (SPLIT only).  The compiler moves the 64-bit address arithmetic
+// of a conditional load out of its block and then cannot fold base + offset into the instruction: every piece costs a 64-bit
+// vector add and a register pair that lives from there to the load - in the Zstd decoder, where the budget is 80 registers,
+// those pairs were spilled.  The compiler does not count these loads: grp_loads_done waits for them and ties the values to the wait.
+__device__ __forceinline__ u32x4 grp_ld128(const gbyte* sbase, uint32_t voff) { u32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
+__device__ __forceinline__ uint32_t grp_ld32(const gbyte* sbase, uint32_t voff) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
+__device__ __forceinline__ uint32_t grp_ld8(const gbyte* sbase, uint32_t voff) { uint32_t v; asm volatile("global_load_ubyte %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
+__device__ __forceinline__ void grp_loads_done(u32x4& a, u32x4& b, u32x4& c, u32x4& d, uint32_t& e, uint32_t& f, uint32_t& g, uint32_t& h, uint32_t& i, uint32_t& j, uint32_t& k)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j), "+v"(k) : : "memory");
+}
 constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | block | slack for the history read behind a full block
 
 // TINY: copies shorter than 4 bytes exist (Snappy, Zstd).  SPLIT: literals and far copies in two rounds of loads instead of one (half
@@ -55,28 +67,26 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
         // two rounds - the literals, then the far copies - with half the registers in flight (the Zstd decoder's budget)
         {
             u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-            uint8_t b0 = 0, b1 = 0, b2 = 0;
-            if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
-            if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
-            if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
-            asm volatile("" ::: "memory");
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, b0 = 0, b1 = 0, b2 = 0;
+            if (l16) { q0 = grp_ld128(src, litsrc); q1 = grp_ld128(src, litsrc + lp16a); q2 = grp_ld128(src, litsrc + lp16b); q3 = grp_ld128(src, litsrc + le16); }
+            if (l4) { r0 = grp_ld32(src, litsrc); r1 = grp_ld32(src, litsrc + lp4a); r2 = grp_ld32(src, litsrc + lp4b); r3 = grp_ld32(src, litsrc + le4); }
+            if (l1) { b0 = grp_ld8(src, litsrc); b1 = grp_ld8(src, litsrc + (lit >> 1)); b2 = grp_ld8(src, litsrc + lit - 1); }
+            grp_loads_done(q0, q1, q2, q3, r0, r1, r2, r3, b0, b1, b2);
             if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
             if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
-            if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
+            if (l1) { ld_[0] = (uint8_t)b0; ld_[lit >> 1] = (uint8_t)b1; ld_[lit - 1] = (uint8_t)b2; }
         }
         asm volatile("" ::: "memory");
         {
             u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
-            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-            uint8_t c0 = 0, c1 = 0, c2 = 0;
-            if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
-            if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
-            if (m1) { c0 = dst[mo]; c1 = dst[mo + (mlen >> 1)]; c2 = dst[mo + mlen - 1]; }
-            asm volatile("" ::: "memory");
+            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, c0 = 0, c1 = 0, c2 = 0;
+            if (m16) { g0 = grp_ld128(dst, mo); g1 = grp_ld128(dst, mo + mp16a); g2 = grp_ld128(dst, mo + mp16b); g3 = grp_ld128(dst, mo + me16); }
+            if (m4) { h0 = grp_ld32(dst, mo); h1 = grp_ld32(dst, mo + mp4a); h2 = grp_ld32(dst, mo + mp4b); h3 = grp_ld32(dst, mo + me4); }
+            if (m1) { c0 = grp_ld8(dst, mo); c1 = grp_ld8(dst, mo + (mlen >> 1)); c2 = grp_ld8(dst, mo + mlen - 1); }
+            grp_loads_done(g0, g1, g2, g3, h0, h1, h2, h3, c0, c1, c2);
             if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
             if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
-            if (m1) { md_[0] = c0; md_[mlen >> 1] = c1; md_[mlen - 1] = c2; }
+            if (m1) { md_[0] = (uint8_t)c0; md_[mlen >> 1] = (uint8_t)c1; md_[mlen - 1] = (uint8_t)c2; }
         }
     } else {
     u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
