@@ -421,8 +421,10 @@ __device__ void huf_bucket_sort(u32* a, int lo0, int hi0, short* todo /* 64 */)
 
 // Code lengths and code values of the literals (HUF_buildCTable_wksp, huf_compress.c:758-794, with HUF_sort :624-668,
 // HUF_buildTree :685-725, HUF_setMaxHeight :378-495).  hist = counts of symbols 0..maxSym (LDS).  Returns the table log.
-__device__ u32 huf_build_wave(HufCT* ct, const u32* hist, const u32 maxSym, const u32 maxNbBits, HufScratch* sc, int lane)
+__device__ u32 huf_build_wave(HufCT* ct_, const u32* hist_, const u32 maxSym_, const u32 maxNbBits_, HufScratch* sc_, int lane)
 {
+    // (a call: the arguments arrive in vector registers and count as divergent - made scalar again, common.hip.h uni_ptr)
+    HufCT* ct = uni_ptr(ct_); const u32* hist = uni_ptr(hist_); const u32 maxSym = uni(maxSym_), maxNbBits = uni(maxNbBits_); HufScratch* sc = uni_ptr(sc_);
     // ---- 1. sort: count descending; equal counts in symbol order (the reference's bucket fill order), except inside a
     //         power-of-two bucket of more than 8 symbols, where the quicksort's own order for ties applies ----
     u32 c[4], key[4];
@@ -625,8 +627,9 @@ __device__ u32 huf_build_wave(HufCT* ct, const u32* hist, const u32 maxSym, cons
 
 // The code lengths as the frame stores them (HUF_writeCTable_wksp, huf_compress.c:256-295): weights, FSE-compressed when
 // that pays (HUF_compressWeights :173-213), else packed two per byte.  Returns bytes written to op (global), 0 on failure.
-__device__ u32 huf_write_table_wave(u8* op, const HufCT* ct, const u32 maxSym, const u32 huffLog, HufScratch* sc, int lane)
+__device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_, const u32 huffLog_, HufScratch* sc_, int lane)
 {
+    u8* op = uni_ptr(op_); const HufCT* ct = uni_ptr(ct_); const u32 maxSym = uni(maxSym_), huffLog = uni(huffLog_); HufScratch* sc = uni_ptr(sc_);   // (a call: see huf_build_wave)
     // weight of symbol s < maxSym (the last symbol's is implied)
     u32 wsym[4];
 #pragma unroll

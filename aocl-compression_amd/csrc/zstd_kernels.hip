@@ -1237,8 +1237,9 @@ __device__ u32 huf_encode_1x(u8* dst, const u8* src, u32 n, const HufCT* ct, u32
     }
     return pk.close(lane);
 }
-__device__ u32 huf_encode_4x(u8* dst, const u8* src, u32 n, const HufCT* ct, u32* tile, int lane)
+__device__ u32 huf_encode_4x(u8* dst_, const u8* src_, u32 n_, const HufCT* ct_, u32* tile_, int lane)
 {   // huf_compress.c:1163-1211
+    u8* dst = uni_ptr(dst_); const u8* src = uni_ptr(src_); const u32 n = uni(n_); const HufCT* ct = uni_ptr(ct_); u32* tile = uni_ptr(tile_);   // (a call: arguments arrive in vector registers)
     const u32 seg = (n + 3) / 4;
     u32 op = 6;
     if (n < 12) return 0;
@@ -1404,8 +1405,12 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
 
 // ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027): block content size, 0 = emit raw
 template <bool FR = false>
-__device__ u32 entropy_compress(u8* dst, Workspace* ws, u32 litSize, u32 nbSeq, EntropyLds* L, int lane, u32 strategy, FrameHuf* fh = nullptr)
+__device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSeq_, EntropyLds* L_, int lane, u32 strategy_, FrameHuf* fh_ = nullptr)
 {
+    // (a call: the arguments arrive in vector registers and count as divergent - made scalar again, or every loop over the
+    //  sequences below is an exec-mask loop with 64-bit vector address arithmetic)
+    u8* dst = uni_ptr(dst_); Workspace* ws = uni_ptr(ws_); const u32 litSize = uni(litSize_), nbSeq = uni(nbSeq_), strategy = uni(strategy_);
+    EntropyLds* L = uni_ptr(L_); FrameHuf* fh = uni_ptr(fh_);
     u32 op = 0;
     const bool suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
     op += compress_literals<FR>(dst, ws->lits, litSize, suspect, L, lane, fh);
