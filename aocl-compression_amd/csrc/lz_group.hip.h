@@ -58,51 +58,104 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
     const uint32_t mo = (uint32_t)((int32_t)op + srel);                        // far copies: source start in dst
     const bool l16 = act && lit >= 16 && lit <= 64, l4 = act && lit >= 4 && lit < 16, l1 = act && lit >= 1 && lit < 4;
     const bool m16 = far && mlen >= 16 && mlen <= 64, m4 = far && mlen >= 4 && mlen < 16, m1 = TINY && far && mlen < 4;
-    const uint32_t le16 = lit - 16, lp16a = le16 < 16 ? le16 : 16u, lp16b = le16 < 32 ? le16 : 32u;
-    const uint32_t le4 = lit - 4, lp4a = le4 < 4 ? le4 : 4u, lp4b = le4 < 8 ? le4 : 8u;
-    const uint32_t me16 = mlen - 16, mp16a = me16 < 16 ? me16 : 16u, mp16b = me16 < 32 ? me16 : 32u;
-    const uint32_t me4 = mlen - 4, mp4a = me4 < 4 ? me4 : 4u, mp4b = me4 < 8 ? me4 : 8u;
+    // Pieces of a run: the first at 0, the last at len - k, and between them only what the length needs (at k and 2k) - a lane
+    // that does not need a piece sits the instruction out: an LDS (and a memory) instruction costs by its active lanes, and most
+    // runs of a class are in its lower half (until late in round 5 all four pieces were always moved, clamped onto each other:
+    // the LZ4 decoder's LDS pipe was 80 % busy, SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES).
+    const uint32_t le16 = lit - 16, le4 = lit - 4, me16 = mlen - 16, me4 = mlen - 4;
+    const bool l16b = l16 && lit > 32, l16c = l16 && lit > 48, l16d = l16 && lit > 16;
+    const bool m16b = m16 && mlen > 32, m16c = m16 && mlen > 48, m16d = m16 && mlen > 16;
+    const bool l4b = l4 && lit > 8, l4c = l4 && lit > 12, l4d = l4 && lit > 4;
+    const bool m4b = m4 && mlen > 8, m4c = m4 && mlen > 12, m4d = m4 && mlen > 4;
     lbyte* ld_ = blk + lpos; lbyte* md_ = blk + mst;
     if constexpr (SPLIT) {
         // two rounds - the literals, then the far copies - with half the registers in flight (the Zstd decoder's budget)
         {
             u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, b0 = 0, b1 = 0, b2 = 0;
-            if (l16) { q0 = grp_ld128(src, litsrc); q1 = grp_ld128(src, litsrc + lp16a); q2 = grp_ld128(src, litsrc + lp16b); q3 = grp_ld128(src, litsrc + le16); }
-            if (l4) { r0 = grp_ld32(src, litsrc); r1 = grp_ld32(src, litsrc + lp4a); r2 = grp_ld32(src, litsrc + lp4b); r3 = grp_ld32(src, litsrc + le4); }
+            if (l16) q0 = grp_ld128(src, litsrc);
+            if (l16b) q1 = grp_ld128(src, litsrc + 16);
+            if (l16c) q2 = grp_ld128(src, litsrc + 32);
+            if (l16d) q3 = grp_ld128(src, litsrc + le16);
+            if (l4) r0 = grp_ld32(src, litsrc);
+            if (l4b) r1 = grp_ld32(src, litsrc + 4);
+            if (l4c) r2 = grp_ld32(src, litsrc + 8);
+            if (l4d) r3 = grp_ld32(src, litsrc + le4);
             if (l1) { b0 = grp_ld8(src, litsrc); b1 = grp_ld8(src, litsrc + (lit >> 1)); b2 = grp_ld8(src, litsrc + lit - 1); }
             grp_loads_done(q0, q1, q2, q3, r0, r1, r2, r3, b0, b1, b2);
-            if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
-            if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
+            if (l16) *(S128*)ld_ = q0;
+            if (l16b) *(S128*)(ld_ + 16) = q1;
+            if (l16c) *(S128*)(ld_ + 32) = q2;
+            if (l16d) *(S128*)(ld_ + le16) = q3;
+            if (l4) *(S32*)ld_ = r0;
+            if (l4b) *(S32*)(ld_ + 4) = r1;
+            if (l4c) *(S32*)(ld_ + 8) = r2;
+            if (l4d) *(S32*)(ld_ + le4) = r3;
             if (l1) { ld_[0] = (uint8_t)b0; ld_[lit >> 1] = (uint8_t)b1; ld_[lit - 1] = (uint8_t)b2; }
         }
         asm volatile("" ::: "memory");
         {
             u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
             uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, c0 = 0, c1 = 0, c2 = 0;
-            if (m16) { g0 = grp_ld128(dst, mo); g1 = grp_ld128(dst, mo + mp16a); g2 = grp_ld128(dst, mo + mp16b); g3 = grp_ld128(dst, mo + me16); }
-            if (m4) { h0 = grp_ld32(dst, mo); h1 = grp_ld32(dst, mo + mp4a); h2 = grp_ld32(dst, mo + mp4b); h3 = grp_ld32(dst, mo + me4); }
+            if (m16) g0 = grp_ld128(dst, mo);
+            if (m16b) g1 = grp_ld128(dst, mo + 16);
+            if (m16c) g2 = grp_ld128(dst, mo + 32);
+            if (m16d) g3 = grp_ld128(dst, mo + me16);
+            if (m4) h0 = grp_ld32(dst, mo);
+            if (m4b) h1 = grp_ld32(dst, mo + 4);
+            if (m4c) h2 = grp_ld32(dst, mo + 8);
+            if (m4d) h3 = grp_ld32(dst, mo + me4);
             if (m1) { c0 = grp_ld8(dst, mo); c1 = grp_ld8(dst, mo + (mlen >> 1)); c2 = grp_ld8(dst, mo + mlen - 1); }
             grp_loads_done(g0, g1, g2, g3, h0, h1, h2, h3, c0, c1, c2);
-            if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
-            if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
+            if (m16) *(S128*)md_ = g0;
+            if (m16b) *(S128*)(md_ + 16) = g1;
+            if (m16c) *(S128*)(md_ + 32) = g2;
+            if (m16d) *(S128*)(md_ + me16) = g3;
+            if (m4) *(S32*)md_ = h0;
+            if (m4b) *(S32*)(md_ + 4) = h1;
+            if (m4c) *(S32*)(md_ + 8) = h2;
+            if (m4d) *(S32*)(md_ + me4) = h3;
             if (m1) { md_[0] = (uint8_t)c0; md_[mlen >> 1] = (uint8_t)c1; md_[mlen - 1] = (uint8_t)c2; }
         }
     } else {
     u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, g0 = q0, g1 = q0, g2 = q0, g3 = q0;
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     uint8_t b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
-    if (l16) { q0 = *(const G128*)(src + litsrc); q1 = *(const G128*)(src + (litsrc + lp16a)); q2 = *(const G128*)(src + (litsrc + lp16b)); q3 = *(const G128*)(src + (litsrc + le16)); }
-    if (m16) { g0 = *(const G128*)(dst + mo); g1 = *(const G128*)(dst + (mo + mp16a)); g2 = *(const G128*)(dst + (mo + mp16b)); g3 = *(const G128*)(dst + (mo + me16)); }
-    if (l4) { r0 = ld32(src + litsrc); r1 = ld32(src + (litsrc + lp4a)); r2 = ld32(src + (litsrc + lp4b)); r3 = ld32(src + (litsrc + le4)); }
-    if (m4) { h0 = ld32(dst + mo); h1 = ld32(dst + (mo + mp4a)); h2 = ld32(dst + (mo + mp4b)); h3 = ld32(dst + (mo + me4)); }
+    if (l16) q0 = *(const G128*)(src + litsrc);
+    if (l16b) q1 = *(const G128*)(src + (litsrc + 16));
+    if (l16c) q2 = *(const G128*)(src + (litsrc + 32));
+    if (l16d) q3 = *(const G128*)(src + (litsrc + le16));
+    if (m16) g0 = *(const G128*)(dst + mo);
+    if (m16b) g1 = *(const G128*)(dst + (mo + 16));
+    if (m16c) g2 = *(const G128*)(dst + (mo + 32));
+    if (m16d) g3 = *(const G128*)(dst + (mo + me16));
+    if (l4) r0 = ld32(src + litsrc);
+    if (l4b) r1 = ld32(src + (litsrc + 4));
+    if (l4c) r2 = ld32(src + (litsrc + 8));
+    if (l4d) r3 = ld32(src + (litsrc + le4));
+    if (m4) h0 = ld32(dst + mo);
+    if (m4b) h1 = ld32(dst + (mo + 4));
+    if (m4c) h2 = ld32(dst + (mo + 8));
+    if (m4d) h3 = ld32(dst + (mo + me4));
     if (l1) { b0 = src[litsrc]; b1 = src[litsrc + (lit >> 1)]; b2 = src[litsrc + lit - 1]; }
     if (m1) { c0 = dst[mo]; c1 = dst[mo + (mlen >> 1)]; c2 = dst[mo + mlen - 1]; }
     asm volatile("" ::: "memory");
-    if (l16) { *(S128*)ld_ = q0; *(S128*)(ld_ + lp16a) = q1; *(S128*)(ld_ + lp16b) = q2; *(S128*)(ld_ + le16) = q3; }
-    if (m16) { *(S128*)md_ = g0; *(S128*)(md_ + mp16a) = g1; *(S128*)(md_ + mp16b) = g2; *(S128*)(md_ + me16) = g3; }
-    if (l4) { *(S32*)ld_ = r0; *(S32*)(ld_ + lp4a) = r1; *(S32*)(ld_ + lp4b) = r2; *(S32*)(ld_ + le4) = r3; }
-    if (m4) { *(S32*)md_ = h0; *(S32*)(md_ + mp4a) = h1; *(S32*)(md_ + mp4b) = h2; *(S32*)(md_ + me4) = h3; }
+    if (l16) *(S128*)ld_ = q0;
+    if (l16b) *(S128*)(ld_ + 16) = q1;
+    if (l16c) *(S128*)(ld_ + 32) = q2;
+    if (l16d) *(S128*)(ld_ + le16) = q3;
+    if (m16) *(S128*)md_ = g0;
+    if (m16b) *(S128*)(md_ + 16) = g1;
+    if (m16c) *(S128*)(md_ + 32) = g2;
+    if (m16d) *(S128*)(md_ + me16) = g3;
+    if (l4) *(S32*)ld_ = r0;
+    if (l4b) *(S32*)(ld_ + 4) = r1;
+    if (l4c) *(S32*)(ld_ + 8) = r2;
+    if (l4d) *(S32*)(ld_ + le4) = r3;
+    if (m4) *(S32*)md_ = h0;
+    if (m4b) *(S32*)(md_ + 4) = h1;
+    if (m4c) *(S32*)(md_ + 8) = h2;
+    if (m4d) *(S32*)(md_ + me4) = h3;
     if (l1) { ld_[0] = b0; ld_[lit >> 1] = b1; ld_[lit - 1] = b2; }
     if (m1) { md_[0] = c0; md_[mlen >> 1] = c1; md_[mlen - 1] = c2; }
     }
