@@ -2557,7 +2557,8 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
 {   // keep: another block of the frame follows and may reuse this block's tables (DecLds)
     // (a call, not inlined: inlined, the kernel's own state competes for the 80 registers and the tile loop spills ten times as
     //  often; the arguments of a call arrive in vector registers and are made scalar again here)
-    DecLds* L = uni_ptr(L_); const u8* src = uni_ptr(src_); const u32 n = uni(n_); u8* dst = uni_ptr(dst_);
+    DecLds* L = L_;                                      // (one call site: the compiler knows the LDS address as a constant - readfirstlane would hide it)
+    const u8* src = uni_ptr(src_); const u32 n = uni(n_); u8* dst = uni_ptr(dst_);
     const u32 opos = uni(opos_), cap = uni(cap_), blockMax = uni(blockMax_); u8* litBuf = uni_ptr(litBuf_);
     const bool keep = uni(keep_ ? 1u : 0u) != 0;
     typedef __attribute__((address_space(3))) u32x4 LV4;
@@ -2743,7 +2744,8 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
                 const int wb8 = wbU * 8;
                 int prel = posU - wb8;
                 const u32 last = nbSeq - q0 - 1;                                 // the frame's last sequence reads no state bits
-                for (u32 k = 0; k < cnt; ++k) {
+                const u32 cntS = uni(cnt);
+                for (u32 k = 0; k < cntS; ++k) {
                     const u32 cell = *(L32*)(uintptr_t)(tabA + __umul24(st, 3u));   // three-byte cells (DecLds); the top byte is the next cell's
                     const u32 nbE = (cell >> 9) & 31u, nbS = (cell >> 20) & 15u, ns = cell & 0x1FFu, sym = (cell >> 14) & 63u;
                     // both bit counts in one register (additional bits <= 3 x 31 stay below 256): one row-shift sum gives lane j the
@@ -2752,7 +2754,8 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
                     const u32 P = x + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
                     const u32 tot = lane_get(P, 0);
                     const int Etot = (int)(tot & 0xFFu), Stot = (int)(tot >> 8);
-                    const u32 fs = field(prel - Etot - (int)(P >> 8), nbS);
+                    const int pe = (int)uni((u32)(prel - Etot));                 // (scalar: one vector subtraction is left)
+                    const u32 fs = field(pe - (int)(P >> 8), nbS);
                     *(L32*)(uintptr_t)(outA + k * outStride) = sym | ((u32)prel << 8);   // the code, and where the sequence's additional bits begin
                     st = ns + fs;
                     prel -= Etot + (k != last ? Stot : 0);
