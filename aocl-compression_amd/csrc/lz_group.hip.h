@@ -32,43 +32,54 @@ __device__ __forceinline__ void grp_loads_done(u32x4& a, u32x4& b, u32x4& c, u32
 }
 constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | block | slack for the history read behind a full block
 
-// The in-block copies of a group, in record order, while they are SHORT AND PLAIN (at most 64 bytes, offset >= length: one pass,
-// no lane reads what the pass writes) - hand-written: a copy is a round trip through LDS that the whole wave sits through, there
-// are ten of them in an average group (a timing-only build without them: 13.3 instead of 17.9 ms for the LZ4 bench), and the
-// compiler's loop spends ~40 instructions and five taken branches on each.  Here: find the lane, four readlanes, two compares,
-// exec = the copy's lanes, read, write, next - 18 instructions and one taken branch per copy.  The LDS unit executes a wave's
-// instructions in issue order, so the next copy's read sees this copy's write without a wait in between.  Returns with m = the
-// copies still to do: empty, or its lowest lane is a copy for the general path (long, or a pattern).
-__device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint32_t mlen, const uint32_t off, const uint32_t spA, const uint32_t dpA, const uint32_t L)
+// The in-block copies of a group, in record order, while they are SHORT AND PLAIN (at most 63 bytes, offset >= length: one pass,
+// no lane reads what the pass writes; `fast` = the lanes whose copy is one) - hand-written: a copy is a round trip through LDS
+// that the whole wave sits through, there are ten of them in an average group (a timing-only build without them: 13.3 instead of
+// 17.9 ms for the LZ4 bench), and the compiler's loop spends ~40 instructions and five taken branches on each.  Here a copy is
+// exec = its lanes (s_bfm), read, write at read + offset; while the read is on its way the NEXT copy is looked up (find the lane,
+// three readlanes), so a copy costs ~20 instructions, one taken branch and no exposed LDS latency.  The LDS unit executes a
+// wave's instructions in issue order: the next copy's read sees this copy's write without a wait in between.  Needs all 64
+// lanes active on entry.  Returns with m = the copies still to do: empty, or its lowest lane is a copy for the general path.
+__device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint64_t fast, const uint32_t mlen, const uint32_t off, const uint32_t spA, const uint32_t L)
 {
-    uint32_t k, ml, of, sp, dp, va, vb; uint64_t save;
+    uint32_t k, ml, of, sp, ml2, of2, sp2, va, vb;
     asm volatile("s_cmp_eq_u64 %0, 0\n\t"
-                 "s_cbranch_scc1 2f\n"
-                 "1:\n\t"
+                 "s_cbranch_scc1 9f\n\t"
                  "s_ff1_i32_b64 %1, %0\n\t"
-                 "v_readlane_b32 %2, %9, %1\n\t"
-                 "v_readlane_b32 %3, %10, %1\n\t"
-                 "v_readlane_b32 %4, %11, %1\n\t"
-                 "v_readlane_b32 %5, %12, %1\n\t"
-                 "s_cmp_gt_u32 %2, 64\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_lt_u32 %3, %2\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "v_cmp_gt_u32_e32 vcc, %2, %13\n\t"
-                 "s_and_saveexec_b64 %8, vcc\n\t"
-                 "v_add_u32_e32 %6, %4, %13\n\t"
-                 "ds_read_u8 %7, %6\n\t"
-                 "v_add_u32_e32 %6, %5, %13\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "ds_write_b8 %6, %7\n\t"
-                 "s_mov_b64 exec, %8\n\t"
+                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_cbranch_scc1 9f\n\t"
+                 "v_readlane_b32 %2, %11, %1\n\t"
+                 "v_readlane_b32 %3, %12, %1\n\t"
+                 "v_readlane_b32 %4, %13, %1\n"
+                 "1:\n\t"
+                 "s_bfm_b64 exec, %2, 0\n\t"
+                 "v_add_u32_e32 %8, %4, %14\n\t"
+                 "ds_read_u8 %9, %8\n\t"
                  "s_bitset0_b64 %0, %1\n\t"
-                 "s_cmp_lg_u64 %0, 0\n\t"
-                 "s_cbranch_scc1 1b\n"
-                 "2:"
-                 : "+s"(m), "=&s"(k), "=&s"(ml), "=&s"(of), "=&s"(sp), "=&s"(dp), "=&v"(va), "=&v"(vb), "=&s"(save)
-                 : "v"(mlen), "v"(off), "v"(spA), "v"(dpA), "v"(L)
-                 : "vcc", "scc", "memory");
+                 "s_cmp_eq_u64 %0, 0\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "s_ff1_i32_b64 %1, %0\n\t"
+                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "v_readlane_b32 %5, %11, %1\n\t"
+                 "v_readlane_b32 %6, %12, %1\n\t"
+                 "v_readlane_b32 %7, %13, %1\n\t"
+                 "v_add_u32_e32 %8, %3, %8\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_write_b8 %8, %9\n\t"
+                 "s_mov_b32 %2, %5\n\t"
+                 "s_mov_b32 %3, %6\n\t"
+                 "s_mov_b32 %4, %7\n\t"
+                 "s_branch 1b\n"
+                 "3:\n\t"
+                 "v_add_u32_e32 %8, %3, %8\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_write_b8 %8, %9\n"
+                 "9:\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+s"(m), "=&s"(k), "=&s"(ml), "=&s"(of), "=&s"(sp), "=&s"(ml2), "=&s"(of2), "=&s"(sp2), "=&v"(va), "=&v"(vb)
+                 : "s"(fast), "v"(mlen), "v"(off), "v"(spA), "v"(L)
+                 : "scc", "memory");
 }
 
 // TINY: copies shorter than 4 bytes exist (Snappy, Zstd).  SPLIT: literals and far copies in two rounds of loads instead of one (half
@@ -214,11 +225,12 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
     // plain ones by lz_near_fast, a long copy or a pattern here
     {
         const uint32_t blkA = (uint32_t)(uintptr_t)blk;
-        const uint32_t spA = blkA + (uint32_t)srel, dpA = blkA + mst;
+        const uint32_t spA = blkA + (uint32_t)srel;              // (a copy's destination is its source + offset)
         uint64_t m = ballot(near);
+        const uint64_t fast = ballot(near && mlen <= 63 && off >= mlen);
         while (m) {
 #ifndef LZ_GROUP_NEAR_CXX
-            lz_near_fast(m, mlen, off, spA, dpA, L);
+            lz_near_fast(m, fast, mlen, off, spA, L);
             if (!m) break;
 #endif
             const int k = (int)__builtin_ctzll(m);
