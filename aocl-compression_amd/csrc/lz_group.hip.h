@@ -37,7 +37,8 @@ constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | bl
 // that the whole wave sits through, there are ten of them in an average group (a timing-only build without them: 13.3 instead of
 // 17.9 ms for the LZ4 bench), and the compiler's loop spends ~40 instructions and five taken branches on each.  Here a copy is
 // exec = its lanes (s_bfm), read, write at read + offset; while the read is on its way the NEXT copy is looked up (find the lane,
-// three readlanes), so a copy costs ~20 instructions, one taken branch and no exposed LDS latency.  The LDS unit executes a
+// three readlanes; the loop is unrolled twice so that the two sets of scalars swap roles without moves), so a copy costs ~17
+// instructions, half a taken branch and no exposed LDS latency.  The LDS unit executes a
 // wave's instructions in issue order: the next copy's read sees this copy's write without a wait in between.  Needs all 64
 // lanes active on entry.  Returns with m = the copies still to do: empty, or its lowest lane is a copy for the general path.
 __device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint64_t fast, const uint32_t mlen, const uint32_t off, const uint32_t spA, const uint32_t L)
@@ -67,12 +68,30 @@ __device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint64_t fast, c
                  "v_add_u32_e32 %8, %3, %8\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "ds_write_b8 %8, %9\n\t"
-                 "s_mov_b32 %2, %5\n\t"
-                 "s_mov_b32 %3, %6\n\t"
-                 "s_mov_b32 %4, %7\n\t"
+                 // second half: the two register sets have swapped roles
+                 "s_bfm_b64 exec, %5, 0\n\t"
+                 "v_add_u32_e32 %8, %7, %14\n\t"
+                 "ds_read_u8 %9, %8\n\t"
+                 "s_bitset0_b64 %0, %1\n\t"
+                 "s_cmp_eq_u64 %0, 0\n\t"
+                 "s_cbranch_scc1 4f\n\t"
+                 "s_ff1_i32_b64 %1, %0\n\t"
+                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_cbranch_scc1 4f\n\t"
+                 "v_readlane_b32 %2, %11, %1\n\t"
+                 "v_readlane_b32 %3, %12, %1\n\t"
+                 "v_readlane_b32 %4, %13, %1\n\t"
+                 "v_add_u32_e32 %8, %6, %8\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_write_b8 %8, %9\n\t"
                  "s_branch 1b\n"
                  "3:\n\t"
                  "v_add_u32_e32 %8, %3, %8\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_write_b8 %8, %9\n\t"
+                 "s_branch 9f\n"
+                 "4:\n\t"
+                 "v_add_u32_e32 %8, %6, %8\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "ds_write_b8 %8, %9\n"
                  "9:\n\t"
