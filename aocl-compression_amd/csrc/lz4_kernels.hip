@@ -1045,27 +1045,25 @@ __device__ __forceinline__ int lz4_decompress_wave(const gbyte* __restrict__ src
             lz_walk_tokens(nx, mask, cur, stop);
             if (mask) {                                       // (a round adds at most 64 / 3 records)
                 // Offset and match-length byte are read by the lanes that ARE tokens - a round has 8 or 9 of them - not by all 64:
-                // where the next token starts does not depend on them, and an LDS instruction costs by its active lanes.  (A match
-                // length past its extension byte is seen only now: the round ends in front of that token, as the walk would have.)
-                uint32_t off = 0, mcode = 0; bool hard2 = false;
+                // where the next token starts does not depend on them, and an LDS instruction costs by its active lanes.  The
+                // same lanes write their records at once.  (A match length past its extension byte is seen only now: the round
+                // ends in front of that token, as the walk would have - its record and those behind it are not counted.)
+                if (nrec == 0) gbase = (uint32_t)ip;
+                const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                bool hard2 = false;
                 if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
                     const uint32_t w2 = *(const S32*)(ring + (q & kRingMask));
                     const uint32_t e2 = (w2 >> 16) & 0xFFu;
-                    off = w2 & 0xFFFFu;
-                    mcode = (t & 15) + (x2 ? e2 : 0u);                 // match length - 4
+                    const uint32_t mcode = (t & 15) + (x2 ? e2 : 0u);  // match length - 4
                     hard2 = x2 && e2 > 240;
+                    *(L32*)(recs + 4u * idx) = (w2 & 0xFFFFu) | (lit << 16) | (mcode << 24);
                 }
                 const uint64_t bad = ballot(hard2);
-                if (bad) { const int k = (int)__builtin_ctzll(bad); mask &= (1ull << k) - 1; cur = (uint32_t)k; stop = 2; }
-                why = (int)stop;
-                if (mask) {
-                    if (nrec == 0) gbase = (uint32_t)ip;
-                    const uint32_t idx = nrec + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (__builtin_amdgcn_inverse_ballot_w64(mask)) *(L32*)(recs + 4u * idx) = off | (lit << 16) | (mcode << 24);
-                    nrec += (uint32_t)__builtin_popcountll(mask); ip += (int32_t)cur;
-                    wave_fence();
-                }
-            } else why = (int)stop;
+                if (__builtin_expect(bad != 0, 0)) { const int k = (int)__builtin_ctzll(bad); mask &= (1ull << k) - 1; cur = (uint32_t)k; stop = 2; }
+                nrec += (uint32_t)__builtin_popcountll(mask); ip += (int32_t)cur;
+                wave_fence();
+            }
+            why = (int)stop;
             DSTAGE(2); DCOUNT(1, (uint32_t)__builtin_popcountll(mask));
             if (why != 0 || rend - ip < 640) break;
         }
