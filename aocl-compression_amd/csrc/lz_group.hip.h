@@ -19,16 +19,42 @@ namespace aoclgpu {
 
 constexpr uint32_t kGrpBlock = 2048, kGrpHist = 64;
 
-// Loads with a scalar base and a 32-bit lane offset, written out (SPLIT only).  The compiler moves the 64-bit address arithmetic
-// of a conditional load out of its block and then cannot fold base + offset into the instruction: every piece costs a 64-bit
-// vector add and a register pair that lives from there to the load - in the Zstd decoder, where the budget is 80 registers,
-// those pairs were spilled.  The compiler does not count these loads: grp_loads_done waits for them and ties the values to the wait.
-__device__ __forceinline__ u32x4 grp_ld128(const gbyte* sbase, uint32_t voff) { u32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
-__device__ __forceinline__ uint32_t grp_ld32(const gbyte* sbase, uint32_t voff) { uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
-__device__ __forceinline__ uint32_t grp_ld8(const gbyte* sbase, uint32_t voff) { uint32_t v; asm volatile("global_load_ubyte %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory"); return v; }
-__device__ __forceinline__ void grp_loads_done(u32x4& a, u32x4& b, u32x4& c, u32x4& d, uint32_t& e, uint32_t& f, uint32_t& g, uint32_t& h, uint32_t& i, uint32_t& j, uint32_t& k)
+// One round of a group's loads (SPLIT only): the pieces of a run as global loads with a scalar base and a 32-bit lane offset,
+// each under the lane mask of its size class, AND the wait for them, in ONE asm statement.  (The compiler moves the 64-bit address
+// arithmetic of a conditional load out of its block and then cannot fold base + offset into the instruction: every piece cost a
+// 64-bit vector add and a register pair that lived from there to the load - in the Zstd decoder, where the budget is 80 registers,
+// those pairs were spilled.  Until round 6 every load was its own asm statement and the wait another one: the compiler does not
+// count loads it cannot see, so nothing kept it from copying or spilling a destination register between a load and the wait.
+// Here the destinations are only defined when the statement ends, behind s_waitcnt.)  Lanes outside a piece's mask keep
+// whatever the register held: the caller writes a piece under the same mask.  exec is saved and restored.
+//   a0: offset of the run; pieces at a0, a0 + 16, a0 + 32, aE16 (16-byte class k16*), a0, a0 + 4, a0 + 8, aE4 (4-byte class k4*),
+//   a0, aMid, aLast (1 .. 3 bytes, k1).
+__device__ __forceinline__ void grp_load_round(const gbyte* sbase, const uint32_t a0, const uint32_t aE16, const uint32_t aE4, const uint32_t aMid, const uint32_t aLast,
+                                               const uint64_t k16, const uint64_t k16b, const uint64_t k16c, const uint64_t k16d,
+                                               const uint64_t k4, const uint64_t k4b, const uint64_t k4c, const uint64_t k4d, const uint64_t k1,
+                                               u32x4& q0, u32x4& q1, u32x4& q2, u32x4& q3, uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3,
+                                               uint32_t& b0, uint32_t& b1, uint32_t& b2)
 {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j), "+v"(k) : : "memory");
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[k16]\n\t"  "global_load_dwordx4 %[q0], %[a0], %[sb]\n\t"
+                 "s_mov_b64 exec, %[k16b]\n\t" "global_load_dwordx4 %[q1], %[a0], %[sb] offset:16\n\t"
+                 "s_mov_b64 exec, %[k16c]\n\t" "global_load_dwordx4 %[q2], %[a0], %[sb] offset:32\n\t"
+                 "s_mov_b64 exec, %[k16d]\n\t" "global_load_dwordx4 %[q3], %[aE16], %[sb]\n\t"
+                 "s_mov_b64 exec, %[k4]\n\t"   "global_load_dword %[r0], %[a0], %[sb]\n\t"
+                 "s_mov_b64 exec, %[k4b]\n\t"  "global_load_dword %[r1], %[a0], %[sb] offset:4\n\t"
+                 "s_mov_b64 exec, %[k4c]\n\t"  "global_load_dword %[r2], %[a0], %[sb] offset:8\n\t"
+                 "s_mov_b64 exec, %[k4d]\n\t"  "global_load_dword %[r3], %[aE4], %[sb]\n\t"
+                 "s_mov_b64 exec, %[k1]\n\t"   "global_load_ubyte %[b0], %[a0], %[sb]\n\t"
+                                                "global_load_ubyte %[b1], %[aMid], %[sb]\n\t"
+                                                "global_load_ubyte %[b2], %[aLast], %[sb]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : [sv] "=&s"(sv), [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3),
+                   [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2)
+                 : [sb] "s"(sbase), [a0] "v"(a0), [aE16] "v"(aE16), [aE4] "v"(aE4), [aMid] "v"(aMid), [aLast] "v"(aLast),
+                   [k16] "s"(k16), [k16b] "s"(k16b), [k16c] "s"(k16c), [k16d] "s"(k16d), [k4] "s"(k4), [k4b] "s"(k4b), [k4c] "s"(k4c), [k4d] "s"(k4d), [k1] "s"(k1)
+                 : "memory");
 }
 constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | block | slack for the history read behind a full block
 
@@ -44,43 +70,45 @@ constexpr uint32_t kGrpLds = kGrpHist + kGrpBlock + 16;      // cb: history | bl
 __device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint64_t fast, const uint32_t mlen, const uint32_t off, const uint32_t spA, const uint32_t L)
 {
     uint32_t k, ml, of, sp, ml2, of2, sp2, va, vb;
-    asm volatile("s_cmp_eq_u64 %0, 0\n\t"
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_cmp_eq_u64 %0, 0\n\t"
                  "s_cbranch_scc1 9f\n\t"
                  "s_ff1_i32_b64 %1, %0\n\t"
-                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_bitcmp0_b64 %11, %1\n\t"
                  "s_cbranch_scc1 9f\n\t"
-                 "v_readlane_b32 %2, %11, %1\n\t"
-                 "v_readlane_b32 %3, %12, %1\n\t"
-                 "v_readlane_b32 %4, %13, %1\n"
+                 "v_readlane_b32 %2, %12, %1\n\t"
+                 "v_readlane_b32 %3, %13, %1\n\t"
+                 "v_readlane_b32 %4, %14, %1\n"
                  "1:\n\t"
                  "s_bfm_b64 exec, %2, 0\n\t"
-                 "v_add_u32_e32 %8, %4, %14\n\t"
+                 "v_add_u32_e32 %8, %4, %15\n\t"
                  "ds_read_u8 %9, %8\n\t"
                  "s_bitset0_b64 %0, %1\n\t"
                  "s_cmp_eq_u64 %0, 0\n\t"
                  "s_cbranch_scc1 3f\n\t"
                  "s_ff1_i32_b64 %1, %0\n\t"
-                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_bitcmp0_b64 %11, %1\n\t"
                  "s_cbranch_scc1 3f\n\t"
-                 "v_readlane_b32 %5, %11, %1\n\t"
-                 "v_readlane_b32 %6, %12, %1\n\t"
-                 "v_readlane_b32 %7, %13, %1\n\t"
+                 "v_readlane_b32 %5, %12, %1\n\t"
+                 "v_readlane_b32 %6, %13, %1\n\t"
+                 "v_readlane_b32 %7, %14, %1\n\t"
                  "v_add_u32_e32 %8, %3, %8\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "ds_write_b8 %8, %9\n\t"
                  // second half: the two register sets have swapped roles
                  "s_bfm_b64 exec, %5, 0\n\t"
-                 "v_add_u32_e32 %8, %7, %14\n\t"
+                 "v_add_u32_e32 %8, %7, %15\n\t"
                  "ds_read_u8 %9, %8\n\t"
                  "s_bitset0_b64 %0, %1\n\t"
                  "s_cmp_eq_u64 %0, 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
                  "s_ff1_i32_b64 %1, %0\n\t"
-                 "s_bitcmp0_b64 %10, %1\n\t"
+                 "s_bitcmp0_b64 %11, %1\n\t"
                  "s_cbranch_scc1 4f\n\t"
-                 "v_readlane_b32 %2, %11, %1\n\t"
-                 "v_readlane_b32 %3, %12, %1\n\t"
-                 "v_readlane_b32 %4, %13, %1\n\t"
+                 "v_readlane_b32 %2, %12, %1\n\t"
+                 "v_readlane_b32 %3, %13, %1\n\t"
+                 "v_readlane_b32 %4, %14, %1\n\t"
                  "v_add_u32_e32 %8, %6, %8\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "ds_write_b8 %8, %9\n\t"
@@ -95,8 +123,8 @@ __device__ __forceinline__ void lz_near_fast(uint64_t& m, const uint64_t fast, c
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "ds_write_b8 %8, %9\n"
                  "9:\n\t"
-                 "s_mov_b64 exec, -1"
-                 : "+s"(m), "=&s"(k), "=&s"(ml), "=&s"(of), "=&s"(sp), "=&s"(ml2), "=&s"(of2), "=&s"(sp2), "=&v"(va), "=&v"(vb)
+                 "s_mov_b64 exec, %[sv]"
+                 : "+s"(m), "=&s"(k), "=&s"(ml), "=&s"(of), "=&s"(sp), "=&s"(ml2), "=&s"(of2), "=&s"(sp2), "=&v"(va), "=&v"(vb), [sv] "=&s"(sv)
                  : "s"(fast), "v"(mlen), "v"(off), "v"(spA), "v"(L)
                  : "scc", "memory");
 }
@@ -140,18 +168,11 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
     if constexpr (SPLIT) {
         // two rounds - the literals, then the far copies - with half the registers in flight (the Zstd decoder's budget)
         {
-            u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, b0 = 0, b1 = 0, b2 = 0;
-            if (l16) q0 = grp_ld128(src, litsrc);
-            if (l16b) q1 = grp_ld128(src, litsrc + 16);
-            if (l16c) q2 = grp_ld128(src, litsrc + 32);
-            if (l16d) q3 = grp_ld128(src, litsrc + le16);
-            if (l4) r0 = grp_ld32(src, litsrc);
-            if (l4b) r1 = grp_ld32(src, litsrc + 4);
-            if (l4c) r2 = grp_ld32(src, litsrc + 8);
-            if (l4d) r3 = grp_ld32(src, litsrc + le4);
-            if (l1) { b0 = grp_ld8(src, litsrc); b1 = grp_ld8(src, litsrc + (lit >> 1)); b2 = grp_ld8(src, litsrc + lit - 1); }
-            grp_loads_done(q0, q1, q2, q3, r0, r1, r2, r3, b0, b1, b2);
+            u32x4 q0, q1, q2, q3;
+            uint32_t r0, r1, r2, r3, b0, b1, b2;
+            grp_load_round(src, litsrc, litsrc + le16, litsrc + le4, litsrc + (lit >> 1), litsrc + lit - 1,
+                           ballot(l16), ballot(l16b), ballot(l16c), ballot(l16d), ballot(l4), ballot(l4b), ballot(l4c), ballot(l4d), ballot(l1),
+                           q0, q1, q2, q3, r0, r1, r2, r3, b0, b1, b2);
             if (l16) *(S128*)ld_ = q0;
             if (l16b) *(S128*)(ld_ + 16) = q1;
             if (l16c) *(S128*)(ld_ + 32) = q2;
@@ -164,18 +185,11 @@ __device__ __forceinline__ uint32_t lz_group_execute(const gbyte* __restrict__ s
         }
         asm volatile("" ::: "memory");
         {
-            u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
-            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, c0 = 0, c1 = 0, c2 = 0;
-            if (m16) g0 = grp_ld128(dst, mo);
-            if (m16b) g1 = grp_ld128(dst, mo + 16);
-            if (m16c) g2 = grp_ld128(dst, mo + 32);
-            if (m16d) g3 = grp_ld128(dst, mo + me16);
-            if (m4) h0 = grp_ld32(dst, mo);
-            if (m4b) h1 = grp_ld32(dst, mo + 4);
-            if (m4c) h2 = grp_ld32(dst, mo + 8);
-            if (m4d) h3 = grp_ld32(dst, mo + me4);
-            if (m1) { c0 = grp_ld8(dst, mo); c1 = grp_ld8(dst, mo + (mlen >> 1)); c2 = grp_ld8(dst, mo + mlen - 1); }
-            grp_loads_done(g0, g1, g2, g3, h0, h1, h2, h3, c0, c1, c2);
+            u32x4 g0, g1, g2, g3;
+            uint32_t h0, h1, h2, h3, c0, c1, c2;
+            grp_load_round(dst, mo, mo + me16, mo + me4, mo + (mlen >> 1), mo + mlen - 1,
+                           ballot(m16), ballot(m16b), ballot(m16c), ballot(m16d), ballot(m4), ballot(m4b), ballot(m4c), ballot(m4d), ballot(m1),
+                           g0, g1, g2, g3, h0, h1, h2, h3, c0, c1, c2);
             if (m16) *(S128*)md_ = g0;
             if (m16b) *(S128*)(md_ + 16) = g1;
             if (m16c) *(S128*)(md_ + 32) = g2;

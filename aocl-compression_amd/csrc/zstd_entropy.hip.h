@@ -21,6 +21,15 @@ namespace aoclgpu {
 namespace zs {
 
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64; typedef int16_t s16;
+// Every pointer of the entropy stage carries its address space (round 6): the tables and scratch areas are LDS, the sequence store,
+// the literal buffer and the staged block are global memory.  As generic pointers (until round 5) every access of this stage
+// was a flat_* instruction - an aperture check per access, and a wait on BOTH counters at every use.
+#define ZLDS __attribute__((address_space(3)))
+#define ZGLB __attribute__((address_space(1)))
+typedef ZLDS u32 l32; typedef ZLDS u16 l16; typedef ZLDS u8 l8; typedef ZLDS int li32;
+typedef ZGLB u32 g32; typedef ZGLB u16 g16; typedef ZGLB u8 g8;
+__device__ __forceinline__ void lds_or(l32* p, u32 v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_add(l32* p, u32 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 __device__ __forceinline__ int hb(u32 v) { return 31 - __builtin_clz(v); }          // ZSTD_highbit32
 
@@ -94,7 +103,7 @@ __device__ __forceinline__ u64 same_value6(u32 v, bool on)
 
 // Bits of one lane each, concatenated in lane order into `out` (global memory), little-endian bit order; returns the
 // number of bytes (the last one zero-padded).  tile: LDS scratch of at least (total bits / 32 + 3) words.
-__device__ u32 wave_emit_bits(u8* out, u64 v, u32 nb, u32* tile, u32 tileWords, int lane)
+__device__ u32 wave_emit_bits(g8* out, u64 v, u32 nb, l32* tile, u32 tileWords, int lane)
 {
     const u32 incl = wscan(nb, lane), total = lane_get(incl, 63);
     const u32 words = (total + 31) / 32 + 2;
@@ -105,13 +114,13 @@ __device__ u32 wave_emit_bits(u8* out, u64 v, u32 nb, u32* tile, u32 tileWords, 
         const u32 bit = incl - nb, w = bit >> 5, sh = bit & 31;
         const u64 a = v << sh;
         const u32 a2 = sh ? (u32)(v >> (64 - sh)) : 0;
-        if ((u32)a) atomicOr(&tile[w], (u32)a);
-        if ((u32)(a >> 32)) atomicOr(&tile[w + 1], (u32)(a >> 32));
-        if (a2) atomicOr(&tile[w + 2], a2);
+        if ((u32)a) lds_or(&tile[w], (u32)a);
+        if ((u32)(a >> 32)) lds_or(&tile[w + 1], (u32)(a >> 32));
+        if (a2) lds_or(&tile[w + 2], a2);
     }
     wave_fence();
     const u32 nbytes = (total + 7) >> 3;
-    const u8* tb = reinterpret_cast<const u8*>(tile);
+    const l8* tb = (const l8*)tile;
     for (u32 i = (u32)lane; i < nbytes; i += kWave) out[i] = tb[i];
     wave_fence();
     return nbytes;
@@ -238,7 +247,7 @@ __device__ int fse_normalize_wave(int& norm, const u32 c, const u32 total, const
 // follows the probability still unassigned, zero runs as repeat codes.  What the reference tracks while walking the
 // alphabet - `remaining`, the width - is a prefix sum over lanes here, every lane forms its own bits (<= 53), and the bit
 // positions are another prefix sum.  Returns bytes written to out (global), 0 on error.
-__device__ u32 fse_write_ncount_wave(u8* out, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
+__device__ u32 fse_write_ncount_wave(g8* out, const int norm, const u32 maxSym, const u32 tableLog, ZLDS FseScratch* sc, int lane)
 {
     const int tableSize = 1 << tableLog;
     const bool valid = (u32)lane <= maxSym;
@@ -281,8 +290,8 @@ __device__ u32 fse_write_ncount_wave(u8* out, const int norm, const u32 maxSym, 
 // lanes take the visit numbers 64 at a time: reserved states are skipped by a ballot count, the symbol of occurrence k
 // comes from a prefix maximum over "first occurrence" marks.  put(state, symbol) stores the result; occ = 2^tableLog
 // bytes of LDS scratch.
-template <class Put>
-__device__ __forceinline__ void fse_spread_wave(u8* occ, const int norm, const u32 maxSym, const u32 tableLog, int lane, Put put)
+template <class Occ, class Put>
+__device__ __forceinline__ void fse_spread_wave(Occ* occ, const int norm, const u32 maxSym, const u32 tableLog, int lane, Put put)
 {
     const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
     const bool valid = (u32)lane <= maxSym;
@@ -321,7 +330,7 @@ __device__ __forceinline__ void fse_spread_wave(u8* occ, const int norm, const u
 
 // Encoding table (FSE_buildCTable_wksp, fse_compress.c:68-214): spread, then a symbol's states are numbered in
 // increasing state order: rank among the lanes holding the same symbol + the symbol's running base.
-__device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSym, const u32 tableLog, FseScratch* sc, int lane)
+__device__ void fse_build_ctable_wave(ZLDS FseCT* ct, const int norm, const u32 maxSym, const u32 tableLog, ZLDS FseScratch* sc, int lane)
 {
     const u32 tableSize = 1u << tableLog;
     const bool valid = (u32)lane <= maxSym;
@@ -353,12 +362,12 @@ __device__ void fse_build_ctable_wave(FseCT* ct, const int norm, const u32 maxSy
         wave_fence();
     }
 }
-__device__ __forceinline__ void fse_build_rle(FseCT* ct, u32 sym)
+__device__ __forceinline__ void fse_build_rle(ZLDS FseCT* ct, u32 sym)
 {   // fse_compress.c:530-548
     ct->tableLog = 0; ct->stateTable[0] = 0; ct->stateTable[1] = 0;
     ct->deltaNbBits[sym] = 0; ct->deltaFindState[sym] = 0;
 }
-__device__ __forceinline__ u32 fse_init_state(const FseCT* ct, u32 sym)
+__device__ __forceinline__ u32 fse_init_state(const ZLDS FseCT* ct, u32 sym)
 {   // FSE_initCState2 (fse.h:451-463)
     const u32 nb = (u32)(ct->deltaNbBits[sym] + (1 << 15)) >> 16;
     const u32 v = (nb << 16) - (u32)ct->deltaNbBits[sym];
@@ -391,7 +400,7 @@ __device__ __forceinline__ u32 huf_bucket(u32 c) { return c < kHufCutoff ? c : (
 // counts can get different code lengths), so such a bucket is sorted by the same scheme: a[lo..hi] are keys
 // (count << 8 | symbol) in symbol order, compared by count only.  Runs on one lane per bucket, all buckets at once;
 // `todo` is that lane's list of ranges still to do (ranges are disjoint, so their order is free).
-__device__ void huf_bucket_sort(u32* a, int lo0, int hi0, short* todo /* 64 */)
+__device__ void huf_bucket_sort(l32* a, int lo0, int hi0, ZLDS short* todo /* 64 */)
 {
     auto insertion = [&](int lo, int hi) {                   // stable, descending by count
         for (int i = lo + 1; i <= hi; i++) {
@@ -421,10 +430,10 @@ __device__ void huf_bucket_sort(u32* a, int lo0, int hi0, short* todo /* 64 */)
 
 // Code lengths and code values of the literals (HUF_buildCTable_wksp, huf_compress.c:758-794, with HUF_sort :624-668,
 // HUF_buildTree :685-725, HUF_setMaxHeight :378-495).  hist = counts of symbols 0..maxSym (LDS).  Returns the table log.
-__device__ u32 huf_build_wave(HufCT* ct_, const u32* hist_, const u32 maxSym_, const u32 maxNbBits_, HufScratch* sc_, int lane)
+__device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSym_, const u32 maxNbBits_, ZLDS HufScratch* sc_, int lane)
 {
     // (a call: the arguments arrive in vector registers and count as divergent - made scalar again, common.hip.h uni_ptr)
-    HufCT* ct = uni_ptr(ct_); const u32* hist = uni_ptr(hist_); const u32 maxSym = uni(maxSym_), maxNbBits = uni(maxNbBits_); HufScratch* sc = uni_ptr(sc_);
+    ZLDS HufCT* ct = uni_ptr(ct_); const l32* hist = uni_ptr(hist_); const u32 maxSym = uni(maxSym_), maxNbBits = uni(maxNbBits_); ZLDS HufScratch* sc = uni_ptr(sc_);
     // ---- 1. sort: count descending; equal counts in symbol order (the reference's bucket fill order), except inside a
     //         power-of-two bucket of more than 8 symbols, where the quicksort's own order for ties applies ----
     u32 c[4], key[4];
@@ -627,9 +636,9 @@ __device__ u32 huf_build_wave(HufCT* ct_, const u32* hist_, const u32 maxSym_, c
 
 // The code lengths as the frame stores them (HUF_writeCTable_wksp, huf_compress.c:256-295): weights, FSE-compressed when
 // that pays (HUF_compressWeights :173-213), else packed two per byte.  Returns bytes written to op (global), 0 on failure.
-__device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_, const u32 huffLog_, HufScratch* sc_, int lane)
+__device__ u32 huf_write_table_wave(g8* op_, const ZLDS HufCT* ct_, const u32 maxSym_, const u32 huffLog_, ZLDS HufScratch* sc_, int lane)
 {
-    u8* op = uni_ptr(op_); const HufCT* ct = uni_ptr(ct_); const u32 maxSym = uni(maxSym_), huffLog = uni(huffLog_); HufScratch* sc = uni_ptr(sc_);   // (a call: see huf_build_wave)
+    g8* op = uni_ptr(op_); const ZLDS HufCT* ct = uni_ptr(ct_); const u32 maxSym = uni(maxSym_), huffLog = uni(huffLog_); ZLDS HufScratch* sc = uni_ptr(sc_);   // (a call: see huf_build_wave)
     // weight of symbol s < maxSym (the last symbol's is implied)
     u32 wsym[4];
 #pragma unroll
@@ -664,7 +673,7 @@ __device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_
                     // FSE_compress_usingCTable (fse_compress.c:558-615) on n > 2 weights, last to first, two interleaved
                     // states: lane k runs the chain of the weights with index parity k, then all lanes place the bits
                     if (n > 2) {
-                        const FseCT* t = &sc->wct;
+                        const ZLDS FseCT* t = &sc->wct;
                         if (lane < 2) {
                             u32 st = 0; bool started = false;
                             for (int i = (int)n - 1; i >= 0; --i) if ((i & 1) == lane) {
@@ -680,7 +689,7 @@ __device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_
                         }
                         wave_fence();
                         // emission order: weight n-1 first; then the two final states (state 1, state 0), then the end mark
-                        u8* dst = op + 1 + hd;
+                        g8* dst = op + 1 + hd;
                         u32 done = 0, carryV = 0, carryN = 0;          // bits (< 8) waiting for the next round
                         for (u32 e0 = 0; e0 < n + 1; e0 += kWave) {
                             const u32 e = e0 + (u32)lane;
@@ -696,7 +705,7 @@ __device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_
                             const u32 by = wave_emit_bits(dst + done, v, nb, sc->fs.bits, 40, lane);
                             const bool lastRound = e0 + kWave >= n + 1;
                             if (lastRound) done += by;
-                            else { done += tot >> 3; carryN = tot & 7; carryV = carryN ? ((u32)reinterpret_cast<const u8*>(sc->fs.bits)[tot >> 3]) : 0u; }
+                            else { done += tot >> 3; carryN = tot & 7; carryV = carryN ? ((u32)((const l8*)sc->fs.bits)[tot >> 3]) : 0u; }
                         }
                         const u32 cs = done;
                         if (cs) h = hd + cs;
@@ -716,27 +725,26 @@ __device__ u32 huf_write_table_wave(u8* op_, const HufCT* ct_, const u32 maxSym_
 // ------------------------------------------------------------------------------------------------
 // wave-parallel bit packer: every lane contributes (value, nbits <= 128 via two 64-bit halves) per round,
 // in lane order; the packer keeps a running bit cursor, ORs the pieces into a zeroed LDS tile and streams
-// completed bytes to global memory.
+// completed DWORDS to global memory (round 6; until then the tile left byte by byte, one store instruction
+// per 64 bytes); up to 31 bits wait in the tile's first word for the next round.
 // ------------------------------------------------------------------------------------------------
 struct WavePacker {
-    u32* tile;          // LDS, kTileWords dwords, zeroed
-    u8* out;            // global destination of this bitstream
-    u32 outPos;         // bytes already flushed
-    u32 carryBits;      // 0..7 bits pending in tile[0]'s low byte
+    l32* tile;          // LDS, kTileWords dwords, zeroed
+    g8* out;            // global destination of this bitstream
+    u32 outPos;         // bytes already flushed (a multiple of 4 until close)
+    u32 carryBits;      // 0..31 bits pending in tile[0]
     static constexpr u32 kTileWords = 64 * 4 + 2;   // 64 lanes x 128 bits + carry
 
-    __device__ void init(u32* ldsTile, u8* dst, int lane)
+    __device__ __forceinline__ void init(l32* ldsTile, g8* dst, int lane)
     {
         tile = ldsTile; out = dst; outPos = 0; carryBits = 0;
         for (u32 i = (u32)lane; i < kTileWords; i += kWave) tile[i] = 0;
         wave_fence();
     }
-    // all lanes call; lo/hi = this lane's bits (LSB first), nb = 0..128
-    __device__ void push(u64 lo, u64 hi, u32 nb, int lane)
+    // all 64 lanes call; lo/hi = this lane's bits (LSB first), nb = 0..128
+    __device__ __forceinline__ void push(u64 lo, u64 hi, u32 nb, int lane)
     {
-        // exclusive prefix sum of nb across lanes
-        u32 incl = nb;
-        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const u32 incl = wave_scan_incl(nb);
         const u32 total = lane_get(incl, 63);
         u32 bit = carryBits + incl - nb;
         if (nb) {
@@ -746,41 +754,44 @@ struct WavePacker {
             u32 w = bit >> 5; const u32 sh = bit & 31;
             const u64 a = lo << sh;
             const u32 a2 = sh ? (u32)(lo >> (64 - sh)) : 0;
-            if ((u32)a) atomicOr(&tile[w], (u32)a);
-            if ((u32)(a >> 32)) atomicOr(&tile[w + 1], (u32)(a >> 32));
-            if (a2) atomicOr(&tile[w + 2], a2);
+            if ((u32)a) lds_or(&tile[w], (u32)a);
+            if ((u32)(a >> 32)) lds_or(&tile[w + 1], (u32)(a >> 32));
+            if (a2) lds_or(&tile[w + 2], a2);
             if (nb > 64) {
                 const u32 nhi = nb - 64;
                 if (nhi < 64) hi &= (1ull << nhi) - 1;
                 bit += 64; w = bit >> 5;
                 const u64 b = hi << sh;
                 const u32 b2 = sh ? (u32)(hi >> (64 - sh)) : 0;
-                if ((u32)b) atomicOr(&tile[w], (u32)b);
-                if ((u32)(b >> 32)) atomicOr(&tile[w + 1], (u32)(b >> 32));
-                if (b2) atomicOr(&tile[w + 2], b2);
+                if ((u32)b) lds_or(&tile[w], (u32)b);
+                if ((u32)(b >> 32)) lds_or(&tile[w + 1], (u32)(b >> 32));
+                if (b2) lds_or(&tile[w + 2], b2);
             }
         }
         wave_fence();
         const u32 endBit = carryBits + total;
-        const u32 nbytes = endBit >> 3;
-        const u8* tb = reinterpret_cast<const u8*>(tile);
-        for (u32 i = (u32)lane; i < nbytes; i += kWave) out[outPos + i] = tb[i];
-        wave_fence();
-        const u32 rem = endBit & 7;
-        const u32 carry = rem ? (u32)tb[nbytes] : 0;
-        wave_fence();
-        const u32 usedWords = (endBit + 31) / 32 + 1;
-        for (u32 i = (u32)lane; i < usedWords && i < kTileWords; i += kWave) tile[i] = 0;
+        const u32 nwords = endBit >> 5;
+        u32 carry = 0;
+        for (u32 i = (u32)lane; i <= nwords; i += kWave) {                // (nwords <= 257: at most five trips)
+            const u32 v = tile[i];
+            if (i < nwords) st32(out + outPos + 4u * i, v); else carry = v;
+            tile[i] = 0;
+        }
+        const u32 rem = endBit & 31;
+        const int cl = (int)(nwords & 63u);                               // the lane that read the partial word
+        carry = lane_get(carry, cl);
         wave_fence();
         if (lane == 0 && rem) tile[0] = carry;
         wave_fence();
-        outPos += nbytes; carryBits = rem;
+        outPos += 4u * nwords; carryBits = rem;
     }
-    // end mark + final partial byte; returns the stream size in bytes
-    __device__ u32 close(int lane)
+    // end mark + final partial word; returns the stream size in bytes
+    __device__ __forceinline__ u32 close(int lane)
     {
         push(lane == 0 ? 1ull : 0ull, 0, lane == 0 ? 1u : 0u, lane);
-        if (carryBits) { if (lane == 0) out[outPos] = (u8)tile[0]; outPos++; }
+        const u32 nb = (carryBits + 7) >> 3;                              // 0..4 bytes left in tile[0]
+        if ((u32)lane < nb) out[outPos + lane] = ((const l8*)tile)[lane];
+        outPos += nb;
         wave_fence();
         if (lane == 0) tile[0] = 0;
         carryBits = 0;

@@ -88,23 +88,26 @@ struct Workspace {
     u32 seqLL[kMaxSeq];      // literal length
     u32 seqML[kMaxSeq];      // match length
     u32 seqSrc[kMaxSeq];     // position of the sequence's literals in the chunk
-    u8  llc[kMaxSeq], ofc[kMaxSeq], mlc[kMaxSeq];
+    u32 codesPad[4];         // (the state chains read code words four at a time, downwards from a sequence)
+    u32 codes[kMaxSeq];      // LL code | ML code << 8 | OF code << 16 (ZSTD_seqToCodes)
+    u16 fseState[3][kMaxSeq + 8];   // state of the LL / ML / OF chain BEFORE encode step e (round 6: the chains run in segments)
     u8  pad[8];
     u8  tmp[2 * kBlockMax + 1024];
 };
+typedef ZGLB Workspace GWorkspace;
 
 // ---- LDS of the entropy stage (overlays the hash table once the match finder is done) ----
 struct EntropyLds {
-    u32 hist[256];
-    u32 count[64];
+    u32 hist[256];           // byte histogram of the literals; then their code as one word per symbol (value | length << 16)
+    u32 cnt3[3][64];         // histograms of the LL / ML / OF codes
     HufCT huf;
     HufScratch hs;           // (its FseScratch also serves the three sequence tables)
     FseCT ctLL, ctOF, ctML;
     u32 tile[WavePacker::kTileWords];
-    u32 fseBits[3][64];      // per tile: (value << 8) | nbBits from the three state chains
     u32 misc[16];
-    int fsePre[3][64][2];    // per tile: {deltaNbBits, deltaFindState} of every sequence's code, looked up by all lanes before the chains run
+    u8  llbits[64], mlbits[64];   // LL_bits / ML_bits by code
 };
+typedef ZLDS EntropyLds LEntropy;
 static_assert(sizeof(EntropyLds) <= 17920, "the entropy stage's LDS overlays the hash table of a 128 KiB chunk (17 920 bytes)");
 
 template <int MLS>
@@ -136,44 +139,59 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 }
 
 // Literal buffer of a block: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the search
-// loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal lengths, short runs one per
-// lane, long runs by the whole wave.  Returns the size of the last literal run (the others were counted by the parse).
-__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
+// loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal lengths, runs up to 64 bytes one
+// per lane - pieces at 0, k, 2k and len - k, every access inside the run, every load of the round before its first store -
+// longer runs by the whole wave; the next round's records travel while this round is copied (round 6; until then a round was
+// two exposed round trips, and every run above 24 bytes a third).  Returns the size of the last literal run.
+__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws_, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
 {
-    u32 lpos = 0;
+    typedef u32x4 __attribute__((aligned(1))) U128;
+    typedef u32 __attribute__((aligned(1))) U32;
+    GWorkspace* ws = (GWorkspace*)ws_;
+    g8* lits = ws->lits;
+    const g32* gLL = ws->seqLL; const g32* gSrc = ws->seqSrc;
+    u32 lpos = 0, ll = 0, sp = 0;
+    if ((u32)lane < nbSeq) { ll = gLL[lane]; sp = gSrc[lane]; }
     for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
-        const u32 q = q0 + (u32)lane;
-        u32 ll = 0, sp = 0;
-        if (q < nbSeq) { ll = ws->seqLL[q]; sp = ws->seqSrc[q]; }
-        u32 inc = ll;
-        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        const u32 qn = q0 + kWave + (u32)lane;
+        u32 nll = 0, nsp = 0;
+        if (qn < nbSeq) { nll = gLL[qn]; nsp = gSrc[qn]; }
+        const u32 inc = wave_scan_incl(ll);
         const u32 dp = lpos + inc - ll;
-        if (ll && ll <= 24) {
-            // short runs, one per lane: three 8-byte loads in ONE round trip and exact-length overlapping stores (a byte loop is a
-            // load -> store round trip per byte)
-            gbyte* d = (gbyte*)ws->lits + dp;
-            if (sp + 24 <= n) {
-                const u64 v0 = ld64(src + sp), v1 = ld64(src + sp + 8), v2 = ld64(src + sp + 16);
-                auto ext = [&](u32 o) -> u64 {                           // bytes [o, o + 8) of v0|v1|v2, o <= 16
-                    const u64 a = o < 8 ? v0 : (o < 16 ? v1 : v2), bb = o < 8 ? v1 : v2;
-                    const u32 sh = (o & 7) * 8;
-                    return sh ? (a >> sh) | (bb << (64 - sh)) : a;
-                };
-                if (ll >= 8) {
-                    st64(d, v0);
-                    if (ll > 8) st64(d + (ll > 16 ? 8 : ll - 8), ext(ll > 16 ? 8 : ll - 8));
-                    if (ll > 16) st64(d + ll - 8, ext(ll - 8));
-                } else if (ll >= 4) { st32(d, (u32)v0); st32(d + ll - 4, (u32)(v0 >> (8 * (ll - 4)))); }
-                else for (u32 i = 0; i < ll; ++i) d[i] = (u8)(v0 >> (8 * i));
-            } else for (u32 i = 0; i < ll; ++i) d[i] = src[sp + i];
-        }
-        for (u64 lm = ballot(ll > 24); lm; lm &= lm - 1) {
+        g8* d = lits + dp; const gbyte* s = src + sp;
+        const bool c16 = ll >= 16 && ll <= 64, c4 = ll >= 4 && ll < 16, c1 = ll >= 1 && ll < 4;
+        const bool c16b = c16 && ll > 32, c16c = c16 && ll > 48, c16d = c16 && ll > 16;
+        const bool c4b = c4 && ll > 8, c4c = c4 && ll > 12, c4d = c4 && ll > 4;
+        const u32 e16 = ll - 16, e4 = ll - 4;
+        u32x4 q0v = {0u, 0u, 0u, 0u}, q1v = q0v, q2v = q0v, q3v = q0v;
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0; u8 b0 = 0, b1 = 0, b2 = 0;
+        if (c16) q0v = *(const ZGLB U128*)s;
+        if (c16b) q1v = *(const ZGLB U128*)(s + 16);
+        if (c16c) q2v = *(const ZGLB U128*)(s + 32);
+        if (c16d) q3v = *(const ZGLB U128*)(s + e16);
+        if (c4) r0 = *(const ZGLB U32*)s;
+        if (c4b) r1 = *(const ZGLB U32*)(s + 4);
+        if (c4c) r2 = *(const ZGLB U32*)(s + 8);
+        if (c4d) r3 = *(const ZGLB U32*)(s + e4);
+        if (c1) { b0 = s[0]; b1 = s[ll >> 1]; b2 = s[ll - 1]; }
+        asm volatile("" ::: "memory");
+        if (c16) *(ZGLB U128*)d = q0v;
+        if (c16b) *(ZGLB U128*)(d + 16) = q1v;
+        if (c16c) *(ZGLB U128*)(d + 32) = q2v;
+        if (c16d) *(ZGLB U128*)(d + e16) = q3v;
+        if (c4) *(ZGLB U32*)d = r0;
+        if (c4b) *(ZGLB U32*)(d + 4) = r1;
+        if (c4c) *(ZGLB U32*)(d + 8) = r2;
+        if (c4d) *(ZGLB U32*)(d + e4) = r3;
+        if (c1) { d[0] = b0; d[ll >> 1] = b1; d[ll - 1] = b2; }
+        for (u64 lm = ballot(ll > 64); lm; lm &= lm - 1) {
             const int k = (int)__builtin_ctzll(lm);
-            wave_copy(ws->lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
+            wave_copy(lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
         }
         lpos += lane_get(inc, 63);
+        ll = nll; sp = nsp;
     }
-    wave_copy(ws->lits + lpos, src + anchor, n - anchor, lane);
+    wave_copy(lits + lpos, src + anchor, n - anchor, lane);
     wave_fence();
     if (seqLits) *seqLits = lpos;                                       // literals of the sequences (the parse need not count them)
     return n - anchor;
@@ -200,6 +218,15 @@ __device__ unsigned long long g_zstd_prof[16];
 #endif
 #else
 #define ZSTAGE(k) do { } while (0)
+#endif
+// entropy-stage profile (experiment build, tools/zstd_entropy_prof.py): drained stamps, previous stamp kept in EntropyLds::misc
+#ifdef ZSTD_PROF
+__device__ unsigned long long g_zstd_eprof[16];
+#define ESTAGE(L, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (lane_id() == 0) { ZLDS unsigned long long* p_ = (ZLDS unsigned long long*)(L)->misc; if ((k) >= 0) atomicAdd(&g_zstd_eprof[(k) < 0 ? 0 : (k)], t_ - *p_); *p_ = t_; } } while (0)
+#else
+#define ESTAGE(L, k) do { } while (0)
 #endif
 // ---- the chain walk of zstd_chain.h as scalar assembly (same inputs, same result; the C++ text stays the specification: the CPU
 //      lane model runs it, -DZSTD_WALK_CXX puts it back into the kernel).  The compiler turns the C++ loop into ~140 scalar
@@ -894,7 +921,15 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
 #endif
     wave_fence();
     u32 seqLits = 0;
+#ifdef ZSTD_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
     const u32 lastLits = gather_literals(src, n, ws, nbSeq, anchor, lane, &seqLits);
+#ifdef ZSTD_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) { atomicAdd(&g_zstd_eprof[0], __builtin_amdgcn_s_memtime() - tg0); atomicAdd(&g_zstd_eprof[12], 1ull); atomicAdd(&g_zstd_eprof[13], (unsigned long long)nbSeq); atomicAdd(&g_zstd_eprof[14], (unsigned long long)(seqLits + lastLits)); }
+#endif
     *litSizeOut = seqLits + lastLits;
     return nbSeq;
 }
@@ -1177,7 +1212,7 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
 // ------------------------------------------------------------------------------------------------
 // literals
 // ------------------------------------------------------------------------------------------------
-__device__ u32 lit_raw(u8* dst, const u8* src, u32 n, u32 type, int lane)
+__device__ u32 lit_raw(g8* dst, const g8* src, u32 n, u32 type, int lane)
 {   // ZSTD_noCompressLiterals / ZSTD_compressRleLiteralsBlock (zstd_compress_literals.c:39-107)
     const u32 fl = 1 + (n > 31) + (n > 4095);
     if (lane == 0) {
@@ -1191,65 +1226,84 @@ __device__ u32 lit_raw(u8* dst, const u8* src, u32 n, u32 type, int lane)
 }
 
 // byte histogram of src[0..n) into hist[256] (LDS)
-__device__ void wave_hist(u32* hist_, const u8* src_, u32 n, int lane)
-{   // 16 bytes per lane and step (one load instead of sixteen round trips of one byte each), counts by LDS atomics
-    typedef __attribute__((address_space(3))) u32 L32;
-    L32* hist = (L32*)hist_;
-    const gbyte* src = (const gbyte*)src_;
+__device__ void wave_hist(l32* hist, const g8* src, u32 n, int lane)
+{   // 16 bytes per lane and step (one load instead of sixteen round trips of one byte each), counts by LDS atomics; the next
+    // step's load travels while this step counts
+    typedef u32x4 __attribute__((aligned(1))) U;
     for (u32 i = (u32)lane; i < 256; i += kWave) hist[i] = 0;
     wave_fence();
     const u32 nv = n >> 4;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if ((u32)lane < nv) v = *(const ZGLB U*)(src + 16u * (u32)lane);
     for (u32 i = (u32)lane; i < nv; i += kWave) {
-        typedef u32x4 __attribute__((aligned(1))) U;
-        const u32x4 v = *(const __attribute__((address_space(1))) U*)(src + 16u * i);
+        u32x4 nx = {0u, 0u, 0u, 0u};
+        if (i + kWave < nv) nx = *(const ZGLB U*)(src + 16u * (i + kWave));
         const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            __hip_atomic_fetch_add(&hist[w[k] & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&hist[(w[k] >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&hist[(w[k] >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&hist[w[k] >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add(&hist[w[k] & 0xFF], 1u);
+            lds_add(&hist[(w[k] >> 8) & 0xFF], 1u);
+            lds_add(&hist[(w[k] >> 16) & 0xFF], 1u);
+            lds_add(&hist[w[k] >> 24], 1u);
         }
+        v = nx;
     }
-    for (u32 i = 16u * nv + (u32)lane; i < n; i += kWave) __hip_atomic_fetch_add(&hist[src[i]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (u32 i = 16u * nv + (u32)lane; i < n; i += kWave) lds_add(&hist[src[i]], 1u);
     wave_fence();
 }
 
-// HUF_compress1X_usingCTable (huf_compress.c:1051-1116): symbols last -> first, 8 symbols per lane per round
-__device__ u32 huf_encode_1x(u8* dst, const u8* src, u32 n, const HufCT* ct, u32* tile, int lane)
+// The code of the literals as one LDS word per symbol: value | length << 16 (one read per symbol in the stream loops).
+template <class CT>
+__device__ __forceinline__ void huf_code_words(l32* cw, CT ct, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const u32 s = 64u * t + (u32)lane; cw[s] = (u32)ct->val[s] | ((u32)ct->nbBits[s] << 16); }
+    wave_fence();
+}
+
+// HUF_compress1X_usingCTable (huf_compress.c:1051-1116): symbols last -> first, 8 symbols per lane per round.  The 8 symbols of
+// a lane are ONE 8-byte load (they are consecutive bytes, taken from the top down), requested a round ahead.
+__device__ u32 huf_encode_1x(g8* dst, const g8* src, u32 n, const l32* cw, l32* tile, int lane)
 {
     WavePacker pk; pk.init(tile, dst, lane);
-    for (u32 done = 0; done < n; done += 512) {
-        // lane handles encode-order items [done + 8*lane, +8): item j is symbol src[n-1-j]
-        u64 lo = 0, hi = 0; u32 nb = 0;
+    // lane handles encode-order items [done + 8*lane, +8): item j is symbol src[n-1-j]: the bytes src[n-8-j0, n-j0) from the top down
+    auto fetch = [&](u32 done) -> u64 {
         const u32 j0 = done + 8u * (u32)lane;
-        for (u32 k = 0; k < 8; ++k) {
-            const u32 j = j0 + k;
-            if (j < n) {
-                const u32 sym = src[n - 1 - j];
-                const u32 l = ct->nbBits[sym]; const u64 v = ct->val[sym];
-                if (nb < 64) { lo |= v << nb; if (nb + l > 64) hi |= v >> (64 - nb); }
-                else hi |= v << (nb - 64);
-                nb += l;
-            }
-        }
-        pk.push(lo, hi, nb, lane);
+        if (j0 + 8 <= n) return ld64(src + (n - 8 - j0));
+        u64 v = 0;
+        if (j0 < n) { const u32 k = n - j0; for (u32 t = 0; t < k; ++t) v |= (u64)src[t] << (8 * (8 - k + t)); }   // the stream's first bytes: its last items
+        return v;
+    };
+    u64 cur = fetch(0);
+    for (u32 done = 0; done < n; done += 512) {
+        const u64 nxt = done + 512 < n ? fetch(done + 512) : 0ull;
+        const u32 j0 = done + 8u * (u32)lane;
+        const u32 cnt = j0 >= n ? 0u : (n - j0 < 8 ? n - j0 : 8u);
+        // two halves of four symbols (<= 44 bits each), then one 128-bit value
+        u64 a = 0, b = 0; u32 na = 0, nb2 = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) if (k < cnt) { const u32 e = cw[(u32)(cur >> (8 * (7 - k))) & 0xFFu]; a |= (u64)(e & 0xFFFFu) << na; na += e >> 16; }
+#pragma unroll
+        for (u32 k = 4; k < 8; ++k) if (k < cnt) { const u32 e = cw[(u32)(cur >> (8 * (7 - k))) & 0xFFu]; b |= (u64)(e & 0xFFFFu) << nb2; nb2 += e >> 16; }
+        const u64 lo = a | (b << na), hi = na ? b >> (64 - na) : 0ull;
+        pk.push(lo, hi, na + nb2, lane);
+        cur = nxt;
     }
     return pk.close(lane);
 }
-__device__ u32 huf_encode_4x(u8* dst_, const u8* src_, u32 n_, const HufCT* ct_, u32* tile_, int lane)
+__device__ u32 huf_encode_4x(g8* dst_, const g8* src_, u32 n_, const l32* cw_, l32* tile_, int lane)
 {   // huf_compress.c:1163-1211
-    u8* dst = uni_ptr(dst_); const u8* src = uni_ptr(src_); const u32 n = uni(n_); const HufCT* ct = uni_ptr(ct_); u32* tile = uni_ptr(tile_);   // (a call: arguments arrive in vector registers)
+    g8* dst = uni_ptr(dst_); const g8* src = uni_ptr(src_); const u32 n = uni(n_); const l32* cw = uni_ptr(cw_); l32* tile = uni_ptr(tile_);   // (a call: arguments arrive in vector registers)
     const u32 seg = (n + 3) / 4;
     u32 op = 6;
     if (n < 12) return 0;
     for (int i = 0; i < 3; ++i) {
-        const u32 c = huf_encode_1x(dst + op, src + (u32)i * seg, seg, ct, tile, lane);
+        const u32 c = huf_encode_1x(dst + op, src + (u32)i * seg, seg, cw, tile, lane);
         if (c == 0 || c > 65535) return 0;
         if (lane == 0) { dst[2 * i] = (u8)c; dst[2 * i + 1] = (u8)(c >> 8); }
         op += c;
     }
-    const u32 c = huf_encode_1x(dst + op, src + 3 * seg, n - 3 * seg, ct, tile, lane);
+    const u32 c = huf_encode_1x(dst + op, src + 3 * seg, n - 3 * seg, cw, tile, lane);
     if (c == 0 || c > 65535) return 0;
     return op + c;
 }
@@ -1258,10 +1312,10 @@ __device__ u32 huf_encode_4x(u8* dst_, const u8* src_, u32 n_, const HufCT* ct_,
 // last block that was written compressed and whether it may be reused (HUF_repeat_check; HUF_repeat_valid only comes from
 // dictionaries).  `fresh` is set when the block just coded wrote a new table into EntropyLds::huf: the frame loop copies it
 // into `prev` if the block is confirmed (ZSTD_blockState_confirmRepcodesAndEntropyTables, zstd_compress.c:4385-4387).
-struct FrameHuf { HufCT* prev; u32 repeat; u32 fresh; u32 disabled; };   // disabled: ZSTD_literalsCompressionIsDisabled
+struct FrameHuf { ZLDS HufCT* prev; u32 repeat; u32 fresh; u32 disabled; };   // disabled: ZSTD_literalsCompressionIsDisabled
 
 // HUF_estimateCompressedSize (huf_compress.c:809-818)
-__device__ u32 huf_estimate(const HufCT* ct, const u32* hist, u32 maxSym, int lane)
+__device__ u32 huf_estimate(const ZLDS HufCT* ct, const l32* hist, u32 maxSym, int lane)
 {
     u32 bits = 0;
     for (u32 i = (u32)lane; i <= maxSym; i += kWave) bits += (u32)ct->nbBits[i] * hist[i];
@@ -1272,7 +1326,7 @@ __device__ u32 huf_estimate(const HufCT* ct, const u32* hist, u32 maxSym, int la
 // (validation :1386-1391, small inputs prefer it :1392-1397, otherwise it is kept when it costs no more than a new table
 // plus its description :1419-1426); `repeat` stays set exactly when the old table coded the literals.
 template <bool FR>
-__device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool suspect, EntropyLds* L, int lane, FrameHuf* fh, u32& repeat)
+__device__ u32 huf_compress(g8* dst, const g8* src, u32 n, bool single, bool suspect, LEntropy* L, int lane, FrameHuf* fh, u32& repeat)
 {
     if (suspect && n >= 4096 * 10) {                                     // :1361-1375
         wave_hist(L->hist, src, 4096, lane);
@@ -1286,6 +1340,7 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
         if (lb + le <= ((2 * 4096) >> 7) + 4) return 0;
     }
     wave_hist(L->hist, src, n, lane);
+    ESTAGE(L, 1);
     u32 largest = 0, maxSym = 0;
     for (u32 i = (u32)lane; i < 256; i += kWave) { const u32 c = L->hist[i]; if (c > largest) largest = c; if (c) maxSym = i; }
     for (int d = 32; d; d >>= 1) {
@@ -1294,8 +1349,10 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
     }
     if (largest == n) { if (lane == 0) dst[0] = src[0]; return 1; }
     if (largest <= (n >> 7) + 4) return 0;
-    auto encode = [&](const HufCT* ct, u32 h) -> u32 {                   // HUF_compressCTable_internal :1216-1240
-        const u32 c = single ? huf_encode_1x(dst + h, src, n, ct, L->tile, lane) : huf_encode_4x(dst + h, src, n, ct, L->tile, lane);
+    auto encode = [&](const ZLDS HufCT* ct, u32 h) -> u32 {              // HUF_compressCTable_internal :1216-1240
+        huf_code_words(L->hist, ct, lane);                               // (the histogram is not needed any more)
+        const u32 c = single ? huf_encode_1x(dst + h, src, n, L->hist, L->tile, lane) : huf_encode_4x(dst + h, src, n, L->hist, L->tile, lane);
+        ESTAGE(L, 4);
         if (!c) return 0;
         if (h + c >= n - 1) return 0;
         return h + c;
@@ -1310,8 +1367,10 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
     }
     u32 huffLog = fse_optimal_log(11, n, maxSym, 1);                     // HUF_optimalTableLog :1268-1283
     huffLog = huf_build_wave(&L->huf, L->hist, maxSym, huffLog, &L->hs, lane);
+    ESTAGE(L, 2);
     const u32 h = huf_write_table_wave(dst, &L->huf, maxSym, huffLog, &L->hs, lane);
     wave_fence();
+    ESTAGE(L, 3);
     if (!h) return 0;
     if constexpr (FR) {
         if (repeat) {
@@ -1326,7 +1385,7 @@ __device__ u32 huf_compress(u8* dst, const u8* src, u32 n, bool single, bool sus
 
 // ZSTD_compressLiterals (zstd_compress_literals.c:129-235)
 template <bool FR>
-__device__ u32 compress_literals(u8* dst, const u8* src, u32 n, bool suspect, EntropyLds* L, int lane, FrameHuf* fh)
+__device__ u32 compress_literals(g8* dst, const g8* src, u32 n, bool suspect, LEntropy* L, int lane, FrameHuf* fh)
 {
     const u32 lh = 3 + (n >= 1024) + (n >= 16384);
     const bool single = n < 256;
@@ -1362,24 +1421,20 @@ __device__ int select_type(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool
     return 2;
 }
 
-// histogram + mode + table description + CTable of one symbol stream (ZSTD_buildCTable :242-288).
-// All lanes call it; returns type (or -1), advances *op, updates *lastCount.
-__device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 nbSeq, u32 maxCode, u32 fseLog,
-                            const s16* defNorm, u32 defLog, u32 defMax, u32* lastCount, EntropyLds* L, int lane, u32 strategy)
+// mode + table description + CTable of one symbol stream from its histogram (ZSTD_buildCTable :242-288); first / last = the
+// stream's codes of sequence 0 / nbSeq - 1.  All lanes call it; returns type (or -1), advances *op, updates *lastCount.
+__device__ int build_stream(g8* base, u32* op, ZLDS FseCT* ct, const l32* count, const u32 first, const u32 last, u32 nbSeq, u32 maxCode, u32 fseLog,
+                            const s16* defNorm, u32 defLog, u32 defMax, u32* lastCount, LEntropy* L, int lane, u32 strategy)
 {
-    for (u32 i = (u32)lane; i < 64; i += kWave) L->count[i] = 0;
-    wave_fence();
-    for (u32 i = (u32)lane; i < nbSeq; i += kWave) atomicAdd(&L->count[codes[i]], 1u);
-    wave_fence();
-    // one symbol per lane from here on (the alphabets have at most 53 symbols)
+    // one symbol per lane (the alphabets have at most 53 symbols)
     int type = 0; u32 adv = 0, lc = 0;
-    u32 c = (u32)lane <= maxCode ? L->count[lane] : 0u;
+    u32 c = (u32)lane <= maxCode ? count[lane] : 0u;
     const u32 max = (u32)top_lane(ballot(c != 0)), most = uni(wmaxu(c));
     const bool defaultAllowed = (defMax == 28) ? (max <= 28) : true;                  // zstd_compress.c:2847-2848
     type = select_type(most, nbSeq, defLog, defaultAllowed, strategy);
-    FseScratch* fs = &L->hs.fs;
+    ZLDS FseScratch* fs = &L->hs.fs;
     if (type == 1) {
-        if (lane == 0) { fse_build_rle(ct, max); base[*op] = codes[0]; }
+        if (lane == 0) { fse_build_rle(ct, max); base[*op] = (u8)first; }
         adv = 1;
     } else if (type == 0) {
         const int norm = (u32)lane <= defMax ? (int)defNorm[lane] : 0;
@@ -1387,7 +1442,6 @@ __device__ int build_stream(u8* base, u32* op, FseCT* ct, const u8* codes, u32 n
     } else {
         u32 nbSeq1 = nbSeq;
         const u32 tableLog = fse_optimal_log(fseLog, nbSeq, max, 2);
-        const u32 last = uni(codes[nbSeq - 1]);
         if (lane_get(c, (int)last) > 1) { if ((u32)lane == last) c--; nbSeq1--; }     // zstd_compress_sequences.c:264-268
         int norm = 0;
         if (fse_normalize_wave(norm, c, nbSeq1, max, tableLog, nbSeq1 >= 2048, lane) < 0) type = -1;
@@ -1408,12 +1462,15 @@ template <bool FR = false>
 __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSeq_, EntropyLds* L_, int lane, u32 strategy_, FrameHuf* fh_ = nullptr)
 {
     // (a call: the arguments arrive in vector registers and count as divergent - made scalar again, or every loop over the
-    //  sequences below is an exec-mask loop with 64-bit vector address arithmetic)
-    u8* dst = uni_ptr(dst_); Workspace* ws = uni_ptr(ws_); const u32 litSize = uni(litSize_), nbSeq = uni(nbSeq_), strategy = uni(strategy_);
-    EntropyLds* L = uni_ptr(L_); FrameHuf* fh = uni_ptr(fh_);
+    //  sequences below is an exec-mask loop with 64-bit vector address arithmetic; and they arrive as generic pointers: given
+    //  their address spaces here, everything below is global_* / ds_*, not flat_*)
+    g8* dst = (g8*)uni_ptr(dst_); GWorkspace* ws = (GWorkspace*)uni_ptr(ws_); const u32 litSize = uni(litSize_), nbSeq = uni(nbSeq_), strategy = uni(strategy_);
+    LEntropy* L = (LEntropy*)uni_ptr(L_); FrameHuf* fh = uni_ptr(fh_);
     u32 op = 0;
     const bool suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
+    ESTAGE(L, -1);
     op += compress_literals<FR>(dst, ws->lits, litSize, suspect, L, lane, fh);
+    ESTAGE(L, 4);
     if (lane == 0) {
         if (nbSeq < 128) dst[op] = (u8)nbSeq;
         else if (nbSeq < 0x7F00) { dst[op] = (u8)((nbSeq >> 8) + 0x80); dst[op + 1] = (u8)nbSeq; }
@@ -1421,78 +1478,182 @@ __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSe
     }
     op += nbSeq < 128 ? 1 : (nbSeq < 0x7F00 ? 2 : 3);
     if (nbSeq == 0) return op;
-    for (u32 i = (u32)lane; i < nbSeq; i += kWave) {                     // ZSTD_seqToCodes :2715-2741
-        const u32 ll = ws->seqLL[i], ml = ws->seqML[i] - 3;
-        ws->llc[i] = (u8)(ll > 0xFFFF ? 35 : ll_code(ll));
-        ws->ofc[i] = (u8)hb(ws->seqOff[i]);
-        ws->mlc[i] = (u8)(ml > 0xFFFF ? 52 : ml_code(ml));
-    }
+    const g32* gLL = ws->seqLL; const g32* gML = ws->seqML; const g32* gOff = ws->seqOff;
+    g32* gCodes = ws->codes;
+    // ---- codes (ZSTD_seqToCodes :2715-2741) and the three histograms in one pass over the sequences, four rounds of loads in
+    //      flight (round 6; until then: one pass for the codes, one byte-load pass per stream for its histogram) ----
+    for (u32 i = (u32)lane; i < 3 * 64; i += kWave) (&L->cnt3[0][0])[i] = 0;
+    if (lane < 36) L->llbits[lane] = kLLbits[lane];
+    if (lane < 53) L->mlbits[lane] = kMLbits[lane];
     wave_fence();
-    const u32 seqHead = op++;
-    u32 lastCount = 0;
-    const int tLL = build_stream(dst, &op, &L->ctLL, ws->llc, nbSeq, 35, 9, kLLnorm, 6, 35, &lastCount, L, lane, strategy);
-    if (tLL < 0) return 0;
-    const int tOF = build_stream(dst, &op, &L->ctOF, ws->ofc, nbSeq, 31, 8, kOFnorm, 5, 28, &lastCount, L, lane, strategy);
-    if (tOF < 0) return 0;
-    const int tML = build_stream(dst, &op, &L->ctML, ws->mlc, nbSeq, 52, 9, kMLnorm, 6, 52, &lastCount, L, lane, strategy);
-    if (tML < 0) return 0;
-    if (lane == 0) dst[seqHead] = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
-
-    // ZSTD_encodeSequences_body (zstd_compress_sequences.c:290-382).  Encode order e = 0..nbSeq-1 handles
-    // sequence i = nbSeq-1-e.  Lanes 0,1,2 run the LL / ML / OF state chains for 64 sequences, then all lanes
-    // pack {OF state bits, ML state bits, LL state bits, LL extra, ML extra, OF extra} of one sequence each.
-    WavePacker pk; pk.init(L->tile, dst + op, lane);
-    const FseCT* myct = lane == 0 ? &L->ctLL : (lane == 1 ? &L->ctML : &L->ctOF);
-    const u8* mycodes = lane == 0 ? ws->llc : (lane == 1 ? ws->mlc : ws->ofc);
-    u32 state = 0;
-    if (lane < 3) state = fse_init_state(myct, mycodes[nbSeq - 1]);
-    for (u32 e0 = 0; e0 < nbSeq; e0 += kWave) {
-        const u32 cnt = nbSeq - e0 < kWave ? nbSeq - e0 : kWave;
-        // what a chain step needs besides the state - the code's deltaNbBits / deltaFindState - is looked up for the tile's 64
-        // sequences by all lanes first: the serial loop below is then one LDS round trip per step (the state table), not a
-        // global byte load + two table reads
-        if ((u32)lane < cnt) {
-            const u32 i = nbSeq - 1 - (e0 + (u32)lane);
-            const u32 cl = ws->llc[i], cm = ws->mlc[i], co = ws->ofc[i];
-            L->fsePre[0][lane][0] = L->ctLL.deltaNbBits[cl]; L->fsePre[0][lane][1] = L->ctLL.deltaFindState[cl];
-            L->fsePre[1][lane][0] = L->ctML.deltaNbBits[cm]; L->fsePre[1][lane][1] = L->ctML.deltaFindState[cm];
-            L->fsePre[2][lane][0] = L->ctOF.deltaNbBits[co]; L->fsePre[2][lane][1] = L->ctOF.deltaFindState[co];
-        }
-        wave_fence();
-        if (lane < 3) {
-            for (u32 k = 0; k < cnt; ++k) {
-                const u32 e = e0 + k;
-                u32 out = 0;
-                if (e > 0) {
-                    const int dnb = L->fsePre[lane][k][0], dfs = L->fsePre[lane][k][1];
-                    const u32 nb = (state + (u32)dnb) >> 16;
-                    out = ((state & ((1u << nb) - 1)) << 8) | nb;
-                    state = myct->stateTable[(int)(state >> nb) + dfs];
-                }
-                L->fseBits[lane][k] = out;
+    for (u32 i0 = (u32)lane; i0 < nbSeq; i0 += 4 * kWave) {
+        u32 ll[4], ml[4], of[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const u32 i = i0 + (u32)t * kWave; ll[t] = 0; ml[t] = 3; of[t] = 1; if (i < nbSeq) { ll[t] = gLL[i]; ml[t] = gML[i]; of[t] = gOff[i]; } }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 i = i0 + (u32)t * kWave;
+            if (i < nbSeq) {
+                const u32 m = ml[t] - 3;
+                const u32 cl = ll[t] > 0xFFFF ? 35u : ll_code(ll[t]), cm = m > 0xFFFF ? 52u : ml_code(m), co = (u32)hb(of[t]);
+                gCodes[i] = cl | (cm << 8) | (co << 16);
+                lds_add(&L->cnt3[0][cl], 1u); lds_add(&L->cnt3[1][cm], 1u); lds_add(&L->cnt3[2][co], 1u);
             }
         }
-        wave_fence();
-        u64 lo = 0, hi = 0; u32 nb = 0;
-        if ((u32)lane < cnt) {
-            const u32 i = nbSeq - 1 - (e0 + (u32)lane);
-            const u32 fl = L->fseBits[0][lane], fm = L->fseBits[1][lane], fo = L->fseBits[2][lane];
-            const u32 llb = kLLbits[ws->llc[i]], mlb = kMLbits[ws->mlc[i]], ofb = ws->ofc[i];
-            auto put = [&](u64 v, u32 l) {
-                if (!l) return;
-                v &= (1ull << l) - 1;
-                if (nb < 64) { lo |= v << nb; if (nb + l > 64) hi |= v >> (64 - nb); }
-                else hi |= v << (nb - 64);
-                nb += l;
-            };
-            put(fo >> 8, fo & 0xFF); put(fm >> 8, fm & 0xFF); put(fl >> 8, fl & 0xFF);
-            put(ws->seqLL[i], llb); put(ws->seqML[i] - 3, mlb); put(ws->seqOff[i], ofb);
-        }
-        pk.push(lo, hi, nb, lane);
-        wave_fence();
     }
+    wave_fence();
+    ESTAGE(L, 5);
+    const u32 seqHead = op++;
+    u32 lastCount = 0;
+    const u32 cwFirst = uni(gCodes[0]), cwLast = uni(gCodes[nbSeq - 1]);
+    const int tLL = build_stream(dst, &op, &L->ctLL, L->cnt3[0], cwFirst & 0xFF, cwLast & 0xFF, nbSeq, 35, 9, kLLnorm, 6, 35, &lastCount, L, lane, strategy);
+    if (tLL < 0) return 0;
+    const int tOF = build_stream(dst, &op, &L->ctOF, L->cnt3[2], (cwFirst >> 16) & 0xFF, (cwLast >> 16) & 0xFF, nbSeq, 31, 8, kOFnorm, 5, 28, &lastCount, L, lane, strategy);
+    if (tOF < 0) return 0;
+    const int tML = build_stream(dst, &op, &L->ctML, L->cnt3[1], (cwFirst >> 8) & 0xFF, (cwLast >> 8) & 0xFF, nbSeq, 52, 9, kMLnorm, 6, 52, &lastCount, L, lane, strategy);
+    if (tML < 0) return 0;
+    if (lane == 0) dst[seqHead] = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
+    ESTAGE(L, 6);
+
+    // ZSTD_encodeSequences_body (zstd_compress_sequences.c:290-382).  Encode step e = 0..nbSeq-1 handles sequence
+    // i = nbSeq-1-e; step 0 only initialises the three states, every later step emits the low bits of a state and moves it:
+    //     nb = (state + deltaNbBits[code]) >> 16;  bits = state & mask(nb);  state = stateTable[(state >> nb) + deltaFindState[code]].
+    // ---- phase A: the state chains, in segments (round 6).  Until round 5 lanes 0-2 walked the three chains from end to end, one
+    //      dependent LDS read per step: 28 % of the entropy stage.  The new state depends on state >> nb only - after a step the
+    //      chain remembers log2(states of the symbol) bits of where it came from - so a chain started from ANY state of the
+    //      right symbol falls into step with the true one within a few dozen steps.  Each stream gets 21 lanes; lane g walks steps
+    //      [b_g, b_g + seg) after a warm-up of 64 steps that starts from the symbol's initial state (for g = 0, whose warm-up
+    //      is empty, that IS the true state), and records the state BEFORE every step (two bytes in the workspace; what the
+    //      step emits follows from it).  Then the proof: lane g is right when the state it entered its segment with equals the
+    //      state lane g-1 left with; a lane that was wrong walks again from that state until it meets a state it recorded
+    //      before (from there on nothing changes), and the check is repeated until every lane agrees with its predecessor -
+    //      lane 0 is right by construction, so all are.  Worst case (no chain ever converges) = the serial walk.
+    const u32 steps = nbSeq - 1;
+    u32 fin = 0;                                                          // lane 0 / 21 / 42: the stream's state after the last step
+    {
+        constexpr u32 kWarm = 64, kLanes = 21;
+        const u32 grp = (u32)lane / kLanes, g = (u32)lane - kLanes * grp;   // grp 0 LL, 1 ML, 2 OF (3: lane 63, idle)
+        const ZLDS FseCT* ct = grp == 0 ? &L->ctLL : (grp == 1 ? &L->ctML : &L->ctOF);
+        const u32 sh = 8u * (grp < 3 ? grp : 0u);
+        g16* gSt = ws->fseState[grp < 3 ? grp : 0u];
+        u32 G = steps / 64; G = G < 1 ? 1u : (G > kLanes ? kLanes : G);
+        const u32 seg = ((steps + G - 1) / G + 3u) & ~3u;                 // a multiple of four steps
+        const u32 b = 1 + g * seg;                                        // first step of the lane's segment
+        const bool on = grp < 3 && b <= steps;
+        const u32 e_end = on ? (b + seg < nbSeq ? b + seg : nbSeq) : 0u;  // one past its last step
+        const u32 w = b > kWarm ? b - kWarm : 1u;                         // first step of its warm-up (w == b for lane 0)
+        typedef u32x4 __attribute__((aligned(1))) U128;
+        // code words of steps e .. e+3 = sequences nbSeq-1-e .. nbSeq-4-e: one 16-byte load, .w first
+        auto codes4 = [&](u32 e) -> u32x4 {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (e < e_end) v = *(const ZGLB U128*)(gCodes + ((int)nbSeq - 4 - (int)e));   // (may reach into codesPad: those steps are masked)
+            return v;
+        };
+        auto step = [&](u32& st, const u32 cword, const bool act) {
+            const u32 c = (cword >> sh) & 0xFFu;
+            const int dnb = ct->deltaNbBits[c], dfs = ct->deltaFindState[c];
+            const u32 nb = (st + (u32)dnb) >> 16;
+            const u32 nx = ct->stateTable[(int)(st >> nb) + dfs];
+            st = act ? nx : st;
+        };
+        u32 st = 0, S = 0;
+        if (grp < 3) {
+            const u32 iw = on ? nbSeq - w : nbSeq - 1;                    // sequence of step w - 1 (lanes that are off: step 0's, for `fin`)
+            st = fse_init_state(ct, (gCodes[iw] >> sh) & 0xFFu);
+        }
+        u32 e = on ? w : 0u;
+        u32x4 cw = codes4(e);
+        const u32 trips = (kWarm + seg) / 4;
+        for (u32 t = 0; t < trips; ++t) {
+            const u32x4 nx = codes4(e + 4);
+            const bool act = e < e_end;
+            if (e == b) S = st;
+            const u32 s0 = st; step(st, cw.w, act && e < e_end);
+            const u32 s1 = st; step(st, cw.z, act && e + 1 < e_end);
+            const u32 s2 = st; step(st, cw.y, act && e + 2 < e_end);
+            const u32 s3 = st; step(st, cw.x, act && e + 3 < e_end);
+            if (act && e >= b) st64(gSt + e, (u64)s0 | ((u64)s1 << 16) | ((u64)s2 << 32) | ((u64)s3 << 48));
+            if (act) e += 4;
+            cw = nx;
+        }
+        if (on && b >= e_end) S = st;                                     // (cannot happen: b <= steps < nbSeq)
+        wave_fence();
+        // the proof, and the repairs
+        for (;;) {
+            const u32 prev = wave_shr1(st);                               // the state lane g-1 left its segment with
+            const bool bad = on && g > 0 && S != prev;
+            if (!any_lane(bad)) break;
+            u32 e2 = bad ? b : e_end, st2 = prev;
+            if (bad) S = prev;
+            bool run = bad;
+            while (any_lane(run)) {
+                u64 rec = 0; u32x4 c4 = {0u, 0u, 0u, 0u};
+                if (run) { rec = ld64(gSt + e2); c4 = *(const ZGLB U128*)(gCodes + ((int)nbSeq - 4 - (int)e2)); }
+                if (run && (u32)(rec & 0xFFFFu) == st2) run = false;      // met the walk recorded before: the rest of the segment stands
+                if (run) {
+                    const u32 s0 = st2; step(st2, c4.w, e2 < e_end);
+                    const u32 s1 = st2; step(st2, c4.z, e2 + 1 < e_end);
+                    const u32 s2 = st2; step(st2, c4.y, e2 + 2 < e_end);
+                    const u32 s3 = st2; step(st2, c4.x, e2 + 3 < e_end);
+                    st64(gSt + e2, (u64)s0 | ((u64)s1 << 16) | ((u64)s2 << 32) | ((u64)s3 << 48));
+                    e2 += 4;
+                    if (e2 >= e_end) { st = st2; run = false; }           // walked to the end: a new final state
+                }
+                wave_fence();
+            }
+        }
+        // final states: the last lane of each stream that is on (or lane g = 0 when there are no steps at all)
+        const u32 used = steps ? (steps + seg - 1) / seg : 1u;            // lanes per stream that walked
+        fin = st;
+        const u32 fLL = lane_get(st, (int)(used - 1)), fML = lane_get(st, (int)(kLanes + used - 1)), fOF = lane_get(st, (int)(2 * kLanes + used - 1));
+        fin = lane == 0 ? fLL : (lane == 1 ? fML : fOF);
+    }
+    wave_fence();
+    ESTAGE(L, 8);
+    // ---- phase B: every lane packs one sequence per round {OF state bits, ML state bits, LL state bits, LL extra, ML extra,
+    //      OF extra}; the next round's seven loads travel while this round is packed ----
+    WavePacker pk; pk.init(L->tile, dst + op, lane);
+    {
+        const g16* sLLp = ws->fseState[0]; const g16* sMLp = ws->fseState[1]; const g16* sOFp = ws->fseState[2];
+        struct Rec { u32 cw, ll, ml, of, sl, sm, so; };
+        auto load = [&](u32 e0) -> Rec {
+            Rec r = {0u, 0u, 3u, 0u, 0u, 0u, 0u};
+            const u32 e = e0 + (u32)lane;
+            if (e < nbSeq) {
+                const u32 i = nbSeq - 1 - e;
+                r.cw = gCodes[i]; r.ll = gLL[i]; r.ml = gML[i]; r.of = gOff[i];
+                if (e > 0) { r.sl = sLLp[e]; r.sm = sMLp[e]; r.so = sOFp[e]; }
+            }
+            return r;
+        };
+        Rec cur = load(0);
+        for (u32 e0 = 0; e0 < nbSeq; e0 += kWave) {
+            const Rec nx = load(e0 + kWave);
+            const u32 e = e0 + (u32)lane;
+            u64 lo = 0, hi = 0; u32 nb = 0;
+            if (e < nbSeq) {
+                const u32 cl = cur.cw & 0xFF, cm = (cur.cw >> 8) & 0xFF, co = (cur.cw >> 16) & 0xFF;
+                auto put = [&](u64 v, u32 l) {
+                    if (!l) return;
+                    v &= (1ull << l) - 1;
+                    if (nb < 64) { lo |= v << nb; if (nb + l > 64) hi |= v >> (64 - nb); }
+                    else hi |= v << (nb - 64);
+                    nb += l;
+                };
+                if (e > 0) {
+                    const u32 no = (cur.so + (u32)L->ctOF.deltaNbBits[co]) >> 16, nm = (cur.sm + (u32)L->ctML.deltaNbBits[cm]) >> 16,
+                              nl = (cur.sl + (u32)L->ctLL.deltaNbBits[cl]) >> 16;
+                    put(cur.so, no); put(cur.sm, nm); put(cur.sl, nl);
+                }
+                put(cur.ll, L->llbits[cl]); put(cur.ml - 3, L->mlbits[cm]); put(cur.of, co);
+            }
+            pk.push(lo, hi, nb, lane);
+            cur = nx;
+        }
+    }
+    ESTAGE(L, 9);
     {   // FSE_flushCState x3: ML, OF, LL (:371-373)
-        const u32 sLL = lane_get(state, 0), sML = lane_get(state, 1), sOF = lane_get(state, 2);
+        const u32 sLL = lane_get(fin, 0), sML = lane_get(fin, 1), sOF = lane_get(fin, 2);
         u64 v = 0; u32 nb = 0;
         if (lane == 0) {
             const u32 lm = (u32)L->ctML.tableLog, lo_ = (u32)L->ctOF.tableLog, ll_ = (u32)L->ctLL.tableLog;
@@ -1505,6 +1666,7 @@ __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSe
     }
     const u32 bs = pk.close(lane);
     op += bs;
+    ESTAGE(L, 10);
     if (lastCount && lastCount + bs < 4) return 0;                       // zstd_compress.c:3017-3023
     return op;
 }
@@ -1632,7 +1794,15 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     const u32 h = 1 + (2 << 1) + (cSize << 3);
     if (lane == 0) { dst[op] = (u8)h; dst[op + 1] = (u8)(h >> 8); dst[op + 2] = (u8)(h >> 16); }
     wave_fence();
+#ifdef ZSTD_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
     wave_copy(dst + op + 3, ws->tmp, cSize, lane);
+#ifdef ZSTD_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&g_zstd_eprof[11], __builtin_amdgcn_s_memtime() - tc0);
+#endif
     return (int)(op + 3 + cSize);
 }
 
@@ -1870,7 +2040,7 @@ __device__ long long zstd_frame_wave(const u8* __restrict__ src, const u64 n64, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
     FrameWindow win = { 2u, 2u, 1u << windowLog };
-    FrameHuf fh = { &L->prev, 0u, 0u, strategy == 1 ? targetLength : 0u };
+    FrameHuf fh = { (ZLDS HufCT*)&L->prev, 0u, 0u, strategy == 1 ? targetLength : 0u };
     u32 rep1 = 1, rep2 = 4;
     for (u32 bs = 0; bs < n; bs += blockMax) {
         const u32 bn = n - bs < blockMax ? n - bs : blockMax;
@@ -3189,6 +3359,14 @@ extern "C" int aoclgpu_debug_zstd_dprof(unsigned long long* host16)
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_dprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_dprof), z, sizeof(z));
+    return 0;
+}
+extern "C" int aoclgpu_debug_zstd_eprof(unsigned long long* host16)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_eprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_eprof), z, sizeof(z));
     return 0;
 }
 extern "C" int aoclgpu_debug_zstd_prof(unsigned long long* host16)

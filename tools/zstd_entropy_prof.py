@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Experiment: per-sub-stage cycle breakdown of the Zstd level-1 entropy stage (drained stamps, wave cycles summed over all
+chunks).  Needs a library built with AOCLGPU_CFLAGS="-DAOCLGPU_EXPERIMENTS -DZSTD_PROF" (build.py --variant prof ...)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import aocl_compression_amd as a
+eng = a.engine(0)
+data = a.corpus.silesia_mix(64 << 20)
+src = torch.from_numpy(data).to(eng.device).repeat(8)
+buf = (C.c_ulonglong * 16)()
+eng.lib.aoclgpu_debug_zstd_eprof(buf)           # reset
+slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072)
+torch.cuda.synchronize()
+eng.lib.aoclgpu_debug_zstd_eprof(buf)
+names = ["gather_literals (in the finder's function)", "literals: histogram (+ the suspect probe)", "literals: Huffman code (sort, tree, lengths, values)",
+         "literals: table description (weights, FSE)", "literals: Huffman streams + header", "sequences: codes", "sequences: 3 x histogram / normalise / description / CTable",
+         "tile: code -> (deltaNbBits, deltaFindState)", "tile: three state chains (lanes 0-2)", "tile: values + bit packer", "final states + close", "staged block -> slot"]
+tot = sum(buf[:12]); chunks = buf[12]; seqs = buf[13]; lits = buf[14]
+for n, v in zip(names, buf[:12]):
+    print(f"{n:66s} {v / tot * 100:6.2f}%  {v / chunks:10.0f} ticks/chunk")
+print(f"total {tot / chunks:.0f} ticks/chunk (s_memtime ticks: 100 MHz)   chunks {chunks}  sequences/chunk {seqs / chunks:.0f}  literals/chunk {lits / chunks:.0f}")
