@@ -390,6 +390,13 @@ struct HufScratch {
     short todo[12][64];   // per-bucket work lists of the tie-order sort
 };
 
+#ifdef ZSTD_PROF            /* experiment build: sub-stages of huf_build_wave (tools/zstd_entropy_prof.py) */
+__device__ unsigned long long g_zstd_hprof[8];
+#define HSTAGE(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) atomicAdd(&g_zstd_hprof[k], t_ - hprev); hprev = t_; } while (0)
+#else
+#define HSTAGE(k) do { } while (0)
+#endif
 constexpr u32 kHufCutoff = 165;      // RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) (huf_compress.c:552)
 // bucket of the reference's sort (huf_compress.c:560-570): one per count below the cutoff, one per power of two above
 __device__ __forceinline__ u32 huf_bucket(u32 c) { return c < kHufCutoff ? c : (u32)hb(c) + 158; }
@@ -436,6 +443,9 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
     ZLDS HufCT* ct = uni_ptr(ct_); const l32* hist = uni_ptr(hist_); const u32 maxSym = uni(maxSym_), maxNbBits = uni(maxNbBits_); ZLDS HufScratch* sc = uni_ptr(sc_);
     // ---- 1. sort: count descending; equal counts in symbol order (the reference's bucket fill order), except inside a
     //         power-of-two bucket of more than 8 symbols, where the quicksort's own order for ties applies ----
+#ifdef ZSTD_PROF
+    unsigned long long hprev = __builtin_amdgcn_s_memtime();
+#endif
     u32 c[4], key[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -453,6 +463,7 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
         for (int t = 0; t < 4; ++t) rank[t] += kj > key[t] ? 1u : 0u;
     }
     wave_fence();
+    HSTAGE(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const u32 s = 64u * t + (u32)lane; if (s <= maxSym) sc->tmp[rank[t]] = (c[t] << 8) | s; }
     wave_fence();
@@ -463,6 +474,7 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
         // all ties, so nine or more of them come out permuted.  Lane 11 owns that bucket.
         const u32 hbv = 7u + (u32)lane;
         int lo = -1, hi = -2;
+        bool ties = false;
         if (lane < 12) {
             const u32 cmin = lane == 11 ? kHufCutoff - 1 : (hbv == 7 ? kHufCutoff : (1u << hbv));
             const u32 cmax = lane == 11 ? kHufCutoff - 1 : (2u << hbv) - 1;
@@ -472,18 +484,29 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
             lo = a; b = (int)nonNull;                        // first index with count < cmin
             while (a < b) { const int m = (a + b) >> 1; if ((sc->tmp[m] >> 8) >= cmin) a = m + 1; else b = m; }
             hi = a - 1;
-            bool ties = false;
             if (hi - lo >= 8) for (int i = lo; i < hi; ++i) ties |= (sc->tmp[i] >> 8) == (sc->tmp[i + 1] >> 8);
-            if (ties) {
-                // back to the bucket's fill order (symbol ascending), then the reference's scheme
-                for (int i = lo + 1; i <= hi; i++) {
-                    const u32 k = sc->tmp[i]; int j = i - 1;
-                    while (j >= lo && (sc->tmp[j] & 0xFF) > (k & 0xFF)) { sc->tmp[j + 1] = sc->tmp[j]; j--; }
-                    sc->tmp[j + 1] = k;
-                }
-                huf_bucket_sort(sc->tmp, lo, hi, sc->todo[lane]);
+        }
+        HSTAGE(6);
+        // back to the bucket's fill order (symbol ascending), then the reference's scheme.  The fill order needs no sort: a
+        // symbol's place in its bucket is the number of smaller symbols with a count in the bucket's range - ballots over the
+        // four symbol slots (until round 6 the owning lane insertion-sorted its bucket in LDS: 37 % of this function).
+        for (u64 tm = ballot(lane < 12 && ties); tm; tm &= tm - 1) {
+            const int bk = (int)__builtin_ctzll(tm);
+            const u32 bmin = bk == 11 ? kHufCutoff - 1 : (bk == 0 ? kHufCutoff : (1u << (7 + bk)));
+            const u32 bmax = bk == 11 ? kHufCutoff - 1 : (2u << (7 + bk)) - 1;
+            const u32 blo = lane_get((u32)lo, bk);
+            u32 before = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool in = c[t] >= bmin && c[t] <= bmax;            // (c is 0 beyond maxSym and for absent symbols)
+                const u64 m = ballot(in);
+                if (in) sc->tmp[blo + before + below(m)] = (c[t] << 8) | (64u * t + (u32)lane);
+                before += (u32)__builtin_popcountll(m);
             }
         }
+        wave_fence();
+        HSTAGE(7);
+        if (lane < 12 && ties) huf_bucket_sort(sc->tmp, lo, hi, sc->todo[lane]);
     }
     wave_fence();
     // sorted leaves, four per lane: leaf i = 64*t + lane
@@ -491,33 +514,47 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; leafCnt[t] = i < nonNull ? sc->tmp[i] >> 8 : 0u; }
 
+    HSTAGE(1);
     // ---- 2. tree: two-queue merge.  Serial by definition; runs as scalar code with the queues in lane registers
     //         (leaf i in lane i & 63 of leafCnt[i >> 6], internal node k likewise in intCnt) ----
-    u32 intCnt[4] = {0, 0, 0, 0}, leafPar[4] = {0, 0, 0, 0}, intPar[4] = {0, 0, 0, 0};
-    auto rd = [&](const u32 (&r)[4], int i) -> u32 {
-        const int t = i >> 6, l = i & 63;
-        return t == 0 ? lane_get(r[0], l) : (t == 1 ? lane_get(r[1], l) : (t == 2 ? lane_get(r[2], l) : lane_get(r[3], l)));
-    };
-    auto wr = [&](u32 (&r)[4], int i, u32 v) {
-        const int t = i >> 6; const bool me = lane == (i & 63);
-        if (t == 0) r[0] = me ? v : r[0]; else if (t == 1) r[1] = me ? v : r[1]; else if (t == 2) r[2] = me ? v : r[2]; else r[3] = me ? v : r[3];
-    };
+    //         Round 6: the queues live in LDS (leaf counts = the sorted array, internal counts in the weight chains' scratch,
+    //         parent links in the sort keys' place, all dead here) and the loop is scalar code around uniform-address reads -
+    //         the next leaf's count is requested when a leaf is taken, an internal node's count was written a node ago at
+    //         least.  (Until then the queues were lane registers: every access a four-way register select around a readlane
+    //         or four compare-and-select writes, ~670 cycles per pick.)
+    u32 leafPar[4] = {0, 0, 0, 0}, intPar[4] = {0, 0, 0, 0};
     const int nInt = (int)nonNull - 1;                       // internal nodes, created in non-decreasing count order
     {
+        l16* lpar = (l16*)sc->key; l16* ipar = lpar + 256; l32* icnt = (l32*)sc->wbits; l32* dummy = (l32*)sc->todo;
+        // (stores of a uniform value: lane 0 writes the slot, the other lanes a scratch word of their own - no exec change)
+        auto put16 = [&](l16* a, int i, u32 v) { l16* q = lane == 0 ? a + i : (l16*)(dummy + lane); *q = (u16)v; };
+        auto put32 = [&](l32* a, int i, u32 v) { l32* q = lane == 0 ? a + i : dummy + lane; *q = v; };
         int li = (int)nonNull - 1, ii = 0;                   // smallest unused leaf, oldest unused internal node
-        u32 lc = rd(leafCnt, li), ic = 0;
+        u32 lc = uni(sc->tmp[li] >> 8), ic = 0;
+        u32 lcn = li > 0 ? sc->tmp[li - 1] >> 8 : 0u;        // the leaf behind it, on its way
         for (int k = 0; k < nInt; ++k) {
             u32 sum = 0;
 #pragma unroll
             for (int pick = 0; pick < 2; ++pick) {           // the smaller of the two queue heads; a leaf only if strictly smaller
                 const bool leaf = li >= 0 && (ii >= k || lc < ic);     // (huf_compress.c:707-708)
-                if (leaf) { sum += lc; wr(leafPar, li, (u32)k); li--; lc = li >= 0 ? rd(leafCnt, li) : 0u; }
-                else { sum += ic; wr(intPar, ii, (u32)k); ii++; ic = ii < k ? rd(intCnt, ii) : 0u; }
+                if (leaf) {
+                    sum += lc; put16(lpar, li, (u32)k); li--;
+                    lc = uni(lcn); lcn = li > 0 ? sc->tmp[li - 1] >> 8 : 0u;
+                }
+                else { sum += ic; put16(ipar, ii, (u32)k); ii++; ic = ii < k ? uni(icnt[ii]) : 0u; }
             }
-            wr(intCnt, k, sum);
+            put32(icnt, k, sum);
             if (ii == k) ic = sum;                           // the node just made is the queue's head when the queue was empty
         }
+        wave_fence();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { leafPar[t] = lpar[64 * t + lane]; intPar[t] = ipar[64 * t + lane]; }
     }
+    auto rd = [&](const u32 (&r)[4], int i) -> u32 {
+        const int t = i >> 6, l = i & 63;
+        return t == 0 ? lane_get(r[0], l) : (t == 1 ? lane_get(r[1], l) : (t == 2 ? lane_get(r[2], l) : lane_get(r[3], l)));
+    };
+    HSTAGE(2);
     // depth of every internal node below the root (node nInt-1): pointer jumping over the parent links
     u32 dep[4], par[4];
 #pragma unroll
@@ -539,6 +576,7 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
     for (int t = 0; t < 4; ++t) { const u32 i = 64u * t + (u32)lane; len[t] = i < nonNull ? gather(dep, leafPar[t]) + 1u : 0u; }
     if (nonNull == 1) len[0] = lane == 0 ? 1u : len[0];
 
+    HSTAGE(3);
     // ---- 3. length limit (HUF_setMaxHeight).  Leaves are in count-descending = length-ascending order ----
     u32 bits;
     {
@@ -603,6 +641,7 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
             bits = target;
         }
     }
+    HSTAGE(4);
     // ---- 4. canonical values: symbols of one length are numbered in symbol order, the lengths' first values come from
     //         the per-length counts, longest first (:776-790) ----
     for (u32 s = (u32)lane; s < 256; s += kWave) ct->nbBits[s] = 0;
@@ -631,6 +670,7 @@ __device__ u32 huf_build_wave(ZLDS HufCT* ct_, const l32* hist_, const u32 maxSy
     for (int t = 0; t < 4; ++t) ct->val[64u * t + (u32)lane] = (u16)val[t];
     if (lane == 0) ct->tableLog = bits;
     wave_fence();
+    HSTAGE(5);
     return bits;
 }
 

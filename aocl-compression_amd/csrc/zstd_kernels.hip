@@ -90,10 +90,11 @@ struct Workspace {
     u32 seqSrc[kMaxSeq];     // position of the sequence's literals in the chunk
     u32 codesPad[4];         // (the state chains read code words four at a time, downwards from a sequence)
     u32 codes[kMaxSeq];      // LL code | ML code << 8 | OF code << 16 (ZSTD_seqToCodes)
-    u16 fseState[3][kMaxSeq + 8];   // state of the LL / ML / OF chain BEFORE encode step e (round 6: the chains run in segments)
-    u8  pad[8];
+    u16 fseState[3][kMaxSeq + 24];   // state of the LL / ML / OF chain BEFORE encode step e (round 6: the chains run in segments)
+    u8  pad[16];             // (keeps sizeof a multiple of 16)
     u8  tmp[2 * kBlockMax + 1024];
 };
+static_assert(sizeof(Workspace) % 16 == 0, "workspaces of neighbouring workgroups stay 16-byte aligned");
 typedef ZGLB Workspace GWorkspace;
 
 // ---- LDS of the entropy stage (overlays the hash table once the match finder is done) ----
@@ -139,57 +140,92 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 }
 
 // Literal buffer of a block: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the search
-// loop never waits on a load->store copy.  64 sequences per round: prefix sum of the literal lengths, runs up to 64 bytes one
-// per lane - pieces at 0, k, 2k and len - k, every access inside the run, every load of the round before its first store -
-// longer runs by the whole wave; the next round's records travel while this round is copied (round 6; until then a round was
-// two exposed round trips, and every run above 24 bytes a third).  Returns the size of the last literal run.
-__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, Workspace* ws_, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
+// loop never waits on a load->store copy.  128 sequences per round, two consecutive ones per lane (their records are one
+// 8-byte load per array, requested a round ahead): prefix sum of the literal lengths; runs up to 64 bytes as pieces at 0, k, 2k
+// and len - k, every access inside the run; the round's first four runs above 64 bytes by the whole wave, 16 bytes per lane
+// (the last piece overlapping) - and EVERY load of the round before its first store: one trip to memory per 128 sequences
+// (until round 6: two per 64, and a third for every run above 24 bytes, which was most of this function's time).
+// Returns the size of the last literal run.
+__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, GWorkspace* ws, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
 {
     typedef u32x4 __attribute__((aligned(1))) U128;
     typedef u32 __attribute__((aligned(1))) U32;
-    GWorkspace* ws = (GWorkspace*)ws_;
+    typedef u64 __attribute__((aligned(1))) U64;
     g8* lits = ws->lits;
     const g32* gLL = ws->seqLL; const g32* gSrc = ws->seqSrc;
-    u32 lpos = 0, ll = 0, sp = 0;
-    if ((u32)lane < nbSeq) { ll = gLL[lane]; sp = gSrc[lane]; }
-    for (u32 q0 = 0; q0 < nbSeq; q0 += kWave) {
-        const u32 qn = q0 + kWave + (u32)lane;
-        u32 nll = 0, nsp = 0;
-        if (qn < nbSeq) { nll = gLL[qn]; nsp = gSrc[qn]; }
-        const u32 inc = wave_scan_incl(ll);
-        const u32 dp = lpos + inc - ll;
-        g8* d = lits + dp; const gbyte* s = src + sp;
-        const bool c16 = ll >= 16 && ll <= 64, c4 = ll >= 4 && ll < 16, c1 = ll >= 1 && ll < 4;
-        const bool c16b = c16 && ll > 32, c16c = c16 && ll > 48, c16d = c16 && ll > 16;
-        const bool c4b = c4 && ll > 8, c4c = c4 && ll > 12, c4d = c4 && ll > 4;
-        const u32 e16 = ll - 16, e4 = ll - 4;
-        u32x4 q0v = {0u, 0u, 0u, 0u}, q1v = q0v, q2v = q0v, q3v = q0v;
-        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0; u8 b0 = 0, b1 = 0, b2 = 0;
-        if (c16) q0v = *(const ZGLB U128*)s;
-        if (c16b) q1v = *(const ZGLB U128*)(s + 16);
-        if (c16c) q2v = *(const ZGLB U128*)(s + 32);
-        if (c16d) q3v = *(const ZGLB U128*)(s + e16);
-        if (c4) r0 = *(const ZGLB U32*)s;
-        if (c4b) r1 = *(const ZGLB U32*)(s + 4);
-        if (c4c) r2 = *(const ZGLB U32*)(s + 8);
-        if (c4d) r3 = *(const ZGLB U32*)(s + e4);
-        if (c1) { b0 = s[0]; b1 = s[ll >> 1]; b2 = s[ll - 1]; }
-        asm volatile("" ::: "memory");
-        if (c16) *(ZGLB U128*)d = q0v;
-        if (c16b) *(ZGLB U128*)(d + 16) = q1v;
-        if (c16c) *(ZGLB U128*)(d + 32) = q2v;
-        if (c16d) *(ZGLB U128*)(d + e16) = q3v;
-        if (c4) *(ZGLB U32*)d = r0;
-        if (c4b) *(ZGLB U32*)(d + 4) = r1;
-        if (c4c) *(ZGLB U32*)(d + 8) = r2;
-        if (c4d) *(ZGLB U32*)(d + e4) = r3;
-        if (c1) { d[0] = b0; d[ll >> 1] = b1; d[ll - 1] = b2; }
-        for (u64 lm = ballot(ll > 64); lm; lm &= lm - 1) {
-            const int k = (int)__builtin_ctzll(lm);
-            wave_copy(lits + lane_get(dp, k), src + lane_get(sp, k), lane_get(ll, k), lane);
+    auto rec2 = [&](const g32* a, u32 q) -> u64 {                        // records q, q+1 (the arrays have room behind nbSeq)
+        u64 v = 0;
+        if (q < nbSeq) v = *(const ZGLB U64*)(a + q);
+        return v;
+    };
+    u32 lpos = 0;
+    u64 llp = rec2(gLL, 2u * (u32)lane), spp = rec2(gSrc, 2u * (u32)lane);
+    for (u32 q0 = 0; q0 < nbSeq; q0 += 2 * kWave) {
+        const u32 qa = q0 + 2u * (u32)lane;
+        const u64 nll = rec2(gLL, qa + 2 * kWave), nsp = rec2(gSrc, qa + 2 * kWave);
+        u32 ll[2] = {(u32)llp, (u32)(llp >> 32)};
+        const u32 sp[2] = {(u32)spp, (u32)(spp >> 32)};
+        if (qa >= nbSeq) ll[0] = 0;
+        if (qa + 1 >= nbSeq) ll[1] = 0;
+        const u32 mine = ll[0] + ll[1];
+        const u32 inc = wave_scan_incl(mine);
+        u32 dp[2];
+        dp[0] = lpos + inc - mine; dp[1] = dp[0] + ll[0];
+        // the first four long runs of the round (uniform parameters)
+        u64 lm0 = ballot(ll[0] > 64), lm1 = ballot(ll[1] > 64);
+        u32 Ln[4] = {0, 0, 0, 0}, Ls[4] = {0, 0, 0, 0}, Ld[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (lm0) { const int k = (int)__builtin_ctzll(lm0); lm0 &= lm0 - 1; Ln[j] = lane_get(ll[0], k); Ls[j] = lane_get(sp[0], k); Ld[j] = lane_get(dp[0], k); }
+            else if (lm1) { const int k = (int)__builtin_ctzll(lm1); lm1 &= lm1 - 1; Ln[j] = lane_get(ll[1], k); Ls[j] = lane_get(sp[1], k); Ld[j] = lane_get(dp[1], k); }
         }
+        u32x4 p0[2], p1[2], p2[2], p3[2], lv[4]; u32 r0[2], r1[2], r2[2], r3[2], b0[2], b1[2], b2[2], lo_[4]; bool la[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32 l = ll[t]; const gbyte* s = src + sp[t];
+            const bool c16 = l >= 16 && l <= 64, c4 = l >= 4 && l < 16, c1 = l >= 1 && l < 4;
+            p0[t] = p1[t] = p2[t] = p3[t] = u32x4{0u, 0u, 0u, 0u}; r0[t] = r1[t] = r2[t] = r3[t] = b0[t] = b1[t] = b2[t] = 0;
+            if (c16) p0[t] = *(const ZGLB U128*)s;
+            if (c16 && l > 32) p1[t] = *(const ZGLB U128*)(s + 16);
+            if (c16 && l > 48) p2[t] = *(const ZGLB U128*)(s + 32);
+            if (c16 && l > 16) p3[t] = *(const ZGLB U128*)(s + (l - 16));
+            if (c4) r0[t] = *(const ZGLB U32*)s;
+            if (c4 && l > 8) r1[t] = *(const ZGLB U32*)(s + 4);
+            if (c4 && l > 12) r2[t] = *(const ZGLB U32*)(s + 8);
+            if (c4 && l > 4) r3[t] = *(const ZGLB U32*)(s + (l - 4));
+            if (c1) { b0[t] = s[0]; b1[t] = s[l >> 1]; b2[t] = s[l - 1]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 nfull = Ln[j] >> 4;                                // (a run's first 1024 bytes; what is behind them follows below)
+            lo_[j] = (u32)lane < nfull ? 16u * (u32)lane : Ln[j] - 16;
+            la[j] = Ln[j] != 0 && ((u32)lane < nfull || ((u32)lane == nfull && (Ln[j] & 15u) != 0));
+            lv[j] = u32x4{0u, 0u, 0u, 0u};
+            if (la[j]) lv[j] = *(const ZGLB U128*)(src + Ls[j] + lo_[j]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32 l = ll[t]; g8* d = lits + dp[t];
+            const bool c16 = l >= 16 && l <= 64, c4 = l >= 4 && l < 16, c1 = l >= 1 && l < 4;
+            if (c16) *(ZGLB U128*)d = p0[t];
+            if (c16 && l > 32) *(ZGLB U128*)(d + 16) = p1[t];
+            if (c16 && l > 48) *(ZGLB U128*)(d + 32) = p2[t];
+            if (c16 && l > 16) *(ZGLB U128*)(d + (l - 16)) = p3[t];
+            if (c4) *(ZGLB U32*)d = r0[t];
+            if (c4 && l > 8) *(ZGLB U32*)(d + 4) = r1[t];
+            if (c4 && l > 12) *(ZGLB U32*)(d + 8) = r2[t];
+            if (c4 && l > 4) *(ZGLB U32*)(d + (l - 4)) = r3[t];
+            if (c1) { d[0] = (u8)b0[t]; d[l >> 1] = (u8)b1[t]; d[l - 1] = (u8)b2[t]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (la[j]) *(ZGLB U128*)(lits + Ld[j] + lo_[j]) = lv[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (Ln[j] > 1024) wave_copy(lits + Ld[j] + 1024, src + Ls[j] + 1024, Ln[j] - 1024, lane);
+        for (; lm0; lm0 &= lm0 - 1) { const int k = (int)__builtin_ctzll(lm0); wave_copy(lits + lane_get(dp[0], k), src + lane_get(sp[0], k), lane_get(ll[0], k), lane); }
+        for (; lm1; lm1 &= lm1 - 1) { const int k = (int)__builtin_ctzll(lm1); wave_copy(lits + lane_get(dp[1], k), src + lane_get(sp[1], k), lane_get(ll[1], k), lane); }
         lpos += lane_get(inc, 63);
-        ll = nll; sp = nsp;
+        llp = nll; spp = nsp;
     }
     wave_copy(lits + lpos, src + anchor, n - anchor, lane);
     wave_fence();
@@ -450,7 +486,7 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
     // (arguments of a non-inlined function arrive in VGPRs and count as divergent: everything the control flow hangs on is
     //  made wave-uniform here, or the scalar walk below is compiled as exec-masked vector code - common.hip.h)
     const gbyte* __restrict__ src = uni_ptr(src_);
-    lbyte* lds = uni_ptr(lds_); Workspace* ws = uni_ptr(ws_);
+    lbyte* lds = uni_ptr(lds_); GWorkspace* ws = (GWorkspace*)uni_ptr(ws_);   // (typed: the record stores are global_*, not flat_*)
     const u32 n = uni(n_), hlog = uni(hlog_), expf = uni(expf_);
     const u32 bs = FRAME ? uni(bs_) : 0u;                               // (a compile-time zero for chunks)
     typedef __attribute__((address_space(3))) T LT;
@@ -974,9 +1010,10 @@ __device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF
 // the offsets go back to it (:393-399, :478-486).
 template <int MLS, bool FRAME = false>
 __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u32 hlogL, const u32 hlogS, u32* tabs, lbyte* lds,
-                           Workspace* ws, u32* litSizeOut, int lane, const u32 bs = 0, const FrameWindow* win = nullptr,
+                           Workspace* ws_, u32* litSizeOut, int lane, const u32 bs = 0, const FrameWindow* win = nullptr,
                            u32* rep1io = nullptr, u32* rep2io = nullptr)
 {
+    GWorkspace* ws = (GWorkspace*)ws_;
     typedef __attribute__((address_space(1))) u32 gu32;
     typedef __attribute__((address_space(3))) uint16_t lu16;
     const u32 n = be;                                        // iend
@@ -1458,6 +1495,9 @@ __device__ int build_stream(g8* base, u32* op, ZLDS FseCT* ct, const l32* count,
 }
 
 // ZSTD_entropyCompressSeqStore_internal (zstd_compress.c:2910-3027): block content size, 0 = emit raw
+#ifndef ZSTD_FSE_WARM
+#define ZSTD_FSE_WARM 128      /* steps a chain segment walks in front of its first step (a multiple of 16) */
+#endif
 template <bool FR = false>
 __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSeq_, EntropyLds* L_, int lane, u32 strategy_, FrameHuf* fh_ = nullptr)
 {
@@ -1531,74 +1571,107 @@ __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSe
     const u32 steps = nbSeq - 1;
     u32 fin = 0;                                                          // lane 0 / 21 / 42: the stream's state after the last step
     {
-        constexpr u32 kWarm = 64, kLanes = 21;
+        constexpr u32 kWarm = ZSTD_FSE_WARM, kLanes = 21;
         const u32 grp = (u32)lane / kLanes, g = (u32)lane - kLanes * grp;   // grp 0 LL, 1 ML, 2 OF (3: lane 63, idle)
         const ZLDS FseCT* ct = grp == 0 ? &L->ctLL : (grp == 1 ? &L->ctML : &L->ctOF);
         const u32 sh = 8u * (grp < 3 ? grp : 0u);
         g16* gSt = ws->fseState[grp < 3 ? grp : 0u];
-        u32 G = steps / 64; G = G < 1 ? 1u : (G > kLanes ? kLanes : G);
-        const u32 seg = ((steps + G - 1) / G + 3u) & ~3u;                 // a multiple of four steps
+        u32 G = steps / 128; G = G < 1 ? 1u : (G > kLanes ? kLanes : G);       // (segments of at least 128 steps)
+        const u32 seg = ((steps + G - 1) / G + 15u) & ~15u;               // a multiple of sixteen steps (one block)
         const u32 b = 1 + g * seg;                                        // first step of the lane's segment
         const bool on = grp < 3 && b <= steps;
         const u32 e_end = on ? (b + seg < nbSeq ? b + seg : nbSeq) : 0u;  // one past its last step
         const u32 w = b > kWarm ? b - kWarm : 1u;                         // first step of its warm-up (w == b for lane 0)
         typedef u32x4 __attribute__((aligned(1))) U128;
-        // code words of steps e .. e+3 = sequences nbSeq-1-e .. nbSeq-4-e: one 16-byte load, .w first
-        auto codes4 = [&](u32 e) -> u32x4 {
+        // code words of steps e .. e+3 = sequences nbSeq-1-e .. nbSeq-4-e: one 16-byte load, .w first (the last block of a chain
+        // may reach into codesPad: those steps are masked)
+        auto codes4 = [&](u32 e, bool p) -> u32x4 {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (e < e_end) v = *(const ZGLB U128*)(gCodes + ((int)nbSeq - 4 - (int)e));   // (may reach into codesPad: those steps are masked)
+            if (p) v = *(const ZGLB U128*)(gCodes + ((int)nbSeq - 4 - (int)e));
             return v;
         };
-        auto step = [&](u32& st, const u32 cword, const bool act) {
-            const u32 c = (cword >> sh) & 0xFFu;
-            const int dnb = ct->deltaNbBits[c], dfs = ct->deltaFindState[c];
-            const u32 nb = (st + (u32)dnb) >> 16;
-            const u32 nx = ct->stateTable[(int)(st >> nb) + dfs];
-            st = act ? nx : st;
+        // four steps.  Every LDS read is unconditional (a lane that is past its end reads entry 0 and keeps its state): no branch
+        // in the chain; the four (deltaNbBits, deltaFindState) pairs are read in front of the four dependent state reads.
+        auto step4 = [&](u32& st, const u32x4 cwv, const u32 e, const u32 lim, u32& r0, u32& r1) {
+            const u32 cws[4] = {cwv.w, cwv.z, cwv.y, cwv.x};
+            int dnb[4], dfs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u32 c = e + (u32)k < lim ? (cws[k] >> sh) & 0xFFu : 0u; dnb[k] = ct->deltaNbBits[c]; dfs[k] = ct->deltaFindState[c]; }
+            u32 sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool act = e + (u32)k < lim;
+                sv[k] = st;
+                const u32 nb = (st + (u32)dnb[k]) >> 16;
+                const u32 nxs = ct->stateTable[act ? (int)(st >> nb) + dfs[k] : 0];
+                st = act ? nxs : st;
+            }
+            r0 = sv[0] | (sv[1] << 16); r1 = sv[2] | (sv[3] << 16);
         };
         u32 st = 0, S = 0;
         if (grp < 3) {
             const u32 iw = on ? nbSeq - w : nbSeq - 1;                    // sequence of step w - 1 (lanes that are off: step 0's, for `fin`)
             st = fse_init_state(ct, (gCodes[iw] >> sh) & 0xFFu);
         }
+        // Blocks of sixteen steps.  A block's four code loads are requested a block ahead, and its sixteen recorded states leave at
+        // the top of the NEXT block - behind the wait for that block's codes: with loads and stores in flight together the wait
+        // is for everything (they may return out of order), and this way everything it waits for is a block old.
         u32 e = on ? w : 0u;
-        u32x4 cw = codes4(e);
-        const u32 trips = (kWarm + seg) / 4;
-        for (u32 t = 0; t < trips; ++t) {
-            const u32x4 nx = codes4(e + 4);
+        u32x4 c0 = codes4(e, e < e_end), c1 = codes4(e + 4, e + 4 < e_end), c2 = codes4(e + 8, e + 8 < e_end), c3 = codes4(e + 12, e + 12 < e_end);
+        u32x4 pa = {0u, 0u, 0u, 0u}, pb = pa; u32 pe = 0; bool pst = false;  // the block whose states wait to be stored
+        const u32 trips = (kWarm + seg) / 16;
+        for (u32 t = 0; t <= trips; ++t) {
+            asm volatile("" ::: "memory");
+            if (pst) { *(ZGLB U128*)(gSt + pe) = pa; *(ZGLB U128*)(gSt + pe + 8) = pb; }
             const bool act = e < e_end;
-            if (e == b) S = st;
-            const u32 s0 = st; step(st, cw.w, act && e < e_end);
-            const u32 s1 = st; step(st, cw.z, act && e + 1 < e_end);
-            const u32 s2 = st; step(st, cw.y, act && e + 2 < e_end);
-            const u32 s3 = st; step(st, cw.x, act && e + 3 < e_end);
-            if (act && e >= b) st64(gSt + e, (u64)s0 | ((u64)s1 << 16) | ((u64)s2 << 32) | ((u64)s3 << 48));
-            if (act) e += 4;
-            cw = nx;
+            const u32 en = act ? e + 16 : e;
+            const u32x4 n0 = codes4(en, act && en < e_end), n1 = codes4(en + 4, act && en + 4 < e_end), n2 = codes4(en + 8, act && en + 8 < e_end),
+                        n3 = codes4(en + 12, act && en + 12 < e_end);
+            if (act && e == b) S = st;
+            const u32 lim = act ? e_end : 0u;
+            u32 ra, rb, rc, rd;
+            step4(st, c0, e, lim, ra, rb); step4(st, c1, e + 4, lim, rc, rd); pa = u32x4{ra, rb, rc, rd};
+            step4(st, c2, e + 8, lim, ra, rb); step4(st, c3, e + 12, lim, rc, rd); pb = u32x4{ra, rb, rc, rd};
+            pst = act && e >= b; pe = e;
+            e = en; c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
-        if (on && b >= e_end) S = st;                                     // (cannot happen: b <= steps < nbSeq)
         wave_fence();
         // the proof, and the repairs
         for (;;) {
             const u32 prev = wave_shr1(st);                               // the state lane g-1 left its segment with
             const bool bad = on && g > 0 && S != prev;
             if (!any_lane(bad)) break;
+#ifdef ZSTD_PROF
+            { const u32 nbad = (u32)__builtin_popcountll(ballot(bad)); if (lane == 0) atomicAdd(&g_zstd_eprof[15], (unsigned long long)nbad); }
+#endif
+            // the same blocks of sixteen steps: the next block's codes and its first recorded state travel while this block is
+            // walked; a block's new states leave at the top of the next trip
             u32 e2 = bad ? b : e_end, st2 = prev;
             if (bad) S = prev;
             bool run = bad;
-            while (any_lane(run)) {
-                u64 rec = 0; u32x4 c4 = {0u, 0u, 0u, 0u};
-                if (run) { rec = ld64(gSt + e2); c4 = *(const ZGLB U128*)(gCodes + ((int)nbSeq - 4 - (int)e2)); }
-                if (run && (u32)(rec & 0xFFFFu) == st2) run = false;      // met the walk recorded before: the rest of the segment stands
+            auto rec16 = [&](u32 ee, bool p) -> u32 { u32 v = 0; if (p) v = (u32)gSt[ee]; return v; };
+            u32x4 d0 = codes4(e2, run), d1 = codes4(e2 + 4, run && e2 + 4 < e_end), d2 = codes4(e2 + 8, run && e2 + 8 < e_end), d3 = codes4(e2 + 12, run && e2 + 12 < e_end);
+            u32 rec = rec16(e2, run);
+            u32x4 qa = {0u, 0u, 0u, 0u}, qb = qa; u32 qe = 0; bool qst = false;
+            while (any_lane(run || qst)) {
+                asm volatile("" ::: "memory");
+                if (qst) { *(ZGLB U128*)(gSt + qe) = qa; *(ZGLB U128*)(gSt + qe + 8) = qb; }
+                qst = false;
+                if (run && rec == st2) run = false;                       // met the walk recorded before: the rest of the segment stands
+                const u32 en = e2 + 16;
+                const bool more = run && en < e_end;
+                const u32x4 n0 = codes4(en, more), n1 = codes4(en + 4, more && en + 4 < e_end), n2 = codes4(en + 8, more && en + 8 < e_end),
+                            n3 = codes4(en + 12, more && en + 12 < e_end);
+                const u32 nrec = rec16(en, more);
                 if (run) {
-                    const u32 s0 = st2; step(st2, c4.w, e2 < e_end);
-                    const u32 s1 = st2; step(st2, c4.z, e2 + 1 < e_end);
-                    const u32 s2 = st2; step(st2, c4.y, e2 + 2 < e_end);
-                    const u32 s3 = st2; step(st2, c4.x, e2 + 3 < e_end);
-                    st64(gSt + e2, (u64)s0 | ((u64)s1 << 16) | ((u64)s2 << 32) | ((u64)s3 << 48));
-                    e2 += 4;
+                    u32 ra, rb, rc, rd;
+                    step4(st2, d0, e2, e_end, ra, rb); step4(st2, d1, e2 + 4, e_end, rc, rd); qa = u32x4{ra, rb, rc, rd};
+                    step4(st2, d2, e2 + 8, e_end, ra, rb); step4(st2, d3, e2 + 12, e_end, rc, rd); qb = u32x4{ra, rb, rc, rd};
+                    qst = true; qe = e2;
+                    e2 = en;
                     if (e2 >= e_end) { st = st2; run = false; }           // walked to the end: a new final state
                 }
+                d0 = n0; d1 = n1; d2 = n2; d3 = n3; rec = nrec;
                 wave_fence();
             }
         }
@@ -1825,8 +1898,9 @@ constexpr u32 kFrScratch = 1024;                // u16 slots for the slot-reuse 
 
 template <int MLS>
 __device__ u32 fast_frame_block(const gbyte* __restrict__ src, const u32 bs, const u32 be, const u32 hlog, u32* tab, lbyte* scr,
-                                const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws, u32* litSizeOut, int lane, const u32* sched_ = nullptr)
+                                const FrameWindow& win, u32& rep1io, u32& rep2io, Workspace* ws_, u32* litSizeOut, int lane, const u32* sched_ = nullptr)
 {
+    GWorkspace* ws = (GWorkspace*)ws_;
     const u32* __restrict__ sched = uni_ptr(sched_);
     typedef __attribute__((address_space(1))) u32 gu32;
     typedef __attribute__((address_space(3))) uint16_t lu16;
@@ -3367,6 +3441,14 @@ extern "C" int aoclgpu_debug_zstd_eprof(unsigned long long* host16)
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_eprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_eprof), z, sizeof(z));
+    return 0;
+}
+extern "C" int aoclgpu_debug_zstd_hprof(unsigned long long* host8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::zs::g_zstd_hprof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::zs::g_zstd_hprof), z, sizeof(z));
     return 0;
 }
 extern "C" int aoclgpu_debug_zstd_prof(unsigned long long* host16)

@@ -10,6 +10,8 @@ data = a.corpus.silesia_mix(64 << 20)
 src = torch.from_numpy(data).to(eng.device).repeat(8)
 buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_zstd_eprof(buf)           # reset
+hb = (C.c_ulonglong * 8)()
+eng.lib.aoclgpu_debug_zstd_hprof(hb)
 slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072)
 torch.cuda.synchronize()
 eng.lib.aoclgpu_debug_zstd_eprof(buf)
@@ -20,3 +22,8 @@ tot = sum(buf[:12]); chunks = buf[12]; seqs = buf[13]; lits = buf[14]
 for n, v in zip(names, buf[:12]):
     print(f"{n:66s} {v / tot * 100:6.2f}%  {v / chunks:10.0f} ticks/chunk")
 print(f"total {tot / chunks:.0f} ticks/chunk (s_memtime ticks: 100 MHz)   chunks {chunks}  sequences/chunk {seqs / chunks:.0f}  literals/chunk {lits / chunks:.0f}")
+eng.lib.aoclgpu_debug_zstd_hprof(hb)
+for n, v in zip(["keys + rank sort", "tie order: the reference's quicksort per bucket", "tree: two-queue merge", "depths (pointer jumping) + lengths", "length limit", "canonical values", "scatter + bucket bounds + tie check", "tie order: back to the fill order"], hb[:8]):
+    print(f"  Huffman code: {n:40s} {v / chunks:10.0f} ticks/chunk")
+if buf[15]:
+    print(f"chain segments walked again: {buf[15] / chunks:.2f} per chunk")
