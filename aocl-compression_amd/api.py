@@ -84,7 +84,7 @@ class LlcDesc(C.Structure):
 
 EXPORTS = [
     "aoclgpu_device_count", "aoclgpu_init", "aoclgpu_last_error", "aoclgpu_version", "aoclgpu_compress_bound",
-    "aoclgpu_lz4_compress_chunks", "aoclgpu_lz4_decompress_chunks",
+    "aoclgpu_lz4_compress_chunks", "aoclgpu_lz4_decompress_chunks", "aoclgpu_lz4_error_value",
     "aoclgpu_snappy_compress_chunks", "aoclgpu_snappy_decompress_chunks",
     "aoclgpu_zstd_compress_chunks", "aoclgpu_zstd_decompress_chunks", "aoclgpu_zstd_last_split_slabs",
     "aoclgpu_compact_slots", "aoclgpu_time_batch", "aoclgpu_compress_host", "aoclgpu_compress_host_ex", "aoclgpu_decompress_host",

@@ -505,7 +505,15 @@ static int64_t host_oneshot(aoclgpu_codec codec, int op, const void* hsrc, size_
         const int rc = fn(&b, c->stream);
         if (rc != 0) { result = AOCLGPU_HOST_FAIL + rc; goto done; }
         CK(hipStreamSynchronize(c->stream));
-        const int32_t r = ((volatile int32_t*)c->hres)[0];
+        int32_t r = ((volatile int32_t*)c->hres)[0];
+        if (r < 0 && op == 1 && codec == AOCLGPU_LZ4 && !(flags & (AOCLGPU_FLAG_RAP_PARTITIONS | AOCLGPU_FLAG_LZ4_LINKED))) {
+            // a malformed LZ4 block: the value the reference returns for it (lz4_kernels.hip, lz4_error_value_kernel)
+            if (aoclgpu_lz4_error_value(c->dsrc, (uint32_t)n, (uint32_t)cap, 64u, (int32_t*)c->hres, c->stream) == 0) {
+                CK(hipStreamSynchronize(c->stream));
+                const int32_t v = ((volatile int32_t*)c->hres)[0];
+                if (v < 0) r = v;                              // (a walk that finds nothing wrong leaves the decoder's own verdict)
+            }
+        }
         if (r > 0) {
             CK(hipMemcpyAsync(hdst, c->ddst, (size_t)r, hipMemcpyDeviceToHost, c->stream));
             CK(hipStreamSynchronize(c->stream));

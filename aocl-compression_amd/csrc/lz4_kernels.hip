@@ -1394,7 +1394,116 @@ int lz4_stream_blocks(const uint8_t* d_src, uint32_t idxBase, const Lz4StreamJob
     hipLaunchKernelGGL(lz4_compress_stream_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_src, idxBase, d_jobs, njobs, d_table, d_dst, slot, d_len, accel);
     return check_launch("lz4_compress_stream_kernel");
 }
+// ------------------------------------------------------------------------------------------------
+// The VALUE LZ4_decompress_safe returns for a malformed block: -(ip - src) - 1 with ip where the reference's decoder stood when
+// it gave up (lz4.c:3799-3802).  The wave-parallel decoder above knows THAT a block is malformed, not where the reference's
+// two-loop decoder notices it: AOCL_LZ4_decompress_generic (lz4.c:3367-3803) runs a fast loop while the output is more than 64
+// bytes from its end and a safe loop afterwards, and the two check in a different order (a match length of 15+ with an offset
+// outside the block fails BEFORE its extension bytes are read in the fast loop, behind them in the safe loop).  So a block the
+// decoder rejected is walked once more here - tokens, lengths and offsets only, nothing is copied - along exactly the
+// reference's control flow (endOnInput, full block, no dictionary), and the walk's result is the return value.  Cold path: one
+// wavefront, scalar code; the stream is read through a 256-byte window held in one vector register.
+//   litDist: distance from either buffer end at which the fast loop hands a long literal run to the safe loop - 64 in the
+//   AVX build of the decoder (AOCL_LZ4_wildCopy64_AVX, :3448), which is what the reference runs on an AVX2 host once its
+//   dispatcher has been set up; 32 in LZ4_decompress_generic (:4396).
+__global__ void __launch_bounds__(64) lz4_error_value_kernel(const uint8_t* src_, const uint32_t n_, const uint32_t cap_, const uint32_t litDist_, int32_t* out)
+{
+    const gbyte* src = (const gbyte*)uni_ptr(src_);
+    const int64_t iend = (int64_t)uni(n_), oend = (int64_t)uni(cap_), litDist = (int64_t)uni(litDist_);
+    const int lane = lane_id();
+    int64_t wbase = -1; uint32_t win = 0;
+    auto B = [&](int64_t p) -> uint32_t {                     // the byte at src[p] (0 outside the block)
+        if (p < 0 || p >= iend) return 0u;
+        if (wbase < 0 || p < wbase || p >= wbase + 256) {
+            wbase = p;
+            const int64_t a = wbase + 4 * lane;
+            win = 0;
+            if (a + 4 <= iend) win = ld32(src + a);
+            else for (int t = 0; t < 4; ++t) if (a + t < iend) win |= (uint32_t)src[a + t] << (8 * t);
+        }
+        const uint32_t o = (uint32_t)(p - wbase);
+        return (lane_get(win, (int)(o >> 2)) >> (8 * (o & 3))) & 0xFFu;
+    };
+    int64_t ip = 0, op = 0, length = 0, offset = 0;
+    uint32_t token = 0;
+    int32_t result = 0;
+    if (oend == 0) { result = (iend == 1 && B(0) == 0) ? 0 : -1; goto done; }          // :3412-3416
+    if (iend == 0) { result = -1; goto done; }                                        // :3418
+    if (oend - op >= 64) {
+        for (;;) {                                            // ---- fast loop (:3427-3560) ----
+            token = B(ip++); length = token >> 4;
+            if (length == 15) {
+                if (ip >= iend - 15) goto error;              // initial_error
+                uint32_t s;
+                do { s = B(ip); ip++; length += s; if (ip >= iend - 15) break; } while (s == 255);   // (loop_error is not an error here, :3440)
+                if (op + length > oend - litDist || ip + length > iend - litDist) goto safe_literal_copy;
+                ip += length; op += length;
+            } else {
+                if (ip > iend - 17) goto safe_literal_copy;
+                ip += length; op += length;
+            }
+            offset = (int64_t)(B(ip) | (B(ip + 1) << 8)); ip += 2;
+            length = token & 15;
+            if (length == 15) {
+                if (offset > op) goto error;                  // :3483: in front of the extension bytes
+                uint32_t s;
+                do { s = B(ip); ip++; length += s; if (ip >= iend - 4) goto error; } while (s == 255);
+                length += 4;
+                if (op + length >= oend - 64) goto safe_match_copy;
+            } else {
+                length += 4;
+                if (op + length >= oend - 64) goto safe_match_copy;
+                if (offset <= op && offset >= 8) { op += length; continue; }
+            }
+            if (offset > op) goto error;                      // :3511
+            op += length;
+        }
+    }
+    for (;;) {                                                // ---- safe loop (:3566-3790) ----
+        token = B(ip++); length = token >> 4;
+        if (length != 15 && ip < iend - 16 && op <= oend - 32) {                      // the two-stage shortcut (:3580-3611)
+            op += length; ip += length;
+            length = token & 15; offset = (int64_t)(B(ip) | (B(ip + 1) << 8)); ip += 2;
+            if (length != 15 && offset >= 8 && offset <= op) { op += length + 4; continue; }
+            goto copy_match;
+        }
+        if (length == 15) {
+            if (ip >= iend - 15) goto error;
+            uint32_t s;
+            do { s = B(ip); ip++; length += s; if (ip >= iend - 15) break; } while (s == 255);
+        }
+    safe_literal_copy:
+        if (op + length > oend - 12 || ip + length > iend - 8) {                      // :3628-3676: the last literals, or an error
+            if (ip + length != iend || op + length > oend) goto error;
+            op += length;
+            result = (int32_t)op; goto done;
+        }
+        ip += length; op += length;
+        offset = (int64_t)(B(ip) | (B(ip + 1) << 8)); ip += 2;
+        length = token & 15;
+    copy_match:
+        if (length == 15) {
+            uint32_t s;
+            do { s = B(ip); ip++; length += s; if (ip >= iend - 4) goto error; } while (s == 255);
+        }
+        length += 4;
+    safe_match_copy:
+        if (offset > op) goto error;                          // :3710
+        if (op + length > oend - 5) goto error;               // :3776 (only looked at above oend - 12)
+        op += length;
+    }
+error:
+    result = (int32_t)(-ip - 1);
+done:
+    if (lane == 0) *out = result;
+}
 }  // namespace aoclgpu
+
+extern "C" int aoclgpu_lz4_error_value(const void* src_dev, uint32_t n, uint32_t cap, uint32_t lit_dist, int32_t* out, void* stream)
+{
+    hipLaunchKernelGGL(aoclgpu::lz4_error_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)src_dev, n, cap, lit_dist, out);
+    return aoclgpu::check_launch("lz4_error_value_kernel");
+}
 
 extern "C" int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream)
 {

@@ -742,20 +742,24 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     bool sized = split && fr.size() >= 2;
     if (sized) for (const FrameSpan& f : fr) sized = sized && f.content >= 0;
     if (!sized) {                                             // one wavefront walks the stream
-        if (split && !fr.empty()) {                           // a known content size that does not fit: dstSize_tooSmall, as the reference says
-            bool known = true; uint64_t tot = 0;
-            for (const FrameSpan& f : fr) { known = known && f.content >= 0; tot += f.content >= 0 ? (uint64_t)f.content : 0; }
-            if (known && tot > cap) return -2;
-        }
+        // (no shortcut for a content size that exceeds `cap`: the reference decodes until the output runs out, and whatever is
+        //  wrong with the stream in front of that point is what it reports)
         const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
-        if (r >= 0 && split && !checksums_ok(fr, (const uint8_t*)hdst, (size_t)r)) return -1;   // checksum_wrong (zstd_decompress.c:1094)
+        if (r >= 0 && split && !checksums_ok(fr, (const uint8_t*)hdst, (size_t)r)) return -22;   // checksum_wrong (zstd_decompress.c:1101)
         return r;
     }
     const size_t K = fr.size();
     uint64_t total = 0;
     std::vector<uint64_t> soff(K), doff(K); std::vector<uint32_t> slen(K), dcap(K);
-    for (size_t k = 0; k < K; ++k) { soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = total; dcap[k] = (uint32_t)fr[k].content; total += (uint64_t)fr[k].content; }
-    if (total > cap) return -2;
+    // a frame gets the room the frames in front of it leave (the reference decodes them in order: the first frame that does not
+    // fit fails with dstSize_tooSmall - or with whatever is wrong with it in front of that point)
+    uint64_t full = 0;
+    for (size_t k = 0; k < K; ++k) {
+        soff[k] = fr[k].off; slen[k] = fr[k].len; doff[k] = full < cap ? full : cap;
+        const uint64_t left = cap - doff[k];
+        dcap[k] = (uint32_t)((uint64_t)fr[k].content < left ? (uint64_t)fr[k].content : left);
+        full += (uint64_t)fr[k].content; total += dcap[k];
+    }
     aoclgpu::DeviceScope devScope(aoclgpu_host_device());
     if (!devScope.ok) { set_error_msg("zstd frames: hipSetDevice"); return AOCLGPU_HOST_FAIL + AOCLGPU_ERR_NO_DEVICE; }
     DevBuf dsrc, ddst, a, bq, c, d, o;
@@ -774,10 +778,13 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     if (rc) return AOCLGPU_HOST_FAIL + rc;
     std::vector<int32_t> res(K);
     HCK(hipMemcpy(res.data(), o.p, K * 4, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < K; ++k) if (res[k] < 0 || (uint32_t)res[k] != dcap[k]) return -1;
     if (total) HCK(hipMemcpy(hdst, ddst.p, total, hipMemcpyDeviceToHost));
 #undef HCK
-    if (!checksums_ok(fr, (const uint8_t*)hdst, (size_t)total)) return -1;
+    for (size_t k = 0; k < K; ++k) {                            // the first frame, in stream order, that failed: its error
+        if (res[k] < 0) return res[k];
+        if ((uint64_t)res[k] != (uint64_t)fr[k].content) return -20;
+        if (fr[k].hasCk && (uint32_t)xxh64((const uint8_t*)hdst + doff[k], (size_t)fr[k].content) != fr[k].ck) return -22;   // checksum_wrong (zstd_decompress.c:1101)
+    }
     return (int64_t)total;
 }
 

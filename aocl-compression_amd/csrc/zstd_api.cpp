@@ -247,6 +247,10 @@ const char* ZSTD_getErrorName(size_t code)
     case kErrFrameParamUnsupported: return "Unsupported frame parameter";
     case kErrFrameWindowTooLarge: return "Frame requires too much memory for decoding";
     case kErrCorrupt: return "Data corruption detected";
+    case 22: return "Restored data doesn't match checksum";
+    case 24: return "Header of Literals' block doesn't respect format specification";
+    case 30: return "Dictionary is corrupted";
+    case 32: return "Dictionary mismatch";
     case kErrParamUnsupported: return "Unsupported parameter";
     case kErrParamOutOfBound: return "Parameter is out of bound";
     case kErrMemory: return "Allocation error : not enough memory";
@@ -326,7 +330,13 @@ size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t co
     const int64_t r = aoclgpu_zstd_decompress_host_frames(src, compressedSize, dst ? dst : (void*)"", dstCapacity);
     if (r >= 0) return (size_t)r;
     if (r <= AOCLGPU_HOST_FAIL / 2) return zerr(kErrGeneric);         // the GPU path itself failed (no device, allocation, launch)
-    return zerr(r == -2 ? kErrDstTooSmall : kErrCorrupt);
+    // the decoder reports the reference's own error code for the check that failed (zstd_kernels.hip zstd_decompress_wave / decode_block)
+    switch ((int)-r) {
+    case kErrPrefix: case kErrFrameParamUnsupported: case kErrFrameWindowTooLarge: case kErrCorrupt: case 22 /* checksum_wrong */:
+    case 24 /* literals_headerWrong */: case 30 /* dictionary_corrupted */: case 32 /* dictionary_wrong */: case kErrDstTooSmall: case kErrSrcSize:
+        return zerr((int)-r);
+    default: return zerr(kErrCorrupt);
+    }
 }
 size_t ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {   // zstd_decompress.c:1246-1250

@@ -2825,19 +2825,23 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
 #else
 #define DCOUNT(k, n) ((void)0)
 #endif
-    if (n < 1) return 0xFFFFFFFFu;
+    // A failure is 0xFFFFFF00 | the reference's error code at the same check (zstd_errors.h:60-106), in the reference's order of checks.
+    constexpr u32 kCorrupt = 0xFFFFFF00u | 20u, kDstSmall = 0xFFFFFF00u | 70u, kSrcSize = 0xFFFFFF00u | 72u, kLitHeader = 0xFFFFFF00u | 24u, kDictCorrupt = 0xFFFFFF00u | 30u;
+    if (n < 2) return kCorrupt;                                          // MIN_CBLOCK_SIZE (zstd_decompress_block.c:174)
+    const u32 room = cap - opos, writeMax = blockMax < room ? blockMax : room;   // expectedWriteSize (:169-170)
     u32 ip = 0, litSize = 0; const u8* litPtr = nullptr;
     {   // ---- literals (ZSTD_decodeLiteralsBlock :162-364) ----
         const u32 b0 = uni(src[0]), type = b0 & 3, fmt = (b0 >> 2) & 3;
         if (type < 2) {
             u32 lh;
             if (fmt == 0 || fmt == 2) { lh = 1; litSize = b0 >> 3; }
-            else if (fmt == 1) { if (n < 2) return 0xFFFFFFFFu; lh = 2; litSize = (b0 | (uni(src[1]) << 8)) >> 4; }
-            else { if (n < 3) return 0xFFFFFFFFu; lh = 3; litSize = (b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16)) >> 4; }
-            if (litSize > blockMax) return 0xFFFFFFFFu;
-            if (type == 0) { if (lh + litSize > n) return 0xFFFFFFFFu; litPtr = src + lh; ip = lh + litSize; }
+            else if (fmt == 1) { if (n < 2) return kCorrupt; lh = 2; litSize = (b0 | (uni(src[1]) << 8)) >> 4; }
+            else { if (n < 3) return kCorrupt; lh = 3; litSize = (b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16)) >> 4; }
+            if (litSize > blockMax) return kCorrupt;
+            if (litSize > writeMax) return kDstSmall;                    // (:290, :331)
+            if (type == 0) { if (lh + litSize > n) return kCorrupt; litPtr = src + lh; ip = lh + litSize; }
             else {
-                if (lh + 1 > n) return 0xFFFFFFFFu;
+                if (lh + 1 > n) return kCorrupt;
                 const u8 v = (u8)uni(src[lh]);
                 for (u32 i = (u32)lane; i < litSize; i += kWave) litBuf[i] = v;
                 wave_fence();
@@ -2845,18 +2849,23 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             }
         } else {
             u32 lh, csize; bool streams4 = true;
-            if (fmt < 2) { if (n < 3) return 0xFFFFFFFFu; const u32 v = b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16); lh = 3; streams4 = (fmt == 1); litSize = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
-            else if (fmt == 2) { if (n < 4) return 0xFFFFFFFFu; const u32 v = uni(ld32(src)); lh = 4; litSize = (v >> 4) & 0x3FFF; csize = v >> 18; }
-            else { if (n < 5) return 0xFFFFFFFFu; const u32 v = uni(ld32(src)); lh = 5; litSize = (v >> 4) & 0x3FFFF; csize = (v >> 22) + (uni(src[4]) << 10); }
-            if (litSize > blockMax || litSize == 0 || lh + csize > n) return 0xFFFFFFFFu;
+            if (fmt < 2) { if (n < 3) return kCorrupt; const u32 v = b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16); lh = 3; streams4 = (fmt == 1); litSize = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+            else if (fmt == 2) { if (n < 4) return kCorrupt; const u32 v = uni(ld32(src)); lh = 4; litSize = (v >> 4) & 0x3FFF; csize = v >> 18; }
+            else { if (n < 5) return kCorrupt; const u32 v = uni(ld32(src)); lh = 5; litSize = (v >> 4) & 0x3FFFF; csize = (v >> 22) + (uni(src[4]) << 10); }
+            if (type == 3 && !uni(L->haveHuf)) return kDictCorrupt;      // set_repeat without a table (:182), in front of every size check
+            if (litSize > blockMax) return kCorrupt;                     // (:222)
+            if (streams4 && litSize < 6) return kLitHeader;              // literals_headerWrong (:223-226)
+            if (lh + csize > n) return kCorrupt;                         // (:227)
+            if (litSize > writeMax) return kDstSmall;                    // (:228)
+            if (litSize == 0) return kCorrupt;                           // (the Huffman decoder refuses an empty output, :267-274)
             u32 hoff = lh, hsz = csize;
             if (type == 2) {
                 const u32 used = huf_read_table(L, src + hoff, hsz, (u16*)(litBuf + kBlockMax + 64), lane);
-                if (used == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+                if (used == 0xFFFFFFFFu) return kCorrupt;
                 if (lane == 0) L->haveHuf = 1;
                 hoff += used; hsz -= used;
             } else {
-                if (!uni(L->haveHuf)) return 0xFFFFFFFFu;
+                if (!uni(L->haveHuf)) return kCorrupt;
                 if (uni(L->hufLog) <= 11) fetch(L->huf, kDecHufPark, sizeof(L->huf));   // (the block that made it was not the frame's last)
             }
             wave_fence();
@@ -2864,9 +2873,9 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             const u16* big = (const u16*)(litBuf + kBlockMax + 64);
             if (!streams4) ok = huf_decode_streams(L, litBuf, litSize, src + hoff, hsz, big, lane == 0, lane);
             else {
-                if (litSize < 6 || hsz < 10) return 0xFFFFFFFFu;
+                if (litSize < 6 || hsz < 10) return kCorrupt;
                 const u32 s1 = uni(ld16(src + hoff)), s2 = uni(ld16(src + hoff + 2)), s3 = uni(ld16(src + hoff + 4)), seg = (litSize + 3) / 4;
-                if (6 + s1 + s2 + s3 > hsz || 3 * seg > litSize) return 0xFFFFFFFFu;
+                if (6 + s1 + s2 + s3 > hsz || 3 * seg > litSize) return kCorrupt;
                 const u32 s4 = hsz - 6 - s1 - s2 - s3;
                 const u32 j = (u32)lane & 3;
                 const u32 so = j == 0 ? 0 : (j == 1 ? s1 : (j == 2 ? s1 + s2 : s1 + s2 + s3));
@@ -2880,11 +2889,11 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
 #ifdef ZSTD_PROF
                                          , dacc, dprev
 #endif
-                                         )) return 0xFFFFFFFFu;
+                                         )) return kCorrupt;
                 } else
                 ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane);
             }
-            if (ballot(!ok) != 0) return 0xFFFFFFFFu;
+            if (ballot(!ok) != 0) return kCorrupt;
             wave_fence();
             if (keep && type == 2 && uni(L->hufLog) <= 11) park(kDecHufPark, L->huf, sizeof(L->huf));
             litPtr = litBuf; ip = lh + csize;
@@ -2893,26 +2902,26 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
     DSTAGE(0);
     litPtr = uni_ptr(litPtr); litSize = uni(litSize); ip = uni(ip);               // (scalar base: the tile's loads take a 32-bit offset each)
     // ---- sequences header (ZSTD_decodeSeqHeaders :707-790) ----
-    if (ip >= n) return 0xFFFFFFFFu;
+    if (ip >= n) return kSrcSize;                                        // MIN_SEQUENCES_SIZE: srcSize_wrong (:717)
     u32 nbSeq = uni(src[ip++]);
     if (nbSeq > 0x7F) {
-        if (nbSeq == 0xFF) { if (ip + 2 > n) return 0xFFFFFFFFu; nbSeq = uni(ld16(src + ip)) + 0x7F00; ip += 2; }
-        else { if (ip >= n) return 0xFFFFFFFFu; nbSeq = ((nbSeq - 0x80) << 8) + uni(src[ip++]); }
+        if (nbSeq == 0xFF) { if (ip + 2 > n) return kSrcSize; nbSeq = uni(ld16(src + ip)) + 0x7F00; ip += 2; }   // (:728)
+        else { if (ip >= n) return kSrcSize; nbSeq = ((nbSeq - 0x80) << 8) + uni(src[ip++]); }                     // (:732)
     }
     nbSeq = uni(nbSeq);                                                          // (wave-uniform: loop counts stay in scalar registers)
     u32 out = opos, litPos = 0;
-    if (nbSeq == 0) { if (ip != n) return 0xFFFFFFFFu; }
+    if (nbSeq == 0) { if (ip != n) return kSrcSize; }                    // (:723)
     else {
-        if (ip >= n) return 0xFFFFFFFFu;
-        const u32 modes = uni(src[ip++]);
-        if (modes & 3) return 0xFFFFFFFFu;
+        if (ip >= n) return kSrcSize;                                    // (:739)
+        const u32 modes = uni(src[ip++]);                                // (the two reserved bits are not looked at, as in :741-743)
         const u32 mLL = modes >> 6, mOF = (modes >> 4) & 3, mML = (modes >> 2) & 3;
-        if ((mLL == 3 || mOF == 3 || mML == 3) && !uni(L->haveLL | L->haveOF | L->haveML)) return 0xFFFFFFFFu;   // nothing to repeat
-        if (!seq_table(L->ll3, 2, &L->llLog, &L->haveLL, mLL, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return 0xFFFFFFFFu;
-        if (!seq_table(L->of3, 0, &L->ofLog, &L->haveOF, mOF, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return 0xFFFFFFFFu;
-        if (!seq_table(L->ml3, 1, &L->mlLog, &L->haveML, mML, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return 0xFFFFFFFFu;
+        if ((mLL == 3 || mOF == 3 || mML == 3) && !uni(L->haveLL | L->haveOF | L->haveML)) return kCorrupt;   // nothing to repeat
+        if (!seq_table(L->ll3, 2, &L->llLog, &L->haveLL, mLL, src, &ip, n, 35, 9, kLLnorm, 35, 6, L, lane)) return kCorrupt;
+        if (!seq_table(L->of3, 0, &L->ofLog, &L->haveOF, mOF, src, &ip, n, 31, 8, kOFnorm, 28, 5, L, lane)) return kCorrupt;
+        if (!seq_table(L->ml3, 1, &L->mlLog, &L->haveML, mML, src, &ip, n, 52, 9, kMLnorm, 52, 6, L, lane)) return kCorrupt;
         // repeated tables, as the frame's last block with sequences left them (after the builds: building a table runs over the
         // places of the tables behind it)
+        if (room == 0) return kDstSmall;                                 // (zstd_decompress_block.c:2087-2088)
         if (mLL == 3) fetch(L->ll3, kDecFsePark, sizeof(L->ll3));
         if (mOF == 3) fetch(L->of3, kDecFsePark + sizeof(L->ll3), sizeof(L->of3));
         if (mML == 3) fetch(L->ml3, kDecFsePark + sizeof(L->ll3) + sizeof(L->of3), sizeof(L->ml3));
@@ -2944,7 +2953,7 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
         };
         {
             const int bits = (int)uni((u32)bit_stream_bits(src + ip, n - ip));
-            if (bits < 0) return 0xFFFFFFFFu;
+            if (bits < 0) return kCorrupt;
             pos = bits;
             refill();
         }
@@ -2952,7 +2961,7 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             b.pos = pos; b.wb = wbase;
             b.grab(win); sLL = b.take(L->llLog); sOF = b.take(L->ofLog); sML = b.take(L->mlLog); if (b.pos < 0) okB = 0;
         }
-        if (!uni(okB)) return 0xFFFFFFFFu;
+        if (!uni(okB)) return kCorrupt;
         u32 R0 = uni(L->rep[0]), R1 = uni(L->rep[1]), R2 = uni(L->rep[2]);       // the offset history entering the next tile (wave-uniform)
         pos = (int)lane_get((u32)b.pos, 0);
         // per-lane roles of the sequence loop
@@ -3028,11 +3037,15 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             if (q0 + cnt >= nbSeq && lane == 0) { L->rep[0] = R0; L->rep[1] = R1; L->rep[2] = R2; }
             const u32 incL = wave_scan_incl(ll), incO = wave_scan_incl(ll + ml);
             const u32 totL = lane_get(incL, 63), totO = lane_get(incO, 63);
-            if (totL > litSize - litPos) return 0xFFFFFFFFu;
-            if ((u64)out + totO > cap || (u64)(out - opos) + totO > blockMax) return 0xFFFFFFFFu;
             const u32 myLit = litPos + incL - ll, myOut = out + incO - (ll + ml);
-            // offsets must point inside what is already produced
-            if (ballot((u32)lane < cnt && off > myOut + ll) != 0) return 0xFFFFFFFFu;
+            {   // A tile that cannot be executed fails as its FIRST failing sequence does in the reference (ZSTD_execSequenceEnd,
+                // zstd_decompress_block.c:906-925): output room first (dstSize_tooSmall), then the literal buffer, then the offset.
+                const bool in = (u32)lane < cnt;
+                const bool fDst = in && (u64)out + incO > cap, fLit = in && incL > litSize - litPos, fOff = in && off > myOut + ll;
+                const u64 fm = ballot(fDst || fLit || fOff);
+                if (fm) return lane_get(fDst ? 1u : 0u, (int)__builtin_ctzll(fm)) ? kDstSmall : kCorrupt;
+                if ((u64)(out - opos) + totO > blockMax) return kCorrupt;    // (a block that regenerates more than the frame's block size)
+            }
             // The tile is executed by the LZ4 / Snappy decoders' group machinery (lz_group.hip.h): the sequences that fit an output
             // block in LDS go one per lane - literals and every match whose source ends in front of the block in ONE round of
             // loads, matches that read the block itself (or the 64 bytes of history in front of it) as LDS-to-LDS copies in
@@ -3076,11 +3089,12 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             litPos += totL; out += totO;
             DSTAGE(4);
         }
-        if (pos > 0) return 0xFFFFFFFFu;                                         // bitstream not fully consumed
+        if (pos > 0) return kCorrupt;                                         // bitstream not fully consumed
         if (keep) park(kDecFsePark, L->ll3, 3840);
     }
     const u32 rest = litSize - litPos;
-    if ((u64)out + rest > cap || (u64)(out - opos) + rest > blockMax) return 0xFFFFFFFFu;
+    if ((u64)out + rest > cap) return kDstSmall;                         // last literals (:1588, :1763)
+    if ((u64)(out - opos) + rest > blockMax) return kCorrupt;
     wave_copy(dst + out, litPtr + litPos, rest, lane);
     wave_fence();
     out += rest;
@@ -3095,72 +3109,80 @@ __device__ __forceinline__ int zstd_decompress_wave(const u8* __restrict__ src_,
     // address derived from it (vector registers, exec-mask loops, 64-bit vector address arithmetic; the spills of that cost the
     // decoder more HBM traffic than its output).
     const u8* src = uni_ptr(src_); const u32 n = uni(n_); u8* dst = uni_ptr(dst_); const u32 cap = uni(cap_); u8* litBuf = uni_ptr(litBuf_);
+    // Failures are -(the reference's error code) at the same check, in the reference's order (zstd_errors.h:60-106;
+    // ZSTD_decompressMultiFrame zstd_decompress.c:1114-1197, ZSTD_decompressFrame :1003-1111, ZSTD_getFrameHeader_advanced :440-560).
+    constexpr int kPrefix = -10, kUnsupported = -14, kWindow = -16, kCorrupt = -20, kChecksum = -22, kDictWrong = -32, kDstSmall = -70, kSrcSize = -72;
     u32 ip = 0, op = 0;
-    if (n == 0) return cap == 0 ? 0 : -1;
-    while (ip < n) {
-        if (n - ip < 4) return -1;
+    bool more = false;                                                           // a frame has been decoded (moreThan1Frame)
+    while (n - ip >= 5) {                                                        // ZSTD_startingInputLength
         const u32 magic = uni(ld32(src + ip));
-        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                              // skippable frame
-            if (n - ip < 8) return -1;
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                              // skippable frame (readSkippableFrameSize :571-586)
+            if (n - ip < 8) return kSrcSize;
             const u32 sz = uni(ld32(src + ip + 4));
-            if ((u64)sz + 8 > n - ip) return -1;
+            if ((u32)(sz + 8) < sz) return kUnsupported;
+            if ((u64)sz + 8 > n - ip) return kSrcSize;
             ip += 8 + sz; continue;
         }
-        if (magic != 0xFD2FB528u) return -1;
-        if (n - ip < 5) return -1;
-        const u32 fhd = uni(src[ip + 4]); ip += 5;                                    // ZSTD_getFrameHeader_advanced :438-560
+        if (n - ip < 9) return kSrcSize;                                         // frame header minimum + one block header (:1017-1019)
+        const u32 fhd = uni(src[ip + 4]);
         const u32 fcsId = fhd >> 6, single = (fhd >> 5) & 1, hasCk = (fhd >> 2) & 1, dictIdSz = fhd & 3;
-        if (fhd & 0x08) return -1;
+        const u32 dsz = dictIdSz == 3 ? 4 : dictIdSz, fl = fcsId == 0 ? single : (fcsId == 1 ? 2u : (fcsId == 2 ? 4u : 8u));
+        const u32 fhs = 5 + (single ? 0u : 1u) + dsz + fl;                       // ZSTD_frameHeaderSize_internal
+        if (n - ip < fhs + 3) return kSrcSize;                                   // (:1025-1026)
+        if (magic != 0xFD2FB528u) return more ? kSrcSize : kPrefix;              // prefix_unknown; behind a decoded frame: srcSize_wrong (:1174-1182)
+        if (fhd & 0x08) return kUnsupported;                                     // reserved bit (:500-502)
+        ip += 5;
         u64 windowSize = 0, fcs = 0; bool haveFcs = false;
         if (!single) {
-            if (ip >= n) return -1;
             const u32 wb = uni(src[ip++]), wl = (wb >> 3) + 10;
-            if (wl > 31) return -1;
+            if (wl > 31) return kWindow;                                         // ZSTD_WINDOWLOG_MAX (:516-521)
             windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wb & 7);
         }
-        {   const u32 dsz = dictIdSz == 3 ? 4 : dictIdSz; u32 id = 0;
-            if (n - ip < dsz) return -1;
+        {   u32 id = 0;
             for (u32 k = 0; k < dsz; ++k) id |= (u32)src[ip + k] << (8 * k);
             id = uni(id);
             ip += dsz;
-            if (id != 0) return -1;                                              // no dictionary support
+            if (fcsId == 0) { if (single) { fcs = uni(src[ip++]); haveFcs = true; } }
+            else if (fcsId == 1) { fcs = (u64)uni(ld16(src + ip)) + 256; ip += 2; haveFcs = true; }
+            else if (fcsId == 2) { fcs = uni(ld32(src + ip)); ip += 4; haveFcs = true; }
+            else { const u64 f8 = ld64(src + ip); fcs = ((u64)uni((u32)(f8 >> 32)) << 32) | uni((u32)f8); ip += 8; haveFcs = true; }
+            if (id != 0) return kDictWrong;                                      // a dictionary ID and no dictionary (ZSTD_decodeFrameHeader :964-965)
         }
-        if (fcsId == 0) { if (single) { if (ip >= n) return -1; fcs = uni(src[ip++]); haveFcs = true; } }
-        else if (fcsId == 1) { if (n - ip < 2) return -1; fcs = (u64)uni(ld16(src + ip)) + 256; ip += 2; haveFcs = true; }
-        else if (fcsId == 2) { if (n - ip < 4) return -1; fcs = uni(ld32(src + ip)); ip += 4; haveFcs = true; }
-        else { if (n - ip < 8) return -1; const u64 f8 = ld64(src + ip); fcs = ((u64)uni((u32)(f8 >> 32)) << 32) | uni((u32)f8); ip += 8; haveFcs = true; }
         if (single) windowSize = fcs;
         const u32 frameStart = op;
         if (lane == 0) { L->rep[0] = 1; L->rep[1] = 4; L->rep[2] = 8; L->haveLL = L->haveOF = L->haveML = L->haveHuf = 0; }
         wave_fence();
         const u32 blockMax = windowSize < kBlockMax ? (u32)windowSize : kBlockMax;
-        for (;;) {                                                               // ZSTD_decompressFrame :1005-1111
-            if (n - ip < 3) return -1;
+        for (;;) {                                                               // ZSTD_decompressFrame :1031-1090
+            if (n - ip < 3) return kSrcSize;                                     // ZSTD_getcBlockSize (:871-872)
             const u32 bh = uni(src[ip] | ((u32)src[ip + 1] << 8) | ((u32)src[ip + 2] << 16)); ip += 3;
             const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
-            if (type == 3) return -1;
+            if (type == 3) return kCorrupt;                                      // bt_reserved (:880)
+            if ((type == 1 ? 1u : bsz) > n - ip) return kSrcSize;                // (:1040)
             if (type == 1) {
-                if (ip >= n || bsz > cap - op || bsz > blockMax) return -1;
+                if (bsz > cap - op) return kDstSmall;                            // ZSTD_setRleBlock (:911)
                 const u8 v = (u8)uni(src[ip]);
                 for (u32 i = (u32)lane; i < bsz; i += kWave) dst[op + i] = v;
                 wave_fence();
                 ip += 1; op += bsz;
             } else if (type == 0) {
-                if (bsz > n - ip || bsz > cap - op || bsz > blockMax) return -1;
+                if (bsz > cap - op) return kDstSmall;                            // ZSTD_copyRawBlock (:895)
                 wave_copy(dst + op, src + ip, bsz, lane);
                 wave_fence();
                 ip += bsz; op += bsz;
             } else {
-                if (bsz > n - ip || bsz > kBlockMax) return -1;
+                if (bsz > blockMax) return kSrcSize;                             // ZSTD_decompressBlock_internal (zstd_decompress_block.c:2064)
                 const u32 r = decode_block(L, src + ip, bsz, dst + frameStart, op - frameStart, cap - frameStart, blockMax, litBuf, lane, last == 0);
-                if (r == 0xFFFFFFFFu) return -1;
+                if (r >= 0xFFFFFF00u) return -(int)(r & 0xFFu);
                 ip += bsz; op += r;
             }
             if (last) break;
         }
-        if (haveFcs && (u64)(op - frameStart) != fcs) return -1;
-        if (hasCk) { if (n - ip < 4) return -1; ip += 4; }                       // content checksum present: skipped, not verified
+        if (haveFcs && (u64)(op - frameStart) != fcs) return kCorrupt;           // (:1092-1095)
+        if (hasCk) { if (n - ip < 4) return kChecksum; ip += 4; }                // the value itself is checked by the host path (rap.hip, checksums_ok)
+        more = true;
     }
+    if (n - ip) return kSrcSize;                                                 // input not entirely consumed (:1194)
     return (int)op;
 }
 

@@ -44,6 +44,23 @@ REF_FUNCS = {"lz4": ("LZ4_compress_default", "LZ4_decompress_safe"), "snappy": (
              "zstd": ("ZSTD_compress", "ZSTD_decompress"), "zstd3": ("ZSTD_compress", "ZSTD_decompress")}
 
 
+# the sources a codec's kernels are built from: profiles/traffic.json records their hash next to the FETCH_SIZE / WRITE_SIZE
+# passes, and a line whose kernels are not the profiled ones says so instead of quoting stale traffic
+KERNEL_SOURCES = {"lz4": ["lz4_kernels.hip", "lz_group.hip.h", "common.hip.h"],
+                  "snappy": ["snappy_kernels.hip", "lz_group.hip.h", "common.hip.h"],
+                  "zstd": ["zstd_kernels.hip", "zstd_entropy.hip.h", "zstd_chain.h", "zstd_hufspec.h", "lz_group.hip.h", "common.hip.h"]}
+KERNEL_SOURCES["zstd3"] = KERNEL_SOURCES["zstd"]
+
+
+def kernel_source_sha16(codec):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[codec]:
+        with open(os.path.join(ROOT, "aocl-compression_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -73,13 +90,10 @@ def self_launch(args):
     stderr are inherited, so rank 0's JSON line is this command's JSON line, and their exit code is this command's exit code.
     The parent never imports torch and never makes a HIP call (no exec of anything from a GPU-initialised process); the
     reference's caller does not launch workers by hand either (threads/threads.c:121-153, lz4.c:2684-2731)."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    # (--standalone: the launcher picks a free rendezvous port itself and keeps it - a port found by bind-then-close here could be
+    #  taken by another process before torch.distributed.run binds it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):          # a stale launcher variable without RANK: the launcher sets its own
@@ -507,8 +521,12 @@ class Run:
         self.db = eng.uniform_decompress_batch(self.slots, self.clen, slot, self.dst, chunk, self.dlen)
         self.kt = {"c": [], "d": []}
         self.df_slabs = 0
-        self.exchange_requested = args.exchange
-        self.fallbacks = []                 # every change of the exchange away from the requested one, with its reason
+        # what the COMMAND asked for (captured once in main, before any codec's run could change args.exchange), and every change of
+        # the exchange away from it so far - a fallback an earlier codec of this run made is this codec's fallback too
+        self.exchange_requested = getattr(args, "exchange_requested", args.exchange)
+        if not hasattr(args, "exchange_fallbacks"):
+            args.exchange_fallbacks = []
+        self.fallbacks = args.exchange_fallbacks
         if world > 1:
             self.setup_exchange()
 
@@ -856,9 +874,16 @@ class Run:
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f).get(self.name)
+            out["roofline"]["kernel_source_sha16"] = kernel_source_sha16(self.name)
             if t and t["kernel"] == kernel and t["gib_per_gpu"] == args.gib and t["chunk_bytes"] == chunk:
-                out["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1000.0
-                out["roofline"]["traffic_source"] = t["source"]
+                if t.get("kernel_source_sha16") == out["roofline"]["kernel_source_sha16"]:
+                    out["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1000.0
+                    out["roofline"]["traffic_source"] = t["source"]
+                    if t.get("launches"):
+                        out["roofline"]["traffic_launches"] = t["launches"]
+                else:
+                    out["roofline"]["traffic_stale"] = (f"profiles/traffic.json holds {(t['fetch_kb'] + t['write_kb']) * 1000.0:.0f} bytes per launch measured on kernel sources "
+                                                        f"{t.get('kernel_source_sha16', '(not recorded)')}; this run's are {out['roofline']['kernel_source_sha16']}")
         except (OSError, ValueError, KeyError):
             pass
         return out
@@ -868,7 +893,15 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(json.loads(args.cpu_worker))
+    args.exchange_requested = args.exchange
+    args.exchange_fallbacks = []
     if args.gpus > 1 and "RANK" not in os.environ:
+        # another launcher's rank variable without torch's RANK: every one of ITS processes would start N ranks of its own
+        foreign = [k for k in ("OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID", "LOCAL_RANK") if k in os.environ]
+        if foreign and os.environ.get("AOCLGPU_BENCH_LAUNCH_ANYWAY") != "1":
+            print(json.dumps({"error": "bench.py --gpus N started under a launcher that does not set RANK / WORLD_SIZE / MASTER_* "
+                              f"({', '.join(foreign)} present): run it once without a launcher, or through python -m torch.distributed.run"}), flush=True)
+            sys.exit(2)
         sys.exit(self_launch(args))
     import numpy as np
     import torch

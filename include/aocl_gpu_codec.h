@@ -121,6 +121,14 @@ size_t aoclgpu_compress_bound(aoclgpu_codec codec, size_t n);
 
 int aoclgpu_lz4_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_lz4_decompress_chunks(const aoclgpu_batch* b, void* stream);
+/* The value LZ4_decompress_safe returns for a MALFORMED block of n bytes at src_dev (device memory) and an output capacity of
+ * cap bytes: -(ip - src) - 1 with ip where the reference's decoder gives up (algos/lz4/lz4.c:3799-3802).  out_len < 0 of
+ * aoclgpu_lz4_decompress_chunks only says that a chunk is malformed; this walks the block's tokens once more along the
+ * reference's control flow (fast loop / safe loop, :3421-3790; nothing is decoded) and writes the value - or the decoded size,
+ * should the block be well-formed - to *out (device-accessible memory).  lit_dist: 64 = the reference's AVX2 build of the
+ * decoder (what it runs on an AVX2 host once set up), 32 = LZ4_decompress_generic.  The host one-shot call
+ * (aoclgpu_decompress_host, LZ4_decompress_safe of include/aocl_native_api.h) does this by itself. */
+int aoclgpu_lz4_error_value(const void* src_dev, uint32_t n, uint32_t cap, uint32_t lit_dist, int32_t* out, void* stream);
 int aoclgpu_snappy_compress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_snappy_decompress_chunks(const aoclgpu_batch* b, void* stream);
 int aoclgpu_zstd_compress_chunks(const aoclgpu_batch* b, void* stream);
@@ -308,7 +316,10 @@ int aoclgpu_zstd_block_sequences(const void* src_dev, uint32_t n, uint32_t* out_
  * 0 when it does not fit `cap`, or <= AOCLGPU_HOST_FAIL/2 on a GPU failure.
  * aoclgpu_zstd_decompress_host_frames: any Zstandard stream; a stream of several frames that all carry their content
  * size is split on the host (frame and block headers only) and its frames are decoded in parallel, one wavefront each,
- * otherwise one wavefront walks the stream.  Returns the decoded size, -1 malformed, -2 dst too small. */
+ * otherwise one wavefront walks the stream.  Returns the decoded size, or -(the error code ZSTD_decompress returns for the
+ * stream, zstd_errors.h:60-106: 20 corruption_detected, 70 dstSize_tooSmall, 72 srcSize_wrong, 10 prefix_unknown, ...) -
+ * the code of the reference's check that fails first, frame by frame and block by block (INTEGRATION.md lists where the decoder
+ * is stricter than the reference's). */
 int64_t aoclgpu_zstd_compress_host_frames(const void* host_src, size_t n, void* host_dst, size_t cap, uint32_t flags);
 int64_t aoclgpu_zstd_decompress_host_frames(const void* host_src, size_t n, void* host_dst, size_t cap);
 

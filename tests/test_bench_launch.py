@@ -25,9 +25,16 @@ def test_dry_run_builds_the_launcher_command_without_importing_torch():
     cmd = rec["launch"]
     assert rec["torch_imported_by_parent"] is False
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"      # the launcher picks (and keeps) its own port
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_under_a_foreign_launcher_it_refuses_to_fan_out():
+    # mpirun / srun set their own rank variables, not RANK: every one of their processes would start N ranks of its own
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       env=_env(AOCLGPU_BENCH_LAUNCH_DRYRUN="1", OMPI_COMM_WORLD_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and '"launch"' not in p.stdout and "OMPI_COMM_WORLD_RANK" in p.stdout
 
 
 def test_under_a_launcher_it_does_not_launch_again():

@@ -1,0 +1,115 @@
+"""Exact RETURN VALUES of the decoders on malformed input, against the real reference (oracle/_ref): the bar for integer work is
+bit-exact, return values included (verdict r05 item 7).
+  LZ4_decompress_safe   -(ip - src) - 1 at the reference's point of failure (lz4.c:3799-3802), the size otherwise
+  ZSTD_decompress       (size_t)-ZSTD_error_xxx (zstd_errors.h:60-106): compared as the raw size_t, which is what ZSTD_getErrorCode decodes
+  snappy_uncompress     SNAPPY_OK / SNAPPY_INVALID_INPUT / SNAPPY_BUFFER_TOO_SMALL (snappy-c.cc:34-88)
+Deviations that are deliberate are listed in INTEGRATION.md and pinned here (KNOWN_*)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import aocl_compression_amd as a
+from aocl_compression_amd import api
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(eng):
+    L = api.load_library()
+    L.LZ4_decompress_safe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ZSTD_decompress.restype = C.c_size_t
+    L.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.snappy_uncompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    return L
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref/libaocl_ref.so not built")
+    r = ol.Ref()
+    r.L.LZ4_decompress_safe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    return r
+
+
+def _mutations(comp: bytes, rng, count, short=4000):
+    yield comp, "intact"
+    for cut in (1, 2, 3, 5, 17, len(comp) // 2):
+        if cut < len(comp):
+            yield comp[:-cut], f"truncated by {cut}"
+    for it in range(count):
+        c = bytearray(comp[:short] if it % 2 else comp)
+        for _ in range(1 + it % 3):
+            c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
+        yield bytes(c), f"mutation {it}"
+
+
+def test_lz4_decompress_safe_returns_the_references_value(lib, ref):
+    rng = np.random.default_rng(61)
+    bad = []
+    n = 0
+    for kind, size in (("binary", 200000), ("text", 70000), ("jsonlog", 262144), ("database", 5000)):
+        raw = a.corpus.make(kind, size, seed=11).tobytes()
+        comp = ref.compress(ol.LZ4, raw)
+        for c, what in _mutations(comp, rng, 120):
+            for cap in (len(raw), len(raw) - 1, len(raw) // 2):
+                w = C.create_string_buffer(max(cap, 1)); g = C.create_string_buffer(max(cap, 1))
+                want = ref.L.LZ4_decompress_safe(c, w, len(c), cap)
+                got = lib.LZ4_decompress_safe(c, g, len(c), cap)
+                n += 1
+                if want != got or (want > 0 and w.raw[:want] != g.raw[:want]):
+                    bad.append((kind, what, cap, want, got))
+    assert not bad, f"{len(bad)} of {n} return values differ from the reference's, e.g. {bad[:8]}"
+
+
+def ERR(code):
+    return (1 << 64) - code
+
+
+def test_zstd_decompress_returns_the_references_error_code(lib, ref):
+    rng = np.random.default_rng(62)
+    bad = []
+    n = strict = 0
+    for kind, size in (("binary", 131072), ("text", 70000), ("jsonlog", 100000), ("random", 3000), ("database", 5000)):
+        raw = a.corpus.make(kind, size, seed=12).tobytes()
+        comp = ref.compress(ol.ZSTD, raw)
+        for c, what in _mutations(comp, rng, 100, short=600):
+            for cap in (len(raw), len(raw) - 1):
+                w = C.create_string_buffer(max(cap, 1)); g = C.create_string_buffer(max(cap, 1))
+                want = ref.L.ZSTD_decompress(w, cap, c, len(c))
+                got = lib.ZSTD_decompress(g, cap, c, len(c))
+                n += 1
+                if want == got and (want > cap or w.raw[:want] == g.raw[:want]):
+                    continue
+                # The ONE deliberate deviation ("Error values"): a Huffman-coded literal stream that does not end exactly
+                # at its first bit is corruption_detected here; the reference's fast decoding loops (huf_decompress.c, table log 11,
+                # streams of 8+ bytes) do not make that check - they return what the damaged stream decodes to, or run out of output
+                # behind it (dstSize_tooSmall).  Never the other way round, and never different bytes with a success value.
+                if got == ERR(20) and (want <= cap or want == ERR(70)):
+                    strict += 1
+                    continue
+                bad.append((kind, what, cap, hex(want), hex(got)))
+    assert not bad, f"{len(bad)} of {n} return values differ from the reference's, e.g. {bad[:8]}"
+    assert strict <= n // 8, f"{strict} of {n} inputs rejected where the reference decodes a damaged literal stream: more than the mutations explain"
+
+
+def test_snappy_uncompress_returns_the_references_status(lib, ref):
+    rng = np.random.default_rng(63)
+    bad = []
+    n = 0
+    for kind, size in (("jsonlog", 65536), ("text", 70000), ("binary", 200000), ("database", 3000)):
+        raw = a.corpus.make(kind, size, seed=13).tobytes()
+        comp = ref.compress(ol.SNAPPY, raw)
+        for c, what in _mutations(comp, rng, 120):
+            for cap in (len(raw), len(raw) - 1, 10):
+                w = C.create_string_buffer(max(cap, 1)); g = C.create_string_buffer(max(cap, 1))
+                wl = C.c_size_t(cap); gl = C.c_size_t(cap)
+                want = ref.L.snappy_uncompress(c, len(c), w, C.byref(wl))
+                got = lib.snappy_uncompress(c, len(c), g, C.byref(gl))
+                n += 1
+                if want != got or (want == 0 and (wl.value != gl.value or w.raw[:wl.value] != g.raw[:gl.value])):
+                    bad.append((kind, what, cap, want, got))
+    assert not bad, f"{len(bad)} of {n} statuses differ from the reference's, e.g. {bad[:8]}"

@@ -27,6 +27,7 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
         f.write([l for l in open(os.path.join(O, f"trace_bench_{c}.json")) if l.startswith("{")][-1])
         f.write(f"\n# separate --pmc passes (one counter per pass, kernel-trace only), python3 bench.py --codec {c} --no-cpu-baseline --no-by-kind --steps 1 --warmup 0; raw counter values (KB) per launch\n")
         kb = {}
+        per_call = int(((bench["roofline"].get("launches") or {}).get("per_compress_call") or {}).get(dom, 1))   # level 3: one launch per slab
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, f"pmc_{c}_{ctr}"), c + "_"], capture_output=True, text=True).stdout
             f.write(txt)
@@ -35,11 +36,14 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
                 if not l.startswith(" "):
                     cur = l.strip()
                 elif ctr in l and cur and dom.split("_kernel")[0] in cur:
-                    kb[ctr] = int(float(l.split()[1]))
+                    kb[ctr] = int(float(l.split()[1])) * per_call          # (the summary prints the mean per dispatch)
     if len(kb) == 2:
         traffic[c] = {"kernel": dom, "gib_per_gpu": bench["config"]["gib_per_gpu"], "chunk_bytes": bench["config"]["chunk_bytes"],
                       "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
+                      "kernel_source_sha16": bench["roofline"].get("kernel_source_sha16"),     # bench.py drops `traffic` when the sources changed since
                       "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, raw KB per launch)"}
+        if per_call > 1:                                                 # per compress CALL: the dominant kernel's launches of one step, summed
+            traffic[c]["launches"] = f"{per_call} x {dom} per compress call (one per slab): fetch_kb / write_kb = {per_call} x the mean per launch"
 # scattered-load calibration of FETCH_SIZE (tools/probe_scatter.py under --pmc FETCH_SIZE)
 try:
     rec = json.loads([l for l in open(os.path.join(O, "scatter8.json")) if l.startswith("{")][-1])
