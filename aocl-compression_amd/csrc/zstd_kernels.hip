@@ -586,6 +586,15 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
             if (lane < 60) *(L32*)(ring + ((u32)b & 1u) * kRingBlk + 4u * (u32)lane) = v;
             if (!(b & 1) && lane < 8) *(L32*)(ring + 2 * kRingBlk + 4u * (u32)lane) = v;
         };
+        // 8 bytes at chunk position P: from the ring when both ends lie in its two blocks (P is wave-uniform)
+        auto ring_or_mem64 = [&](u32 P) -> u64 {
+#ifndef ZSTD_NO_RING_TAIL
+            const u32 r0 = P - bs, r1 = r0 + 7;
+            const int32_t blo = (int32_t)(((u64)r0 * 17895698ull) >> 32), bhi = (int32_t)(((u64)r1 * 17895698ull) >> 32);   // / 240
+            if (rb >= 0 && blo >= rb - 1 && bhi <= rb) return lds_ld64(ring + ((u32)blo & 1u) * kRingBlk + (r0 - kRingBlk * (u32)blo));
+#endif
+            return ld64(src + P);
+        };
         // immediate rep2 matches behind a sequence that ends at ip0 (:690-702); returns where the next search starts
         auto rep_loop = [&](u32 ip0) -> u32 {
             bool hit = uni(ld32(src + ip0) == ld32(src + ip0 - rep2) ? 1u : 0u) != 0;
@@ -793,7 +802,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     for (int t = 0; t < 3; ++t) {                       // the chain's last table writes, one by one
                         if (t >= 3 - wo.ntail) {
                             const int idx = wo.tail[t];
-                            const u32 hh = idx < 64 ? lane_get(b_h, idx) : z_hash<MLS>(ld64(src + pos0 + (u32)idx), hlog);
+                            // (behind lane 63 - a match that ends behind the batch: the bytes are in the source ring more often than
+                            //  not; a trip to memory here is exposed, the next batch's loads queue up behind it)
+                            const u32 hh = idx < 64 ? lane_get(b_h, idx) : z_hash<MLS>(ring_or_mem64(pos0 + (u32)idx), hlog);
                             if (lane == 0) tput(hh, pos0 + (u32)idx + 2);
                             wave_fence();
                         }
