@@ -146,8 +146,15 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
 // (the last piece overlapping) - and EVERY load of the round before its first store: one trip to memory per 128 sequences
 // (until round 6: two per 64, and a third for every run above 24 bytes, which was most of this function's time).
 // Returns the size of the last literal run.
-__device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, GWorkspace* ws, const u32 nbSeq, const u32 anchor, int lane, u32* seqLits = nullptr)
+// anchor_ == 0xFFFFFFFF: the caller only knows the block's total literal size (litTotal) - the last run is what the sequences leave
+// (the double-fast finder kernel does not gather: its 32 waves per CU live on 64 registers; the entropy kernel gathers).
+__device__ u32 gather_literals(const gbyte* __restrict__ src_, const u32 n_, GWorkspace* ws_, const u32 nbSeq_, const u32 anchor__, int lane, u32* seqLits = nullptr,
+                               const u32 litTotal_ = 0)
 {
+    // (where this is a call, the arguments arrive in vector registers: scalar bases again, or every one of the round's ~50 accesses
+    //  carries a 64-bit address pair of its own - the function then needs 194 registers)
+    const gbyte* __restrict__ src = uni_ptr(src_); GWorkspace* ws = uni_ptr(ws_);
+    const u32 n = uni(n_), nbSeq = uni(nbSeq_), anchor_ = uni(anchor__), litTotal = uni(litTotal_);
     typedef u32x4 __attribute__((aligned(1))) U128;
     typedef u32 __attribute__((aligned(1))) U32;
     typedef u64 __attribute__((aligned(1))) U64;
@@ -227,6 +234,7 @@ __device__ u32 gather_literals(const gbyte* __restrict__ src, const u32 n, GWork
         lpos += lane_get(inc, 63);
         llp = nll; spp = nsp;
     }
+    const u32 anchor = anchor_ != 0xFFFFFFFFu ? anchor_ : n - (litTotal - lpos);
     wave_copy(lits + lpos, src + anchor, n - anchor, lane);
     wave_fence();
     if (seqLits) *seqLits = lpos;                                       // literals of the sequences (the parse need not count them)
@@ -1019,7 +1027,7 @@ __device__ __forceinline__ u32 z_hash8(u64 v, u32 hlog) { return (u32)((v * 0xCF
 // FRAME = false: the only block of a fresh frame (tables cleared here, repeat offsets {1,4,8}, no window limit).
 // FRAME = true: block [bs, be) of a frame - tables, window and repeat offsets come from the frame loop (zstd_frame_wave) and
 // the offsets go back to it (:393-399, :478-486).
-template <int MLS, bool FRAME = false>
+template <int MLS, bool FRAME = false, bool GATHER = true>
 __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u32 hlogL, const u32 hlogS, u32* tabs, lbyte* lds,
                            Workspace* ws_, u32* litSizeOut, int lane, const u32 bs = 0, const FrameWindow* win = nullptr,
                            u32* rep1io = nullptr, u32* rep2io = nullptr)
@@ -1253,7 +1261,8 @@ __device__ u32 dfast_block(const gbyte* __restrict__ src, const u32 be, const u3
     }
     flush_seq(nbSeq & ~63u, nbSeq & 63u);
     wave_fence();
-    *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    if constexpr (GATHER) *litSizeOut = litSize + gather_literals(src, n, ws, nbSeq, anchor, lane);
+    else *litSizeOut = litSize + (n - anchor);                           // (the literal buffer is filled by the kernel that codes the block)
     return nbSeq;
 }
 
@@ -1815,8 +1824,8 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
         if (n >= 7) {
             u32 litSize = 0, nbSeq = 0;
             if (2u * 2u * kDfScratch > ldsBytes) return 0;
-            if (zp.mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
-            else nbSeq = dfast_block<5>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+            if (zp.mls == 4) nbSeq = dfast_block<4, false, false>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
+            else nbSeq = dfast_block<5, false, false>((const gbyte*)src, n, zp.hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
             if (lane == 0) { meta[0] = nbSeq; meta[1] = litSize; }
         }
         return 0;
@@ -1836,7 +1845,10 @@ __device__ int zstd_compress_wave(const u8* __restrict__ src, const u32 n, u8* _
     if (n >= 7) {                                                        // ZSTD_buildSeqStore :3268
         u32 litSize = 0, nbSeq;
         const u32 hlog = zp.hlog, mls = zp.mls;
-        if constexpr (PHASE == 2) { nbSeq = uni(meta[0]); litSize = uni(meta[1]); (void)hlog; (void)mls; }
+        if constexpr (PHASE == 2) {
+            nbSeq = uni(meta[0]); litSize = uni(meta[1]); (void)hlog; (void)mls;
+            (void)gather_literals((const gbyte*)src, n, (GWorkspace*)ws, nbSeq, 0xFFFFFFFFu, lane, nullptr, litSize);
+        }
         else if constexpr (DF) {
             if (2u * 2u * kDfScratch > ldsBytes) return 0;
             if (mls == 4) nbSeq = dfast_block<4>((const gbyte*)src, n, hlog, zp.clog, tabs, (lbyte*)lds, ws, &litSize, lane);
