@@ -283,6 +283,26 @@ __device__ unsigned long long g_zstd_eprof[16];
 #define ZW_TB  "s[86:87]"
 #define ZW_OFF_CHUNK "s_and_b32 s98, s88, 0x1ffff\n\t"
 #define ZW_OFF_FRAME "v_readlane_b32 s98, %[offv], s93\n\t"
+#define ZW_SEQ_BLOCK \
+    "s_mov_b32 m0, %[rl]\n\t" \
+    "v_writelane_b32 %[qll], s97, m0\n\t" \
+    "v_writelane_b32 %[qoff], s98, m0\n\t" \
+    "v_writelane_b32 %[qml], s99, m0\n\t" \
+    "s_add_i32 %[rl], %[rl], 1\n\t" \
+    "s_mov_b32 %[arel], s94\n\t" \
+    "s_mov_b32 %[S], s94\n\t" \
+    "s_sub_i32 s88, s94, 2\n\t" \
+    "s_cmp_ge_u32 s88, %[lim]\n\t" \
+    "s_cbranch_scc1 94f\n\t"                            /* table writes behind the trustworthy lanes */ \
+    "s_cmp_lg_u32 s101, 0\n\t" \
+    "s_cbranch_scc1 94f\n\t"                            /* immediate rep2 test not decidable from the maps */ \
+    "s_lshl_b64 " ZW_TA ", -1, s83\n\t" \
+    "s_add_i32 s89, s93, 2\n\t" \
+    "s_lshl_b64 " ZW_TB ", -2, s89\n\t" \
+    "s_andn2_b64 " ZW_TA ", " ZW_TA ", " ZW_TB "\n\t" \
+    "s_or_b64 %[commit], %[commit], " ZW_TA "\n\t" \
+    "s_bitset1_b64 %[commit], s88\n\t" \
+    "s_branch 1b\n"
 #define ZSTD_WALK_ASM(OFFLINE) \
     "1:\n\t"                                            /* ---- loop top ---- */ \
     "s_cmp_ge_u32 %[S], %[lim]\n\t" \
@@ -296,51 +316,15 @@ __device__ unsigned long long g_zstd_eprof[16];
     "s_ff1_i32_b64 s92, " ZW_TB "\n\t"                  /* dm, -1: none */ \
     "s_mov_b32 s83, %[S]\n\t"                           /* Sev */ \
     "s_cmp_lt_u32 s92, s91\n\t" \
-    "s_cbranch_scc1 20f\n\t"                            /* table match in front of the first repcode event */ \
-    "s_cmp_eq_u32 s91, -1\n\t" \
-    "s_cbranch_scc1 95f\n\t"                            /* neither */ \
-    /* ---- repcode found by even probe k at k + 2 ---- */ \
-    "s_add_i32 s93, %[S], s91\n\t"                      /* k */ \
-    "s_cmp_ge_u32 s93, %[lim]\n\t" \
-    "s_cbranch_scc1 91f\n\t" \
-    "s_add_i32 s88, s93, 1\n\t" \
-    "s_lshr_b64 " ZW_TA ", %[eq1], s88\n\t"             /* e1k */ \
-    "s_and_b32 s96, s84, 1\n\t"                         /* back1 */ \
-    "s_lshr_b64 " ZW_TA ", " ZW_TA ", 5\n\t" \
-    "s_not_b64 " ZW_TA ", " ZW_TA "\n\t" \
-    "s_ff1_i32_b64 s95, " ZW_TA "\n\t"                  /* f */ \
-    "s_add_i32 s94, s93, s95\n\t" \
-    "s_add_i32 s94, s94, 6\n\t"                         /* E */ \
-    "s_add_i32 s88, s94, 4\n\t" \
-    "s_bfe_u32 s89, %[ends], 0x80008\n\t"               /* end2 */ \
-    "s_min_u32 s90, %[rep2], 1\n\t"                     /* rep2 != 0 */ \
-    "s_cmp_le_u32 s88, s89\n\t" \
-    "s_cselect_b32 s100, s90, 0\n\t"                    /* imm */ \
-    "s_lshr_b64 " ZW_TA ", %[q2], s94\n\t" \
-    "s_and_b32 s88, s84, s100\n\t"                      /* immediate rep2 match */ \
-    "s_and_b32 s89, %[ends], 0xff\n\t"                  /* end1 */ \
-    "s_xor_b32 s101, s100, s90\n\t"                     /* post = rep2 != 0 && !imm */ \
-    "s_sub_i32 s97, s93, s96\n\t" \
-    "s_sub_i32 s97, s97, %[arel]\n\t" \
-    "s_add_i32 s97, s97, 2\n\t"                         /* ll */ \
-    "s_mov_b32 s98, 1\n\t"                              /* offBase */ \
-    "s_add_i32 s99, s96, s95\n\t" \
-    "s_add_i32 s99, s99, 4\n\t"                         /* ml */ \
-    "s_cmp_ge_u32 s94, s89\n\t" \
-    "s_cbranch_scc1 92f\n\t"                            /* the run leaves the known part of the map */ \
-    "s_cmp_lg_u32 s88, 0\n\t" \
-    "s_cbranch_scc1 92f\n\t" \
-    "s_branch 50f\n" \
-    /* ---- table match at lane j ---- */ \
-    "20:\n\t" \
+    "s_cbranch_scc0 30f\n\t"                            /* no table match in front of the first repcode event */ \
+    /* ---- table match at lane j (the fall-through: the common event) ---- */ \
     "s_add_i32 s93, %[S], s92\n\t"                      /* j */ \
     "s_and_b32 s89, %[ends], 0xff\n\t"                  /* end1 */ \
-    "s_cmp_lg_u32 s91, -1\n\t" \
-    "s_cbranch_scc1 21f\n\t" \
     "s_add_i32 s88, s93, 5\n\t"                         /* no repcode event at all: the tests are known below end1 - 5 only */ \
+    "s_cmp_eq_u32 s91, -1\n\t" \
+    "s_cselect_b32 s88, s88, 0\n\t" \
     "s_cmp_ge_u32 s88, s89\n\t" \
-    "s_cbranch_scc1 95f\n" \
-    "21:\n\t" \
+    "s_cbranch_scc1 95f\n\t" \
     "v_readlane_b32 s88, %[info], s93\n\t" \
     "s_bfe_u32 s95, s88, 0x50011\n\t"                   /* fw */ \
     "s_bfe_u32 s96, s88, 0x30016\n\t"                   /* catch-up code */ \
@@ -383,26 +367,42 @@ __device__ unsigned long long g_zstd_eprof[16];
     "s_lshl_b32 s89, s89, 8\n\t" \
     "s_or_b32 %[ends], s89, s88\n" \
     /* ---- one sequence: park the record, move on ---- */ \
-    "50:\n\t" \
-    "s_mov_b32 m0, %[rl]\n\t" \
-    "v_writelane_b32 %[qll], s97, m0\n\t" \
-    "v_writelane_b32 %[qoff], s98, m0\n\t" \
-    "v_writelane_b32 %[qml], s99, m0\n\t" \
-    "s_add_i32 %[rl], %[rl], 1\n\t" \
-    "s_mov_b32 %[arel], s94\n\t" \
-    "s_mov_b32 %[S], s94\n\t" \
-    "s_sub_i32 s88, s94, 2\n\t" \
-    "s_cmp_ge_u32 s88, %[lim]\n\t" \
-    "s_cbranch_scc1 94f\n\t"                            /* table writes behind the trustworthy lanes */ \
-    "s_cmp_lg_u32 s101, 0\n\t" \
-    "s_cbranch_scc1 94f\n\t"                            /* immediate rep2 test not decidable from the maps */ \
-    "s_lshl_b64 " ZW_TA ", -1, s83\n\t" \
-    "s_add_i32 s89, s93, 2\n\t" \
-    "s_lshl_b64 " ZW_TB ", -2, s89\n\t" \
-    "s_andn2_b64 " ZW_TA ", " ZW_TA ", " ZW_TB "\n\t" \
-    "s_or_b64 %[commit], %[commit], " ZW_TA "\n\t" \
-    "s_bitset1_b64 %[commit], s88\n\t" \
-    "s_branch 1b\n" \
+    ZW_SEQ_BLOCK \
+    "30:\n\t" \
+    "s_cmp_eq_u32 s91, -1\n\t" \
+    "s_cbranch_scc1 95f\n\t"                            /* neither */ \
+    /* ---- repcode found by even probe k at k + 2 ---- */ \
+    "s_add_i32 s93, %[S], s91\n\t"                      /* k */ \
+    "s_cmp_ge_u32 s93, %[lim]\n\t" \
+    "s_cbranch_scc1 91f\n\t" \
+    "s_add_i32 s88, s93, 1\n\t" \
+    "s_lshr_b64 " ZW_TA ", %[eq1], s88\n\t"             /* e1k */ \
+    "s_and_b32 s96, s84, 1\n\t"                         /* back1 */ \
+    "s_lshr_b64 " ZW_TA ", " ZW_TA ", 5\n\t" \
+    "s_not_b64 " ZW_TA ", " ZW_TA "\n\t" \
+    "s_ff1_i32_b64 s95, " ZW_TA "\n\t"                  /* f */ \
+    "s_add_i32 s94, s93, s95\n\t" \
+    "s_add_i32 s94, s94, 6\n\t"                         /* E */ \
+    "s_add_i32 s88, s94, 4\n\t" \
+    "s_bfe_u32 s89, %[ends], 0x80008\n\t"               /* end2 */ \
+    "s_min_u32 s90, %[rep2], 1\n\t"                     /* rep2 != 0 */ \
+    "s_cmp_le_u32 s88, s89\n\t" \
+    "s_cselect_b32 s100, s90, 0\n\t"                    /* imm */ \
+    "s_lshr_b64 " ZW_TA ", %[q2], s94\n\t" \
+    "s_and_b32 s88, s84, s100\n\t"                      /* immediate rep2 match */ \
+    "s_and_b32 s89, %[ends], 0xff\n\t"                  /* end1 */ \
+    "s_xor_b32 s101, s100, s90\n\t"                     /* post = rep2 != 0 && !imm */ \
+    "s_sub_i32 s97, s93, s96\n\t" \
+    "s_sub_i32 s97, s97, %[arel]\n\t" \
+    "s_add_i32 s97, s97, 2\n\t"                         /* ll */ \
+    "s_mov_b32 s98, 1\n\t"                              /* offBase */ \
+    "s_add_i32 s99, s96, s95\n\t" \
+    "s_add_i32 s99, s99, 4\n\t"                         /* ml */ \
+    "s_cmp_ge_u32 s94, s89\n\t" \
+    "s_cbranch_scc1 92f\n\t"                            /* the run leaves the known part of the map */ \
+    "s_cmp_lg_u32 s88, 0\n\t" \
+    "s_cbranch_scc1 92f\n\t" \
+    ZW_SEQ_BLOCK                                        /* (its own copy of the sequence block: no taken branch to it) */ \
     /* ---- exits ---- */ \
     "90:\n\t" "s_mov_b32 %[xw], 0\n\t" "s_branch 99f\n" \
     "91:\n\t" "s_mov_b32 %[xw], 1\n\t" "s_branch 99f\n" \

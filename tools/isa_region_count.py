@@ -2,9 +2,12 @@
 """Static instruction counts of one kernel of a hipcc -S listing, split at the `; <marker>` comments the sources plant with
 asm volatile (e.g. "; batch begin" / "; resolve begin" in csrc/lz4_kernels.hip), by issue class.  What is counted is every
 instruction that lies between two markers in the listing - rarely taken side paths included - so it bounds a stage from above.
-usage: tools/isa_region_count.py <listing.s> <kernel symbol substring>"""
+A kernel that holds several inlined instances of one function repeats its markers: `--first <marker>` starts a new table at every
+occurrence of that marker (e.g. "batch begin"), so each instance is counted on its own.
+usage: tools/isa_region_count.py <listing.s> <kernel symbol substring> [--first <marker>]"""
 import re, sys, collections
 path, sym = sys.argv[1], sys.argv[2]
+first = sys.argv[sys.argv.index("--first") + 1] if "--first" in sys.argv else None
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^[_A-Za-z0-9]+:", l) and sym in l)
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
@@ -18,12 +21,15 @@ def cls(op):
     if op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_") or op.startswith("scratch_"): return "vmem_wr"
     if op.startswith("v_"): return "valu"
     return "other"
-regions, cur = collections.OrderedDict(), "prologue"
+tables = [collections.OrderedDict()]
+regions, cur = tables[0], "prologue"
 regions[cur] = collections.Counter()
 for l in lines[start + 1:end + 1]:
     t = l.strip()
     m = re.match(r"^; ([a-z0-9 +<>-]+ (begin|end))$", t)
     if m:
+        if first and m.group(1) == first and any(k != "prologue" for k in regions):
+            tables.append(collections.OrderedDict()); regions = tables[-1]
         cur = "after: " + m.group(1)
         regions.setdefault(cur, collections.Counter())
         continue
@@ -32,6 +38,8 @@ for l in lines[start + 1:end + 1]:
     if not re.match(r"^[a-z_0-9]+$", op): continue
     regions[cur][cls(op)] += 1
 cols = ["salu", "branch", "valu", "lds", "vmem_rd", "vmem_wr", "smem", "wait/nop"]
-print(f"{'region':34s}" + "".join(f"{c:>9s}" for c in cols) + "    total")
-for r, c in regions.items():
-    print(f"{r:34s}" + "".join(f"{c[k]:9d}" for k in cols) + f"{sum(c.values()):9d}")
+for i, regions in enumerate(tables):
+    if len(tables) > 1: print(f"--- instance {i}")
+    print(f"{'region':34s}" + "".join(f"{c:>9s}" for c in cols) + "    total")
+    for r, c in regions.items():
+        print(f"{r:34s}" + "".join(f"{c[k]:9d}" for k in cols) + f"{sum(c.values()):9d}")
