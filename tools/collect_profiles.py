@@ -29,7 +29,7 @@ for c in (sys.argv[3:] or ["lz4", "snappy", "zstd"]):
         kb = {}
         per_call = int(((bench["roofline"].get("launches") or {}).get("per_compress_call") or {}).get(dom, 1))   # level 3: one launch per slab
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, f"pmc_{c}_{ctr}"), c + "_"], capture_output=True, text=True).stdout
+            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(O, f"pmc_{c}_{ctr}"), ("zstd_" if c.startswith("zstd") else c + "_")], capture_output=True, text=True).stdout
             f.write(txt)
             cur = None
             for l in txt.splitlines():
