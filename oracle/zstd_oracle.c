@@ -1315,7 +1315,7 @@ static size_t decode_block(zdec_state* st, const u8* src, size_t n, u8* dst, siz
             br_t b; u32 sLL, sOF, sML; size_t i; u8 modes;
             if (ip >= iend) { free(lits); return ZERR; }
             modes = *ip++;
-            if (modes & 3) { free(lits); return ZERR; }
+            /* (the two reserved bits of the modes byte are not looked at: ZSTD_decodeSeqHeaders, zstd_decompress_block.c:739-743) */
             if (seq_table(st->ll, &st->llLog, &st->haveLL, modes >> 6, &ip, iend, 35, 9, kLLnorm, 35, 6)
              || seq_table(st->of, &st->ofLog, &st->haveOF, (modes >> 4) & 3, &ip, iend, 31, 8, kOFnorm, 28, 5)
              || seq_table(st->ml, &st->mlLog, &st->haveML, (modes >> 2) & 3, &ip, iend, 52, 9, kMLnorm, 52, 6)) { free(lits); return ZERR; }
@@ -1364,7 +1364,7 @@ static size_t decode_block(zdec_state* st, const u8* src, size_t n, u8* dst, siz
 size_t orc_zstd_decompress(const u8* src, size_t n, u8* dst, size_t dstCap)
 {
     size_t ip = 0, op = 0;
-    if (n == 0) return dstCap == 0 ? 0 : ZERR;       /* ZSTD_decompressMultiFrame: empty input -> srcSize_wrong unless nothing expected */
+    if (n == 0) return 0;                             /* ZSTD_decompressMultiFrame (zstd_decompress.c:1123-1197): the frame loop is not entered, nothing is left over */
     while (ip < n) {
         u32 magic;
         if (n - ip < 4) return ZERR;
@@ -1413,14 +1413,14 @@ size_t orc_zstd_decompress(const u8* src, size_t n, u8* dst, size_t dstCap)
                     last = bh & 1; type = (bh >> 1) & 3; bsz = bh >> 3;
                     if (type == 3) { free(st); return ZERR; }
                     if (type == 1) {
-                        if (ip >= n || bsz > dstCap - op || bsz > blockMax) { free(st); return ZERR; }
+                        if (ip >= n || bsz > dstCap - op) { free(st); return ZERR; }            /* (no block-size limit on RLE / raw blocks: ZSTD_setRleBlock, ZSTD_copyRawBlock) */
                         memset(dst + op, src[ip], bsz); ip += 1; op += bsz;
                     } else if (type == 0) {
-                        if (bsz > n - ip || bsz > dstCap - op || bsz > blockMax) { free(st); return ZERR; }
+                        if (bsz > n - ip || bsz > dstCap - op) { free(st); return ZERR; }
                         memcpy(dst + op, src + ip, bsz); ip += bsz; op += bsz;
                     } else {
                         size_t r;
-                        if (bsz > n - ip || bsz > (128u << 10)) { free(st); return ZERR; }
+                        if (bsz > n - ip || bsz > blockMax) { free(st); return ZERR; }            /* ZSTD_decompressBlock_internal: srcSize > blockSizeMax */
                         r = decode_block(st, src + ip, bsz, dst + frameStart, op - frameStart, dstCap - frameStart, blockMax);
                         if (r == ZERR) { free(st); return ZERR; }
                         ip += bsz; op += r;

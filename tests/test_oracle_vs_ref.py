@@ -93,6 +93,56 @@ def test_decoder_on_mutated_streams(oracle, ref, codec):
         assert stricter == 0     # LZ4 / Snappy: identical accept set on this fuzz corpus
 
 
+def test_decoder_on_mutated_multi_block_zstd_frames(oracle, ref):
+    """Multi-block frames (small windows: dozens of blocks, repeat modes, RLE and raw blocks) mutated, truncated, extended, with a
+    capacity a few bytes off: the oracle never accepts what the reference rejects and never decodes other bytes; it may only be
+    stricter - and since round 6 only where a damaged Huffman stream is not consumed exactly (the reference's fast loops do not
+    check that): the reserved bits of the sequence-modes byte, RLE / raw blocks above the frame's block size and the empty input
+    are accepted as the reference accepts them (found by tools/fuzz_decode_frames_campaign.py seed 6134 after the GPU decoder
+    had been aligned with the reference's error codes)."""
+    import ctypes as C
+    f = oracle.L.orc_zstd_compress_frame_cp; f.restype = C.c_size_t
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int] + [C.c_uint] * 5
+    rng = np.random.default_rng(6134)
+    stricter = total = 0
+    for it in range(120):
+        kind = ["text", "mixed", "low", "rep", "zeros", "jsonlog", "random"][int(rng.integers(0, 7))]
+        n = int(rng.choice([rng.integers(1, 5000), rng.integers(5000, 100000), rng.integers(131073, 200000)]))
+        raw = zfc.make(kind, n, int(rng.integers(0, 1 << 30)))
+        out = C.create_string_buffer(n + (n >> 8) + 64)
+        r = f(raw, n, out, n + (n >> 8) + 64, int(rng.integers(1, 3)), int(rng.choice([10, 12, 14, 17, 19])), int(rng.integers(7, 16)), int(rng.integers(7, 16)),
+              int(rng.integers(4, 8)), 0)
+        assert r > 0
+        for _ in range(4):
+            comp = bytearray(out.raw[:r]); cap = n
+            m = int(rng.integers(0, 8))
+            if m <= 3:
+                for _ in range(m if m else 1):
+                    comp[int(rng.integers(0, len(comp)))] = int(rng.integers(0, 256))
+            elif m == 4 and len(comp) > 2:
+                comp = comp[:int(rng.integers(1, len(comp)))]
+            elif m == 5:
+                comp += bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+            elif m == 6:
+                cap = max(0, n + int(rng.integers(-5, 6)))
+            x, y = oracle.decompress(ol.ZSTD, bytes(comp), cap), ref.decompress(ol.ZSTD, bytes(comp), cap)
+            total += 1
+            if x is not None:
+                assert y == x, it
+            elif y is not None:
+                stricter += 1
+    assert stricter <= total // 10, (stricter, total)
+    assert oracle.decompress(ol.ZSTD, b"", 16) == ref.decompress(ol.ZSTD, b"", 16) == b""
+    # one sequence-modes byte with its reserved bits set: both accept
+    raw = zfc.make("text", 3000, 5)
+    c = bytearray(ref.compress(ol.ZSTD, raw))
+    for i in range(9, len(c)):                       # find a byte whose low two bits the reference ignores: flip them everywhere, keep what it accepts
+        d = bytearray(c); d[i] ^= 3
+        y = ref.decompress(ol.ZSTD, bytes(d), len(raw))
+        if y == raw:
+            assert oracle.decompress(ol.ZSTD, bytes(d), len(raw)) == raw, i
+
+
 def test_decode_foreign_zstd_frames(oracle, ref):
     import ctypes as C
     rng = random.Random(3)
