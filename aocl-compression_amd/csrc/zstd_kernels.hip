@@ -139,6 +139,9 @@ __device__ u32 wave_count(const gbyte* __restrict__ src, u32 a, u32 b, u32 end, 
     }
 }
 
+#ifdef ZSTD_PROF
+__device__ unsigned long long g_zstd_gprof[4];      // gather: runs above 64 bytes, of them beyond the round's first four, of them above 1024 bytes, rounds
+#endif
 // Literal buffer of a block: gathered after the parse (ZSTD_storeSeq's copies + ZSTD_storeLastLiterals), so the search
 // loop never waits on a load->store copy.  128 sequences per round, two consecutive ones per lane (their records are one
 // 8-byte load per array, requested a round ahead): prefix sum of the literal lengths; runs up to 64 bytes as pieces at 0, k, 2k
@@ -180,6 +183,11 @@ __device__ u32 gather_literals(const gbyte* __restrict__ src_, const u32 n_, GWo
         dp[0] = lpos + inc - mine; dp[1] = dp[0] + ll[0];
         // the first four long runs of the round (uniform parameters)
         u64 lm0 = ballot(ll[0] > 64), lm1 = ballot(ll[1] > 64);
+#ifdef ZSTD_PROF
+        if (lane == 0) { const unsigned long long nl = (unsigned long long)(__builtin_popcountll(lm0) + __builtin_popcountll(lm1));
+                         atomicAdd(&g_zstd_gprof[0], nl); atomicAdd(&g_zstd_gprof[1], nl > 4 ? nl - 4 : 0ull);
+                         atomicAdd(&g_zstd_gprof[2], (unsigned long long)(__builtin_popcountll(ballot(ll[0] > 1024)) + __builtin_popcountll(ballot(ll[1] > 1024)))); atomicAdd(&g_zstd_gprof[3], 1ull); }
+#endif
         u32 Ln[4] = {0, 0, 0, 0}, Ls[4] = {0, 0, 0, 0}, Ld[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1656,6 +1664,7 @@ __device__ u32 entropy_compress(u8* dst_, Workspace* ws_, u32 litSize_, u32 nbSe
             e = en; c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
         wave_fence();
+        ESTAGE(L, 7);
         // the proof, and the repairs
         for (;;) {
             const u32 prev = wave_shr1(st);                               // the state lane g-1 left its segment with
@@ -3486,6 +3495,14 @@ extern "C" int aoclgpu_debug_zstd_eprof(unsigned long long* host16)
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(aoclgpu::g_zstd_eprof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_eprof), z, sizeof(z));
+    return 0;
+}
+extern "C" int aoclgpu_debug_zstd_gprof(unsigned long long* host4)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host4, HIP_SYMBOL(aoclgpu::g_zstd_gprof), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[4] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_zstd_gprof), z, sizeof(z));
     return 0;
 }
 extern "C" int aoclgpu_debug_zstd_hprof(unsigned long long* host8)

@@ -12,12 +12,14 @@ buf = (C.c_ulonglong * 16)()
 eng.lib.aoclgpu_debug_zstd_eprof(buf)           # reset
 hb = (C.c_ulonglong * 8)()
 eng.lib.aoclgpu_debug_zstd_hprof(hb)
+gb = (C.c_ulonglong * 4)()
+eng.lib.aoclgpu_debug_zstd_gprof(gb)
 slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072)
 torch.cuda.synchronize()
 eng.lib.aoclgpu_debug_zstd_eprof(buf)
 names = ["gather_literals (in the finder's function)", "literals: histogram (+ the suspect probe)", "literals: Huffman code (sort, tree, lengths, values)",
          "literals: table description (weights, FSE)", "literals: Huffman streams + header", "sequences: codes", "sequences: 3 x histogram / normalise / description / CTable",
-         "tile: code -> (deltaNbBits, deltaFindState)", "tile: three state chains (lanes 0-2)", "tile: values + bit packer", "final states + close", "staged block -> slot"]
+         "FSE state chains: the segments' first walk (3 x 21 lanes)", "FSE state chains: proof and repairs", "tile: values + bit packer", "final states + close", "staged block -> slot"]
 tot = sum(buf[:12]); chunks = buf[12]; seqs = buf[13]; lits = buf[14]
 for n, v in zip(names, buf[:12]):
     print(f"{n:66s} {v / tot * 100:6.2f}%  {v / chunks:10.0f} ticks/chunk")
@@ -27,3 +29,5 @@ for n, v in zip(["keys + rank sort", "tie order: the reference's quicksort per b
     print(f"  Huffman code: {n:40s} {v / chunks:10.0f} ticks/chunk")
 if buf[15]:
     print(f"chain segments walked again: {buf[15] / chunks:.2f} per chunk")
+eng.lib.aoclgpu_debug_zstd_gprof(gb)
+print(f"literal gather: {gb[3] / chunks:.1f} rounds per chunk, {gb[0] / chunks:.1f} runs above 64 bytes per chunk ({gb[1] / chunks:.2f} beyond a round's first four, {gb[2] / chunks:.2f} above 1024 bytes)")
