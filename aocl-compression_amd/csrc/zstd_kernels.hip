@@ -183,7 +183,7 @@ __device__ u32 gather_literals(const gbyte* __restrict__ src_, const u32 n_, GWo
         dp[0] = lpos + inc - mine; dp[1] = dp[0] + ll[0];
         // the first four long runs of the round (uniform parameters)
         u64 lm0 = ballot(ll[0] > 64), lm1 = ballot(ll[1] > 64);
-#ifdef ZSTD_PROF
+#if defined(ZSTD_PROF) && !defined(ZSTD_PROF_TOP)
         if (lane == 0) { const unsigned long long nl = (unsigned long long)(__builtin_popcountll(lm0) + __builtin_popcountll(lm1));
                          atomicAdd(&g_zstd_gprof[0], nl); atomicAdd(&g_zstd_gprof[1], nl > 4 ? nl - 4 : 0ull);
                          atomicAdd(&g_zstd_gprof[2], (unsigned long long)(__builtin_popcountll(ballot(ll[0] > 1024)) + __builtin_popcountll(ballot(ll[1] > 1024)))); atomicAdd(&g_zstd_gprof[3], 1ull); }
@@ -573,6 +573,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
     }
 #ifdef ZSTD_PROF
     unsigned long long zacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zprev = __builtin_amdgcn_s_memtime(), zbatches = 0;
+#ifdef ZSTD_PROF_TOP
+    unsigned long long ztop[4] = {0, 0, 0, 0};
+#endif
     unsigned long long zcnt[6] = {0, 0, 0, 0, 0, 0};     // chain outcomes: restart, continue, event; one-match batches; immediate repcodes; refreshes
 #define ZCOUNT(k) (zcnt[k]++)
 #else
@@ -639,6 +642,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
         u32 b_pos0 = 0, b_h = 0, b_ent = 0, b_info = 0, b_eqb = 0, b_off = 0, b_pb0 = 0, b_flags = 0;   // flags: 1 match below lim, 2 hard
         int b_lim = 0; u64 b_later = 0;                                 // b_later: later lanes of the batch on this lane's slot
         for (;;) {                                                      // _start
+#ifdef ZSTD_PROF_TOP
+#define ZTT(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+            ZTT(tt0);
+#endif
             u32 i0 = 0; int ev = 0;                                     // 1 = table match, 2 = repcode
             u32 e_pos = 0, e_cand = 0, e_sig = 0, e_st = 0, e_half = 0, e_p1 = 0, e_h1 = 0, e_h2 = 0;
             bool e_ok1 = false, e_ok2 = false;
@@ -652,6 +659,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                 // ---------------- chain batch: the 64 consecutive probes a search starts with; every sequence they
                 //                  hold is resolved from registers by the scalar walk of zstd_chain.h ----------------
                 asm volatile("; batch begin");
+#ifdef ZSTD_PROF_TOP
+                ZTT(tt1);
+                ztop[0] += tt1 - tt0;
+#endif
                 u64 e1 = 0, e2 = 0;
                 if (!resume) {
                     const u32 pos0 = uni(s), pos = pos0 + (u32)lane;
@@ -671,6 +682,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                         pend = blk_load(rb + 1); have_pend = true;
                         wave_fence();
                     }
+#ifdef ZSTD_PROF_TOP
+                    ZTT(tt2);
+                    ztop[1] += tt2 - tt1;
+#endif
                     u32 ro = rel0 - kRingBlk * (u32)bl + ((u32)bl & 1u) * kRingBlk + (u32)lane;
                     if (ro >= 2 * kRingBlk) ro -= 2 * kRingBlk;
                     const u32x4 pa = lds_ld128(ring + ro), pb = lds_ld128(ring + ro + 16);
@@ -678,6 +693,10 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
                     const u32 b1 = src[pos - rep1];
                     u32 b2 = 0x100;
                     if (rep2) b2 = src[pos - rep2];
+#ifdef ZSTD_PROF_TOP
+                    { ZTT(tt3);
+                      ztop[2] += tt3 - tt2; ztop[3]++; }
+#endif
                     ZSTAGE(0);
 #ifdef ZSTD_PROF
                     zbatches++;
@@ -970,6 +989,9 @@ __device__ u32 fast_block(const gbyte* __restrict__ src_, const u32 n_, const u3
         }
     }
 #ifdef ZSTD_PROF
+#ifdef ZSTD_PROF_TOP
+    if (lane == 0) for (int k = 0; k < 4; ++k) atomicAdd(&g_zstd_gprof[k], ztop[k]);
+#endif
     if (lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_zstd_prof[k], zacc[k]); atomicAdd(&g_zstd_prof[8], zbatches); atomicAdd(&g_zstd_prof[9], (unsigned long long)nbSeq);
                      for (int k = 0; k < 6; ++k) atomicAdd(&g_zstd_prof[10 + k], zcnt[k]); }
 #endif

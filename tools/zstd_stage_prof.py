@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import aocl_compression_amd as a
 eng = a.engine(0)
-data = a.corpus.silesia_mix(64 << 20)
+data = a.corpus.make(sys.argv[1], 64 << 20, seed=7) if len(sys.argv) > 1 else a.corpus.silesia_mix(64 << 20)     # [kind]: one corpus kind instead of the mix
 src = torch.from_numpy(data).to(eng.device).repeat(8)
 ZEXP = int(os.environ.get("ZEXP", "0"))
 slots, out_len, slot = eng.compress_chunks(a.ZSTD, src, 131072, flags=ZEXP)
