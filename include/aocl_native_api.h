@@ -27,7 +27,7 @@ const char* LZ4_versionString(void);                       /* "1.9.3" */
 int         LZ4_compressBound(int inputSize);              /* 0 if inputSize > 0x7E000000 */
 int         LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);   /* 0 = failure */
 int         LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration); /* any acceleration (clamped to 1..65537) */
-int         LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);    /* < 0 = malformed */
+int         LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);    /* malformed: -(ip - src) - 1 at the reference's point of failure (lz4.c:3799-3802), the same value */
 char*       aocl_setup_lz4(int optOff, int optLevel, size_t insize, size_t level, size_t windowLog); /* NULL */
 void        aocl_destroy_lz4(void);
 
@@ -114,7 +114,7 @@ size_t      ZSTD_compressBound(size_t srcSize);
 unsigned    ZSTD_isError(size_t code);
 const char* ZSTD_getErrorName(size_t code);
 size_t      ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
-size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
+size_t      ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);   /* errors: the reference's code for the check that fails first (deviations: "Error VALUES") */
 unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
 unsigned long long ZSTD_getDecompressedSize(const void* src, size_t srcSize);   /* 0 = unknown or error */
 unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);       /* over all frames of the stream */
