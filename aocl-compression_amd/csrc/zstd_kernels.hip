@@ -2575,12 +2575,16 @@ __device__ __forceinline__ u32 huf_read_table(DecLds* L, const u8* src, u32 n, u
 // symbols per container), the whole wave refilling the LDS windows in between.  All 64 lanes call it; returns false
 // on a lane whose stream is malformed.  (Kept inline: as a called function under a partial exec mask this loop was
 // miscompiled by ROCm 7.2's hipcc.)
+// lenient: the stream is one of four that the reference decodes with its fast loops (huf_decompress.c :790-840 / :1600-1655), which
+// make no end-of-stream check: bits left over are no error (the symbols are the same), and a last byte of zero has no end mark to
+// find - all eight bits are data (HUF_initFastDStream :167-176).  A stream that runs out of bits is still refused.
 template <class TAB>
 __device__ __forceinline__ bool huf_decode_streams_t(DecLds* L, u8* out_, u32 nout, const u8* src_, u32 n, TAB tab, const u32 tl,
-                                                     const bool mine, int lane)
+                                                     const bool mine, int lane, const bool lenient = false)
 {
     gbyte* out = (gbyte*)out_; const gbyte* src = (const gbyte*)src_;
     BitL b; b.pos = mine ? bit_stream_bits(src_, n) : 0; b.wb = 0; b.c = 0;
+    if (lenient && mine && n != 0 && src_[n - 1] == 0) b.pos = (int)(8u * n);
     bool ok = !mine || b.pos >= 0;
     u32 i = 0;
     const u32 todo = (mine && ok) ? nout : 0;
@@ -2624,15 +2628,16 @@ __device__ __forceinline__ bool huf_decode_streams_t(DecLds* L, u8* out_, u32 no
         }
         wave_fence();
     }
-    return ok && (!mine || b.pos == 0);
+    return ok && (!mine || b.pos == 0 || (lenient && b.pos > 0));
 }
-__device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout, const u8* src, u32 n, const u16* big, const bool mine, int lane)
+__device__ __forceinline__ bool huf_decode_streams(DecLds* L, u8* out, u32 nout, const u8* src, u32 n, const u16* big, const bool mine, int lane,
+                                                   const bool lenient = false)
 {
     typedef __attribute__((address_space(3))) const u16 LT;
     typedef __attribute__((address_space(1))) const u16 GT;
     const u32 tl = uni(L->hufLog);
-    if (tl == 12) return huf_decode_streams_t(L, out, nout, src, n, (GT*)big, tl, mine, lane);
-    return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane);
+    if (tl == 12) return huf_decode_streams_t(L, out, nout, src, n, (GT*)big, tl, mine, lane, lenient);
+    return huf_decode_streams_t(L, out, nout, src, n, (LT*)L->huf, tl, mine, lane, lenient);
 }
 
 #ifdef ZSTD_PROF
@@ -2943,9 +2948,17 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
 #ifdef ZSTD_PROF
                                          , dacc, dprev
 #endif
-                                         )) return kCorrupt;
+                                         )) {
+                        // (cold) The speculative decoder wants every stream consumed exactly; the reference's fast loops - which run
+                        // whenever the four streams have 16 / 8 / 8 / 8 bytes and the fourth segment is not empty, every decoding table
+                        // being rescaled to log 11 for them (huf_decompress.c :184-270, :320-347, :1157) - make no such check.  Decode
+                        // again, one lane per stream, and accept what leaves bits over.
+                        if (!(s1 >= 16 && s2 >= 8 && s3 >= 8 && s4 >= 8 && 3 * seg < litSize)) return kCorrupt;
+                        ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane, true);
+                    }
                 } else
-                ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane);
+                ok = huf_decode_streams(L, litBuf + j * seg, no, src + hoff + 6 + so, sl, big, lane < 4, lane,
+                                        s1 >= 16 && s2 >= 8 && s3 >= 8 && s4 >= 8 && 3 * seg < litSize);
             }
             if (ballot(!ok) != 0) return kCorrupt;
             wave_fence();
@@ -3071,6 +3084,10 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             }
             pos = (int)uni((u32)posOut);
             wave_fence();
+            // A tile that read below the stream's first bit: the block is refused here, before it is executed.  (The reference does
+            // not notice - its reads wrap around the 64-bit container, bitstream.h:343-351 - and decodes garbage or fails later;
+            // until round 6 this decoder read zeros there and could return other bytes than the reference's with a success value.)
+            if (pos < 0) return kCorrupt;
             DSTAGE(2);
             // execute: prefix sums give every sequence its literal source and its output position
             u32 ll = 0, ml = 0, off = 0;

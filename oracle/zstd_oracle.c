@@ -1209,10 +1209,16 @@ static size_t huf_read_table(huf_dt* dt, const u8* src, size_t n)
     dt->tableLog = tableLog;
     return used;
 }
-static int huf_decode_stream(u8* out, size_t nout, const u8* src, size_t n, const huf_dt* dt)
+/* lenient: the stream is one of four that the reference decodes with its fast loops (huf_decompress.c
+ * HUF_decompress4X{1,2}_usingDTable_internal_fast, :790-840 / :1600-1655): those make no end-of-stream check - a stream that
+ * holds MORE bits than its symbols need decodes to the same symbols and is accepted (bits left over), and a last byte of zero
+ * is no error there (HUF_initFastDStream :167-176: all eight bits are data).  A stream that holds FEWER bits than its symbols
+ * need is still refused here: the reference goes on reading the bytes in front of it, which this restatement does not follow. */
+static int huf_decode_stream(u8* out, size_t nout, const u8* src, size_t n, const huf_dt* dt, int lenient)
 {
     br_t b; size_t i; const int tl = (int)dt->tableLog;
-    if (br_init(&b, src, n)) return -1;
+    if (lenient && n != 0 && src[n - 1] == 0) { b.p = src; b.pos = (int64_t)n * 8; }
+    else if (br_init(&b, src, n)) return -1;
     for (i = 0; i < nout; i++) {
         u32 idx; int k;
         /* peek tableLog bits (zero-padded below the start of the stream) */
@@ -1220,7 +1226,7 @@ static int huf_decode_stream(u8* out, size_t nout, const u8* src, size_t n, cons
         for (k = 0; k < tl; k++) { const int64_t bit = b.pos - tl + k; if (bit >= 0) idx |= (u32)((b.p[bit >> 3] >> (bit & 7)) & 1) << k; }
         out[i] = dt->symbol[idx]; b.pos -= dt->nbBits[idx];
     }
-    return b.pos == 0 ? 0 : -1;                      /* every stream must be consumed exactly */
+    return (b.pos == 0 || (lenient && b.pos > 0)) ? 0 : -1;   /* strict decoder (BIT_endOfDStream): every stream must be consumed exactly */
 }
 
 typedef struct {
@@ -1285,7 +1291,7 @@ static size_t decode_block(zdec_state* st, const u8* src, size_t n, u8* dst, siz
                     st->haveHuf = 1; hp += used; hsz -= used;
                 } else if (!st->haveHuf) return ZERR;
                 lits = (u8*)malloc(litSize + 8);
-                if (!streams4) { if (huf_decode_stream(lits, litSize, hp, hsz, &st->huf)) { free(lits); return ZERR; } }
+                if (!streams4) { if (huf_decode_stream(lits, litSize, hp, hsz, &st->huf, 0)) { free(lits); return ZERR; } }
                 else {
                     size_t s1, s2, s3, s4; const size_t seg = (litSize + 3) / 4;
                     if (litSize < 6 || hsz < 10) { free(lits); return ZERR; }   /* huf_decompress.c: 4X needs >= 10 bytes, zstd :251 */
@@ -1293,9 +1299,14 @@ static size_t decode_block(zdec_state* st, const u8* src, size_t n, u8* dst, siz
                     if (6 + s1 + s2 + s3 > hsz) { free(lits); return ZERR; }
                     s4 = hsz - 6 - s1 - s2 - s3;
                     if (3 * seg > litSize) { free(lits); return ZERR; }
-                    if (huf_decode_stream(lits, seg, hp + 6, s1, &st->huf) || huf_decode_stream(lits + seg, seg, hp + 6 + s1, s2, &st->huf)
-                     || huf_decode_stream(lits + 2 * seg, seg, hp + 6 + s1 + s2, s3, &st->huf)
-                     || huf_decode_stream(lits + 3 * seg, litSize - 3 * seg, hp + 6 + s1 + s2 + s3, s4, &st->huf)) { free(lits); return ZERR; }
+                    {   /* the reference's fast loops run when every decoding table has log 11 - they all do: HUF_rescaleStats :320-347,
+                         * HUF_readDTableX2_wksp :1157 - the streams have at least 16 / 8 / 8 / 8 bytes and the fourth segment is not empty
+                         * (HUF_DecompressFastArgs_init :184-270); otherwise the strict decoder with its end-of-stream check */
+                        const int len = s1 >= 16 && s2 >= 8 && s3 >= 8 && s4 >= 8 && 3 * seg < litSize;
+                        if (huf_decode_stream(lits, seg, hp + 6, s1, &st->huf, len) || huf_decode_stream(lits + seg, seg, hp + 6 + s1, s2, &st->huf, len)
+                         || huf_decode_stream(lits + 2 * seg, seg, hp + 6 + s1 + s2, s3, &st->huf, len)
+                         || huf_decode_stream(lits + 3 * seg, litSize - 3 * seg, hp + 6 + s1 + s2 + s3, s4, &st->huf, len)) { free(lits); return ZERR; }
+                    }
                 }
                 litPtr = lits; ip += lh + csize;
             }
@@ -1352,7 +1363,12 @@ static size_t decode_block(zdec_state* st, const u8* src, size_t n, u8* dst, siz
                 { size_t k; for (k = 0; k < ml; k++) dst[out + k] = dst[out - offset + k]; }
                 out += ml;
             }
-            if (b.pos > 0) { free(lits); return ZERR; }                     /* bitstream not fully consumed */
+            /* The stream must be consumed exactly.  More bits than the sequences need: the reference refuses too
+             * (BIT_reloadDStream < BIT_DStream_completed, zstd_decompress_block.c:1583).  FEWER bits: the reference does not notice -
+             * a read below the stream's first bit wraps around its 64-bit container (bitstream.h:343-351, bitsConsumed & 63) and
+             * the block decodes to whatever that gives, or fails later; this restatement refuses the block (round 6; until then
+             * it read zeros there and, like the GPU decoder, could return other bytes than the reference's with a success value). */
+            if (b.pos != 0) { free(lits); return ZERR; }
         }
         if (out + (litSize - litPos) > cap || (out - opos) + (litSize - litPos) > blockMax) { free(lits); return ZERR; }
         memcpy(dst + out, litPtr + litPos, litSize - litPos); out += litSize - litPos;

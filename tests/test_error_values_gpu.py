@@ -84,10 +84,10 @@ def test_zstd_decompress_returns_the_references_error_code(lib, ref):
                 n += 1
                 if want == got and (want > cap or w.raw[:want] == g.raw[:want]):
                     continue
-                # The ONE deliberate deviation ("Error values"): a Huffman-coded literal stream that does not end exactly
-                # at its first bit is corruption_detected here; the reference's fast decoding loops (huf_decompress.c: every literal table
-                # is rescaled to log 11 for them; four streams of 16 / 8 / 8 / 8+ bytes) do not make that check - they return what the damaged stream decodes to, or run out of output
-                # behind it (dstSize_tooSmall).  Never the other way round, and never different bytes with a success value.
+                # The ONE deliberate kind of deviation ("Error VALUES"): a Huffman stream or a sequence bitstream that RUNS
+                # OUT of bits is corruption_detected here; the reference's bit readers wrap around / read on in front of the stream and
+                # return what that decodes to (success, or dstSize_tooSmall when the output then runs out).  Never the other way round,
+                # and never different bytes with a success value.
                 if got == ERR(20) and (want <= cap or want == ERR(70)):
                     strict += 1
                     continue
