@@ -113,3 +113,66 @@ def test_snappy_uncompress_returns_the_references_status(lib, ref):
                 if want != got or (want == 0 and (wl.value != gl.value or w.raw[:wl.value] != g.raw[:gl.value])):
                     bad.append((kind, what, cap, want, got))
     assert not bad, f"{len(bad)} of {n} statuses differ from the reference's, e.g. {bad[:8]}"
+
+
+def test_zstd_damaged_small_blocks_never_other_bytes(lib, ref):
+    """The adversarial shape of tests/test_oracle_vs_ref.py (small blocks of skewed alphabets, one or two damaged bytes, a third of
+    them zeroed) through the GPU decoder against the reference itself: same value, or corruption_detected where the reference's
+    bit readers wrap around a stream that ran out of bits - never success with other bytes, never success where the reference fails."""
+    rng = np.random.default_rng(15)
+    bad = []
+    n_calls = strict = 0
+    for it in range(500):
+        nsym = int(rng.choice([2, 3, 4, 6, 10, 30, 100, 256]))
+        n = int(rng.choice([rng.integers(256, 600), rng.integers(600, 3000), rng.integers(3000, 40000)]))
+        p = rng.dirichlet(np.ones(nsym) * rng.choice([0.2, 1.0, 5.0]))
+        raw = rng.choice(nsym, size=n, p=p).astype(np.uint8).tobytes()
+        comp0 = ref.compress(ol.ZSTD, raw)
+        for mu in range(4):
+            comp = bytearray(comp0)
+            for _ in range(int(rng.integers(1, 3))):
+                i = int(rng.integers(min(8, len(comp) - 1), len(comp)))
+                comp[i] = int(rng.integers(0, 256)) if rng.random() < 0.7 else 0
+            c = bytes(comp)
+            w = C.create_string_buffer(n); g = C.create_string_buffer(n)
+            want = ref.L.ZSTD_decompress(w, n, c, len(c)); got = lib.ZSTD_decompress(g, n, c, len(c))
+            n_calls += 1
+            if want == got and (want > n or w.raw[:want] == g.raw[:want]):
+                continue
+            if got == ERR(20) and (want <= n or want == ERR(70)):
+                strict += 1
+                continue
+            bad.append((it, mu, n, hex(want), hex(got)))
+    assert not bad, f"{len(bad)} of {n_calls}: {bad[:8]}"
+    assert strict <= n_calls // 5, (strict, n_calls)
+
+
+def test_lz4_and_snappy_damaged_small_blocks(lib, ref):
+    """The same adversarial shape for the two byte-oriented decoders: exact value / status and bytes, no exception."""
+    rng = np.random.default_rng(16)
+    bad = []
+    for it in range(400):
+        nsym = int(rng.choice([2, 4, 10, 100, 256]))
+        n = int(rng.choice([rng.integers(20, 300), rng.integers(300, 3000), rng.integers(3000, 70000)]))
+        p = rng.dirichlet(np.ones(nsym) * rng.choice([0.2, 1.0, 5.0]))
+        raw = rng.choice(nsym, size=n, p=p).astype(np.uint8).tobytes()
+        for codec in (ol.LZ4, ol.SNAPPY):
+            comp0 = ref.compress(codec, raw)
+            for mu in range(3):
+                comp = bytearray(comp0)
+                for _ in range(int(rng.integers(1, 3))):
+                    i = int(rng.integers(0, len(comp)))
+                    comp[i] = int(rng.integers(0, 256)) if rng.random() < 0.7 else 0
+                c = bytes(comp)
+                cap = n if mu else max(0, n - int(rng.integers(0, 4)))
+                w = C.create_string_buffer(max(cap, 1)); g = C.create_string_buffer(max(cap, 1))
+                if codec == ol.LZ4:
+                    want = ref.L.LZ4_decompress_safe(c, w, len(c), cap); got = lib.LZ4_decompress_safe(c, g, len(c), cap)
+                    ok = want == got and (want <= 0 or w.raw[:want] == g.raw[:want])
+                else:
+                    wl = C.c_size_t(cap); gl = C.c_size_t(cap)
+                    want = ref.L.snappy_uncompress(c, len(c), w, C.byref(wl)); got = lib.snappy_uncompress(c, len(c), g, C.byref(gl))
+                    ok = want == got and (want != 0 or (wl.value == gl.value and w.raw[:wl.value] == g.raw[:gl.value]))
+                if not ok:
+                    bad.append((codec, it, mu, n, cap, want, got))
+    assert not bad, f"{len(bad)}: {bad[:8]}"
