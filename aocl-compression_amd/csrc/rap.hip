@@ -780,9 +780,16 @@ extern "C" int64_t aoclgpu_zstd_decompress_host_frames(const void* hsrc, size_t 
     HCK(hipMemcpy(res.data(), o.p, K * 4, hipMemcpyDeviceToHost));
     if (total) HCK(hipMemcpy(hdst, ddst.p, total, hipMemcpyDeviceToHost));
 #undef HCK
-    for (size_t k = 0; k < K; ++k) {                            // the first frame, in stream order, that failed: its error
-        if (res[k] < 0) return res[k];
-        if ((uint64_t)res[k] != (uint64_t)fr[k].content) return -20;
+    for (size_t k = 0; k < K; ++k) {
+        if (res[k] < 0 || (uint64_t)res[k] != (uint64_t)fr[k].content) {
+            // A frame failed.  WHICH error the reference reports depends on what it had decoded when it noticed: it gives every
+            // frame all the room that is left (a frame whose header understates its size runs on to its end and is then
+            // corruption_detected, not dstSize_tooSmall) - so the stream is walked once more by one wavefront, in the reference's
+            // order with the reference's capacities; its verdict is the return value.  (Cold path: errors only.)
+            const int64_t r = aoclgpu_decompress_host(AOCLGPU_ZSTD, hsrc, n, hdst, cap);
+            if (r >= 0 && !checksums_ok(fr, (const uint8_t*)hdst, (size_t)r)) return -22;
+            return r >= 0 ? (res[k] < 0 ? res[k] : -20) : r;    // (a walk that finds nothing wrong leaves the parallel decode's verdict)
+        }
         if (fr[k].hasCk && (uint32_t)xxh64((const uint8_t*)hdst + doff[k], (size_t)fr[k].content) != fr[k].ck) return -22;   // checksum_wrong (zstd_decompress.c:1101)
     }
     return (int64_t)total;

@@ -176,3 +176,44 @@ def test_lz4_and_snappy_damaged_small_blocks(lib, ref):
                 if not ok:
                     bad.append((codec, it, mu, n, cap, want, got))
     assert not bad, f"{len(bad)}: {bad[:8]}"
+
+
+def test_zstd_streams_of_several_frames(lib, ref):
+    """Concatenated frames (each with its content size: the host path decodes them side by side), skippable frames between them,
+    a capacity that ends inside the second or third frame, damage in one of them, trailing bytes: the value of the FIRST failure in
+    stream order, as the reference's frame loop reports it (zstd_decompress.c:1114-1197)."""
+    import struct
+    rng = np.random.default_rng(17)
+    bad = []
+    n_calls = strict = 0
+    for it in range(150):
+        parts = [a.corpus.make(["text", "binary", "jsonlog", "database"][int(rng.integers(0, 4))], int(rng.integers(1, 60000)), seed=it * 7 + k).tobytes()
+                 for k in range(int(rng.integers(2, 5)))]
+        frames = [ref.compress(ol.ZSTD, p_) for p_ in parts]
+        if rng.random() < 0.3:
+            frames.insert(int(rng.integers(0, len(frames) + 1)), struct.pack("<II", 0x184D2A50 + int(rng.integers(0, 16)), 5) + b"skip!")
+        stream = bytearray(b"".join(frames)); total = sum(len(p_) for p_ in parts)
+        for mu in range(4):
+            c = bytearray(stream); cap = total
+            m = int(rng.integers(0, 6))
+            if m == 0:
+                cap = max(0, total - int(rng.integers(1, total + 1)))
+            elif m == 1:
+                c = c[:int(rng.integers(1, len(c)))]
+            elif m == 2:
+                c += bytes(rng.integers(0, 256, int(rng.integers(1, 12)), dtype=np.uint8))
+            elif m <= 4:
+                for _ in range(m - 2):
+                    c[int(rng.integers(0, len(c)))] = int(rng.integers(0, 256))
+            cb = bytes(c)
+            w = C.create_string_buffer(max(cap, 1)); g = C.create_string_buffer(max(cap, 1))
+            want = ref.L.ZSTD_decompress(w, cap, cb, len(cb)); got = lib.ZSTD_decompress(g, cap, cb, len(cb))
+            n_calls += 1
+            if want == got and (want > cap or w.raw[:want] == g.raw[:want]):
+                continue
+            if got == ERR(20) and (want <= cap or want == ERR(70)):
+                strict += 1
+                continue
+            bad.append((it, mu, m, cap, total, hex(want), hex(got)))
+    assert not bad, f"{len(bad)} of {n_calls}: {bad[:8]}"
+    assert strict <= n_calls // 8, (strict, n_calls)
