@@ -88,6 +88,7 @@ __device__ __forceinline__ uint32_t put_len_bytes(gbyte* d, uint32_t rem, int la
 }
 
 #ifdef AOCLGPU_EXPERIMENTS
+__device__ unsigned long long g_lz4_prof2[8];     // -DLZ4_PROF_SPLIT: stage 4 in pieces (walk, anchors + cover, commit = what is left in stage 4)
 __device__ unsigned long long g_lz4_prof[16];     // per-stage cycle sums of the PROF instantiation (tools/lz4_stage_prof.py)
 __device__ unsigned long long g_lz4_cond[8];      // conditional lanes: could-match duplicates, conditional ones, stops taken, stops cut, cut with no written lane on the slot
 #define LZ4_CC(k, n) (ccnt[k] += (n))
@@ -171,6 +172,14 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
 #else
 #define STAGE(k) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc[k] += t_ - tprev; tprev = t_; } } while (0)
+#endif
+
+#if defined(AOCLGPU_EXPERIMENTS) && defined(LZ4_PROF_SPLIT)
+    uint64_t tacc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAGE2(k) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tacc2[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define STAGE2(k) do { } while (0)
 #endif
 
     // Table entries of the u32 table carry, above the position, a few "check" bits derived from the 4 bytes at
@@ -566,6 +575,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                         }
                     }
                 }
+                STAGE2(0);
                 // per lane: the anchor of the sequence it belongs to = end of the last match that starts below it
                 const int32_t arel0 = (int32_t)(anchor - s0);       // <= 0; negative: literals carried in from earlier batches
                 bool marked = __builtin_amdgcn_inverse_ballot_w64(marks);
@@ -588,6 +598,7 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                 const uint64_t cover = ballot(marked || (uint32_t)lane < qend);               // lanes inside a match [m, endl) (below `special`: of the sequences kept)
                 uint32_t cur = 0;                             // first lane of the unfinished search
                 if (marks) cur = lane_get(endl, 63 - (int)__builtin_clzll(marks));
+                STAGE2(1);
                 {   // table writes the reference performs: every probed lane of every search, plus the ip-2 back-fills
                     const uint32_t R = special >= 0 ? (uint32_t)special + 1 : (marks == 0 ? (own < lim ? own : lim) : (cur >= lim ? cur : lim));
                     const uint64_t belowR = R >= 64 ? ~0ull : ~(~0ull << R);
@@ -708,9 +719,9 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
                     back = b4 < maxback ? b4 : maxback;
                     const bool more_back = b4 == 4 && maxback > 4;
                     bool eqb = false;
-                    if (more_back && back + (uint32_t)lane < maxback) eqb = src[m_pos - 1 - back - (uint32_t)lane] == src[m_cand - 1 - back - (uint32_t)lane];
                     uint32_t x = 0xFFFFFFFFu;
                     const uint32_t fa = m_pos + kMinMatch, fb = m_cand + kMinMatch;
+                    if (more_back && back + (uint32_t)lane < maxback) eqb = src[m_pos - 1 - back - (uint32_t)lane] == src[m_cand - 1 - back - (uint32_t)lane];
                     if (more_fwd) {
                         const uint32_t o = fwd + 4u * (uint32_t)lane, pa = fa + o;
                         if (pa < matchlimit) {
@@ -787,7 +798,11 @@ __device__ __forceinline__ int lz4_compress_wave(const gbyte* __restrict__ src_,
 #ifdef AOCLGPU_EXPERIMENTS
     if (PROF && lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[k], (unsigned long long)tacc[k]); for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof[8 + k], (unsigned long long)cnt[k]); }
     if (lane == 0) for (int k = 0; k < 8; ++k) if (ccnt[k]) atomicAdd(&g_lz4_cond[k], (unsigned long long)ccnt[k]);
+#ifdef LZ4_PROF_SPLIT
+    if (PROF && lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_lz4_prof2[k], (unsigned long long)tacc2[k]);
 #endif
+#endif
+#undef STAGE2
 #undef STAGE
     return (int)op;
 }
@@ -1317,6 +1332,13 @@ extern "C" int aoclgpu_debug_lz4_cond(unsigned long long* host8)
     if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::g_lz4_cond), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[8] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_cond), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+extern "C" int aoclgpu_debug_lz4_prof2(unsigned long long* host8)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(aoclgpu::g_lz4_prof2), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(aoclgpu::g_lz4_prof2), z, sizeof(z));
+    return 0;
 }
 extern "C" int aoclgpu_debug_lz4_prof(unsigned long long* host16)
 {   /* experiment build: per-stage cycle sums accumulated by launches made with batch.reserved & 8 */

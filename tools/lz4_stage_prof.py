@@ -18,6 +18,11 @@ names = ["ring + probe windows + backfill", "hash + table lookup", "cand loads +
 tot = sum(buf[:8]); c = list(buf[8:16]); nseq = max(c[1], 1)
 for n, v in zip(names, buf[:8]):
     print(f"{n:46s} {v/tot*100:6.2f}%  {v/nseq:8.1f} cyc/seq  {v/max(c[0],1):8.1f} cyc/batch")
+if hasattr(eng.lib, "aoclgpu_debug_lz4_prof2"):           # -DLZ4_PROF_SPLIT
+    b2 = (C.c_ulonglong * 8)(); eng.lib.aoclgpu_debug_lz4_prof2(b2)
+    if sum(b2):
+        for n, v in zip(["  (split) walk", "  (split) anchors + cover", "  (split) commit = 'walk + anchors + commit' above"], [b2[0], b2[1], buf[4]]):
+            print(f"{n:46s} {v/(tot+sum(b2))*100:6.2f}%  {v/nseq:8.1f} cyc/seq  {v/max(c[0],1):8.1f} cyc/batch")
 print("total cyc/seq", tot / nseq, " cyc/batch", tot / max(c[0], 1))
 print("batches", c[0], "(general", c[2], ", consecutive batches of a continuing search", c[3], ") sequences", c[1], "seq/batch", c[1] / max(c[0], 1),
       "avg lim", c[6] / max(c[0], 1), "bytes/batch", src.numel() / max(c[0], 1))
