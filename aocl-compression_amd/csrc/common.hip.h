@@ -55,6 +55,11 @@ __device__ __forceinline__ u32x4 lds_ld128(const lbyte* p)
     typedef u32x4 __attribute__((aligned(1))) U;
     return *(const __attribute__((address_space(3))) U*)p;
 }
+__device__ __forceinline__ uint32_t lds_ld32(const lbyte* p)
+{
+    typedef uint32_t __attribute__((aligned(1))) U;
+    return *(const __attribute__((address_space(3))) U*)p;
+}
 __device__ __forceinline__ uint64_t lds_ld64(const lbyte* p)
 {
     typedef uint64_t __attribute__((aligned(1))) U;

@@ -2717,7 +2717,10 @@ __device__ __forceinline__ bool seq_table(u8* tab3, const int kind, u32* log, u3
     auto cell3 = [&](u32 c) -> u32 {                                     // FseD (newState | symbol << 16 | nbBits << 24) -> the three-byte cell
         const u32 sym = (c >> 16) & 0xFFu;
         const u32 eb = kind == 0 ? sym : (kind == 1 ? (u32)kMLbits[sym < 53 ? sym : 0] : (u32)kLLbits[sym < 36 ? sym : 0]);
-        return (c & 0x1FFu) | (eb & 31u) << 9 | (sym & 63u) << 14 | ((c >> 24) & 15u) << 20;
+        // additional bits of the code (5) | code, low half (3) | state bits (4) | new state base (9) | code, high half (3): the
+        // sequence loop takes both bit counts with ONE mask (cell & 0xF1F: the counts one byte apart, as its row sums want them)
+        // and leaves the code where it is (cell & 0xE000E0, the sequence's bit position in the 13 bits between the halves)
+        return (eb & 31u) | (sym & 7u) << 5 | ((c >> 24) & 15u) << 8 | (c & 0x1FFu) << 12 | ((sym >> 3) & 7u) << 21;
     };
     auto pack = [&](u32 tl) {                                            // tile by tile, upwards: the packed cells trail the cells still to read
         lbyte* t = (lbyte*)tab3;
@@ -3057,29 +3060,29 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
             const int posU = (int)uni((u32)pos), wbU = (int)uni((u32)wbase);
             int posOut = posU;
             if (lane < 8) {
-                auto field = [&](int q, u32 nb) -> u32 {                         // the nb (<= 32) bits from window bit q upwards
-                    const uint64_t w = lds_ld64((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
-                    return __builtin_amdgcn_ubfe((u32)(w >> (q & 7)), 0u, nb);
-                };
                 const int wb8 = wbU * 8;
                 int prel = posU - wb8;
-                const u32 last = nbSeq - q0 - 1;                                 // the frame's last sequence reads no state bits
                 const u32 cntS = uni(cnt);
+                u32 Slast = 0;
                 for (u32 k = 0; k < cntS; ++k) {
-                    const u32 cell = *(L32*)(uintptr_t)(tabA + __umul24(st, 3u));   // three-byte cells (DecLds); the top byte is the next cell's
-                    const u32 nbE = (cell >> 9) & 31u, nbS = (cell >> 20) & 15u, ns = cell & 0x1FFu, sym = (cell >> 14) & 63u;
-                    // both bit counts in one register (additional bits <= 3 x 31 stay below 256): one row-shift sum gives lane j the
+                    const u32 cell = *(L32*)(uintptr_t)(tabA + __umul24(st, 3u));   // three-byte cells (seq_table); the top byte is the next cell's
+                    // both bit counts in one register (additional bits <= 3 x 31 stay below 256): row-shift sums give lane j the
                     // counts of lanes j .. j+2, lane 0 the sequence's totals, and its high byte where lane j's state field begins
-                    const u32 x = nbE | (nbS << 8);
-                    const u32 P = x + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true) + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
+                    const u32 x = cell & 0xF1Fu;
+                    const u32 P1 = x + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true);
+                    const u32 P = P1 + (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
                     const u32 tot = lane_get(P, 0);
-                    const int Etot = (int)(tot & 0xFFu), Stot = (int)(tot >> 8);
+                    const int Etot = (int)(tot & 0xFFu);
+                    Slast = tot >> 8;
                     const int pe = (int)uni((u32)(prel - Etot));                 // (scalar: one vector subtraction is left)
-                    const u32 fs = field(pe - (int)(P >> 8), nbS);
-                    *(L32*)(uintptr_t)(outA + k * outStride) = sym | ((u32)prel << 8);   // the code, and where the sequence's additional bits begin
-                    st = ns + fs;
-                    prel -= Etot + (k != last ? Stot : 0);
+                    const int q = pe - (int)((P >> 8) & 0xFFu);                  // the state field: <= 9 bits from window bit q upwards
+                    const u32 w = lds_ld32((const lbyte*)(uintptr_t)(winA + (u32)(q >> 3)));
+                    const u32 fs = __builtin_amdgcn_ubfe(w, (u32)q & 7u, x >> 8);
+                    *(L32*)(uintptr_t)(outA + k * outStride) = (cell & 0xE000E0u) | ((u32)prel << 8);   // the code, and where the sequence's additional bits begin
+                    st = __builtin_amdgcn_ubfe(cell, 12u, 9u) + fs;
+                    prel = pe - (int)Slast;
                 }
+                if (q0 + cnt >= nbSeq) prel += (int)Slast;                       // the frame's last sequence reads no state bits
                 posOut = prel + wb8;
             }
             pos = (int)uni((u32)posOut);
@@ -3099,7 +3102,8 @@ __device__ u32 decode_block(DecLds* L_, const u8* __restrict__ src_, u32 n_, u8*
                     return base + __builtin_amdgcn_ubfe((u32)(x >> (q & 7)), 0u, nb);
                 };
                 // (additional bits are stored offset, match length, literal length from the top)
-                const u32 tl = L->llTab[ll & 0xFFu], tm = L->mlTab[ml & 0xFFu], so = off & 0xFFu, top = off >> 8;
+                auto code = [](u32 w) -> u32 { return ((w >> 5) & 7u) | ((w >> 18) & 0x38u); };   // (the record of the loop above)
+                const u32 tl = L->llTab[code(ll)], tm = L->mlTab[code(ml)], so = code(off), top = (off >> 8) & 0x1FFFu;
                 off = value(top, 1u << so, so);
                 ml = value(top - so, tm & 0xFFFFFFu, tm >> 24);
                 ll = value(top - so - (tm >> 24), tl & 0xFFFFFFu, tl >> 24);
