@@ -129,6 +129,13 @@ HS_FN int run_write(Ld ld, Tab tab, const uint32_t tl, const int start, const in
     return p;
 }
 
+// The FIRST run of a lane only has to find where the lane leaves its segment - the start of the lane behind it - and prefix
+// codes fall into step within a few symbols: it decodes the segment's last kProbeBits bits, not the segment (round 6; the
+// runs that follow, from the starts the probes found, count the symbols and confirm the exits - a probe that had not fallen
+// into step yet is one more repair round, as a wrong guess always was).
+constexpr int kProbeBits = 384;
+HS_FN int probe_start(int start, int limit) { return start - limit > kProbeBits ? limit + kProbeBits : start; }
+
 // segment geometry: lane j of `lanes` decodes the codes that start in (limit, start]
 HS_FN int seg_bits(int top, int lanes) { return (top + lanes - 1) / lanes; }
 HS_FN int seg_start(int top, int seg, int j) { const int v = top - j * seg; return v > 0 ? v : 0; }

@@ -2648,8 +2648,10 @@ __device__ unsigned long long g_zstd_dprof[16];
 #define DSTAGE(k) do { } while (0)
 #endif
 // The four Huffman streams of a literals section, 16 lanes per stream (zstd_hufspec.h): every lane runs its segment from a
-// guessed start, lanes whose predecessor left somewhere else run again until nothing changes (lane 0 of a stream is exact, so
-// round r settles lane r; prefix codes fall into step within a few symbols, so two or three rounds are the rule), then the
+// guessed start - in the first round only the segment's tail, which is enough to tell where the lane leaves it (zstd_hufspec.h:
+// kProbeBits) -, lanes whose predecessor left somewhere else run again until nothing changes (lane 0 of a stream is exact from the
+// second round, so round r + 1 settles lane r; prefix codes fall into step within a few symbols, so a probe, one counting run and
+// the writing run are the rule: ~2.1 passes over the streams, three before round 6), then the
 // symbol counts become write positions by a prefix sum and one more run writes.  so / sl: this lane's stream inside src,
 // oo / no: where its symbols go and how many there must be.  Accepts exactly what the one-lane-per-stream decoder accepts:
 // `no` symbols that end on bit 0 of the stream.  Table logs <= 11 (table in LDS).
@@ -2669,8 +2671,9 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
     bool ok = top >= 0;
     if (!ok) top = 0;
     const int seg = hufspec::seg_bits(top, 16);
-    int start = hufspec::seg_start(top, seg, sub);
+    const int segTop = hufspec::seg_start(top, seg, sub);
     const int limit = hufspec::seg_start(top, seg, sub + 1);
+    int start = hufspec::probe_start(segTop, limit);                     // first run: the segment's tail, for its exit (zstd_hufspec.h)
     auto ld = [&](int off) -> u64 {
         if (off >= 0 && (u32)off + 8 <= sl) return ld64(sp + off);
         u64 v = 0;
@@ -2684,10 +2687,11 @@ __device__ __forceinline__ bool huf_decode_spec(DecLds* L, u8* out_, const u8* s
     for (int round = 0; ; ++round) {
         if (dirty) ex = hufspec::run_count(ld, tab, tl, start, limit, &cnt);
         const int prev = __shfl_up(ex, 1);
-        dirty = sub != 0 && prev != start;
-        if (dirty) start = prev;
+        const int want = sub == 0 ? segTop : prev;                       // (lane 0 of a stream starts at the stream's top)
+        dirty = want != start;
+        if (dirty) start = want;
         if (!any_lane(dirty)) break;
-        if (round > 20) return false;                                    // (cannot happen: round r settles lane r of every stream)
+        if (round > 21) return false;                                    // (cannot happen: round r + 1 settles lane r of every stream)
     }
     DSTAGE(6);
     u32 inc = cnt;

@@ -105,7 +105,7 @@ def test_random_codes(model, tl):
         assert r0 == 0 and r1 == 0, (tl, it, r0, r1)
         assert np.array_equal(a, np.array(data, dtype=np.uint8)) and np.array_equal(a, b), (tl, it)
         worst = max(worst, int(st[0]))
-    assert worst <= 17
+    assert worst <= 18                                # (a probe round in front of the rounds that settle lane after lane)
 
 
 def test_other_lane_counts(model):
@@ -121,7 +121,7 @@ def test_work_is_a_fraction_of_a_sequential_pass(model):
     stream, cells, tle, data = make_case(rng, 11, 120, 32768, 1.0)
     r0, a, r1, b, st = both(model, stream, cells, tle, len(data))
     assert r0 == 0 and r1 == 0 and np.array_equal(a, b)
-    assert st[0] <= 4 and st[1] < 4 * len(data)         # a few rounds; < 4 passes in all = 0.25 of a pass per lane
+    assert st[0] <= 4 and st[1] < 2.6 * len(data)       # a probe of the segments' tails, one counting run, the writing run (three full passes before round 6)
 
 
 def test_damaged_streams_agree_with_the_sequential_decoder(model):

@@ -54,7 +54,11 @@ extern "C" int hufspec_model_decode(const uint8_t* s, uint32_t n, const uint16_t
     const int seg = hufspec::seg_bits(top, lanes);
     std::vector<int> start(lanes), limit(lanes), exitp(lanes);
     std::vector<uint32_t> cnt(lanes);
-    for (int j = 0; j < lanes; ++j) { start[j] = hufspec::seg_start(top, seg, j); limit[j] = hufspec::seg_start(top, seg, j + 1); }
+    std::vector<int> segTop(lanes);
+    for (int j = 0; j < lanes; ++j) {                // first run: the segment's tail only (hufspec::probe_start)
+        segTop[j] = hufspec::seg_start(top, seg, j); limit[j] = hufspec::seg_start(top, seg, j + 1);
+        start[j] = hufspec::probe_start(segTop[j], limit[j]);
+    }
     uint32_t rounds = 0, steps = 0;
     std::vector<char> dirty(lanes, 1);
     for (;;) {                                       // one round = one lock-step run of the dirty lanes
@@ -62,10 +66,13 @@ extern "C" int hufspec_model_decode(const uint8_t* s, uint32_t n, const uint16_t
         for (int j = 0; j < lanes; ++j) if (dirty[j]) { exitp[j] = hufspec::run_count(ld, tab, tl, start[j], limit[j], &cnt[j]); steps += cnt[j]; }
         bool any = false;
         std::vector<char> nd(lanes, 0);
-        for (int j = 1; j < lanes; ++j) if (exitp[j - 1] != start[j]) { start[j] = exitp[j - 1]; nd[j] = 1; any = true; }
+        for (int j = 0; j < lanes; ++j) {
+            const int want = j == 0 ? segTop[0] : exitp[j - 1];
+            if (want != start[j]) { start[j] = want; nd[j] = 1; any = true; }
+        }
         dirty = nd;
         if (!any) break;
-        if (rounds > (uint32_t)lanes + 1) return -2; // cannot happen: round r settles lane r
+        if (rounds > (uint32_t)lanes + 2) return -2; // cannot happen: round r + 1 settles lane r
     }
     uint32_t total = 0;
     for (int j = 0; j < lanes; ++j) total += cnt[j];
