@@ -133,7 +133,10 @@ HS_FN int run_write(Ld ld, Tab tab, const uint32_t tl, const int start, const in
 // codes fall into step within a few symbols: it decodes the segment's last kProbeBits bits, not the segment (round 6; the
 // runs that follow, from the starts the probes found, count the symbols and confirm the exits - a probe that had not fallen
 // into step yet is one more repair round, as a wrong guess always was).
-constexpr int kProbeBits = 384;
+#ifndef ZSTD_HUF_PROBE_BITS
+#define ZSTD_HUF_PROBE_BITS 384
+#endif
+constexpr int kProbeBits = ZSTD_HUF_PROBE_BITS;
 HS_FN int probe_start(int start, int limit) { return start - limit > kProbeBits ? limit + kProbeBits : start; }
 
 // segment geometry: lane j of `lanes` decodes the codes that start in (limit, start]
