@@ -3,6 +3,8 @@ threads call LZ4_compress_default / snappy_compress / ZSTD_compress / aocl_llc_c
 form) and the matching decoders in a loop on their own inputs; every output must equal the real reference's
 (csrc/capi.hip context pool and scratch pool, csrc/rap.hip buffer cache)."""
 import ctypes as C
+import os
+import sys
 import threading
 
 import pytest
@@ -14,6 +16,7 @@ from test_native_api import lib  # noqa: F401  (the bound native entry points)
 pytestmark = pytest.mark.gpu
 
 THREADS, ROUNDS = 8, 6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_eight_threads_through_the_one_shot_apis(lib, eng, ref):  # noqa: F811
@@ -56,3 +59,14 @@ def test_eight_threads_through_the_one_shot_apis(lib, eng, ref):  # noqa: F811
     for th in ths: th.start()
     for th in ths: th.join()
     assert not errors, errors
+
+
+def test_two_batches_in_flight_on_two_streams(eng):  # noqa: F811
+    """bench.py's `two_batches_in_flight` leg at a small size: LZ4 batches on two HIP streams with their own output buffers overlap on
+    the chip and both decode back to the source (LZ4 keeps all its state in LDS; Snappy's and Zstd's workspaces are per stream)."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    args = types.SimpleNamespace(gib=0.25, chunk=0)
+    r = bench.two_batches_in_flight(eng, args, a.corpus.silesia_mix(8 << 20, seed=5), steps=4)
+    assert r["round_trip"] is True and r["two_streams_ms_per_step"] > 0 and r["one_stream_ms_per_step"] > 0
